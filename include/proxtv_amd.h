@@ -1,0 +1,158 @@
+/*
+ * proxtv_amd.h -- C-ABI of libproxtv_amd.so, the MI355X (gfx950) TV-proximity library.
+ *
+ * PART 1 is the drop-in boundary: the same unmangled symbols, argument meaning, ownership and
+ * return/info conventions as the reference's `extern "C"` block (reference: src/TVopt.h:88-141,
+ * src/condat_fast_tv.h:76-81).  All pointers in part 1 are HOST pointers; the library stages them
+ * to HBM, runs the HIP path and copies the result back.  Arrays are column-major (dimension 0
+ * fastest), float64.  `info` is caller-owned double[3] or NULL: {iterations, gap/stop, return code}
+ * (reference: src/general.h:58-73).  Functions never throw; a HIP failure or an unsupported
+ * argument prints "<fn>: <reason>" to stdout like the reference's CANCEL macros, sets
+ * info[2]=RC_ERROR and returns 0.  THERE IS NO CPU FALLBACK: without a usable gfx950 device every
+ * entry point fails that way.
+ *
+ * PART 2 is new API (not in the reference): device-pointer entry points used by bench.py and by
+ * callers that already hold data in HBM, plus the batch solver that shards independent images.
+ *
+ * Only the p = 1 (TV-L1) norm is implemented -- the hot path of BASELINE.json.  The TV-L2 / TV-Lp /
+ * projected-Newton / Kolmogorov / Johnson-DP entry points of the reference are out of scope
+ * (DESIGN.md "Out of scope") and are not exported.
+ */
+#ifndef PROXTV_AMD_H
+#define PROXTV_AMD_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- constants shared with the reference ------------------------------------------------------ */
+#define N_INFO 3              /* src/general.h:58 */
+#define INFO_ITERS 0
+#define INFO_GAP 1
+#define INFO_RC 2
+#define RC_OK 0               /* src/general.h:70-73 */
+#define RC_ITERS 1
+#define RC_STUCK 2
+#define RC_ERROR 3
+#define STOP_PD 1e-6          /* src/TVopt.h:71 */
+#define MAX_ITERS_PD 35       /* src/TVopt.h:73 */
+#define MAX_ITERS_DR 35       /* src/TVopt.h:83 */
+#define MAX_ITERS_YANG 35     /* src/TVopt.h:85 */
+
+/* Opaque, ABI-only (reference: src/utils.h:20-34).  The HIP path keeps its scratch in HBM and
+   ignores workspaces; callers (like the reference's Python layer) pass NULL. */
+typedef struct Workspace Workspace;
+
+/* =============================== PART 1: drop-in entry points ================================== */
+
+/* replaces src/TVgenopt.cpp:30 `TV` -- p == 1 only; p < 1 or p != 1 -> RC_ERROR, returns 0 */
+int TV(double *y, double lambda, double *x, double *info, int n, double p, Workspace *ws);
+
+/* replaces src/TVL1opt.cpp:359 */
+int linearizedTautString_TV1(double *y, double lambda, double *x, int n);
+/* replaces src/TVL1opt_tautstring.cpp:355 and :256 */
+int classicTautString_TV1(double *signal, int n, double lam, double *prox);
+int classicTautString_TV1_offset(double *signal, int n, double lam, double *prox, double offset);
+/* replaces src/TVL1opt_hybridtautstring.cpp:237 and :56.  The 1-D TV-L1 prox is unique, so all
+   five unweighted entry points run the same exact HIP solver; `backtracksexp` is accepted and has
+   no observable effect on the result. */
+void hybridTautString_TV1(double *y, int n, double lambda, double *x);
+void hybridTautString_TV1_custom(double *y, int n, double lambda, double *x, double backtracksexp);
+/* replaces src/TVL1Wopt.cpp:364 -- lambda has n-1 entries */
+int tautString_TV1_Weighted(double *y, double *lambda, double *x, int n);
+/* replaces src/condat_fast_tv.cpp:78 -- no-op when width <= 0 or lambda < 0; in-place allowed */
+void TV1D_denoise(double *input, double *output, const int width, const double lambda);
+
+/* replaces src/TV2Dopt.cpp:352 -- returns 0 on success (sic) */
+int DR2_TV(size_t M, size_t N, double *unary, double W1, double W2, double norm1, double norm2,
+           double *s, int nThreads, int maxit, double *info);
+/* replaces src/TV2DWopt.cpp:46 -- W1 is (M-1)xN, W2 is Mx(N-1), column-major; returns 0 on success (sic) */
+int DR2L1W_TV(size_t M, size_t N, double *unary, double *W1, double *W2, double *s, int nThreads,
+              int maxit, double *info);
+/* replaces src/TV2Dopt.cpp:59 -- npen in {1,2}; dims are 1-based doubles */
+int PD2_TV(double *y, double *lambdas, double *norms, double *dims, double *x, double *info, int *ns,
+           int nds, int npen, int ncores, int maxIters);
+/* replaces src/TVNDopt.cpp:48 -- multiplies lambdas[] by npen in caller memory, like the reference */
+int PD_TV(double *y, double *lambdas, double *norms, double *dims, double *x, double *info, int *ns,
+          int nds, int npen, int ncores, int maxIters);
+/* replaces src/TVNDopt.cpp:280 -- multiplies lambdas[] by npen in caller memory, like the reference */
+int PDR_TV(double *y, double *lambdas, double *norms, double *dims, double *x, double *info, int *ns,
+           int nds, int npen, int ncores, int maxIters);
+/* replaces src/TV2Dopt.cpp:787 */
+int Yang2_TV(size_t M, size_t N, double *Y, double lambda, double *X, int maxit, double *info);
+/* replaces src/TVNDopt.cpp:678 */
+int Yang3_TV(size_t M, size_t N, size_t O, double *Y, double lambda, double *X, int maxit, double *info);
+
+/* Workspace allocator shims (reference: src/utils.cpp:79-237).  ABI-only: they return / accept
+   small host objects so reference callers that create workspaces keep linking. */
+Workspace *newWorkspace(int n);
+void resetWorkspace(Workspace *ws);
+void freeWorkspace(Workspace *ws);
+Workspace **newWorkspaces(int n, int p);
+void freeWorkspaces(Workspace **wa, int p);
+
+/* =============================== PART 2: MI355X-native extensions ============================== */
+
+/* Library / device state.  proxtv_init returns 0 when a gfx950 device is usable, else non-zero and
+   prints the reason.  device < 0 keeps the current HIP device. */
+int  proxtv_init(int device);
+const char *proxtv_version(void);
+const char *proxtv_last_error(void);
+/* free every cached HBM scratch block held by the calling thread's pool */
+void proxtv_release_scratch(void);
+
+/* Knobs (returns previous value).  key: "chunk" (samples per speculative chunk, 0 = sequential
+   lane-per-fibre kernels only), "warmup", "verbose". */
+int proxtv_set_option(const char *key, int value);
+
+/* Device-pointer solvers: every double* is an HBM pointer valid on the current device, `stream` is
+   a hipStream_t (NULL = the library's per-thread stream), `info` is a HOST double[3] or NULL.
+   Work is enqueued AND completed (the call synchronises `stream`) unless `info` is NULL and
+   PD-type stopping is not involved; see DESIGN.md.  Same return conventions as part 1. */
+int proxtv_DR2_TV_dev(size_t M, size_t N, const double *unary, double W1, double W2, double *s,
+                      int maxit, double *info, void *stream);
+int proxtv_DR2L1W_TV_dev(size_t M, size_t N, const double *unary, const double *W1, const double *W2,
+                         double *s, int maxit, double *info, void *stream);
+int proxtv_PD2_TV_dev(const double *y, const double *lambdas /*host*/, const double *dims /*host*/,
+                      double *x, double *info, const int *ns /*host*/, int nds, int npen, int maxIters,
+                      void *stream);
+int proxtv_PD_TV_dev(const double *y, const double *lambdas_scaled /*host, already * npen*/,
+                     const double *dims /*host*/, double *x, double *info, const int *ns /*host*/,
+                     int nds, int npen, int maxIters, void *stream);
+int proxtv_PDR_TV_dev(const double *y, const double *lambdas_scaled /*host*/, const double *dims /*host*/,
+                      double *x, double *info, const int *ns /*host*/, int nds, int npen, int maxIters,
+                      void *stream);
+/* Yang ADMM on a 2-D or 3-D array with one lambda per dimension (scalar-lambda reference behaviour
+   when all entries are equal).  order follows the reference: 2-D rows then columns, 3-D dims 1,2,3. */
+int proxtv_Yang_TV_dev(const int *ns /*host*/, int nds, const double *Y, const double *lambdas /*host, nds*/,
+                       double *X, int maxit, double *info, void *stream);
+
+/* Batched exact 1-D TV-L1 prox along one dimension of an N-D column-major array (the per-sweep
+   kernel of every solver above): out = prox_{lambda}(in) on every fibre along dimension `dim`
+   (0-based).  weights == NULL -> uniform lambda; otherwise `weights` has the shape of `in` with
+   ns[dim] reduced by one and holds per-edge penalties. */
+int proxtv_tv1_fibres_dev(const double *in, double *out, const int *ns /*host*/, int nds, int dim,
+                          double lambda, const double *weights, void *stream);
+
+/* Batch of B independent MxN images stored back to back (image b at unary + b*M*N), each solved
+   with DR2_TV semantics (oracle = loop of DR2_TV).  All B images advance together, one
+   launch per sweep over B*N (columns) / B*M (rows) fibres. */
+int proxtv_DR2_TV_batch_dev(size_t M, size_t N, size_t B, const double *unary, double W1, double W2,
+                            double *s, int maxit, double *info, void *stream);
+
+/* Same on HOST pointers (stages through HBM like part 1). */
+int proxtv_DR2_TV_batch(size_t M, size_t N, size_t B, const double *unary, double W1, double W2, double *s,
+                        int maxit, double *info);
+
+/* Timing hook for bench.py: average device time in milliseconds of the `which`-th kernel family
+   over the last solve (0 = column sweep, 1 = row sweep, 2 = everything else), measured with
+   hipEvents on the solve's own stream when option "profile" is 1. */
+double proxtv_last_kernel_ms(int which);
+long   proxtv_last_kernel_launches(int which);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PROXTV_AMD_H */

@@ -1,0 +1,251 @@
+r"""proxtv_amd -- Total-Variation proximity operators on AMD Instinct MI355X (gfx950).
+
+The module mirrors the Python surface of proxTV (reference: ``prox_tv/__init__.py``) for the TV-L1 solver path:
+same function names, argument order, defaults, assertions, dtype / memory-order coercions and return shapes,
+so ``import proxtv_amd as prox_tv`` is a drop-in for
+
+    tv1_1d, tv1w_1d, tv1_2d (methods 'dr', 'pd', 'yang'), tv1w_2d, tvp_2d (p = 1), tvgen.
+
+Every call runs hand-written HIP kernels through the C-ABI of ``libproxtv_amd.so`` (``include/proxtv_amd.h``);
+there is no CPU path.  Without a gfx950 device the functions raise :class:`ProxTVError`.
+
+New (not in the reference): :func:`tv1_2d_batch` for stacks of independent images, and :mod:`proxtv_amd.device`
+for arrays that already live in HBM (torch tensors).
+
+Out of scope (raise ``NotImplementedError``): the TV-L2 / TV-Lp solvers (``tv2_1d``, ``tvp_1d``, ``tvp_2d`` with
+p != 1) and the pointwise 2-D baselines ('condat', 'chambolle-pock', 'chambolle-pock-acc', 'kolmogorov').
+"""
+import numpy as np
+
+from . import _lib
+from ._lib import ProxTVError  # noqa: F401
+
+__all__ = ["tv1_1d", "tv1w_1d", "tv2_1d", "tvp_1d", "tv1_2d", "tv1w_2d", "tvp_2d", "tvgen", "tv1_2d_batch",
+           "force_float_scalar", "force_float_matrix", "ProxTVError"]
+
+# The maximum number of returned info parameters (reference: prox_tv/__init__.py:67).
+_N_INFO = 3
+
+
+def _ptr(a):
+    return a.ctypes.data
+
+
+def force_float_scalar(x):
+    """Forces a scalar value into float format (reference: prox_tv/__init__.py:80-96)."""
+    if not isinstance(x, float):
+        return float(x)
+    return x
+
+
+def force_float_matrix(x):
+    """Forces a numpy matrix into float64 format; float64 arrays are returned as the SAME object
+    (reference: prox_tv/__init__.py:99-121)."""
+    if not isinstance(x, np.ndarray):
+        try:
+            x = np.array(x)
+        except Exception:
+            raise TypeError("Input must be a numpy matrix or compatible object")
+    if x.dtype != np.dtype("float64"):
+        return x.astype("float")
+    return x
+
+
+def _contig(x):
+    """The reference hands ndarray.ctypes.data to C assuming a dense buffer; make that assumption true."""
+    if x.flags.c_contiguous or x.flags.f_contiguous:
+        return x
+    return np.ascontiguousarray(x)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# 1-D
+# ------------------------------------------------------------------------------------------------------------------
+def tv1_1d(x, w, method="hybridtautstring", sigma=0.05, maxbacktracks=None):
+    r"""1D proximal operator for :math:`\ell_1`:  min_y 1/2 ||x-y||^2 + w sum_i |y_i - y_{i+1}|.
+
+    Mirrors prox_tv.tv1_1d (reference: prox_tv/__init__.py:124-179).  The minimiser is unique, so every
+    ``method`` name of the reference is accepted and served by the same exact HIP solver; the names that map onto
+    a C entry point of the hot path ('hybridtautstring', 'linearizedtautstring', 'classictautstring', 'condat')
+    call that entry point, the remaining ones ('pn', 'dp', 'condattautstring', 'kolmogorov': alternative CPU
+    algorithms, out of scope) are aliases of 'hybridtautstring'.
+    """
+    methods = ("classictautstring", "linearizedtautstring", "hybridtautstring", "pn", "condat", "dp",
+               "condattautstring", "kolmogorov")
+    assert method in methods
+    assert w >= 0
+    w = force_float_scalar(w)
+    x = _contig(force_float_matrix(x))
+    y = np.zeros(np.size(x))
+    lib = _lib.require_device()
+    n = int(np.size(x))
+    if method == "classictautstring":
+        lib.classicTautString_TV1(_ptr(x), n, w, _ptr(y))
+    elif method == "linearizedtautstring":
+        lib.linearizedTautString_TV1(_ptr(x), w, _ptr(y), n)
+    elif method == "condat":
+        lib.TV1D_denoise(_ptr(x), _ptr(y), n, w)
+    elif method == "hybridtautstring" and maxbacktracks is not None:
+        lib.hybridTautString_TV1_custom(_ptr(x), n, w, _ptr(y), float(maxbacktracks))
+    else:
+        lib.hybridTautString_TV1(_ptr(x), n, w, _ptr(y))
+    _lib.check("tv1_1d")
+    return y
+
+
+def tv1w_1d(x, w, method="tautstring", sigma=0.05):
+    r"""Weighted 1D proximal operator for :math:`\ell_1` (reference: prox_tv/__init__.py:218-254).
+    Both method names ('tautstring', 'pn') run the exact weighted HIP solver."""
+    assert np.all(w >= 0)
+    assert np.size(x) - 1 == np.size(w)
+    w = _contig(force_float_matrix(w))
+    x = _contig(force_float_matrix(x))
+    y = np.zeros(np.size(x))
+    lib = _lib.require_device()
+    lib.tautString_TV1_Weighted(_ptr(x), _ptr(w), _ptr(y), int(np.size(x)))
+    _lib.check("tv1w_1d")
+    return y
+
+
+def tv2_1d(x, w, method="mspg"):
+    """TV-L2 (reference: prox_tv/__init__.py:257-296) is outside the TV-L1 hot path."""
+    raise NotImplementedError("proxtv_amd implements the TV-L1 solver path only (tv2_1d is out of scope)")
+
+
+def tvp_1d(x, w, p, method="gpfw", max_iters=0):
+    """TV-Lp (reference: prox_tv/__init__.py:311-352) is outside the TV-L1 hot path."""
+    raise NotImplementedError("proxtv_amd implements the TV-L1 solver path only (tvp_1d is out of scope)")
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# 2-D
+# ------------------------------------------------------------------------------------------------------------------
+def tv1_2d(x, w, n_threads=1, max_iters=0, method="dr"):
+    r"""2D proximal operator for :math:`\ell_1` (anisotropic TV), reference: prox_tv/__init__.py:355-407.
+
+    ``method``: 'dr' (Douglas-Rachford, DR2_TV), 'pd' (proximal Dykstra, PD2_TV), 'yang' (Yang2_TV).
+    ``n_threads`` is accepted for compatibility; the GPU path ignores it.
+    """
+    methods = ("yang", "dr", "pd", "kolmogorov", "condat", "chambolle-pock", "chambolle-pock-acc")
+    assert w >= 0
+    assert method in methods
+    if method not in ("yang", "dr", "pd"):
+        raise NotImplementedError(f"tv1_2d(method={method!r}): the pointwise 2-D baselines are out of scope")
+    x = np.asfortranarray(x, dtype="float64")
+    w = force_float_scalar(w)
+    y = np.asfortranarray(np.zeros(x.shape))
+    info = np.zeros(_N_INFO)
+    lib = _lib.require_device()
+    if method == "dr":      # prox_tv/__init__.py:413-416
+        lib.DR2_TV(x.shape[0], x.shape[1], _ptr(x), w, w, 1.0, 1.0, _ptr(y), int(n_threads), int(max_iters), _ptr(info))
+    elif method == "pd":    # prox_tv/__init__.py:418-421
+        lam = np.array([w, w], dtype=np.float64)
+        norms = np.array([1.0, 1.0])
+        dims = np.array([1.0, 2.0])
+        ns = np.array(x.shape, dtype=np.int32)
+        lib.PD2_TV(_ptr(x), _ptr(lam), _ptr(norms), _ptr(dims), _ptr(y), _ptr(info), _ptr(ns), 2, 2,
+                   int(n_threads), int(max_iters))
+    else:                   # prox_tv/__init__.py:409-411
+        lib.Yang2_TV(x.shape[0], x.shape[1], _ptr(x), w, _ptr(y), int(max_iters), _ptr(info))
+    _lib.check("tv1_2d")
+    return y
+
+
+def tv1w_2d(x, w_col, w_row, max_iters=0, n_threads=1):
+    r"""2D weighted proximal operator for :math:`\ell_1` using DR splitting (reference: prox_tv/__init__.py:445-481).
+    ``w_col`` is (M-1) x N, ``w_row`` is M x (N-1)."""
+    assert np.all(w_col >= 0)
+    assert np.all(w_row >= 0)
+    M, N = x.shape
+    assert w_col.shape == (M - 1, N)
+    assert w_row.shape == (M, N - 1)
+    x = np.asfortranarray(x, dtype="float64")
+    y = np.zeros(x.shape, order="F")
+    w_col = np.asfortranarray(w_col, dtype="float64")
+    w_row = np.asfortranarray(w_row, dtype="float64")
+    info = np.zeros(_N_INFO)
+    lib = _lib.require_device()
+    lib.DR2L1W_TV(M, N, _ptr(x), _ptr(w_col), _ptr(w_row), _ptr(y), int(n_threads), int(max_iters), _ptr(info))
+    _lib.check("tv1w_2d")
+    return y
+
+
+def tvp_2d(x, w_col, w_row, p_col, p_row, n_threads=1, max_iters=0):
+    r"""2D proximal operator for :math:`\ell_p` norms (reference: prox_tv/__init__.py:484-530); only
+    p_col == p_row == 1 is implemented (DR2_TV with separate column / row penalties)."""
+    assert w_col >= 0
+    assert w_row >= 0
+    assert p_col >= 1
+    assert p_row >= 1
+    if p_col != 1 or p_row != 1:
+        raise NotImplementedError("proxtv_amd implements the TV-L1 solver path only (tvp_2d needs p_col = p_row = 1)")
+    info = np.zeros(_N_INFO)
+    x = np.asfortranarray(x, dtype="float64")
+    w_col = force_float_scalar(w_col)
+    w_row = force_float_scalar(w_row)
+    y = np.zeros(np.shape(x), order="F")
+    lib = _lib.require_device()
+    lib.DR2_TV(x.shape[0], x.shape[1], _ptr(x), w_col, w_row, 1.0, 1.0, _ptr(y), int(n_threads), int(max_iters), _ptr(info))
+    _lib.check("tvp_2d")
+    return y
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# N-D
+# ------------------------------------------------------------------------------------------------------------------
+def tvgen(x, ws, ds, ps, n_threads=1, max_iters=0):
+    r"""General TV proximal operator for multidimensional signals (reference: prox_tv/__init__.py:533-600).
+
+    Observable dispatch of the reference, reproduced: two penalty terms -> PD2_TV (proximal Dykstra); any other
+    count -> PD_TV (parallel proximal Dykstra).  (The reference's "2-D => Douglas-Rachford" branch at
+    prox_tv/__init__.py:585 can never be taken because of operator precedence, so it is not mirrored.)
+    Like the reference, a float64 ndarray ``ws`` is passed to PD_TV by reference and comes back multiplied by the
+    number of penalties (src/TVNDopt.cpp:100-101).
+    """
+    assert len(ws) == len(ds)
+    assert len(ws) == len(ps)
+    assert n_threads >= 1
+    assert max_iters >= 0
+    info = np.zeros(_N_INFO)
+    x = np.asfortranarray(x, dtype="float64")
+    ws = force_float_matrix(ws)
+    ps = force_float_matrix(ps)
+    y = np.zeros(np.shape(x), order="F")
+    if np.any(ps != 1):
+        raise NotImplementedError("proxtv_amd implements the TV-L1 solver path only (tvgen needs every p = 1)")
+    dims = np.array(ds, dtype=np.float64)            # cffi turns the `ds` sequence into a temporary double[]
+    ns = np.array(x.shape, dtype=np.int32)           # ... and x.shape into a temporary int[]
+    if not (ws.flags.c_contiguous or ws.flags.f_contiguous):
+        ws = np.ascontiguousarray(ws)
+    lib = _lib.require_device()
+    if len(ws) == 2:
+        lib.PD2_TV(_ptr(x), _ptr(ws), _ptr(ps), _ptr(dims), _ptr(y), _ptr(info), _ptr(ns), len(x.shape), 2,
+                   int(n_threads), int(max_iters))
+    else:
+        lib.PD_TV(_ptr(x), _ptr(ws), _ptr(ps), _ptr(dims), _ptr(y), _ptr(info), _ptr(ns), len(x.shape), len(ws),
+                  int(n_threads), int(max_iters))
+    _lib.check("tvgen")
+    return y
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# new API: batches of independent images
+# ------------------------------------------------------------------------------------------------------------------
+def tv1_2d_batch(xs, w, max_iters=0):
+    r"""Anisotropic TV-L1 prox (Douglas-Rachford, DR2_TV semantics) of a stack of independent images.
+
+    ``xs`` has shape (B, M, N); the result has the same shape and equals ``tv1_2d(xs[b], w)`` for every b.
+    All B images advance together: one kernel launch per sweep over all B*N column (B*M row) fibres.
+    """
+    assert w >= 0
+    xs = np.asarray(xs, dtype=np.float64)
+    assert xs.ndim == 3
+    B, M, N = xs.shape
+    # image b column-major, images back to back == a Fortran-ordered (M, N, B) array
+    stack = np.asfortranarray(np.transpose(xs, (1, 2, 0)))
+    out = np.zeros_like(stack, order="F")
+    info = np.zeros(_N_INFO)
+    lib = _lib.require_device()
+    lib.proxtv_DR2_TV_batch(M, N, B, _ptr(stack), float(w), float(w), _ptr(out), int(max_iters), _ptr(info))
+    _lib.check("tv1_2d_batch")
+    return np.ascontiguousarray(np.transpose(out, (2, 0, 1)))

@@ -1,0 +1,101 @@
+"""ctypes binding of libproxtv_amd.so (the C-ABI declared in include/proxtv_amd.h).
+
+The library is the product: there is no Python or CPU fallback.  If the shared object is missing it is built
+in-tree with hipcc (proxtv_amd/build.py); if that is impossible, or no gfx950 device is usable at call time,
+the caller gets an exception -- never a silently different code path.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libproxtv_amd.so")
+
+_dp = C.c_void_p      # double* (host or device, per entry point)
+_ip = C.c_void_p      # int*
+
+SIGNATURES = {
+    # ---- part 1: drop-in entry points (reference: src/TVopt.h:88-141) ----
+    "TV": (C.c_int, [_dp, C.c_double, _dp, _dp, C.c_int, C.c_double, C.c_void_p]),
+    "linearizedTautString_TV1": (C.c_int, [_dp, C.c_double, _dp, C.c_int]),
+    "classicTautString_TV1": (C.c_int, [_dp, C.c_int, C.c_double, _dp]),
+    "classicTautString_TV1_offset": (C.c_int, [_dp, C.c_int, C.c_double, _dp, C.c_double]),
+    "hybridTautString_TV1": (None, [_dp, C.c_int, C.c_double, _dp]),
+    "hybridTautString_TV1_custom": (None, [_dp, C.c_int, C.c_double, _dp, C.c_double]),
+    "tautString_TV1_Weighted": (C.c_int, [_dp, _dp, _dp, C.c_int]),
+    "TV1D_denoise": (None, [_dp, _dp, C.c_int, C.c_double]),
+    "DR2_TV": (C.c_int, [C.c_size_t, C.c_size_t, _dp, C.c_double, C.c_double, C.c_double, C.c_double, _dp,
+                         C.c_int, C.c_int, _dp]),
+    "DR2L1W_TV": (C.c_int, [C.c_size_t, C.c_size_t, _dp, _dp, _dp, _dp, C.c_int, C.c_int, _dp]),
+    "PD2_TV": (C.c_int, [_dp, _dp, _dp, _dp, _dp, _dp, _ip, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "PD_TV": (C.c_int, [_dp, _dp, _dp, _dp, _dp, _dp, _ip, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "PDR_TV": (C.c_int, [_dp, _dp, _dp, _dp, _dp, _dp, _ip, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "Yang2_TV": (C.c_int, [C.c_size_t, C.c_size_t, _dp, C.c_double, _dp, C.c_int, _dp]),
+    "Yang3_TV": (C.c_int, [C.c_size_t, C.c_size_t, C.c_size_t, _dp, C.c_double, _dp, C.c_int, _dp]),
+    "newWorkspace": (C.c_void_p, [C.c_int]),
+    "resetWorkspace": (None, [C.c_void_p]),
+    "freeWorkspace": (None, [C.c_void_p]),
+    "newWorkspaces": (C.c_void_p, [C.c_int, C.c_int]),
+    "freeWorkspaces": (None, [C.c_void_p, C.c_int]),
+    # ---- part 2: MI355X-native extensions ----
+    "proxtv_init": (C.c_int, [C.c_int]),
+    "proxtv_version": (C.c_char_p, []),
+    "proxtv_last_error": (C.c_char_p, []),
+    "proxtv_release_scratch": (None, []),
+    "proxtv_set_option": (C.c_int, [C.c_char_p, C.c_int]),
+    "proxtv_DR2_TV_dev": (C.c_int, [C.c_size_t, C.c_size_t, _dp, C.c_double, C.c_double, _dp, C.c_int, _dp, C.c_void_p]),
+    "proxtv_DR2L1W_TV_dev": (C.c_int, [C.c_size_t, C.c_size_t, _dp, _dp, _dp, _dp, C.c_int, _dp, C.c_void_p]),
+    "proxtv_PD2_TV_dev": (C.c_int, [_dp, _dp, _dp, _dp, _dp, _ip, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "proxtv_PD_TV_dev": (C.c_int, [_dp, _dp, _dp, _dp, _dp, _ip, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "proxtv_PDR_TV_dev": (C.c_int, [_dp, _dp, _dp, _dp, _dp, _ip, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "proxtv_Yang_TV_dev": (C.c_int, [_ip, C.c_int, _dp, _dp, _dp, C.c_int, _dp, C.c_void_p]),
+    "proxtv_tv1_fibres_dev": (C.c_int, [_dp, _dp, _ip, C.c_int, C.c_int, C.c_double, _dp, C.c_void_p]),
+    "proxtv_DR2_TV_batch_dev": (C.c_int, [C.c_size_t, C.c_size_t, C.c_size_t, _dp, C.c_double, C.c_double, _dp,
+                                          C.c_int, _dp, C.c_void_p]),
+    "proxtv_DR2_TV_batch": (C.c_int, [C.c_size_t, C.c_size_t, C.c_size_t, _dp, C.c_double, C.c_double, _dp, C.c_int, _dp]),
+    "proxtv_last_kernel_ms": (C.c_double, [C.c_int]),
+    "proxtv_last_kernel_launches": (C.c_long, [C.c_int]),
+}
+
+_lib = None
+
+
+class ProxTVError(RuntimeError):
+    """A HIP-path failure reported by libproxtv_amd (no device, HIP error, unsupported argument)."""
+
+
+def load(build_if_missing=True):
+    """Return the ctypes handle with argtypes set; builds the library in-tree if it is not there."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        if not build_if_missing:
+            raise ImportError("libproxtv_amd.so is not built (run `python -m proxtv_amd.build`)")
+        from . import build as _build
+        _build.build()
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)   # AttributeError here == the C-ABI lost a symbol
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+def last_error():
+    msg = load().proxtv_last_error()
+    return msg.decode() if msg else ""
+
+
+def require_device():
+    """Raise unless a gfx950 device is usable.  Called by the Python surface before any solve."""
+    lib = load()
+    if lib.proxtv_init(-1) != 0:
+        raise ProxTVError("proxtv_amd: " + last_error())
+    return lib
+
+
+def check(what):
+    """Raise if the last C call on this thread recorded an error (the C-ABI itself never throws)."""
+    msg = last_error()
+    if msg:
+        raise ProxTVError(f"{what}: {msg}")

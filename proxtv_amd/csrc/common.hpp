@@ -1,0 +1,101 @@
+// common.hpp -- host-side plumbing shared by the HIP translation units of libproxtv_amd.so:
+// error capture, the per-thread stream, the HBM scratch pool, fibre geometry.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/proxtv_amd.h"
+
+namespace ptv {
+
+// ---- error capture -------------------------------------------------------------------------------------------
+void set_error(const char *fmt, ...);
+const char *last_error();
+
+struct HipFailure {
+    hipError_t code;
+};
+
+#define PTV_HIP(call)                                                                                  \
+    do {                                                                                               \
+        hipError_t _e = (call);                                                                        \
+        if (_e != hipSuccess) {                                                                        \
+            ::ptv::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(_e), __FILE__, __LINE__); \
+            throw ::ptv::HipFailure{_e};                                                               \
+        }                                                                                              \
+    } while (0)
+
+// ---- options (see proxtv_set_option) ---------------------------------------------------------------------------
+struct Options {
+    int chunk = 32;     // samples per speculative chunk (0 = sequential lane-per-fibre kernels only)
+    int warmup = 16;    // warm-up / synchronisation zone in samples (<= 32)
+    int verbose = 0;
+    int profile = 0;    // per-kernel-family hipEvent timing
+};
+Options &options();
+
+// ---- device / stream -------------------------------------------------------------------------------------------
+// Throws HipFailure (with last_error set) when no usable gfx950 device exists.
+void ensure_device();
+hipStream_t thread_stream();
+
+// ---- HBM scratch pool ------------------------------------------------------------------------------------------
+// Per-thread cache of device allocations: solvers ask for a handful of image-sized arrays per call and
+// hipMalloc/hipFree cost ~100 us each, so blocks are kept and reused by exact byte size.
+class Scratch {
+  public:
+    explicit Scratch(size_t bytes);
+    ~Scratch();
+    Scratch(const Scratch &) = delete;
+    Scratch &operator=(const Scratch &) = delete;
+    template <class T> T *as() const { return static_cast<T *>(ptr_); }
+    double *d() const { return static_cast<double *>(ptr_); }
+    size_t bytes() const { return bytes_; }
+
+  private:
+    void *ptr_ = nullptr;
+    size_t bytes_ = 0;
+};
+void release_scratch();
+
+// ---- fibre geometry ---------------------------------------------------------------------------------------------
+// Fibres of an N-D column-major array along one dimension (reference addressing: src/TV2Dopt.cpp:140-145,184):
+// fibre j starts at (j / inc) * inc * len + (j % inc), its samples are `inc` elements apart.
+struct FibreGeom {
+    long inc;    // stride between consecutive samples of one fibre
+    int len;     // samples per fibre
+    long count;  // number of fibres
+};
+
+inline FibreGeom fibres_along(const int *ns, int nds, int d) {
+    long n = 1, inc = 1;
+    for (int i = 0; i < nds; i++) n *= ns[i];
+    for (int i = 0; i < d; i++) inc *= ns[i];
+    return FibreGeom{inc, ns[d], ns[d] > 0 ? n / ns[d] : 0};
+}
+
+// ---- per-family kernel timing (bench.py roofline leg) ------------------------------------------------------------
+enum KernelFamily { FAM_COL = 0, FAM_ROW = 1, FAM_OTHER = 2, FAM_COUNT = 3 };
+struct FamilyTimer {
+    // usage: { FamilyTimer t(fam, stream); launch...; }
+    FamilyTimer(int fam, hipStream_t s);
+    ~FamilyTimer();
+    int fam;
+    hipStream_t s;
+    hipEvent_t a = nullptr, b = nullptr;
+};
+void timing_reset();
+void timing_collect();  // resolves pending events (call after the stream is synchronised)
+double timing_ms(int fam);
+long timing_launches(int fam);
+
+}  // namespace ptv

@@ -1,0 +1,35 @@
+// solvers.hpp -- device-resident splitting loops (solvers.hip).  All pointers are HBM pointers.
+#pragma once
+
+#include "common.hpp"
+
+namespace ptv {
+
+struct SolveInfo {
+    double iters = 0;
+    double gap = 0;
+    bool gap_set = false;  // DR / Yang leave info[INFO_GAP] untouched, like the reference
+    int rc = RC_OK;
+};
+
+// out = prox along dimension `dim` of every fibre of `in` (uniform lam, or per-edge `weights`)
+void tv1_fibres(const double *in, double *out, const int *ns, int nds, int dim, double lam, const double *weights,
+                hipStream_t s);
+
+// Douglas-Rachford on B stacked MxN images (B = 1: DR2_TV / DR2L1W_TV).  W1m/W2m != nullptr selects the weighted
+// solver (per-edge penalties, (M-1)xN and Mx(N-1) per image); otherwise scalars W1 (columns) / W2 (rows).
+SolveInfo dr2(size_t M, size_t N, size_t B, const double *unary, double W1, double W2, const double *W1m,
+              const double *W2m, double *out, int maxit, hipStream_t s);
+
+SolveInfo pd2(const double *y, const double *lambdas, const double *dims, double *x, const int *ns, int nds, int npen,
+              int maxIters, hipStream_t s);
+// lambdas already scaled by npen (the C-ABI wrapper does the in-place scaling the reference does)
+SolveInfo pd(const double *y, const double *lambdas, const double *dims, double *x, const int *ns, int nds, int npen,
+             int maxIters, hipStream_t s);
+SolveInfo pdr(const double *y, const double *lambdas, const double *dims, double *x, const int *ns, int nds, int npen,
+              int maxIters, hipStream_t s);
+// order[k] = 0-based dimension of the k-th (Z_k, U_k) pair, lambdas[k] its penalty
+SolveInfo yang(const int *ns, int nds, const int *order, const double *lambdas, const double *Y, double *X, int maxit,
+               hipStream_t s);
+
+}  // namespace ptv

@@ -1,0 +1,21 @@
+// sweep.hpp -- host interface of the fibre-sweep kernels (sweep.hip).
+#pragma once
+
+#include "common.hpp"
+#include "ops.hpp"
+
+namespace ptv {
+
+// One sweep: for every fibre of `g`, y = Op::load_y, x = prox(y), Op::store.
+// `weighted` selects per-edge penalties args.w (length len-1 per fibre, laid out like the data array with the
+// fibre dimension shortened by one); otherwise the uniform penalty args.lam.
+// `fam` tags the launch for the per-family timers (FAM_COL / FAM_ROW / FAM_OTHER).
+//
+// Aliasing contract: outputs may alias operands element-for-element ONLY when options().chunk == 0 or
+// `allow_chunked` is false (sequential kernel: each element is read and written by the one lane that owns the
+// fibre, and never re-read after it was written).  The chunked kernels read operand rows that other workgroups
+// write, so their callers pass distinct in/out arrays (ping-pong) -- see solvers.hip.
+void launch_sweep(OpId op, bool weighted, const SweepArgs &args, const FibreGeom &g, hipStream_t stream, int fam,
+                  bool allow_chunked);
+
+}  // namespace ptv

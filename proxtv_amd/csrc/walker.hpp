@@ -1,0 +1,137 @@
+// walker.hpp -- the exact 1-D TV-L1 prox state machine as run by ONE wavefront lane.
+//
+// The prox  argmin_x 1/2||x-y||^2 + sum_i r_i |x_i - x_{i+1}|  is the derivative of the shortest path through the
+// tube (cumsum(y) +- r).  The walker advances sample by sample keeping two candidate straight pieces that leave
+// the last knot k0: `lo` hugging the tube floor and `hi` hugging the ceiling; hlo/hhi are their heights relative
+// to the tube centre at the current sample, klo/khi the last samples where each touched its own wall.  When the
+// low piece pokes through the ceiling (or the high one through the floor) the string must bend at klo (khi): the
+// piece up to there is final, and the walk restarts at the next sample in closed form.
+//
+// Behaviourally this is the reference's linearized taut string (src/TVL1opt.cpp:359-564, identical arithmetic and
+// operation order; weighted form src/TVL1Wopt.cpp:364-567), restructured as ONE loop with one sample per trip so
+// that the 64 lanes of a wavefront, each owning a different fibre, execute the same instruction stream with
+// predication instead of diverging into separate inner loops.
+//
+// The key structural fact used by the chunked kernels (sweep.hip): right after a bend the walker state depends
+// only on (restart index, bend type) -- everything before is forgotten.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+namespace ptv {
+
+constexpr double kEps = 1e-10;  // absolute tolerance of the last-sample tests (reference: src/general.h:64-67)
+
+enum BendType : int { BEND_CEIL = 0, BEND_FLOOR = 1 };
+
+// Per-lane walker registers.
+struct Walker {
+    double lo, hi, hlo, hhi;
+    int i, k0, klo, khi;
+};
+
+// Source concept (duck-typed template parameter `S`):
+//   double y(int i)            sample i of this lane's fibre
+//   double r(int i)            per-edge half-width (weighted only; edge i joins samples i and i+1)
+//   void   piece(int from, int to, double v)   samples from..to (inclusive) of the prox equal v
+//   void   bend(int restart, int type)         a bend happened; the walk restarts at sample `restart`
+//   bool   keep_going(int i)   polled once per trip (chunked kernels stop early; sequential returns true)
+
+// Start a walk at sample `at` as if the fibre began there (free left end: string height 0).
+template <bool WEIGHTED, class S>
+__device__ __forceinline__ void walker_start(Walker &w, S &src, int at, double lam) {
+    const double y0 = src.y(at);
+    const double r0 = WEIGHTED ? src.r(at) : lam;
+    w.hlo = w.hhi = 0.0;
+    w.lo = -r0 + y0;
+    w.hi = r0 + y0;
+    w.k0 = at - 1;
+    w.klo = w.khi = at;
+    w.i = at;
+}
+
+// Run until the fibre end (sample n-1 closed) or until src.keep_going() says stop.
+// Returns true when the fibre end was reached and the closing piece was emitted.
+template <bool WEIGHTED, class S>
+__device__ __forceinline__ bool walker_run(Walker &w, S &src, int n, double lam) {
+    const int last = n - 1;
+    while (w.i < n) {
+        if (!src.keep_going(w.i)) return false;
+        const int i = w.i;
+        const double yi = src.y(i);
+        const bool interior = i < last;
+        const double r = interior ? (WEIGHTED ? src.r(i) : lam) : 0.0;
+
+        // low piece vs ceiling, then (only if that held) high piece vs floor -- reference order
+        w.hlo += w.lo - yi;
+        const bool cv = interior ? (r < w.hlo) : (w.hlo > kEps);
+        bool fv = false;
+        if (!cv) {
+            w.hhi += w.hi - yi;
+            fv = interior ? (-r > w.hhi) : (w.hhi < -kEps);
+        }
+
+        if (cv || fv) {
+            const int brk = cv ? w.klo : w.khi;
+            src.piece(w.k0 + 1, brk, cv ? w.lo : w.hi);
+            const int at = brk + 1;
+            src.bend(at, cv ? BEND_CEIL : BEND_FLOOR);
+            w.k0 = brk;
+            w.klo = w.khi = at;
+            w.i = at;
+            if (at < n) {  // at == n only for negative lambda (reference reads y[n] there and exits)
+                const double yn = (at == i) ? yi : src.y(at);
+                if (interior) {
+                    // closed-form first sample of the new piece, then step past it
+                    if (WEIGHTED) {
+                        const double wp = src.r(at - 1), wc = src.r(at);
+                        if (cv) { w.lo = yn + wp - wc; w.hi = yn + wp + wc; }
+                        else    { w.hi = yn - wp + wc; w.lo = yn - wp - wc; }
+                        w.hhi = wc;
+                        w.hlo = -wc;
+                    } else {
+                        if (cv) { w.lo = yn; w.hi = 2 * lam + yn; }
+                        else    { w.hi = yn; w.lo = 2 * (-lam) + yn; }
+                        w.hhi = lam;
+                        w.hlo = -lam;
+                    }
+                    w.i = at + 1;
+                } else {
+                    // bend detected at the last sample: restart WITHOUT stepping (may itself be the last sample)
+                    if (WEIGHTED) {
+                        const double wp = src.r(at - 1);
+                        const double wc = (at == last) ? 0.0 : src.r(at);
+                        if (cv) { w.lo = yn + wp - wc; w.hi = yn + wp + wc; w.hhi = w.hlo = -wp; }
+                        else    { w.hi = yn - wp + wc; w.lo = yn - wp - wc; w.hhi = w.hlo = wp; }
+                    } else {
+                        if (cv) { w.lo = yn; w.hi = 2 * lam + yn; w.hhi = w.hlo = -lam; }
+                        else    { w.hi = yn; w.lo = 2 * (-lam) + yn; w.hhi = w.hlo = lam; }
+                    }
+                }
+            }
+            continue;
+        }
+
+        if (interior) {
+            // pull the pieces back inside the tube where they left it
+            const int span = i - w.k0;
+            if (w.hhi >= r) {
+                w.hi += (r - w.hhi) / span;
+                w.hhi = r;
+                w.khi = i;
+            }
+            if (w.hlo <= -r) {
+                w.lo += (-r - w.hlo) / span;
+                w.hlo = -r;
+                w.klo = i;
+            }
+        } else {
+            if (w.hlo <= 0) w.lo += (-w.hlo) / (i - w.k0);
+        }
+        w.i = i + 1;
+    }
+    src.piece(w.k0 + 1, last, w.lo);
+    return true;
+}
+
+}  // namespace ptv

@@ -1,0 +1,100 @@
+"""BASELINE.json configurations at full size on the GPU, checked against fingerprints of the compiled reference's
+outputs (tests/golden/golden_large.npz: strided subsample + moments, made by oracle/gen_golden.py --large) and
+through size-independent properties of the prox.  Inputs are re-created from the same seeds and verified against
+the fixture's input fingerprint first."""
+import numpy as np
+import pytest
+
+from conftest import assert_close
+
+pytestmark = pytest.mark.gpu
+
+
+def _check_digest(y, g, key, tol=1e-6):
+    flat = np.asarray(y).ravel(order="F")
+    step = int(g["step"]) if not key.startswith("hard") else 1031
+    assert_close(flat[::step], g[f"{key}/sub"], tol=tol, what=f"{key} subsample")
+    scale = float(g[f"{key}/abs"])
+    assert abs(flat.sum() - float(g[f"{key}/sum"])) <= tol * scale, key
+    assert abs(np.abs(flat).sum() - scale) <= tol * scale, key
+    assert abs((flat * flat).sum() - float(g[f"{key}/sq"])) <= tol * float(g[f"{key}/sq"]), key
+
+
+def _tv_aniso(y):
+    return sum(np.abs(np.diff(y, axis=a)).sum() for a in range(y.ndim))
+
+
+def test_c2_dr_4096(ptv, glarge):
+    """Config #2 (north-star): tv1_2d DR on one 4096x4096 float64 image, lambda = 0.1, 35 pinned iterations."""
+    X = np.asfortranarray(np.random.default_rng(0).standard_normal((4096, 4096)))
+    np.testing.assert_array_equal(X.ravel(order="F")[::int(glarge["step"])], glarge["c2/X/sub"])
+    y = ptv.tv1_2d(X, 0.1)
+    _check_digest(y, glarge, "c2/dr2")
+    assert glarge["c2/dr2_info"][0] == 35
+    # properties: mean preserved by every prox sweep; TV decreases; the prox moves each pixel by at most 4*lambda
+    assert abs(y.mean() - X.mean()) < 1e-9
+    assert _tv_aniso(y) < _tv_aniso(X)
+    assert np.max(np.abs(y - X)) <= 4 * 0.1 + 1e-6
+
+
+def test_c3_weighted_dr_4096(ptv, glarge):
+    """Config #3: tv1w_2d on 4096x4096 with per-pixel weights ~ U(0.05, 0.15)."""
+    rng = np.random.default_rng(0)
+    X = np.asfortranarray(rng.standard_normal((4096, 4096)))
+    W1 = np.asfortranarray(rng.uniform(0.05, 0.15, (4095, 4096)))
+    W2 = np.asfortranarray(rng.uniform(0.05, 0.15, (4096, 4095)))
+    np.testing.assert_array_equal(W2.ravel(order="F")[::int(glarge["step"])], glarge["c3/W2/sub"])
+    y = ptv.tv1w_2d(X, W1, W2)
+    _check_digest(y, glarge, "c3/dr2w")
+    assert abs(y.mean() - X.mean()) < 1e-9
+
+
+def test_c4_volume(ptv, clib, glarge):
+    """Config #4: 512x512x64 volume (float32 up-cast like the reference surface does), lambda = [0.1, 0.1, 0.05].
+    tvgen runs PD_TV (35 iterations, RC_ITERS) -- plus scalar-lambda Yang3_TV, the C entry point BASELINE names."""
+    V32 = np.random.default_rng(0).standard_normal((512, 512, 64)).astype(np.float32)
+    y = ptv.tvgen(V32, [0.1, 0.1, 0.05], [1, 2, 3], [1, 1, 1])
+    assert y.dtype == np.float64 and y.flags.f_contiguous
+    _check_digest(y, glarge, "c4/pd")
+    want = glarge["c4/pd_info"]
+    assert want[0] == 35 and want[2] == 1
+    V = np.asfortranarray(V32.astype(np.float64))
+    out, info = np.zeros(V.shape, order="F"), np.zeros(3)
+    rc = clib.Yang3_TV(512, 512, 64, V.ctypes.data, 0.1, out.ctypes.data, 0, info.ctypes.data)
+    assert rc == 1 and info[0] == glarge["c4/yang3_info"][0] == 36
+    _check_digest(out, glarge, "c4/yang3")
+
+
+def test_c5_batch_items(ptv, glarge):
+    """Config #5 (per-GPU shard shape): independent 2048x2048 images solved as one batch == reference DR2_TV per image."""
+    xs = np.stack([np.random.default_rng(k).standard_normal((2048, 2048)) for k in range(3)])
+    ys = ptv.tv1_2d_batch(xs, 0.1)
+    for k in range(3):
+        _check_digest(np.asfortranarray(ys[k]), glarge, f"c5/{k}/dr2")
+
+
+def test_hard_blocks_image(ptv, glarge):
+    """Back-tracking-heavy variant (8x8 random blocks + noise, lambda = 0.5): the exactness-under-rewinds case."""
+    rng = np.random.default_rng(7)
+    Xh = np.asfortranarray(np.kron(rng.standard_normal((8, 8)), np.ones((128, 128))) + 0.2 * rng.standard_normal((1024, 1024)))
+    np.testing.assert_array_equal(Xh.ravel(order="F")[::1031], glarge["hard/X/sub"])
+    _check_digest(ptv.tv1_2d(Xh, 0.5), glarge, "hard/dr2")
+
+
+def test_sweep_kernel_properties_full_size(ptv):
+    """Properties of the per-sweep kernel at 4096 fibres x 4096 samples, both orientations (no oracle needed):
+    per-fibre mean preserved, lambda = 0 is the identity, huge lambda gives the fibre mean, idempotence."""
+    torch = pytest.importorskip("torch")
+    from proxtv_amd import device
+    g = torch.Generator(device="cpu").manual_seed(1)
+    X = torch.randn((4096, 4096), generator=g, dtype=torch.float64)
+    xd = device.to_colmajor(X.cuda())
+    for dim in (0, 1):
+        y = device.tv1_fibres(xd, 0.1, dim)
+        assert torch.allclose(y.mean(dim=dim), xd.mean(dim=dim), atol=1e-12)
+        assert torch.equal(device.tv1_fibres(xd, 0.0, dim), xd)
+        big = device.tv1_fibres(xd, 1e6, dim)
+        assert torch.allclose(big, xd.mean(dim=dim, keepdim=True).expand_as(xd), atol=1e-9)
+        # the fibre TV never grows and the dual certificate holds: |cumsum(x - y)| <= lambda along the fibre
+        u = torch.cumsum(xd - y, dim=dim)
+        assert float(u.abs().max()) <= 0.1 * (1 + 1e-9)

@@ -1,0 +1,185 @@
+"""HIP path vs golden vectors and vs the CPU oracle: 2-D solvers (DR2_TV, DR2L1W_TV, PD2_TV, Yang2_TV) through the
+prox_tv-compatible surface and the C symbols, including info[] / return-code conventions."""
+import numpy as np
+import pytest
+
+from conftest import assert_close
+
+pytestmark = pytest.mark.gpu
+
+
+def _call_dr2(clib, X, w1, w2, maxit=0, n1=1.0, n2=1.0):
+    X = np.asfortranarray(X, dtype=np.float64)
+    out = np.zeros(X.shape, order="F")
+    info = np.array([-7.0, -7.0, -7.0])
+    rc = clib.DR2_TV(X.shape[0], X.shape[1], X.ctypes.data, w1, w2, n1, n2, out.ctypes.data, 1, maxit, info.ctypes.data)
+    return out, info, rc
+
+
+def test_golden_dr2(ptv, clib, g2d):
+    for name in g2d["names"]:
+        X, lam = g2d[f"{name}/X"], float(g2d[f"{name}/lam"])
+        y = ptv.tv1_2d(X, lam)
+        assert y.flags.f_contiguous and y.shape == X.shape
+        assert_close(y, g2d[f"{name}/dr2"], what=f"{name}:dr2")
+        assert_close(ptv.tv1_2d(X, lam, max_iters=7), g2d[f"{name}/dr2_it7"], what=f"{name}:dr2_it7")
+        assert_close(ptv.tvp_2d(X, lam, 0.5 * lam, 1, 1), g2d[f"{name}/dr2_aniso"], what=f"{name}:dr2_aniso")
+        out, info, rc = _call_dr2(clib, X, lam, lam)
+        # DR returns 0 on success and leaves info[1] untouched (src/TV2Dopt.cpp:433-440)
+        assert rc == int(g2d[f"{name}/dr2_rc"]) == 0
+        assert info[0] == g2d[f"{name}/dr2_info"][0] == 35 and info[1] == -7.0 and info[2] == 0
+        out, info, rc = _call_dr2(clib, X, lam, lam, maxit=7)
+        assert info[0] == 7
+
+
+def test_golden_dr2w(ptv, g2d):
+    for name in g2d["names"]:
+        X = g2d[f"{name}/X"]
+        y = ptv.tv1w_2d(X, g2d[f"{name}/W1"], g2d[f"{name}/W2"])
+        assert y.flags.f_contiguous
+        assert_close(y, g2d[f"{name}/dr2w"], what=f"{name}:dr2w")
+
+
+def test_golden_pd2(ptv, clib, g2d):
+    for name in g2d["names"]:
+        X, lam = g2d[f"{name}/X"], float(g2d[f"{name}/lam"])
+        assert_close(ptv.tv1_2d(X, lam, method="pd"), g2d[f"{name}/pd2"], what=f"{name}:pd2")
+        assert_close(ptv.tv1_2d(X, lam, method="pd", max_iters=3), g2d[f"{name}/pd2_it3"], what=f"{name}:pd2_it3")
+        # two-penalty tvgen == PD2 (the reference's DR branch is unreachable, prox_tv/__init__.py:585)
+        assert_close(ptv.tvgen(X, [lam, lam], [1, 2], [1, 1]), g2d[f"{name}/pd2"], what=f"{name}:tvgen2")
+        # info: iterations pinned, stop value equal to ~1e-10 relative, RC per the MAX_ITERS_PD macro
+        Xf = np.asfortranarray(X)
+        out = np.zeros(X.shape, order="F")
+        info = np.zeros(3)
+        lams, norms, dims = np.array([lam, lam]), np.ones(2), np.array([1.0, 2.0])
+        ns = np.array(X.shape, dtype=np.int32)
+        rc = clib.PD2_TV(Xf.ctypes.data, lams.ctypes.data, norms.ctypes.data, dims.ctypes.data, out.ctypes.data,
+                         info.ctypes.data, ns.ctypes.data, 2, 2, 1, 0)
+        want = g2d[f"{name}/pd2_info"]
+        assert rc == int(g2d[f"{name}/pd2_rc"]) == 1
+        assert info[0] == want[0] and info[2] == want[2], (name, info, want)
+        assert abs(info[1] - want[1]) <= 1e-9 * max(abs(want[1]), 1e-30) + 1e-18
+        # single penalty along rows / 1-penalty tvgen (-> PD_TV)
+        lam1, dim1 = np.array([lam]), np.array([2.0])
+        info[:] = 0
+        clib.PD2_TV(Xf.ctypes.data, lam1.ctypes.data, norms.ctypes.data, dim1.ctypes.data, out.ctypes.data,
+                    info.ctypes.data, ns.ctypes.data, 2, 1, 1, 0)
+        assert_close(out, g2d[f"{name}/pd2_single"], what=f"{name}:pd2_single")
+        assert info[0] == g2d[f"{name}/pd2_single_info"][0] == 1
+        assert_close(ptv.tvgen(X, [lam], [1], [1]), g2d[f"{name}/pd_single"], what=f"{name}:tvgen1")
+
+
+def test_golden_yang2(ptv, clib, g2d):
+    for name in g2d["names"]:
+        X, lam = g2d[f"{name}/X"], float(g2d[f"{name}/lam"])
+        assert_close(ptv.tv1_2d(X, lam, method="yang"), g2d[f"{name}/yang2"], what=f"{name}:yang2")
+        Xf = np.asfortranarray(X)
+        out, info = np.zeros(X.shape, order="F"), np.array([-7.0, -7.0, -7.0])
+        rc = clib.Yang2_TV(X.shape[0], X.shape[1], Xf.ctypes.data, lam, out.ctypes.data, 0, info.ctypes.data)
+        want = g2d[f"{name}/yang2_info"]
+        assert rc == int(g2d[f"{name}/yang2_rc"]) == 1
+        assert info[0] == want[0] == 36 and info[1] == -7.0 and info[2] == 0   # maxit + 1, gap untouched
+
+
+def test_emengd_regression(ptv, g2d):
+    """prox_tv_test.py:169-178: integer weight arrays must not break the weighted solver."""
+    a = -np.array([[1, 2, 3], [4, 5, 6], [7, 8, 9]]) / 10.0
+    sol1 = ptv.tv1w_2d(a, np.array([[1, 1, 1], [1, 1, 1]]), np.array([[1, 1], [1, 1], [1, 1]]), max_iters=100)
+    sol2 = ptv.tv1_2d(a, 1)
+    assert_close(sol1, g2d["emengd/dr2w_it100"], what="emengd weighted")
+    assert_close(sol2, g2d["emengd/dr2"], what="emengd unweighted")
+    assert np.allclose(sol1, sol2, atol=1e-3)
+
+
+def test_blocks_image(ptv, g2d):
+    X = g2d["blocks/X"]
+    assert_close(ptv.tv1_2d(X, 0.5), g2d["blocks/dr2_l0p5"], what="blocks dr2")
+    assert_close(ptv.tv1_2d(X, 0.5, method="pd"), g2d["blocks/pd2_l0p5"], what="blocks pd2")
+
+
+def test_multireg_and_lambda_mutation(ptv, g2d):
+    """prox_tv_test.py:212-226: several penalties on one dimension -> PD_TV with 5 terms.  A float64 ndarray `ws`
+    is scaled in place by npen exactly like the reference (src/TVNDopt.cpp:100-101); a list is not."""
+    X = g2d["multireg/X"]
+    ws = g2d["multireg/lams"].copy()
+    y = ptv.tvgen(X, ws, [1, 1, 2, 2, 2], [1, 1, 1, 1, 1], max_iters=1000)
+    assert_close(y, g2d["multireg/pd_it1000"], what="multireg")
+    np.testing.assert_allclose(ws, g2d["multireg/lams_after"], rtol=0, atol=0)
+    wl = list(g2d["multireg/lams"])
+    ptv.tvgen(X, wl, [1, 1, 2, 2, 2], [1, 1, 1, 1, 1], max_iters=2)
+    assert wl == list(g2d["multireg/lams"])
+
+
+def test_cross_method_consistency(ptv):
+    """prox_tv_test.py:106-116 with seeds: the three implemented 2-D methods agree once converged."""
+    rng = np.random.default_rng(21)
+    for _ in range(3):
+        x = 100 * rng.standard_normal((int(rng.integers(10, 30)), int(rng.integers(10, 30))))
+        w = 20 * rng.random()
+        sols = [ptv.tv1_2d(x, w, method=m, max_iters=5000) for m in ("yang", "pd", "dr")]
+        for s in sols[1:]:
+            assert np.allclose(s, sols[0], atol=1e-3)
+
+
+def test_weighted_equals_unweighted_for_constant_weights(ptv):
+    """prox_tv_test.py:129-166 (incl. the tiny 2..3 x 2..3 shapes)."""
+    rng = np.random.default_rng(22)
+    for _ in range(40):
+        r, c = int(rng.integers(2, 4)), int(rng.integers(2, 4))
+        x = 100 * rng.standard_normal((r, c))
+        w1 = rng.random()
+        a = ptv.tv1w_2d(x, np.ones((r - 1, c)) * w1, np.ones((r, c - 1)) * w1, max_iters=5000)
+        b = ptv.tv1_2d(x, w1, max_iters=5000)
+        assert np.allclose(a, b, atol=1e-3)
+    for _ in range(3):
+        r, c = int(rng.integers(10, 30)), int(rng.integers(10, 30))
+        x = 100 * rng.standard_normal((r, c))
+        w = 20 * rng.random()
+        a = ptv.tv1w_2d(x, w * np.ones((r - 1, c)), w * np.ones((r, c - 1)), max_iters=5000)
+        assert np.allclose(a, ptv.tv1_2d(x, w, max_iters=5000), atol=1e-3)
+
+
+def test_random_shapes_vs_oracle(ptv, oracle):
+    rng = np.random.default_rng(23)
+    for M, N in [(1, 1), (1, 9), (9, 1), (2, 2), (33, 70), (70, 33), (64, 64), (127, 129), (200, 65)]:
+        X = rng.standard_normal((M, N))
+        for lam in (0.05, 0.8):
+            assert_close(ptv.tv1_2d(X, lam), oracle.dr2(X, lam)[0], what=f"dr2 {M}x{N} {lam}")
+            if M > 1 and N > 1:
+                W1, W2 = rng.uniform(0, 2 * lam, (M - 1, N)), rng.uniform(0, 2 * lam, (M, N - 1))
+                assert_close(ptv.tv1w_2d(X, W1, W2), oracle.dr2w(X, W1, W2)[0], what=f"dr2w {M}x{N} {lam}")
+            assert_close(ptv.tv1_2d(X, lam, method="pd"), oracle.pd2(X, [lam, lam], [1, 2])[0], what=f"pd2 {M}x{N}")
+            assert_close(ptv.tv1_2d(X, lam, method="yang"), oracle.yang2(X, lam)[0], what=f"yang2 {M}x{N}")
+
+
+def test_input_coercions(ptv, oracle):
+    """C-ordered, float32 and integer inputs are converted like the reference (F-order float64)."""
+    rng = np.random.default_rng(24)
+    Xc = np.ascontiguousarray(rng.standard_normal((20, 31)))
+    want = oracle.dr2(Xc, 0.3)[0]
+    assert_close(ptv.tv1_2d(Xc, 0.3), want)
+    assert_close(ptv.tv1_2d(Xc.astype(np.float32), 0.3), oracle.dr2(Xc.astype(np.float32).astype(np.float64), 0.3)[0])
+    Xi = (10 * Xc).astype(int)
+    assert_close(ptv.tv1_2d(Xi, 2), oracle.dr2(Xi.astype(float), 2.0)[0])
+    assert_close(ptv.tv1_2d(Xc[::2, ::3], 0.3), oracle.dr2(np.ascontiguousarray(Xc[::2, ::3]), 0.3)[0])
+
+
+def test_unsupported_norms_fail_loudly(clib):
+    X = np.asfortranarray(np.random.default_rng(25).standard_normal((8, 8)))
+    out, info = np.zeros((8, 8), order="F"), np.zeros(3)
+    rc = clib.DR2_TV(8, 8, X.ctypes.data, 0.1, 0.1, 2.0, 1.0, out.ctypes.data, 1, 0, info.ctypes.data)
+    assert rc == 0 and info[2] == 3    # RC_ERROR
+    lams, norms, dims, ns = np.array([.1, .1, .1]), np.ones(3), np.array([1., 2., 1.]), np.array([8, 8], dtype=np.int32)
+    rc = clib.PD2_TV(X.ctypes.data, lams.ctypes.data, norms.ctypes.data, dims.ctypes.data, out.ctypes.data,
+                     info.ctypes.data, ns.ctypes.data, 2, 3, 1, 0)
+    assert rc == 0 and info[2] == 3    # "can not work with more than 2 penalties" (src/TV2Dopt.cpp:95-96)
+
+
+def test_batch_equals_loop(ptv, oracle):
+    rng = np.random.default_rng(26)
+    xs = rng.standard_normal((5, 40, 72))
+    ys = ptv.tv1_2d_batch(xs, 0.2)
+    assert ys.shape == xs.shape
+    for b in range(5):
+        assert_close(ys[b], oracle.dr2(xs[b], 0.2)[0], what=f"batch item {b}")
+        np.testing.assert_array_equal(ys[b], ptv.tv1_2d(xs[b], 0.2))   # bit-identical to the single-image path

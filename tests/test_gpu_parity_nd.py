@@ -1,0 +1,151 @@
+"""HIP path vs golden vectors and vs the CPU oracle: N-D solvers (PD_TV, PDR_TV, PD2_TV on N-D arrays, Yang3_TV)."""
+import numpy as np
+import pytest
+
+from conftest import assert_close
+
+pytestmark = pytest.mark.gpu
+
+
+def _pd_like(fn, X, lams, dims, maxit=0):
+    X = np.asfortranarray(X, dtype=np.float64)
+    lam = np.array(lams, dtype=np.float64)
+    npen = lam.size
+    norms, dm = np.ones(npen), np.array(dims, dtype=np.float64)
+    ns = np.array(X.shape, dtype=np.int32)
+    out, info = np.zeros(X.shape, order="F"), np.zeros(3)
+    rc = fn(X.ctypes.data, lam.ctypes.data, norms.ctypes.data, dm.ctypes.data, out.ctypes.data, info.ctypes.data,
+            ns.ctypes.data, X.ndim, npen, 1, maxit)
+    return out, info, rc, lam
+
+
+def _check_info(info, want, name):
+    assert info[0] == want[0] and info[2] == want[2], (name, info, want)
+    assert abs(info[1] - want[1]) <= 1e-9 * abs(want[1]) + 1e-18, (name, info, want)
+
+
+def test_golden_pd(ptv, clib, gnd):
+    for name in gnd["names"]:
+        X, lams = gnd[f"{name}/X"], gnd[f"{name}/lams"]
+        dims = list(range(1, X.ndim + 1))
+        assert_close(ptv.tvgen(X, list(lams), dims, [1] * X.ndim), gnd[f"{name}/pd"], what=f"{name}:tvgen")
+        out, info, rc, lam_after = _pd_like(clib.PD_TV, X, lams, dims)
+        assert rc == int(gnd[f"{name}/pd_rc"]) == 1
+        assert_close(out, gnd[f"{name}/pd"], what=f"{name}:pd")
+        _check_info(info, gnd[f"{name}/pd_info"], name)
+        np.testing.assert_array_equal(lam_after, gnd[f"{name}/pd_lams_after"])   # scaled in caller memory
+        out, info, rc, _ = _pd_like(clib.PD_TV, X, lams, dims, maxit=4)
+        assert_close(out, gnd[f"{name}/pd_it4"], what=f"{name}:pd_it4")
+        _check_info(info, gnd[f"{name}/pd_it4_info"], name)
+
+
+def test_golden_pdr(clib, gnd):
+    for name in gnd["names"]:
+        X, lams = gnd[f"{name}/X"], gnd[f"{name}/lams"]
+        dims = list(range(1, X.ndim + 1))
+        out, info, rc, _ = _pd_like(clib.PDR_TV, X, lams, dims)
+        assert rc == int(gnd[f"{name}/pdr_rc"]) == 1
+        assert_close(out, gnd[f"{name}/pdr"], what=f"{name}:pdr")
+        _check_info(info, gnd[f"{name}/pdr_info"], name)
+
+
+def test_golden_pd2_nd(ptv, clib, gnd):
+    for name in gnd["names"]:
+        X, lams = gnd[f"{name}/X"], gnd[f"{name}/lams"]
+        nd = X.ndim
+        out, info, rc, _ = _pd_like(clib.PD2_TV, X, [lams[0], lams[nd - 1]], [1, nd])
+        assert_close(out, gnd[f"{name}/pd2_first_last"], what=f"{name}:pd2_first_last")
+        _check_info(info, gnd[f"{name}/pd2_first_last_info"], name)
+        out, info, rc, _ = _pd_like(clib.PD2_TV, X, [lams[1], lams[1]], [2, 2])
+        assert_close(out, gnd[f"{name}/pd2_22"], what=f"{name}:pd2_22")
+    # colour-image idiom of the reference demos: penalise dims 1,2 of an (M,N,3) array
+    assert_close(ptv.tvgen(gnd["color/X"], [0.15, 0.15], [1, 2], [1, 1]), gnd["color/pd2_12"], what="color")
+
+
+def test_golden_yang3(clib, gnd):
+    for name in gnd["names"]:
+        if f"{name}/yang3" not in gnd:
+            continue
+        X = np.asfortranarray(gnd[f"{name}/X"])
+        for maxit, key in ((0, "yang3"), (5, "yang3_it5")):
+            out, info = np.zeros(X.shape, order="F"), np.array([-7.0, -7.0, -7.0])
+            rc = clib.Yang3_TV(X.shape[0], X.shape[1], X.shape[2], X.ctypes.data, 0.2, out.ctypes.data, maxit,
+                               info.ctypes.data)
+            assert rc == 1
+            assert_close(out, gnd[f"{name}/{key}"], what=f"{name}:{key}")
+            want = gnd[f"{name}/{key}_info"]
+            assert info[0] == want[0] and info[1] == -7.0 and info[2] == 0
+
+
+def test_random_nd_vs_oracle(ptv, oracle):
+    rng = np.random.default_rng(31)
+    for shape in [(3, 4, 5), (70, 6, 5), (6, 70, 3), (5, 4, 66), (2, 3, 4, 5), (9,)]:
+        X = rng.standard_normal(shape)
+        nd = len(shape)
+        lams = list(rng.uniform(0.05, 0.5, nd))
+        dims = list(range(1, nd + 1))
+        want = (oracle.pd2(X, lams, dims) if nd == 2 else oracle.pd(X, lams, dims))[0]
+        assert_close(ptv.tvgen(X, lams, dims, [1] * nd), want, what=f"tvgen {shape}")
+
+
+def test_tvgen_1d_matches_tv1_1d(ptv):
+    """prox_tv_test.py:181-189."""
+    rng = np.random.default_rng(32)
+    for _ in range(5):
+        x = 100 * rng.standard_normal(int(rng.integers(10, 30)))
+        w = 20 * rng.random()
+        assert np.allclose(ptv.tv1_1d(x, w), ptv.tvgen(x, [w], [1], [1]), atol=1e-3)
+
+
+def test_tvgen_nd_smoke_with_negative_weights(ptv, oracle):
+    """prox_tv_test.py:202-209: 3-4-D tensors, weights drawn from N(0,1) (may be negative): must not crash or hang,
+    and must do what the reference's solver does with them."""
+    rng = np.random.default_rng(33)
+    for _ in range(6):
+        nd = int(rng.integers(3, 5))
+        shape = tuple(int(v) for v in rng.integers(2, 10, size=nd))
+        x = rng.standard_normal(shape)
+        w = rng.standard_normal(nd)
+        got = ptv.tvgen(x, w.copy(), list(range(1, nd + 1)), np.ones(nd))
+        want = oracle.pd(x, w.copy(), list(range(1, nd + 1)))[0]
+        assert got.shape == shape
+        assert_close(got, want, what=f"negative weights {shape}")
+
+
+def test_device_api_yang_perdim(oracle):
+    """Per-dimension-lambda Yang (extension): checked against the oracle's own extension, and against the
+    reference-pinned scalar-lambda Yang3 when all lambdas are equal."""
+    torch = pytest.importorskip("torch")
+    from proxtv_amd import device
+    rng = np.random.default_rng(34)
+    X = rng.standard_normal((20, 17, 9))
+    xd = device.to_colmajor(torch.from_numpy(X).cuda())
+    y, info = device.tvgen(xd, [0.2, 0.2, 0.2], [1, 2, 3], method="yang")
+    assert_close(y.cpu().numpy(), oracle.yang3(X, 0.2)[0], what="yang equal lambdas")
+    assert info[0] == 36
+    y, info = device.tvgen(xd, [0.1, 0.1, 0.05], [1, 2, 3], method="yang")
+    assert_close(y.cpu().numpy(), oracle.yang3(X, [0.1, 0.1, 0.05])[0], what="yang per-dim lambdas")
+
+
+def test_device_api_matches_host_api(ptv, oracle):
+    torch = pytest.importorskip("torch")
+    from proxtv_amd import device
+    rng = np.random.default_rng(35)
+    X = rng.standard_normal((48, 80))
+    xd = device.to_colmajor(torch.from_numpy(X).cuda())
+    for method in ("dr", "pd", "yang"):
+        y, info = device.tv1_2d(xd, 0.3, method=method)
+        np.testing.assert_array_equal(y.cpu().numpy(), ptv.tv1_2d(X, 0.3, method=method))
+    W1, W2 = rng.uniform(0, 1, (47, 80)), rng.uniform(0, 1, (48, 79))
+    y, _ = device.tv1w_2d(xd, device.to_colmajor(torch.from_numpy(W1).cuda()), device.to_colmajor(torch.from_numpy(W2).cuda()))
+    np.testing.assert_array_equal(y.cpu().numpy(), ptv.tv1w_2d(X, W1, W2))
+    V = rng.standard_normal((12, 9, 7))
+    vd = device.to_colmajor(torch.from_numpy(V).cuda())
+    y, _ = device.tvgen(vd, [0.1, 0.2, 0.3], [1, 2, 3])
+    np.testing.assert_array_equal(y.cpu().numpy(), ptv.tvgen(V, [0.1, 0.2, 0.3], [1, 2, 3], [1, 1, 1]))
+    y, _ = device.tvgen(vd, [0.1, 0.2, 0.3], [1, 2, 3], method="pdr")
+    assert_close(y.cpu().numpy(), oracle.pdr(V, [0.1, 0.2, 0.3], [1, 2, 3])[0])
+    # the per-sweep kernel on its own, every dimension, weighted and not
+    for dim in range(3):
+        want = np.apply_along_axis(lambda f: oracle.tv1_hybrid(f, 0.4), dim, V)
+        assert_close(device.tv1_fibres(vd, 0.4, dim).cpu().numpy(), want, what=f"fibres dim {dim}")
