@@ -1,0 +1,145 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the hot path (BASELINE.json): 2-D TV-L1 Douglas-Rachford, 4096x4096 float64,
+lambda = 0.1, 35 pinned iterations, on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one complete DR solve (DR2_TV semantics, through the C-ABI's device-pointer entry point) of one
+synthetic 4096x4096 image that is already resident in HBM; the result stays in HBM.  With N > 1 (one process per
+GPU, launched by torch.distributed.run) every rank solves its own independent image per step -- the path shards
+over images with no collective in the data path ("scaling": "weak"); value = pixels all ranks processed / max-over-
+ranks wall time.  Rank 0 prints ONE JSON line.
+
+Extra objects on that line:
+  roofline     -- the dominant sweep kernel: algorithmic HBM bytes per launch / average launch duration, measured
+                  with hipEvents on the library's own stream during the timed steps (DESIGN.md "Measurement").
+  cpu_baseline -- the compiled reference (oracle/_ref, kind "reference") or, if it did not travel, this repo's
+                  C restatement (kind "port"), timed on the host cores on a bounded sample (rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+M = N = 4096
+LAM = 0.1
+ITERS = 35
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy peak is ~6290 GB/s
+
+
+def cpu_baseline():
+    """Reference OpenMP CPU path on this box's host cores, bounded sample (one DR solve)."""
+    from oracle import cpu
+    cores = os.cpu_count() or 1
+    if cpu.have_reference():
+        lib, kind = cpu.reference(), "reference"
+    else:
+        lib, kind = cpu.oracle(), "port"
+    side = 4096 if cores >= 8 else 2048          # keep the CPU leg to ~10-30 s
+    X = np.asfortranarray(np.random.default_rng(0).standard_normal((side, side)))
+    t0 = time.perf_counter()
+    _, info, _ = lib.dr2(X, LAM, n_threads=cores)
+    dt = time.perf_counter() - t0
+    return {"value": side * side / dt / 1e6, "unit": "Mpixel/s", "cores": cores, "kind": kind,
+            "sample": f"one DR2_TV solve, {side}x{side} f64, lambda={LAM}, {int(info[0])} iterations, "
+                      f"{cores} OpenMP threads, {dt:.2f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    from proxtv_amd import _lib, device
+    lib = _lib.require_device()
+
+    # synthetic input of the BASELINE shape, a different image per rank, resident in HBM before timing starts
+    x_host = np.random.default_rng(rank).standard_normal((M, N))
+    xd = device.to_colmajor(torch.from_numpy(x_host).cuda())
+    yd = device.colmajor_empty((M, N))
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        device.tv1_2d(xd, LAM, out=yd)
+
+    lib.proxtv_set_option(b"profile", 1)
+    fam_ms = [0.0, 0.0, 0.0]
+    fam_n = [0, 0, 0]
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        _, info = device.tv1_2d(xd, LAM, out=yd)
+        for f in range(3):
+            fam_ms[f] += lib.proxtv_last_kernel_ms(f)
+            fam_n[f] += lib.proxtv_last_kernel_launches(f)
+    barrier()
+    dt = time.perf_counter() - t0
+    lib.proxtv_set_option(b"profile", 0)
+    assert int(info[0]) == ITERS, info
+
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        ms_per_step = dt / args.steps * 1e3
+        value = world * M * N * args.steps / dt / 1e6
+        # dominant kernel family and its algorithmic traffic per launch: column sweep R t, W s' = 16 B/px;
+        # fused row sweep R s', R U, R t, W t = 32 B/px
+        per_px = {0: 16, 1: 32}
+        dom = 0 if fam_ms[0] >= fam_ms[1] else 1
+        avg_ms = fam_ms[dom] / max(fam_n[dom], 1)
+        achieved = per_px[dom] * M * N / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        line = {
+            "metric": "Mpixel/s on 2D TV-L1 DR (4096x4096 f64, lambda=0.1); % HBM roofline",
+            "value": value, "unit": "Mpixel/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "tv1_2d (DR2_TV, 35 iterations) on one 4096x4096 float64 N(0,1) image per GPU per step, "
+                                   "lambda=0.1, input and output resident in HBM", "images_per_step": world,
+                       "parallelism": f"independent images, {world} rank(s), no data-path collective"},
+            "roofline": {"bound": "hbm", "kernel": ["column sweep (DR_COL)", "row sweep (DR_ROW, fused reflections+combiner)"][dom],
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "avg_launch_ms": avg_ms, "launches": fam_n[dom],
+                         "algorithmic_bytes_per_launch": per_px[dom] * M * N,
+                         "family_ms_per_solve": {"col": fam_ms[0] / args.steps, "row": fam_ms[1] / args.steps,
+                                                 "other": fam_ms[2] / args.steps}},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -130,6 +130,10 @@ static int tube_walk(const double *y, const double *w, double lam, int n, double
             i++; walked++;
         }
 
+        /* Only reachable with a negative lambda (bend at sample 0, restart steps to i == n when n == 2): the
+           reference falls through and reads y[n] (hybrid :172 after :110) -- undefined.  Stop instead. */
+        if (i > last) break;
+
         /* last sample: tube collapses to its centre, tested with the absolute
            tolerance of src/general.h:64-67 (hybrid :172-230 ; weighted :488-553) */
         s.hlo += s.lo - y[i];

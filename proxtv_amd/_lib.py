@@ -63,6 +63,33 @@ class ProxTVError(RuntimeError):
     """A HIP-path failure reported by libproxtv_amd (no device, HIP error, unsupported argument)."""
 
 
+def _preload_hip_runtime():
+    """One HIP runtime per process.
+
+    libproxtv_amd.so needs `libamdhip64.so.7`.  The PyTorch-ROCm wheel bundles its own copy of that runtime (same
+    SONAME, private directory); two HIP/HSA runtimes in one process cannot both open the GPU.  Whenever torch is
+    installed, load ITS runtime first (without importing torch): the dynamic loader then binds our library to the
+    already-loaded SONAME, and a later `import torch` finds the very same file.  Without torch the system runtime
+    under /opt/rocm is picked up through the library's RUNPATH as usual.
+    """
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return  # torch already brought its runtime in
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def load(build_if_missing=True):
     """Return the ctypes handle with argtypes set; builds the library in-tree if it is not there."""
     global _lib
@@ -73,6 +100,7 @@ def load(build_if_missing=True):
             raise ImportError("libproxtv_amd.so is not built (run `python -m proxtv_amd.build`)")
         from . import build as _build
         _build.build()
+    _preload_hip_runtime()
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)   # AttributeError here == the C-ABI lost a symbol

@@ -16,7 +16,9 @@
 // only on (restart index, bend type) -- everything before is forgotten.
 #pragma once
 
+#ifndef PTV_HOST_TEST   // tests/host_harness.cpp compiles this header with g++ to check the logic without a GPU
 #include <hip/hip_runtime.h>
+#endif
 
 namespace ptv {
 

@@ -36,7 +36,13 @@ def _check(t, name):
 
 
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    """hipStream_t handle for the C-ABI.  torch's legacy default stream has handle 0, which the library reads as "use
+    my own per-thread (non-blocking) stream"; that stream does not order against the null stream, so drain torch's
+    producers first.  Every *_dev entry point synchronises before returning, so consumers need no extra fence."""
+    cur = torch.cuda.current_stream()
+    if cur.cuda_stream == 0:
+        cur.synchronize()
+    return cur.cuda_stream
 
 
 def tv1_2d(x, w, max_iters=0, method="dr", out=None, w_row=None):

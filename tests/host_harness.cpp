@@ -1,0 +1,55 @@
+// host_harness.cpp -- TEST-ONLY: compiles the device walker (proxtv_amd/csrc/walker.hpp) with g++ so that the
+// state machine the HIP kernels run can be checked against the oracle on a machine without a GPU.
+// Never linked into libproxtv_amd.so; built on demand by tests/test_walker_host.py into a temp directory.
+#define PTV_HOST_TEST 1
+#define __device__
+#define __forceinline__ inline
+#include <cstring>
+
+#include "../proxtv_amd/csrc/walker.hpp"
+
+using namespace ptv;
+
+namespace {
+struct HostSource {
+    const double *yy;
+    const double *ww;
+    double *x;
+    int stop_after;   // chunk emulation: stop once a piece reached this sample (<0: never)
+    int bends = 0;
+    bool done = false;
+    double y(int i) const { return yy[i]; }
+    double r(int i) const { return ww[i]; }
+    void piece(int a, int b, double v) {
+        for (int j = a; j <= b; j++) x[j] = v;
+        if (stop_after >= 0 && b >= stop_after) done = true;
+    }
+    void bend(int, int) { bends++; }
+    bool keep_going(int) const { return !done; }
+};
+}  // namespace
+
+extern "C" {
+
+// full sequential walk, what sweep_seq_kernel does per lane
+int host_walk(const double *y, const double *w, double lam, double *x, int n) {
+    if (n <= 0) return 0;
+    if (w && n == 1) { x[0] = y[0]; return 0; }
+    HostSource s{y, w, x, -1};
+    Walker wk;
+    if (w) { walker_start<true>(wk, s, 0, lam); walker_run<true>(wk, s, n, lam); }
+    else   { walker_start<false>(wk, s, 0, lam); walker_run<false>(wk, s, n, lam); }
+    return s.bends;
+}
+
+// speculative walk: start at `from` as if the fibre began there, stop once sample `until` is covered.
+// Writes only what it covers; returns the first sample index whose value is final-and-equal to the true walk
+// if that can be told (the restart index of the first bend), else -1.
+int host_walk_from(const double *y, const double *w, double lam, double *x, int n, int from, int until) {
+    HostSource s{y, w, x, until};
+    Walker wk;
+    if (w) { walker_start<true>(wk, s, from, lam); walker_run<true>(wk, s, n, lam); }
+    else   { walker_start<false>(wk, s, from, lam); walker_run<false>(wk, s, n, lam); }
+    return s.bends;
+}
+}

@@ -1,0 +1,124 @@
+"""No-GPU checks of the drop-in boundary: the shared library loads, exports every symbol include/proxtv_amd.h declares,
+fails loudly without a device (no CPU fallback), and the Python surface mirrors the reference's argument checks."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _has_gpu():
+    return os.path.exists("/dev/kfd")
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "proxtv_amd.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = re.findall(r"^\s*(?:const\s+)?(?:int|void|double|long|char|Workspace)\s*\**\s*(\w+)\s*\(", text, flags=re.M)
+    return sorted(set(names))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    from proxtv_amd import _lib
+    lib = _lib.load()
+    names = declared_symbols()
+    # the hot-path entry points the reference's cffi cdef / mex gateways bind (prox_tv/prox_tv_build.py:13-76)
+    for must in ["TV", "hybridTautString_TV1", "hybridTautString_TV1_custom", "linearizedTautString_TV1",
+                 "classicTautString_TV1", "classicTautString_TV1_offset", "tautString_TV1_Weighted", "TV1D_denoise",
+                 "DR2_TV", "DR2L1W_TV", "PD2_TV", "PD_TV", "PDR_TV", "Yang2_TV", "Yang3_TV", "newWorkspace",
+                 "freeWorkspace", "proxtv_DR2_TV_batch_dev", "proxtv_tv1_fibres_dev"]:
+        assert must in names, must
+    for n in names:
+        assert hasattr(lib, n), f"libproxtv_amd.so does not export {n}"
+    assert set(_lib.SIGNATURES) == set(names), set(_lib.SIGNATURES) ^ set(names)
+    assert lib.proxtv_version().startswith(b"proxtv_amd")
+
+
+def test_code_object_is_gfx950_only():
+    """The library carries hand-written gfx950 code objects and nothing else (no multi-arch / fallback bundles)."""
+    from proxtv_amd import _lib
+    blob = open(_lib.LIB_PATH, "rb").read()
+    archs = set(re.findall(rb"amdgcn-amd-amdhsa--(gfx[0-9a-f]+)", blob))
+    assert archs == {b"gfx950"}, archs
+
+
+def test_workspace_shims_are_callable_without_gpu():
+    from proxtv_amd import _lib
+    lib = _lib.load()
+    ws = lib.newWorkspace(128)
+    assert ws
+    lib.resetWorkspace(ws)
+    lib.freeWorkspace(ws)
+    wa = lib.newWorkspaces(64, 3)
+    assert wa
+    lib.freeWorkspaces(wa, 3)
+
+
+@pytest.mark.skipif(_has_gpu(), reason="checks the no-device failure mode")
+def test_fails_loudly_without_device(capfd):
+    import proxtv_amd
+    from proxtv_amd import _lib
+    lib = _lib.load()
+    assert lib.proxtv_init(-1) != 0
+    with pytest.raises(proxtv_amd.ProxTVError):
+        proxtv_amd.tv1_2d(np.zeros((4, 4)), 0.1)
+    with pytest.raises(proxtv_amd.ProxTVError):
+        proxtv_amd.tv1_1d(np.zeros(4), 0.1)
+    # straight through the C-ABI: reference CANCEL convention -- message, info[RC] = RC_ERROR, return 0, output untouched
+    X = np.asfortranarray(np.ones((4, 4)))
+    out, info = np.full((4, 4), 7.0, order="F"), np.zeros(3)
+    rc = lib.DR2_TV(4, 4, X.ctypes.data, 0.1, 0.1, 1.0, 1.0, out.ctypes.data, 1, 0, info.ctypes.data)
+    assert rc == 0 and info[2] == 3 and (out == 7.0).all()
+    lam, norms, dims, ns = np.array([.1, .1]), np.ones(2), np.array([1., 2.]), np.array([4, 4], dtype=np.int32)
+    rc = lib.PD2_TV(X.ctypes.data, lam.ctypes.data, norms.ctypes.data, dims.ctypes.data, out.ctypes.data,
+                    info.ctypes.data, ns.ctypes.data, 2, 2, 1, 0)
+    assert rc == 0 and info[2] == 3 and (out == 7.0).all()
+    assert "no CPU fallback" in capfd.readouterr().out
+
+
+def test_python_surface_argument_checks():
+    """Same assertions as the reference, raised before anything touches the device
+    (prox_tv/__init__.py:160-161, 245-246, 400-401, 473-477, 569-572)."""
+    import proxtv_amd as ptv
+    x = np.zeros((4, 5))
+    with pytest.raises(AssertionError):
+        ptv.tv1_1d(np.zeros(5), -1.0)
+    with pytest.raises(AssertionError):
+        ptv.tv1_1d(np.zeros(5), 1.0, method="nope")
+    with pytest.raises(AssertionError):
+        ptv.tv1w_1d(np.zeros(5), np.ones(5))            # needs n-1 weights
+    with pytest.raises(AssertionError):
+        ptv.tv1w_1d(np.zeros(5), -np.ones(4))
+    with pytest.raises(AssertionError):
+        ptv.tv1_2d(x, -0.1)
+    with pytest.raises(AssertionError):
+        ptv.tv1_2d(x, 0.1, method="nope")
+    with pytest.raises(AssertionError):
+        ptv.tv1w_2d(x, np.ones((4, 5)), np.ones((4, 4)))  # w_col must be (M-1, N)
+    with pytest.raises(AssertionError):
+        ptv.tv1w_2d(x, -np.ones((3, 5)), np.ones((4, 4)))
+    with pytest.raises(AssertionError):
+        ptv.tvgen(x, [1, 2], [1], [1, 1])
+    with pytest.raises(AssertionError):
+        ptv.tvgen(x, [1], [1], [1], n_threads=0)
+    with pytest.raises(AssertionError):
+        ptv.tvgen(x, [1], [1], [1], max_iters=-1)
+    with pytest.raises(AssertionError):
+        ptv.tvp_2d(x, 1, 1, 0.5, 1)
+    # out-of-scope solvers say so instead of silently doing something else
+    for call in (lambda: ptv.tv2_1d(np.zeros(5), 1.0), lambda: ptv.tvp_1d(np.zeros(5), 1.0, 1.5),
+                 lambda: ptv.tvp_2d(x, 1, 1, 2, 2), lambda: ptv.tv1_2d(x, 0.1, method="condat"),
+                 lambda: ptv.tv1_2d(x, 0.1, method="kolmogorov"), lambda: ptv.tvgen(x, [1, 1], [1, 2], [1, 2])):
+        with pytest.raises(NotImplementedError):
+            call()
+
+
+def test_force_float_helpers():
+    import proxtv_amd as ptv
+    assert isinstance(ptv.force_float_scalar(3), float)
+    a = np.arange(4.0)
+    assert ptv.force_float_matrix(a) is a                          # float64 passes through as the same object (Q3)
+    assert ptv.force_float_matrix([1, 2]).dtype == np.float64
+    assert ptv.force_float_matrix(np.arange(3)).dtype == np.float64
