@@ -150,6 +150,10 @@ int proxtv_DR2_TV_batch(size_t M, size_t N, size_t B, const double *unary, doubl
    over the last solve (0 = column sweep, 1 = row sweep, 2 = everything else), measured with
    hipEvents on the solve's own stream when option "profile" is 1. */
 double proxtv_last_kernel_ms(int which);
+/* Fibres the speculative-chunk kernel could not prove and re-solved sequentially during the last solve on this
+   thread's stream (0 for noisy data; large when lambda dwarfs the noise).  Diagnostic only: results are exact
+   either way. */
+long   proxtv_last_fixups(void);
 long   proxtv_last_kernel_launches(int which);
 
 #ifdef __cplusplus

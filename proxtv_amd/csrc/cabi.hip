@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "solvers.hpp"
+#include "sweep.hpp"
 
 using namespace ptv;
 
@@ -67,7 +68,10 @@ hipStream_t pick(void *stream) { return stream ? (hipStream_t)stream : thread_st
 
 struct SolveScope {
     hipStream_t s;
-    explicit SolveScope(hipStream_t st) : s(st) { if (options().profile) timing_reset(); }
+    explicit SolveScope(hipStream_t st) : s(st) {
+        if (options().profile) timing_reset();
+        chunk_stats_reset(st);
+    }
     void finish() {
         if (options().profile) {
             PTV_HIP(hipStreamSynchronize(s));
@@ -322,10 +326,15 @@ int proxtv_set_option(const char *key, int value) {
     else if (!strcmp(key, "warmup")) slot = &o.warmup;
     else if (!strcmp(key, "verbose")) slot = &o.verbose;
     else if (!strcmp(key, "profile")) slot = &o.profile;
+    else if (!strcmp(key, "ablate")) slot = &o.ablate;
     if (!slot) return -1;
     const int old = *slot;
     *slot = value;
     return old;
+}
+
+long proxtv_last_fixups(void) {
+    try { return chunk_stats_fixups(thread_stream()); } catch (...) { return -1; }
 }
 
 double proxtv_last_kernel_ms(int which) { return timing_ms(which); }

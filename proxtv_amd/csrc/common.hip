@@ -20,6 +20,7 @@ Options &options() {
         if (const char *e = getenv("PROXTV_CHUNK")) v.chunk = atoi(e);
         if (const char *e = getenv("PROXTV_WARMUP")) v.warmup = atoi(e);
         if (const char *e = getenv("PROXTV_VERBOSE")) v.verbose = atoi(e);
+        if (const char *e = getenv("PROXTV_ABLATE")) v.ablate = atoi(e);
         return v;
     }();
     return o;

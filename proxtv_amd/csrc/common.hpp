@@ -36,10 +36,11 @@ struct HipFailure {
 
 // ---- options (see proxtv_set_option) ---------------------------------------------------------------------------
 struct Options {
-    int chunk = 32;     // samples per speculative chunk (0 = sequential lane-per-fibre kernels only)
+    int chunk = 16;     // samples per speculative chunk: 16 or 32 (0 = sequential lane-per-fibre kernels only)
     int warmup = 16;    // warm-up / synchronisation zone in samples (<= 32)
     int verbose = 0;
     int profile = 0;    // per-kernel-family hipEvent timing
+    int ablate = 0;     // profiling aid, see ChunkPlan::ablate (results are WRONG when non-zero)
 };
 Options &options();
 

@@ -52,8 +52,8 @@ __global__ __launch_bounds__(kThreads) void finish_kernel(const double *partials
     if (threadIdx.x == 0) out[blockIdx.x] = acc;
 }
 
-__global__ __launch_bounds__(kThreads) void dr_fill_kernel(double *t, long n, const double *sums) {
-    const double v = 2 * sums[blockIdx.y] / n;
+__global__ __launch_bounds__(kThreads) void dr_fill_kernel(double *t, long n, const double *sums, double sign) {
+    const double v = sign * (2 * sums[blockIdx.y] / n);
     double *seg = t + (long)blockIdx.y * n;
     for (long i = (long)blockIdx.x * kThreads + threadIdx.x; i < n; i += (long)gridDim.x * kThreads) seg[i] = v;
 }
@@ -122,8 +122,8 @@ void sum_to(const double *a, long n, long segments, double *partials, double *ou
     PTV_HIP(hipGetLastError());
 }
 
-void dr_fill(double *t, long n, long segments, const double *sums, hipStream_t s) {
-    hipLaunchKernelGGL(dr_fill_kernel, dim3(grid_for(n, 1024), (unsigned)segments), dim3(kThreads), 0, s, t, n, sums);
+void dr_fill(double *t, long n, long segments, const double *sums, double sign, hipStream_t s) {
+    hipLaunchKernelGGL(dr_fill_kernel, dim3(grid_for(n, 1024), (unsigned)segments), dim3(kThreads), 0, s, t, n, sums, sign);
     PTV_HIP(hipGetLastError());
 }
 

@@ -14,8 +14,8 @@ constexpr int kReduceBlocks = 1024;  // partial sums per reduction (fixed => run
 
 // out[b] = sum(a[b*n .. (b+1)*n)) for b < segments       `partials` holds segments * kReduceBlocks doubles
 void sum_to(const double *a, long n, long segments, double *partials, double *out, hipStream_t s);
-// t[b*n + i] = 2 * sums[b] / n                             (DR initialisation, src/TV2Dopt.cpp:390-395)
-void dr_fill(double *t, long n, long segments, const double *sums, hipStream_t s);
+// t[b*n + i] = sign * (2 * sums[b] / n)                    (DR initialisation, src/TV2Dopt.cpp:390-395)
+void dr_fill(double *t, long n, long segments, const double *sums, double sign, hipStream_t s);
 // *out = sum |a - b|
 void absdiff_to(const double *a, const double *b, long n, double *partials, double *out, hipStream_t s);
 

@@ -70,14 +70,21 @@ SolveInfo dr2(size_t M, size_t N, size_t B, const double *unary, double W1, doub
     double *t = t0.d(), *tn = t1.d();
 
     sum_to(unary, n1, (long)B, partials.d(), sums.d(), s);
-    dr_fill(t, n1, (long)B, sums.d(), s);
+    dr_fill(t, n1, (long)B, sums.d(), 1.0, s);
 
     SweepArgs col, row;
     col.lam = W1; col.w = W1m; col.o0 = sp.d();
     row.lam = W2; row.w = W2m; row.a = sp.d(); row.b = unary;
     for (int it = 0; it < maxit; it++) {
         col.a = t;
-        launch_sweep(OP_DR_COL, weighted, col, cols, s, FAM_COL, true);
+        if (it == 0) {
+            // t is constant per image, and the prox of a constant fibre is that constant: s = t - prox(t) = 0,
+            // s' = 2 s - t = -t.  (One flat piece per fibre is also the worst case for any taut-string walk.)
+            FamilyTimer tm(FAM_OTHER, s);
+            dr_fill(sp.d(), n1, (long)B, sums.d(), -1.0, s);
+        } else {
+            launch_sweep(OP_DR_COL, weighted, col, cols, s, FAM_COL, true);
+        }
         row.c = t; row.o0 = tn;
         launch_sweep(weighted ? OP_DRW_ROW : OP_DR_ROW, weighted, row, rows, s, FAM_ROW, true);
         std::swap(t, tn);

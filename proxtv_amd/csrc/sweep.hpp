@@ -18,4 +18,8 @@ namespace ptv {
 void launch_sweep(OpId op, bool weighted, const SweepArgs &args, const FibreGeom &g, hipStream_t stream, int fam,
                   bool allow_chunked);
 
+// Fibres that the chunked path had to re-solve sequentially (unproven chunk links) since the last reset, on this thread.
+void chunk_stats_reset(hipStream_t s);
+long chunk_stats_fixups(hipStream_t s);
+
 }  // namespace ptv
