@@ -1,0 +1,56 @@
+"""Batch sharding across the GPUs of a node: one process per GPU, independent images, no collective in the data path.
+
+The reference has no batch or multi-device concept; images of a batch are independent TV problems, so the
+batch is block-partitioned over ranks, every rank runs the single-GPU HIP path on its shard (all images of the shard
+advance together, one launch per sweep), and a single gather over RCCL (xGMI) collects the results only if the
+caller wants them in one place.  Within one image nothing is sharded: every sweep needs all fibres of the previous,
+orthogonal sweep, which would be an all-to-all of the whole image 72 times per solve.
+
+`torch.distributed` is plumbing (backend "nccl" is RCCL on ROCm; "gloo" drives the CPU tests).
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(n_items, world, rank):
+    """Block partition of range(n_items): the first n_items % world ranks get one extra item."""
+    base, extra = divmod(int(n_items), int(world))
+    start = rank * base + min(rank, extra)
+    return start, start + base + (1 if rank < extra else 0)
+
+
+def shard_sizes(n_items, world):
+    return [shard_bounds(n_items, world, r)[1] - shard_bounds(n_items, world, r)[0] for r in range(world)]
+
+
+def solve_sharded(get_images, n_items, solve, gather_to=0, group=None):
+    """Solve a batch of `n_items` independent images across the ranks of `group`.
+
+    get_images(start, stop) -> tensor of this rank's images, shape (stop - start, ...), already on the rank's device
+    solve(images)           -> tensor of the same shape (the single-GPU path)
+    gather_to               -> rank that receives the full result in batch order (None: leave results sharded)
+
+    Returns (local_result, gathered_or_None).  The only communication is the final gather.
+    """
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    start, stop = shard_bounds(n_items, world, rank)
+    local = solve(get_images(start, stop))
+    if gather_to is None or world == 1:
+        return local, (local if (gather_to is not None) else None)
+    sizes = shard_sizes(n_items, world)
+    item_shape = tuple(local.shape[1:])
+    # ragged shards: pad every contribution to the largest shard so one gather collective suffices
+    pad_to = max(sizes)
+    send = local
+    if local.shape[0] < pad_to:
+        pad = torch.zeros((pad_to - local.shape[0],) + item_shape, dtype=local.dtype, device=local.device)
+        send = torch.cat([local, pad], dim=0)
+    send = send.contiguous()
+    if rank == gather_to:
+        bufs = [torch.empty_like(send) for _ in range(world)]
+        dist.gather(send, gather_list=bufs, dst=gather_to, group=group)
+        full = torch.cat([b[:n] for b, n in zip(bufs, sizes)], dim=0)
+        return local, full
+    dist.gather(send, gather_list=None, dst=gather_to, group=group)
+    return local, None
