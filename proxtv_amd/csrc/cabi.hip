@@ -327,6 +327,7 @@ int proxtv_set_option(const char *key, int value) {
     else if (!strcmp(key, "verbose")) slot = &o.verbose;
     else if (!strcmp(key, "profile")) slot = &o.profile;
     else if (!strcmp(key, "ablate")) slot = &o.ablate;
+    else if (!strcmp(key, "blocks_per_wg")) slot = &o.blocks_per_wg;
     if (!slot) return -1;
     const int old = *slot;
     *slot = value;

@@ -21,6 +21,7 @@ Options &options() {
         if (const char *e = getenv("PROXTV_WARMUP")) v.warmup = atoi(e);
         if (const char *e = getenv("PROXTV_VERBOSE")) v.verbose = atoi(e);
         if (const char *e = getenv("PROXTV_ABLATE")) v.ablate = atoi(e);
+        if (const char *e = getenv("PROXTV_BLOCKS_PER_WG")) v.blocks_per_wg = atoi(e);
         return v;
     }();
     return o;

@@ -36,8 +36,9 @@ struct HipFailure {
 
 // ---- options (see proxtv_set_option) ---------------------------------------------------------------------------
 struct Options {
-    int chunk = 16;     // samples per speculative chunk: 16 or 32 (0 = sequential lane-per-fibre kernels only)
-    int warmup = 16;    // warm-up / synchronisation zone in samples (<= 32)
+    int chunk = 16;     // non-zero: speculative-chunk kernels (16-sample chunks); 0 = sequential lane-per-fibre kernels only
+    int warmup = 16;    // (reserved) warm-up zone in samples; the chunk kernels are built for kWarm = 16
+    int blocks_per_wg = 0;  // blocks pipelined per workgroup in the chunk kernel; 0 = pick from the problem size
     int verbose = 0;
     int profile = 0;    // per-kernel-family hipEvent timing
     int ablate = 0;     // profiling aid, see ChunkPlan::ablate (results are WRONG when non-zero)

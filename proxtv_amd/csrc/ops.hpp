@@ -4,12 +4,13 @@
 // build the fibre from a pointwise combination of arrays, prox it, scatter a pointwise combination back".
 // The reference does the gather / scatter with per-thread copies and runs the remaining pointwise updates as
 // separate (serial) loops (src/TV2Dopt.cpp:411,419,422).  Here both ends are fused into the sweep kernel:
-//   y   = Op::load_y(args, idx)            what the walker sees at element idx
-//   ext = Op::fetch(args, idx)             the operand values the epilogue needs (global loads only, so a kernel
-//                                          can issue a batch of them before any dependent work)
-//   Op::finish(args, idx, ext, y, x)       x = prox value at idx; computes and writes every output of the sweep
-// The arithmetic inside each op follows the reference's operation order (cited per op) so results agree to the
-// last ulps with the CPU path.
+//   y   = Op::load_y(args, idx)        what the walker sees at element idx; split as fetch_in (global loads only,
+//                                      NIN operands) + y_of (arithmetic) so a kernel can batch the loads of a window
+//   ext = Op::fetch(args, idx)         the operand values the epilogue needs (global loads only, so a kernel can
+//                                      issue a batch of them before any dependent work)
+//   Op::finish(args, idx, ext, x)      x = prox value at idx; computes and writes every output of the sweep
+// The arithmetic follows the reference's operation order (cited per op) except where noted, so results agree to
+// the last ulps with the CPU path.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -31,10 +32,9 @@ enum OpId : int {
     OP_PROX = 0,       // o0 = prox(a)
     OP_DR_COL,         // reflection through B_cols
     OP_DR_COL_FINAL,   // projection onto B_cols
-    OP_DR_ROW,         // reflection through B_{-rows*} + combiner, unweighted sign convention
-    OP_DR_ROW_FINAL,   // recovery step, unweighted
-    OP_DRW_ROW,        // weighted sign convention (src/TV2DWopt.cpp)
-    OP_DRW_ROW_FINAL,
+    OP_DR_ROW,         // reflection through B_{-rows*} + combiner (both sign conventions of the reference)
+    OP_DR_ROW_FINAL,   // recovery step, unweighted sign convention
+    OP_DRW_ROW_FINAL,  // recovery step, weighted sign convention (src/TV2DWopt.cpp)
     OP_PD2_A,          // first Dykstra term
     OP_PD2_B,          // second Dykstra term
     OP_YANG,           // Z/U update of Yang's ADMM
@@ -42,89 +42,96 @@ enum OpId : int {
 };
 
 struct Ext {
-    double e0, e1, e2;
+    double e0, e1;
 };
 
 template <int ID> struct Op;
 
-// o0 = prox(a)                                  (PD_TV :164-209, PDR_TV :405-458, batched tv1_1d)
-template <> struct Op<OP_PROX> {
+// ---- one-operand inputs: y = a ---------------------------------------------------------------------------------------
+struct InA {
+    static constexpr int NIN = 1;
+    __device__ static __forceinline__ void fetch_in(const SweepArgs &p, long idx, double &i0, double &i1) { i0 = p.a[idx]; i1 = 0.0; }
+    __device__ static __forceinline__ double y_of(const SweepArgs &, double i0, double) { return i0; }
     __device__ static __forceinline__ double load_y(const SweepArgs &p, long idx) { return p.a[idx]; }
-    __device__ static __forceinline__ Ext fetch(const SweepArgs &, long) { return Ext{0, 0, 0}; }
-    __device__ static __forceinline__ void finish(const SweepArgs &p, long idx, const Ext &, double, double x) { p.o0[idx] = x; }
+};
+// ---- y = b - a  (DR rows: unary - s') ----------------------------------------------------------------------------------
+struct InBminusA {
+    static constexpr int NIN = 2;
+    __device__ static __forceinline__ void fetch_in(const SweepArgs &p, long idx, double &i0, double &i1) { i0 = p.b[idx]; i1 = p.a[idx]; }
+    __device__ static __forceinline__ double y_of(const SweepArgs &, double i0, double i1) { return i0 - i1; }
+    __device__ static __forceinline__ double load_y(const SweepArgs &p, long idx) { return p.b[idx] - p.a[idx]; }
+};
+// ---- y = a + b  (Dykstra: iterate + correction) ------------------------------------------------------------------------
+struct InAplusB {
+    static constexpr int NIN = 2;
+    __device__ static __forceinline__ void fetch_in(const SweepArgs &p, long idx, double &i0, double &i1) { i0 = p.a[idx]; i1 = p.b[idx]; }
+    __device__ static __forceinline__ double y_of(const SweepArgs &, double i0, double i1) { return i0 + i1; }
+    __device__ static __forceinline__ double load_y(const SweepArgs &p, long idx) { return p.a[idx] + p.b[idx]; }
+};
+
+// o0 = prox(a)                                  (PD_TV :164-209, PDR_TV :405-458, batched tv1_1d)
+template <> struct Op<OP_PROX> : InA {
+    __device__ static __forceinline__ Ext fetch(const SweepArgs &, long) { return Ext{0, 0}; }
+    __device__ static __forceinline__ void finish(const SweepArgs &p, long idx, const Ext &, double x) { p.o0[idx] = x; }
 };
 
 // DR, columns (a = t): s = t - prox(t) ; s' = 2 s - t          (src/TV2Dopt.cpp:408-411, 539-547)
-template <> struct Op<OP_DR_COL> {
-    __device__ static __forceinline__ double load_y(const SweepArgs &p, long idx) { return p.a[idx]; }
-    __device__ static __forceinline__ Ext fetch(const SweepArgs &, long) { return Ext{0, 0, 0}; }
-    __device__ static __forceinline__ void finish(const SweepArgs &p, long idx, const Ext &, double y, double x) {
-        const double s = y - x;
-        p.o0[idx] = 2 * s - y;
+template <> struct Op<OP_DR_COL> : InA {
+    __device__ static __forceinline__ Ext fetch(const SweepArgs &p, long idx) { return Ext{p.a[idx], 0}; }
+    __device__ static __forceinline__ void finish(const SweepArgs &p, long idx, const Ext &e, double x) {
+        const double s = e.e0 - x;
+        p.o0[idx] = 2 * s - e.e0;
     }
 };
 // final projection: s = t - prox(t)                              (src/TV2Dopt.cpp:427)
-template <> struct Op<OP_DR_COL_FINAL> {
-    __device__ static __forceinline__ double load_y(const SweepArgs &p, long idx) { return p.a[idx]; }
-    __device__ static __forceinline__ Ext fetch(const SweepArgs &, long) { return Ext{0, 0, 0}; }
-    __device__ static __forceinline__ void finish(const SweepArgs &p, long idx, const Ext &, double y, double x) { p.o0[idx] = y - x; }
+template <> struct Op<OP_DR_COL_FINAL> : InA {
+    __device__ static __forceinline__ Ext fetch(const SweepArgs &p, long idx) { return Ext{p.a[idx], 0}; }
+    __device__ static __forceinline__ void finish(const SweepArgs &p, long idx, const Ext &e, double x) { p.o0[idx] = e.e0 - x; }
 };
 
-// DR, rows (a = s', b = unary, c = t_old, o0 = t_new):
-//   v = U - s' ; tb = U - (v - prox(v)) ; tb' = 2 tb - s' ; t = 0.5 (t + tb')      (src/TV2Dopt.cpp:417-422, 514-520)
-template <> struct Op<OP_DR_ROW> {
-    __device__ static __forceinline__ double load_y(const SweepArgs &p, long idx) { return p.b[idx] - p.a[idx]; }
-    __device__ static __forceinline__ Ext fetch(const SweepArgs &p, long idx) { return Ext{p.b[idx], p.a[idx], p.c[idx]}; }
-    __device__ static __forceinline__ void finish(const SweepArgs &p, long idx, const Ext &e, double y, double x) {
-        double tb = e.e0 - (y - x);
-        tb = 2 * tb - e.e1;
-        p.o0[idx] = 0.5 * (e.e2 + tb);
+// DR, rows (a = s', b = unary, c = t_old, o0 = t_new).  Reference (src/TV2Dopt.cpp:417-422, 514-520):
+//   v = U - s' ; tb = U - (v - prox(v)) ; tb' = 2 tb - s' ; t = 0.5 (t + tb')
+// and, weighted (src/TV2DWopt.cpp:114-119, 218): tbw = (v - prox(v)) - U ; tb' = -2 tbw - s' ; same t.
+// Both are t = 0.5 (t + (s' + 2 prox(v))) once U - v is replaced by s' (it IS s' up to the rounding of v): evaluated
+// in that form, which needs s' and t but not U at the epilogue -- a few ulps of |U| away from the reference's order.
+template <> struct Op<OP_DR_ROW> : InBminusA {
+    __device__ static __forceinline__ Ext fetch(const SweepArgs &p, long idx) { return Ext{p.a[idx], p.c[idx]}; }
+    __device__ static __forceinline__ void finish(const SweepArgs &p, long idx, const Ext &e, double x) {
+        const double tb = e.e0 + 2 * x;
+        p.o0[idx] = 0.5 * (e.e1 + tb);
     }
 };
 // recovery (a = s, b = unary): out = (U - (v - prox(v))) - s                         (src/TV2Dopt.cpp:429-430)
-template <> struct Op<OP_DR_ROW_FINAL> {
-    __device__ static __forceinline__ double load_y(const SweepArgs &p, long idx) { return p.b[idx] - p.a[idx]; }
-    __device__ static __forceinline__ Ext fetch(const SweepArgs &p, long idx) { return Ext{p.b[idx], p.a[idx], 0}; }
-    __device__ static __forceinline__ void finish(const SweepArgs &p, long idx, const Ext &e, double y, double x) {
+template <> struct Op<OP_DR_ROW_FINAL> : InBminusA {
+    __device__ static __forceinline__ Ext fetch(const SweepArgs &p, long idx) { return Ext{p.b[idx], p.a[idx]}; }
+    __device__ static __forceinline__ void finish(const SweepArgs &p, long idx, const Ext &e, double x) {
+        const double y = e.e0 - e.e1;
         const double tb = e.e0 - (y - x);
         p.o0[idx] = tb - e.e1;
     }
 };
-
-// weighted DR rows: tbw = (v - prox(v)) - U ; tb' = -2 tbw - s' ; t = 0.5 (t + tb')   (src/TV2DWopt.cpp:114-119, 218)
-template <> struct Op<OP_DRW_ROW> {
-    __device__ static __forceinline__ double load_y(const SweepArgs &p, long idx) { return p.b[idx] - p.a[idx]; }
-    __device__ static __forceinline__ Ext fetch(const SweepArgs &p, long idx) { return Ext{p.b[idx], p.a[idx], p.c[idx]}; }
-    __device__ static __forceinline__ void finish(const SweepArgs &p, long idx, const Ext &e, double y, double x) {
-        double tb = (y - x) - e.e0;
-        tb = -2 * tb - e.e1;
-        p.o0[idx] = 0.5 * (e.e2 + tb);
-    }
-};
-// weighted recovery: out = -s - tbw                                                    (src/TV2DWopt.cpp:124-126)
-template <> struct Op<OP_DRW_ROW_FINAL> {
-    __device__ static __forceinline__ double load_y(const SweepArgs &p, long idx) { return p.b[idx] - p.a[idx]; }
-    __device__ static __forceinline__ Ext fetch(const SweepArgs &p, long idx) { return Ext{p.b[idx], p.a[idx], 0}; }
-    __device__ static __forceinline__ void finish(const SweepArgs &p, long idx, const Ext &e, double y, double x) {
+// weighted recovery: tbw = (v - prox(v)) - U ; out = -s - tbw                          (src/TV2DWopt.cpp:124-126, 218)
+template <> struct Op<OP_DRW_ROW_FINAL> : InBminusA {
+    __device__ static __forceinline__ Ext fetch(const SweepArgs &p, long idx) { return Ext{p.b[idx], p.a[idx]}; }
+    __device__ static __forceinline__ void finish(const SweepArgs &p, long idx, const Ext &e, double x) {
+        const double y = e.e0 - e.e1;
         const double tb = (y - x) - e.e0;
         p.o0[idx] = -e.e1 - tb;
     }
 };
 
 // Dykstra term 1 (a = x, b = p_in, o0 = z, o1 = p_out): z = prox(x + p) ; p += x - z   (src/TV2Dopt.cpp:187-213)
-template <> struct Op<OP_PD2_A> {
-    __device__ static __forceinline__ double load_y(const SweepArgs &p, long idx) { return p.a[idx] + p.b[idx]; }
-    __device__ static __forceinline__ Ext fetch(const SweepArgs &p, long idx) { return Ext{p.a[idx], p.b[idx], 0}; }
-    __device__ static __forceinline__ void finish(const SweepArgs &p, long idx, const Ext &e, double, double x) {
+template <> struct Op<OP_PD2_A> : InAplusB {
+    __device__ static __forceinline__ Ext fetch(const SweepArgs &p, long idx) { return Ext{p.a[idx], p.b[idx]}; }
+    __device__ static __forceinline__ void finish(const SweepArgs &p, long idx, const Ext &e, double x) {
         p.o0[idx] = x;
         p.o1[idx] = e.e1 + (e.e0 - x);
     }
 };
 // Dykstra term 2 (a = z, b = q_in, o0 = x, o1 = q_out): x = prox(z + q) ; q += z - x    (src/TV2Dopt.cpp:234-263)
-template <> struct Op<OP_PD2_B> {
-    __device__ static __forceinline__ double load_y(const SweepArgs &p, long idx) { return p.a[idx] + p.b[idx]; }
-    __device__ static __forceinline__ Ext fetch(const SweepArgs &p, long idx) { return Ext{p.a[idx], p.b[idx], 0}; }
-    __device__ static __forceinline__ void finish(const SweepArgs &p, long idx, const Ext &e, double, double x) {
+template <> struct Op<OP_PD2_B> : InAplusB {
+    __device__ static __forceinline__ Ext fetch(const SweepArgs &p, long idx) { return Ext{p.a[idx], p.b[idx]}; }
+    __device__ static __forceinline__ void finish(const SweepArgs &p, long idx, const Ext &e, double x) {
         p.o0[idx] = x;
         p.o1[idx] = e.e1 + (e.e0 - x);
     }
@@ -133,11 +140,12 @@ template <> struct Op<OP_PD2_B> {
 // Yang ADMM (a = X, b = U_in, o0 = Z, o1 = U_out, s0 = rho):
 //   Z = prox_{lambda/rho}(-1/rho U + X) ; U += rho (Z - X)          (src/TV2Dopt.cpp:836-862 ; src/TVNDopt.cpp:733-788)
 template <> struct Op<OP_YANG> {
-    __device__ static __forceinline__ double load_y(const SweepArgs &p, long idx) {
-        return -1. / p.s0 * p.b[idx] + p.a[idx];
-    }
-    __device__ static __forceinline__ Ext fetch(const SweepArgs &p, long idx) { return Ext{p.a[idx], p.b[idx], 0}; }
-    __device__ static __forceinline__ void finish(const SweepArgs &p, long idx, const Ext &e, double, double x) {
+    static constexpr int NIN = 2;
+    __device__ static __forceinline__ void fetch_in(const SweepArgs &p, long idx, double &i0, double &i1) { i0 = p.a[idx]; i1 = p.b[idx]; }
+    __device__ static __forceinline__ double y_of(const SweepArgs &p, double i0, double i1) { return -1. / p.s0 * i1 + i0; }
+    __device__ static __forceinline__ double load_y(const SweepArgs &p, long idx) { return -1. / p.s0 * p.b[idx] + p.a[idx]; }
+    __device__ static __forceinline__ Ext fetch(const SweepArgs &p, long idx) { return Ext{p.a[idx], p.b[idx]}; }
+    __device__ static __forceinline__ void finish(const SweepArgs &p, long idx, const Ext &e, double x) {
         p.o0[idx] = x;
         p.o1[idx] = e.e1 + p.s0 * (x - e.e0);
     }

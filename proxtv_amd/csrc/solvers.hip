@@ -86,7 +86,7 @@ SolveInfo dr2(size_t M, size_t N, size_t B, const double *unary, double W1, doub
             launch_sweep(OP_DR_COL, weighted, col, cols, s, FAM_COL, true);
         }
         row.c = t; row.o0 = tn;
-        launch_sweep(weighted ? OP_DRW_ROW : OP_DR_ROW, weighted, row, rows, s, FAM_ROW, true);
+        launch_sweep(OP_DR_ROW, weighted, row, rows, s, FAM_ROW, true);
         std::swap(t, tn);
     }
     col.a = t;

@@ -14,9 +14,9 @@
 // a bend: its state right after one depends only on (restart index, bend type).  So a walk started anywhere from a
 // guessed state coincides with the true walk from the first bend they have in common.  Each fibre is cut into
 // chunks of C samples; the lane owning chunk c starts H samples early from a free-end state, and owns the outputs
-// of [cC, (c+1)C).  Every lane records (as bit masks over the H-sample zone before a chunk boundary) where its walk
-// bent; chunk c is proven exact iff its own bends and those of chunk c-1's lane (which walks through the same zone
-// on its way to closing its last piece) share one bend at or before the boundary.  Fibres with an unproven link
+// of [cC, (c+1)C).  Every lane remembers its last bend before its chunk start and before its chunk end; chunk c is
+// proven exact iff its last bend at-or-before cC equals that of chunk c-1's lane (which walks through the same zone
+// on its way to closing its last piece): two walks share their last bend or none.  Fibres with an unproven link
 // (long flat pieces: lambda large against the noise) are re-solved by kernel 1 in `sweep_fix_kernel`, so the result
 // is exact for every input; for noisy data the two walks coincide within a handful of samples.
 // A workgroup = NW wavefronts = NW consecutive chunks of the same 64 fibres, sharing one LDS window
@@ -44,7 +44,7 @@ struct SeqSource {
     __device__ __forceinline__ void piece(int from, int to, double v) const {
         for (int j = from; j <= to; j++) {
             const long idx = base + (long)j * inc;
-            Op<OP>::finish(p, idx, Op<OP>::fetch(p, idx), Op<OP>::load_y(p, idx), v);
+            Op<OP>::finish(p, idx, Op<OP>::fetch(p, idx), v);
         }
     }
     __device__ __forceinline__ void bend(int, int) const {}
@@ -57,7 +57,7 @@ __device__ __forceinline__ void solve_fibre_seq(const SweepArgs &p, const FibreG
     SeqSource<OP, WEIGHTED> src{p, blk * g.inc * g.len + off, g.inc, blk * g.inc * (g.len - 1) + off};
     if (WEIGHTED && g.len == 1) {  // no edge at all: prox is the identity (the reference reads lambda[0] out of bounds here)
         const double y0 = src.y(0);
-        Op<OP>::finish(p, src.base, Op<OP>::fetch(p, src.base), y0, y0);
+        Op<OP>::finish(p, src.base, Op<OP>::fetch(p, src.base), y0);
         return;
     }
     Walker w;
@@ -74,10 +74,8 @@ __global__ __launch_bounds__(64) void sweep_seq_kernel(SweepArgs p, FibreGeom g)
 
 // ---- kernel 2: speculative chunks over an LDS window -----------------------------------------------------------------
 struct ChunkPlan {
-    int H;      // warm-up / synchronisation zone, samples (<= 32)
-    int T;      // look-ahead rows kept in LDS past the workgroup's last chunk
-    int Q;      // workgroups (chunk blocks) per fibre
-    int rows;   // LDS window rows = H + NW*C + T
+    int Q;      // blocks (NW chunks each) per fibre
+    int qpw;    // consecutive blocks of one fibre group processed (software-pipelined) by one workgroup
     int ablate; // profiling aid (option "ablate"): 1 = skip the walk, 2 = skip the epilogue, 4 = skip the window loads
 };
 
@@ -87,12 +85,13 @@ struct ChunkSource {
     long base, inc, wbase;     // this lane's fibre in global memory
     const double *Y;           // LDS window, already offset to this lane's column; row r of the fibre at Y[(r - lo) * PITCH]
     const double *Wt;          // LDS per-edge penalties, same addressing (weighted sweeps)
-    double *V;                 // LDS piece values: V[(brk - vrow0) * PITCH] = value of the piece ending at brk
     int lo, hi;                // window rows present in LDS
     int cs, ce;                // samples owned by this lane: [cs, ce)
-    int vrow0;                 // first row of the workgroup's V plane
     int len;                   // fibre length
+    // The walk stores no piece VALUES: it records where pieces end inside the chunk and with which bend type; the
+    // values are rebuilt afterwards from the window in closed form (see rebuild_pieces).
     unsigned ends = 0;         // bit k: a piece ends at sample cs + k (k < ce - 1 - cs; chunks are at most 32 samples)
+    unsigned types = 0;        // bit k: bend type (BEND_FLOOR = 1) of the bend that ended that piece
     // Link proof.  Two walks that share one bend are identical from it on, so inside the zone before a chunk boundary
     // they either share their LAST bend or share none: it is enough to remember, as (restart << 1 | type), the last
     // bend at or before the own chunk start (`mine`) and at or before the own chunk end (`next`, read by the lane of
@@ -111,7 +110,6 @@ struct ChunkSource {
             vclose = v;
             done = true;
         } else if (to >= cs) {
-            V[(to - vrow0) * PITCH] = v;
             ends |= 1u << (to - cs);
         }
     }
@@ -119,6 +117,8 @@ struct ChunkSource {
         const unsigned code = ((unsigned)at << 1) | (unsigned)type;
         mine = (at <= cs) ? code : mine;
         next = (at <= ce) ? code : next;
+        const int e = at - 1 - cs;                       // the piece that this bend ended, relative to the chunk
+        if (e >= 0 && at < ce) types |= (unsigned)type << e;
     }
     __device__ __forceinline__ bool keep_going(int i) {
         if (done) return false;
@@ -206,23 +206,76 @@ __device__ __forceinline__ void walker_run_interior(Walker &w, S &src, int n, do
     }
 }
 
-// LDS carve (dynamic, 16-byte aligned base): Y | Wt (weighted) | V | next-masks
+
+constexpr int kWarm = 16;   // H: samples a speculative walk starts before its chunk (its synchronisation zone)
+constexpr int kTail = 8;    // T: look-ahead rows kept in LDS past the last chunk of a block
+
+// Piece values from piece ends.  Between two knots of the taut string the prox is constant, and the string's height
+// above the tube centre at a knot is -r after a CEIL bend (the knot sits on the tube floor), +r after a FLOOR bend,
+// 0 at the fibre ends (r = the tube half-width there: lambda, or the edge's own penalty).  Summing x - y over a
+// piece [a, b] therefore gives   v = ( sum_{a..b} y + h_b - h_{a-1} ) / (b - a + 1).
+// For one-sample pieces this is bit-for-bit the walker's closed-form restart value (y, y +- 2 lambda); for longer
+// pieces it agrees with the walker's running slope to a few ulps (checked on the host: < 1e-15 relative).
+// Pass A walks forward from the start `a0` of the piece that straddles the chunk start (the restart index of the
+// lane's last bend at-or-before cs, i.e. its `mine` code) and leaves each piece's value at the piece's END row, in
+// place in the window; pass B (after a barrier) fills backwards so that row k of the chunk holds x_k.
+// In-place is safe: a row is read by another lane only inside a piece that straddles a chunk boundary, and proven
+// links guarantee no piece END lies inside such a stretch (unproven fibres are re-solved anyway).
+template <bool WEIGHTED, int PITCH>
+__device__ __forceinline__ void rebuild_piece_ends(double *Ycol, const double *Wcol, int lo, int cs, int ce, int start,
+                                                   unsigned mine, unsigned ends, unsigned types, double lam) {
+    int a0 = cs;
+    double hprev = 0.0;
+    if (mine != 0) {
+        a0 = (int)(mine >> 1);
+        const double r = WEIGHTED ? Wcol[(a0 - 1 - lo) * PITCH] : lam;
+        hprev = (mine & 1u) ? r : -r;
+    } else if (start == 0) {
+        a0 = 0;   // no bend yet and the walk began at the fibre start: the first piece starts at sample 0, height 0
+    }
+    double s = 0.0;
+    int cnt = 0;
+    for (int k = a0; k <= ce - 2; k++) {
+        s += Ycol[(k - lo) * PITCH];
+        cnt++;
+        const int e = k - cs;
+        if (e >= 0 && ((ends >> e) & 1u)) {
+            const double r = WEIGHTED ? Wcol[(k - lo) * PITCH] : lam;
+            const double hk = ((types >> e) & 1u) ? r : -r;
+            const double sc = (double)cnt;
+            Ycol[(k - lo) * PITCH] = div_by(s + (hk - hprev), sc, refined_rcp(sc));
+            s = 0.0;
+            cnt = 0;
+            hprev = hk;
+        }
+    }
+}
+
+// One workgroup = NW waves = NW consecutive chunks (a "block" of NW*C samples) of the same 64 fibres; it processes
+// plan.qpw consecutive blocks of those fibres.  Per block:
+//   1. stage the window [block start - H, block end + T) into LDS through the op's input functor: all loads of a
+//      thread are issued before the first is waited for; for dimension-0 sweeps the tile is transposed on the way;
+//   2. every wave walks its chunk speculatively (LDS only), recording piece ends, bend types and link codes;
+//   3. links between consecutive chunks are proven through LDS (and, across workgroups, by sweep_fix_kernel);
+//   4. piece values are rebuilt in place (pass A, barrier, pass B), then the block's rows are streamed out through
+//      the op's output functor with the operand fetches of UL rows in flight.
+// LDS carve (dynamic, 16-byte aligned base): Y window | Wt window (weighted) | link codes.
 template <int OP, bool WEIGHTED, bool TRANSPOSED, int C, int NW>
-__global__ __launch_bounds__(64 * NW) void sweep_chunk_kernel(SweepArgs p, FibreGeom g, ChunkPlan plan, link_t *link_in,
-                                                               link_t *link_out, int *failflags) {
+__global__ __launch_bounds__(64 * NW, (WEIGHTED ? 2 : 4)) void sweep_chunk_kernel(SweepArgs p, FibreGeom g, ChunkPlan plan,
+                                                                                   link_t *link_in, link_t *link_out,
+                                                                                   int *failflags) {
     constexpr int PITCH = TRANSPOSED ? 65 : 64;
+    constexpr int H = kWarm, T = kTail, ROWS = H + NW * C + T;
+    constexpr int RB = (ROWS + 63) / 64;                                      // transposed: 64-row blocks per fibre
+    constexpr int NST = TRANSPOSED ? (64 / NW) * RB : (ROWS + NW - 1) / NW;   // staged window elements per thread
+    constexpr int UL = 8;                                                     // epilogue rows in flight per lane
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double *Yp = reinterpret_cast<double *>(smem);
-    double *Wp = Yp + (WEIGHTED ? (size_t)plan.rows * PITCH : 0);
-    double *Vp = Wp + (size_t)plan.rows * PITCH;
-    link_t *nextmask = reinterpret_cast<link_t *>(Vp + (size_t)NW * C * PITCH);
+    double *Wp = Yp + (WEIGHTED ? (size_t)ROWS * PITCH : 0);
+    link_t *codes = reinterpret_cast<link_t *>(Wp + (size_t)ROWS * PITCH);   // [NW + 1][64]; slot NW carries over blocks
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int len = g.len;
-    const int q = blockIdx.y;
-    const int cs_wg = q * NW * C;
-    const int lo = max(0, cs_wg - plan.H);
-    const int hi = min(len, cs_wg + NW * C + plan.T);
     const long j0 = (long)blockIdx.x * 64;
     const long j = j0 + lane;
     const bool active = j < g.count;
@@ -233,164 +286,183 @@ __global__ __launch_bounds__(64 * NW) void sweep_chunk_kernel(SweepArgs p, Fibre
         wbase = blk * g.inc * (len - 1) + off;
     }
 
-    // ---- stage the window: every global read is a coalesced 512-byte row -------------------------------------------
-    // Loads are issued in batches of UL independent requests per lane before anything waits on them: the window is
-    // small, so memory-level parallelism inside the wave is what hides the HBM latency.
-    constexpr int UL = 8;
-    if (plan.ablate & 4) {
-        for (int e = tid; e < plan.rows * PITCH; e += 64 * NW) Yp[e] = (double)((e * 2654435761u) >> 20) * 1e-3;
-    } else if (!TRANSPOSED) {
-        if (active) {
-            for (int r0 = lo + wave * UL; r0 < hi; r0 += NW * UL) {
-                double ty[UL], tw[UL];
+    // Strided sweeps: element u of a thread is row lo + wave + NW*u of its own fibre (each wave instruction = one
+    // coalesced 512-byte row).  Dimension-0 sweeps (fibres contiguous): lanes run ALONG the fibre, element u is row
+    // lo + 64*(u % RB) + lane of fibre wave + NW*(u / RB), and the tile is transposed on its way into LDS (pitch 65).
+    auto stage = [&](int q) {
+        const int cs_wg = q * NW * C;
+        const int lo = max(0, cs_wg - H), hi = min(len, cs_wg + NW * C + T);
+        double s0[NST], s1[NST], sw[NST];
 #pragma unroll
-                for (int u = 0; u < UL; u++) {
-                    const int r = r0 + u;
-                    ty[u] = (r < hi) ? Op<OP>::load_y(p, base + (long)r * g.inc) : 0.0;
-                    if (WEIGHTED) tw[u] = (r < len - 1) ? p.w[wbase + (long)r * g.inc] : 0.0;
+        for (int u = 0; u < NST; u++) {
+            int r;
+            long idx, widx;
+            bool ok;
+            if (!TRANSPOSED) {
+                r = lo + wave + NW * u;
+                ok = active && r < hi;
+                idx = base + (long)r * g.inc;
+                widx = wbase + (long)r * g.inc;
+            } else {
+                const long jf = j0 + wave + NW * (u / RB);
+                r = lo + (u % RB) * 64 + lane;
+                ok = jf < g.count && r < hi;
+                idx = jf * len + r;
+                widx = jf * (len - 1) + r;
+            }
+            s0[u] = s1[u] = 0.0;
+            if (ok) Op<OP>::fetch_in(p, idx, s0[u], s1[u]);
+            if (WEIGHTED) sw[u] = (ok && r < len - 1) ? p.w[widx] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < NST; u++) {
+            int r, col;
+            bool ok;
+            if (!TRANSPOSED) {
+                r = lo + wave + NW * u;
+                col = lane;
+                ok = active && r < hi;
+            } else {
+                col = wave + NW * (u / RB);
+                r = lo + (u % RB) * 64 + lane;
+                ok = j0 + col < g.count && r < hi;
+            }
+            if (ok) {
+                Yp[(r - lo) * PITCH + col] = Op<OP>::y_of(p, s0[u], s1[u]);
+                if (WEIGHTED) Wp[(r - lo) * PITCH + col] = sw[u];
+            }
+        }
+    };
+
+    const int q_first = blockIdx.y * plan.qpw;
+    const int nblk = min(plan.qpw, plan.Q - q_first);
+
+    for (int kb = 0; kb < nblk; kb++) {
+        const int q = q_first + kb;
+        if (plan.ablate & 4) {
+            if (kb == 0)
+                for (int e = tid; e < ROWS * PITCH; e += 64 * NW) Yp[e] = (double)((e * 2654435761u) >> 20) * 1e-3;
+        } else {
+            stage(q);
+        }
+        __syncthreads();
+
+        const int cs_wg = q * NW * C;
+        const int lo = max(0, cs_wg - H);
+        const int hi = min(len, cs_wg + NW * C + T);
+
+        // ---- speculative walk of this wave's chunk --------------------------------------------------------------------
+        const int cs = cs_wg + wave * C;
+        const int ce = min(cs + C, len);
+        const bool has_chunk = active && cs < len;
+        const int start = max(0, cs - H);
+        ChunkSource<OP, WEIGHTED, PITCH> src{p, base, g.inc, wbase, Yp + lane, Wp + lane, lo, hi, cs, ce, len};
+        if (has_chunk && !(plan.ablate & 1)) {
+            Walker w;
+            walker_start<WEIGHTED>(w, src, start, p.lam);
+            walker_run_interior<WEIGHTED>(w, src, len, p.lam);   // the hot part
+            walker_run<WEIGHTED>(w, src, len, p.lam);            // fibre end / window end (no-op for most lanes)
+            if (src.failed) failflags[j] = 1;
+        }
+
+        // ---- prove the links between consecutive chunks ------------------------------------------------------------------
+        codes[wave * 64 + lane] = src.next;
+        __syncthreads();   // all walks done: link codes visible, window rows no longer read as walk input
+        if (has_chunk) {
+            const bool true_start = (start == 0);
+            if (wave > 0 || kb > 0) {
+                const link_t prev = (wave > 0) ? codes[(wave - 1) * 64 + lane] : codes[NW * 64 + lane];
+                if (!true_start && (src.mine == 0 || src.mine != prev)) failflags[j] = 1;
+            } else if (q > 0) {
+                // first chunk of the workgroup: the previous chunk lives in another workgroup -> checked by sweep_fix_kernel
+                link_in[(long)blockIdx.y * g.count + j] = true_start ? kLinkAlwaysOk : src.mine;
+            }
+            if (wave == NW - 1 && kb == nblk - 1 && q + 1 < plan.Q) link_out[(long)blockIdx.y * g.count + j] = src.next;
+            // pass A: piece values at the piece-end rows
+            rebuild_piece_ends<WEIGHTED, PITCH>(Yp + lane, Wp + lane, lo, cs, ce, start, src.mine, src.ends, src.types, p.lam);
+        }
+        __syncthreads();
+        if (wave == NW - 1) codes[NW * 64 + lane] = src.next;   // carried to the next block's first chunk
+        // pass B: every row of the chunk gets its prox value
+        if (has_chunk) {
+            double cur = src.vclose;
+            for (int k = ce - 1; k >= cs; k--) {
+                if (k < ce - 1 && ((src.ends >> (k - cs)) & 1u)) cur = Yp[(k - lo) * PITCH + lane];
+                Yp[(k - lo) * PITCH + lane] = cur;
+            }
+        }
+        __syncthreads();
+
+        // ---- stream the block's NW*C rows out: coalesced 512-byte rows, UL operand fetches in flight per lane ------------------
+        const int ce_wg = min(len, cs_wg + NW * C);
+        if (!(plan.ablate & 2)) {
+            if (!TRANSPOSED) {
+                if (active) {
+                    for (int k0 = cs_wg + wave * UL; k0 < ce_wg; k0 += NW * UL) {
+                        Ext ex[UL];
+#pragma unroll
+                        for (int u = 0; u < UL; u++) {
+                            const int k = min(k0 + u, ce_wg - 1);
+                            ex[u] = Op<OP>::fetch(p, base + (long)k * g.inc);
+                        }
+#pragma unroll
+                        for (int u = 0; u < UL; u++) {
+                            const int k = k0 + u;
+                            if (k < ce_wg) Op<OP>::finish(p, base + (long)k * g.inc, ex[u], Yp[(k - lo) * PITCH + lane]);
+                        }
+                    }
                 }
+            } else {
+                constexpr int ERB = (NW * C + 63) / 64;
+                constexpr int items = (64 / NW) * ERB;
 #pragma unroll
-                for (int u = 0; u < UL; u++) {
-                    const int r = r0 + u;
-                    if (r < hi) {
-                        Yp[(r - lo) * PITCH + lane] = ty[u];
-                        if (WEIGHTED) Wp[(r - lo) * PITCH + lane] = tw[u];
+                for (int t0 = 0; t0 < items; t0 += UL) {
+                    Ext ex[UL];
+#pragma unroll
+                    for (int u = 0; u < UL; u++) {
+                        const int t = t0 + u;
+                        const long jf = j0 + wave + NW * (t / ERB);
+                        const int k = cs_wg + (t % ERB) * 64 + lane;
+                        const bool ok = t < items && jf < g.count && k < ce_wg;
+                        ex[u] = ok ? Op<OP>::fetch(p, jf * len + k) : Ext{0, 0};
+                    }
+#pragma unroll
+                    for (int u = 0; u < UL; u++) {
+                        const int t = t0 + u;
+                        const int f = wave + NW * (t / ERB);
+                        const int k = cs_wg + (t % ERB) * 64 + lane;
+                        if (t < items && j0 + f < g.count && k < ce_wg)
+                            Op<OP>::finish(p, (j0 + f) * len + k, ex[u], Yp[(k - lo) * PITCH + f]);
                     }
                 }
             }
         }
-    } else {
-        // fibres are contiguous (inc == 1): lanes run along the fibre, the tile is transposed on its way into LDS.
-        // Work item t of a wave = (fibre wave + NW * (t / RB), row block t % RB); UL items in flight.
-        const int nrows = hi - lo;
-        const int RB = (nrows + 63) / 64;
-        const int items = (64 / NW) * RB;
-        for (int t0 = 0; t0 < items; t0 += UL) {
-            double ty[UL], tw[UL];
-#pragma unroll
-            for (int u = 0; u < UL; u++) {
-                const int t = t0 + u;
-                const int f = wave + NW * (t / RB);
-                const int r = lo + (t % RB) * 64 + lane;
-                const long jf = j0 + f;
-                const bool ok = t < items && jf < g.count && r < hi;
-                ty[u] = ok ? Op<OP>::load_y(p, jf * len + r) : 0.0;
-                if (WEIGHTED) tw[u] = (ok && r < len - 1) ? p.w[jf * (len - 1) + r] : 0.0;
-            }
-#pragma unroll
-            for (int u = 0; u < UL; u++) {
-                const int t = t0 + u;
-                const int f = wave + NW * (t / RB);
-                const int r = lo + (t % RB) * 64 + lane;
-                if (t < items && j0 + f < g.count && r < hi) {
-                    Yp[(r - lo) * PITCH + f] = ty[u];
-                    if (WEIGHTED) Wp[(r - lo) * PITCH + f] = tw[u];
-                }
-            }
-        }
-    }
-    __syncthreads();
-
-    // ---- speculative walk of this wave's chunk ------------------------------------------------------------------------
-    const int cs = cs_wg + wave * C;
-    const int ce = min(cs + C, len);
-    const bool has_chunk = active && cs < len;
-    const int start = max(0, cs - plan.H);
-    ChunkSource<OP, WEIGHTED, PITCH> src{p, base, g.inc, wbase, Yp + lane, Wp + lane, Vp + lane,
-                                         lo, hi, cs, ce, cs_wg, len};
-    if (has_chunk && !(plan.ablate & 1)) {
-        Walker w;
-        walker_start<WEIGHTED>(w, src, start, p.lam);
-        walker_run_interior<WEIGHTED>(w, src, len, p.lam);   // the hot part
-        walker_run<WEIGHTED>(w, src, len, p.lam);            // fibre end / window end (no-op for most lanes)
-        if (src.failed) failflags[j] = 1;
-    }
-
-    // ---- prove the links between consecutive chunks ----------------------------------------------------------------------
-    nextmask[wave * 64 + lane] = src.next;
-    __syncthreads();
-    if (has_chunk) {
-        const bool true_start = (start == 0);
-        if (wave > 0) {
-            if (!true_start && (src.mine == 0 || src.mine != nextmask[(wave - 1) * 64 + lane])) failflags[j] = 1;
-        } else if (q > 0) {
-            link_in[(long)q * g.count + j] = true_start ? kLinkAlwaysOk : src.mine;
-        }
-        // the lane owning the workgroup's last chunk publishes its bends for the next workgroup's first chunk
-        if (q + 1 < plan.Q && (wave == NW - 1)) link_out[(long)q * g.count + j] = src.next;
-    }
-
-    // ---- write the outputs of [cs, ce): backward fill from the piece ends ---------------------------------------------------
-    // Step 1 (LDS only): expand the piece ends into one prox value per owned sample, in place in the V plane.
-    if (has_chunk) {
-        double cur = src.vclose;
-        for (int k = ce - 1; k >= cs; k--) {
-            if (k < ce - 1 && ((src.ends >> (k - cs)) & 1)) cur = Vp[(k - cs_wg) * PITCH + lane];
-            Vp[(k - cs_wg) * PITCH + lane] = cur;
-        }
-    }
-    __syncthreads();
-    // Step 2: the whole workgroup streams its NW*C rows out, every global access a coalesced 512-byte row, the
-    // operand fetches of UL rows in flight before the first dependent store.
-    const int ce_wg = min(len, cs_wg + NW * C);
-    if (plan.ablate & 2) return;
-    if (!TRANSPOSED) {
-        if (active) {
-            for (int k0 = cs_wg + wave * UL; k0 < ce_wg; k0 += NW * UL) {
-                Ext ex[UL];
-#pragma unroll
-                for (int u = 0; u < UL; u++) {
-                    const int k = min(k0 + u, ce_wg - 1);
-                    ex[u] = Op<OP>::fetch(p, base + (long)k * g.inc);
-                }
-#pragma unroll
-                for (int u = 0; u < UL; u++) {
-                    const int k = k0 + u;
-                    if (k < ce_wg)
-                        Op<OP>::finish(p, base + (long)k * g.inc, ex[u], Yp[(k - lo) * PITCH + lane],
-                                       Vp[(k - cs_wg) * PITCH + lane]);
-                }
-            }
-        }
-    } else {
-        const int nrows = ce_wg - cs_wg;
-        const int RB = (nrows + 63) / 64;
-        const int items = (64 / NW) * RB;
-        for (int t0 = 0; t0 < items; t0 += UL) {
-            Ext ex[UL];
-#pragma unroll
-            for (int u = 0; u < UL; u++) {
-                const int t = t0 + u;
-                const int f = wave + NW * (t / RB);
-                const int k = cs_wg + (t % RB) * 64 + lane;
-                const long jf = j0 + f;
-                const bool ok = t < items && jf < g.count && k < ce_wg;
-                ex[u] = ok ? Op<OP>::fetch(p, jf * len + k) : Ext{0, 0, 0};
-            }
-#pragma unroll
-            for (int u = 0; u < UL; u++) {
-                const int t = t0 + u;
-                const int f = wave + NW * (t / RB);
-                const int k = cs_wg + (t % RB) * 64 + lane;
-                const long jf = j0 + f;
-                if (t < items && jf < g.count && k < ce_wg)
-                    Op<OP>::finish(p, jf * len + k, ex[u], Yp[(k - lo) * PITCH + f], Vp[(k - cs_wg) * PITCH + f]);
-            }
-        }
+        if (kb + 1 < nblk) __syncthreads();   // every wave is done reading this block's window
     }
 }
 
 // Re-solves, sequentially and from the untouched operands, every fibre with an unproven link.
+// WQ = number of workgroup rows of the chunk kernel (links between blocks of one workgroup were checked in-kernel).
 template <int OP, bool WEIGHTED>
-__global__ __launch_bounds__(64) void sweep_fix_kernel(SweepArgs p, FibreGeom g, int Q, const link_t *link_in,
+__global__ __launch_bounds__(64) void sweep_fix_kernel(SweepArgs p, FibreGeom g, int WQ, const link_t *link_in,
                                                         const link_t *link_out, int *failflags, int *failcount) {
     const long j = (long)blockIdx.x * 64 + threadIdx.x;
     if (j >= g.count) return;
     int bad = failflags[j];
-    for (int q = 1; q < Q; q++)
-    {
-        const link_t in = link_in[(long)q * g.count + j];
-        if (in != kLinkAlwaysOk && (in == 0 || in != link_out[(long)(q - 1) * g.count + j])) bad = 1;
+    // cross-workgroup links, 16 boundaries (32 independent loads) in flight per lane: the common case of this kernel
+    // is "nothing to repair", so its cost is the latency of reading the link words
+    constexpr int UB = 16;
+    for (int q0 = 1; q0 < WQ; q0 += UB) {
+        link_t in[UB], out[UB];
+#pragma unroll
+        for (int u = 0; u < UB; u++) {
+            const int q = min(q0 + u, WQ - 1);
+            in[u] = link_in[(long)q * g.count + j];
+            out[u] = link_out[(long)(q - 1) * g.count + j];
+        }
+#pragma unroll
+        for (int u = 0; u < UB; u++)
+            if (in[u] != kLinkAlwaysOk && (in[u] == 0 || in[u] != out[u])) bad = 1;
     }
     if (!bad) return;
     failflags[j] = 0;
@@ -407,20 +479,20 @@ void launch_seq(const SweepArgs &args, const FibreGeom &g, hipStream_t stream) {
     PTV_HIP(hipGetLastError());
 }
 
-// persistent per-thread scratch of the chunked path: link masks, fail flags, fail counter
+// persistent per-thread scratch of the chunked path: link codes, fail flags, fail counter
 struct ChunkScratch {
     std::unique_ptr<Scratch> links, flags;
     size_t link_bytes = 0, flag_count = 0;
     link_t *link_in = nullptr, *link_out = nullptr;
     int *failflags = nullptr, *failcount = nullptr;
-    void ensure(long count, int Q, hipStream_t s) {
-        const size_t need = sizeof(link_t) * (size_t)count * (size_t)Q * 2;
+    void ensure(long count, int WQ, hipStream_t s) {
+        const size_t need = sizeof(link_t) * (size_t)count * (size_t)WQ * 2;
         if (need > link_bytes) {
             links.reset(new Scratch(need));
             link_bytes = need;
         }
         link_in = links->as<link_t>();
-        link_out = link_in + (size_t)count * (size_t)Q;
+        link_out = link_in + (size_t)count * (size_t)WQ;
         if ((size_t)count + 1 > flag_count) {
             flags.reset(new Scratch(sizeof(int) * ((size_t)count + 1)));
             flag_count = (size_t)count + 1;
@@ -432,22 +504,29 @@ struct ChunkScratch {
 };
 static thread_local ChunkScratch g_chunk;
 
-template <int OP, bool WEIGHTED, bool TRANSPOSED, int C, int NW>
-void launch_chunk_cfg(const SweepArgs &args, const FibreGeom &g, hipStream_t stream) {
+// Chunk geometry: C = 16 samples per chunk, 8 waves (chunks) per block of 128 samples.  LDS per workgroup = one window
+// of 16 + 128 + 8 rows x 512 B ~ 77 KiB (twice that with the penalty window of weighted sweeps): two workgroups
+// = 16 waves per CU unweighted, one (8 waves) weighted.
+template <int OP, bool WEIGHTED, bool TRANSPOSED>
+void launch_chunk(const SweepArgs &args, const FibreGeom &g, hipStream_t stream) {
+    constexpr int C = 16, NW = 8;
     constexpr int PITCH = TRANSPOSED ? 65 : 64;
+    constexpr int ROWS = kWarm + NW * C + kTail;
     ChunkPlan plan;
-    plan.H = options().warmup < 1 ? 1 : (options().warmup > 32 ? 32 : options().warmup);
-    plan.T = 8;
     plan.Q = (g.len + NW * C - 1) / (NW * C);
-    plan.rows = plan.H + NW * C + plan.T;
-    plan.ablate = options().ablate;
-    const size_t lds = sizeof(double) * PITCH * ((size_t)plan.rows * (WEIGHTED ? 2 : 1) + (size_t)NW * C) +
-                       sizeof(link_t) * NW * 64;
-    if (lds > 160 * 1024) {
-        set_error("chunk geometry needs %zu bytes of LDS", lds);
-        throw HipFailure{hipErrorInvalidValue};
+    // blocks per workgroup: enough workgroups to fill the chip a few times over, then as deep a pipeline as possible
+    const long groups = (g.count + 63) / 64;
+    int qpw = options().blocks_per_wg;
+    if (qpw <= 0) {
+        qpw = 8;
+        while (qpw > 1 && groups * ((plan.Q + qpw - 1) / qpw) < 2048) qpw >>= 1;
     }
-    g_chunk.ensure(g.count, plan.Q, stream);
+    plan.qpw = qpw < plan.Q ? qpw : plan.Q;
+    plan.ablate = options().ablate;
+    const int WQ = (plan.Q + plan.qpw - 1) / plan.qpw;
+    constexpr size_t lds = sizeof(double) * PITCH * (size_t)ROWS * (WEIGHTED ? 2 : 1) + sizeof(link_t) * (NW + 1) * 64;
+    static_assert(lds <= 160 * 1024, "chunk geometry does not fit the LDS of a CU");
+    g_chunk.ensure(g.count, WQ, stream);
     auto kern = sweep_chunk_kernel<OP, WEIGHTED, TRANSPOSED, C, NW>;
     static thread_local bool attr_set = false;
     if (!attr_set) {
@@ -455,30 +534,19 @@ void launch_chunk_cfg(const SweepArgs &args, const FibreGeom &g, hipStream_t str
                                     160 * 1024));
         attr_set = true;
     }
-    const dim3 grid((unsigned)((g.count + 63) / 64), (unsigned)plan.Q);
+    const dim3 grid((unsigned)groups, (unsigned)WQ);
     hipLaunchKernelGGL(kern, grid, dim3(64 * NW), lds, stream, args, g, plan, g_chunk.link_in, g_chunk.link_out,
                        g_chunk.failflags);
     if (!plan.ablate)
-        hipLaunchKernelGGL((sweep_fix_kernel<OP, WEIGHTED>), dim3((unsigned)((g.count + 63) / 64)), dim3(64), 0, stream,
-                           args, g, plan.Q, g_chunk.link_in, g_chunk.link_out, g_chunk.failflags, g_chunk.failcount);
+        hipLaunchKernelGGL((sweep_fix_kernel<OP, WEIGHTED>), dim3((unsigned)groups), dim3(64), 0, stream, args, g, WQ,
+                           g_chunk.link_in, g_chunk.link_out, g_chunk.failflags, g_chunk.failcount);
     PTV_HIP(hipGetLastError());
-}
-
-// Chunk geometries that fit the 160 KiB of LDS per CU (window + piece values [+ penalties]):
-//   unweighted  C = 32, NW = 4 : ~150 KiB -> 1 workgroup (4 waves) per CU;  C = 16, NW = 4 : ~79 KiB -> 2 per CU
-//   weighted    C = 16, NW = 4 : ~125 KiB -> 1 per CU
-template <int OP, bool WEIGHTED, bool TRANSPOSED>
-void launch_chunk(const SweepArgs &args, const FibreGeom &g, hipStream_t stream) {
-    constexpr int NW = 4;
-    if (WEIGHTED || options().chunk <= 16) launch_chunk_cfg<OP, WEIGHTED, TRANSPOSED, 16, NW>(args, g, stream);
-    else                                   launch_chunk_cfg<OP, WEIGHTED, TRANSPOSED, 32, NW>(args, g, stream);
 }
 
 template <int OP, bool WEIGHTED>
 void launch_op_w(const SweepArgs &args, const FibreGeom &g, hipStream_t stream, bool allow_chunked) {
-    const int c = options().chunk;
-    // chunking pays once a fibre spans several workgroups' worth of chunks; short fibres stay sequential
-    const bool chunked = allow_chunked && c > 0 && g.len >= 256;
+    // chunking pays once a fibre spans several blocks; short fibres stay sequential
+    const bool chunked = allow_chunked && options().chunk > 0 && g.len >= 256;
     if (!chunked) launch_seq<OP, WEIGHTED>(args, g, stream);
     else if (g.inc == 1) launch_chunk<OP, WEIGHTED, true>(args, g, stream);
     else launch_chunk<OP, WEIGHTED, false>(args, g, stream);
@@ -513,9 +581,8 @@ void launch_sweep(OpId op, bool weighted, const SweepArgs &args, const FibreGeom
         PTV_CASE(OP_PROX)
         PTV_CASE(OP_DR_COL)
         PTV_CASE(OP_DR_COL_FINAL)
-        PTV_CASE_U(OP_DR_ROW)
+        PTV_CASE(OP_DR_ROW)
         PTV_CASE_U(OP_DR_ROW_FINAL)
-        PTV_CASE_W(OP_DRW_ROW)
         PTV_CASE_W(OP_DRW_ROW_FINAL)
         PTV_CASE_U(OP_PD2_A)
         PTV_CASE_U(OP_PD2_B)
