@@ -154,6 +154,9 @@ double proxtv_last_kernel_ms(int which);
    thread's stream (0 for noisy data; large when lambda dwarfs the noise).  Diagnostic only: results are exact
    either way. */
 long   proxtv_last_fixups(void);
+/* Geometry policy the adaptive chunk kernel currently uses on this thread: 0 = 16-sample warm-up zones (noisy data,
+   small lambda), 1 = 64-sample zones (pieces of ~10 samples), 2 = sequential kernel (very long pieces). */
+int    proxtv_chunk_mode(void);
 long   proxtv_last_kernel_launches(int which);
 
 #ifdef __cplusplus

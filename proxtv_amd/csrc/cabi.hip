@@ -328,11 +328,14 @@ int proxtv_set_option(const char *key, int value) {
     else if (!strcmp(key, "profile")) slot = &o.profile;
     else if (!strcmp(key, "ablate")) slot = &o.ablate;
     else if (!strcmp(key, "blocks_per_wg")) slot = &o.blocks_per_wg;
+    else if (!strcmp(key, "chunk_mode")) slot = &o.chunk_mode;
     if (!slot) return -1;
     const int old = *slot;
     *slot = value;
     return old;
 }
+
+int proxtv_chunk_mode(void) { return chunk_stats_mode(); }
 
 long proxtv_last_fixups(void) {
     try { return chunk_stats_fixups(thread_stream()); } catch (...) { return -1; }

@@ -17,8 +17,9 @@
 // of [cC, (c+1)C).  Every lane remembers its last bend before its chunk start and before its chunk end; chunk c is
 // proven exact iff its last bend at-or-before cC equals that of chunk c-1's lane (which walks through the same zone
 // on its way to closing its last piece): two walks share their last bend or none.  Fibres with an unproven link
-// (long flat pieces: lambda large against the noise) are re-solved by kernel 1 in `sweep_fix_kernel`, so the result
-// is exact for every input; for noisy data the two walks coincide within a handful of samples.
+// (long flat pieces: lambda large against the noise) get their unproven stretches re-walked by `sweep_repair_kernel`
+// from the last proven bend, so the result is exact for every input; for noisy data the two walks coincide within a
+// handful of samples and nothing needs repair.
 // A workgroup = NW wavefronts = NW consecutive chunks of the same 64 fibres, sharing one LDS window
 // [first chunk - H, last chunk + T) of the fibre samples; the walk itself touches only LDS.
 #include "sweep.hpp"
@@ -32,7 +33,7 @@ namespace ptv {
 namespace {
 
 using link_t = unsigned;                 // (restart << 1 | bend type) of a walk's last bend before a chunk boundary
-constexpr link_t kLinkAlwaysOk = 0xffffffffu;   // the chunk's walk began at sample 0: exact by construction
+constexpr link_t kLinkBad = 0xfffffffeu;        // the chunk's walk ran off its LDS window: trust nothing it recorded
 
 // ---- kernel 1: sequential walk straight from / to global memory --------------------------------------------------
 template <int OP, bool WEIGHTED>
@@ -207,8 +208,12 @@ __device__ __forceinline__ void walker_run_interior(Walker &w, S &src, int n, do
 }
 
 
-constexpr int kWarm = 16;   // H: samples a speculative walk starts before its chunk (its synchronisation zone)
-constexpr int kTail = 8;    // T: look-ahead rows kept in LDS past the last chunk of a block
+constexpr int kWarm = 16;       // H: samples a speculative walk starts before its chunk (its synchronisation zone)
+constexpr int kWarmLong = 64;   // ... for data whose walks need longer to meet (moderate lambda: pieces of ~10 samples)
+constexpr int kTail = 8;    // T: look-ahead rows kept in LDS past the last chunk of a block (short-zone geometry)
+// The last chunk of a block must see the end of the piece that covers its last sample: the look-ahead has to scale
+// with the piece length the geometry is meant for, like the warm-up zone does.
+constexpr int tail_rows(int H) { return H > kWarm ? H : kTail; }
 
 // Piece values from piece ends.  Between two knots of the taut string the prox is constant, and the string's height
 // above the tube centre at a knot is -r after a CEIL bend (the knot sits on the tube floor), +r after a FLOOR bend,
@@ -260,12 +265,12 @@ __device__ __forceinline__ void rebuild_piece_ends(double *Ycol, const double *W
 //   4. piece values are rebuilt in place (pass A, barrier, pass B), then the block's rows are streamed out through
 //      the op's output functor with the operand fetches of UL rows in flight.
 // LDS carve (dynamic, 16-byte aligned base): Y window | Wt window (weighted) | link codes.
-template <int OP, bool WEIGHTED, bool TRANSPOSED, int C, int NW>
-__global__ __launch_bounds__(64 * NW, (WEIGHTED ? 2 : 4)) void sweep_chunk_kernel(SweepArgs p, FibreGeom g, ChunkPlan plan,
-                                                                                   link_t *link_in, link_t *link_out,
+template <int OP, bool WEIGHTED, bool TRANSPOSED, int C, int NW, int H>
+__global__ __launch_bounds__(64 * NW, ((WEIGHTED || H > 16) ? 2 : 4)) void sweep_chunk_kernel(SweepArgs p, FibreGeom g, ChunkPlan plan,
+                                                                                   link_t *code_mine, link_t *code_next,
                                                                                    int *failflags) {
     constexpr int PITCH = TRANSPOSED ? 65 : 64;
-    constexpr int H = kWarm, T = kTail, ROWS = H + NW * C + T;
+    constexpr int T = tail_rows(H), ROWS = H + NW * C + T;
     constexpr int RB = (ROWS + 63) / 64;                                      // transposed: 64-row blocks per fibre
     constexpr int NST = TRANSPOSED ? (64 / NW) * RB : (ROWS + NW - 1) / NW;   // staged window elements per thread
     constexpr int UL = 8;                                                     // epilogue rows in flight per lane
@@ -362,7 +367,11 @@ __global__ __launch_bounds__(64 * NW, (WEIGHTED ? 2 : 4)) void sweep_chunk_kerne
             walker_start<WEIGHTED>(w, src, start, p.lam);
             walker_run_interior<WEIGHTED>(w, src, len, p.lam);   // the hot part
             walker_run<WEIGHTED>(w, src, len, p.lam);            // fibre end / window end (no-op for most lanes)
-            if (src.failed) failflags[j] = 1;
+            if (src.failed) {   // ran off the window: nothing this lane recorded may be trusted
+                failflags[j] = 1;
+                src.mine = kLinkBad;
+                src.next = 0;
+            }
         }
 
         // ---- prove the links between consecutive chunks ------------------------------------------------------------------
@@ -373,11 +382,12 @@ __global__ __launch_bounds__(64 * NW, (WEIGHTED ? 2 : 4)) void sweep_chunk_kerne
             if (wave > 0 || kb > 0) {
                 const link_t prev = (wave > 0) ? codes[(wave - 1) * 64 + lane] : codes[NW * 64 + lane];
                 if (!true_start && (src.mine == 0 || src.mine != prev)) failflags[j] = 1;
-            } else if (q > 0) {
-                // first chunk of the workgroup: the previous chunk lives in another workgroup -> checked by sweep_fix_kernel
-                link_in[(long)blockIdx.y * g.count + j] = true_start ? kLinkAlwaysOk : src.mine;
             }
-            if (wave == NW - 1 && kb == nblk - 1 && q + 1 < plan.Q) link_out[(long)blockIdx.y * g.count + j] = src.next;
+            // Every chunk publishes its two codes: sweep_repair_kernel proves the links between workgroups with them
+            // and, for a fibre with an unproven link, finds where a repair walk may stop.
+            const long slot = (long)(q * NW + wave) * g.count + j;
+            code_mine[slot] = src.mine;
+            code_next[slot] = src.next;
             // pass A: piece values at the piece-end rows
             rebuild_piece_ends<WEIGHTED, PITCH>(Yp + lane, Wp + lane, lo, cs, ce, start, src.mine, src.ends, src.types, p.lam);
         }
@@ -441,33 +451,119 @@ __global__ __launch_bounds__(64 * NW, (WEIGHTED ? 2 : 4)) void sweep_chunk_kerne
     }
 }
 
-// Re-solves, sequentially and from the untouched operands, every fibre with an unproven link.
-// WQ = number of workgroup rows of the chunk kernel (links between blocks of one workgroup were checked in-kernel).
+// ---- kernel 3: local repair of unproven stretches -----------------------------------------------------------------------
+// One lane per fibre.  Fast path (the common case): every link is proven -> return.  Otherwise the lane scans its
+// chunks in order keeping `cur` = the last bend of the TRUE walk (chunk 0 is true by construction; a chunk whose
+// `mine` code equals `cur` continues the true walk, so its outputs and its `next` code are true).  At the first
+// chunk that does not, a sequential walk restarts from `cur` -- the walker state after a bend is a function of the
+// bend alone -- rewrites the outputs from that chunk on, and after every chunk boundary it crosses checks whether the
+// chunk recorded there continues ITS walk (same last bend): if so the recorded outputs beyond are exact and the walk
+// stops; the scan resumes there.  Cost: the unproven stretches only (plus the overhang of their last piece), not
+// the fibre.  Data with pieces much longer than a chunk fail everywhere and degrade to one sequential walk per fibre.
+constexpr link_t kFromStart = 1;   // "no bend yet: the true walk is still in its first piece" (real codes are >= 2)
+
 template <int OP, bool WEIGHTED>
-__global__ __launch_bounds__(64) void sweep_fix_kernel(SweepArgs p, FibreGeom g, int WQ, const link_t *link_in,
-                                                        const link_t *link_out, int *failflags, int *failcount) {
+struct RepairSource {
+    const SweepArgs &p;
+    long base, inc, wbase;
+    const link_t *code_mine;   // [chunk][fibre]
+    long count, j;
+    int C, len;
+    int wfrom;                 // outputs are (re)written from this sample on
+    int boundary;              // next chunk boundary whose chunk may take over
+    link_t last;               // last bend of this walk so far
+    bool stop = false;
+    int resume_chunk = 0;
+    link_t resume_code = 0;
+
+    __device__ __forceinline__ double y(int i) const { return Op<OP>::load_y(p, base + (long)i * inc); }
+    __device__ __forceinline__ double r(int i) const { return p.w[wbase + (long)i * inc]; }
+    __device__ __forceinline__ void piece(int from, int to, double v) const {
+        for (int k = max(from, wfrom); k <= to; k++) {
+            const long idx = base + (long)k * inc;
+            Op<OP>::finish(p, idx, Op<OP>::fetch(p, idx), v);
+        }
+    }
+    __device__ __forceinline__ void bend(int at, int type) {
+        const link_t code = ((link_t)at << 1) | (link_t)type;
+        while (!stop && boundary < len && at >= boundary) {
+            const link_t here = (at == boundary) ? code : last;      // this walk's last bend at-or-before `boundary`
+            const int c = boundary / C;
+            const link_t m = code_mine[(long)c * count + j];
+            if (m != 0 && m == here) {
+                stop = true;
+                resume_chunk = c;
+                resume_code = here;
+            } else {
+                boundary += C;
+            }
+        }
+        last = code;
+    }
+    __device__ __forceinline__ bool keep_going(int) const { return !stop; }
+};
+
+template <int OP, bool WEIGHTED>
+__global__ __launch_bounds__(64) void sweep_repair_kernel(SweepArgs p, FibreGeom g, int C, int H, int chunks_per_wg,
+                                                           const link_t *code_mine, const link_t *code_next,
+                                                           int *failflags, int *failcount) {
     const long j = (long)blockIdx.x * 64 + threadIdx.x;
     if (j >= g.count) return;
+    const int len = g.len;
+    const int NC = (len + C - 1) / C;
     int bad = failflags[j];
-    // cross-workgroup links, 16 boundaries (32 independent loads) in flight per lane: the common case of this kernel
-    // is "nothing to repair", so its cost is the latency of reading the link words
+    // links between workgroups (inside a workgroup they were checked through LDS): 16 boundaries = 32 independent
+    // loads in flight per lane -- the cost of the common case is the latency of these reads
     constexpr int UB = 16;
-    for (int q0 = 1; q0 < WQ; q0 += UB) {
+    for (int c0 = chunks_per_wg; c0 < NC; c0 += UB * chunks_per_wg) {
         link_t in[UB], out[UB];
 #pragma unroll
         for (int u = 0; u < UB; u++) {
-            const int q = min(q0 + u, WQ - 1);
-            in[u] = link_in[(long)q * g.count + j];
-            out[u] = link_out[(long)(q - 1) * g.count + j];
+            const int c = min(c0 + u * chunks_per_wg, NC - 1);
+            in[u] = code_mine[(long)c * g.count + j];
+            out[u] = code_next[(long)(c - 1) * g.count + j];
         }
 #pragma unroll
-        for (int u = 0; u < UB; u++)
-            if (in[u] != kLinkAlwaysOk && (in[u] == 0 || in[u] != out[u])) bad = 1;
+        for (int u = 0; u < UB; u++) {
+            const int c = c0 + u * chunks_per_wg;
+            if (c < NC && c * C - H > 0 && (in[u] == 0 || in[u] != out[u])) bad = 1;
+        }
     }
     if (!bad) return;
     failflags[j] = 0;
-    atomicAdd(failcount, 1);
-    solve_fibre_seq<OP, WEIGHTED>(p, g, j);
+    atomicAdd(failcount, 1);       // fibres that needed a repair
+    int walks = 0;
+
+    const long blk = j / g.inc, off = j % g.inc;
+    const long base = blk * g.inc * len + off, wbase = blk * g.inc * (len - 1) + off;
+    link_t cur = kFromStart;
+    int c = 0;
+    // Two-phase loop so that the lanes of a wave repair TOGETHER: first every lane scans ahead to its next unproven
+    // chunk, then all lanes that found one walk at the same time (a walk nested inside the scan would serialise the
+    // lanes, each reaching its repair at a different trip).
+    while (true) {
+        while (c < NC) {
+            const link_t m = code_mine[(long)c * g.count + j];
+            // a chunk whose walk began at sample 0 is the true walk unless it ran off its window (kLinkBad)
+            const bool accept = (c * C - H <= 0) ? (m != kLinkBad) : (m != 0 && m == cur);
+            if (!accept) break;
+            const link_t nx = code_next[(long)c * g.count + j];
+            if (nx != 0) cur = nx;
+            c++;
+        }
+        if (c >= NC) break;
+        RepairSource<OP, WEIGHTED> src{p, base, g.inc, wbase, code_mine, g.count, j, C, len, c * C, (c + 1) * C,
+                                       (cur == kFromStart) ? 0u : cur};
+        Walker w;
+        if (cur == kFromStart) walker_start<WEIGHTED>(w, src, 0, p.lam);
+        else walker_restart<WEIGHTED>(w, src, (int)(cur >> 1), (int)(cur & 1u), len, p.lam);
+        walker_run<WEIGHTED>(w, src, len, p.lam);
+        walks += src.stop ? (src.resume_chunk - c) : (NC - c);   // chunks this walk had to rewrite
+        if (!src.stop) break;                   // walked to the fibre end: everything from chunk c on is rewritten
+        c = src.resume_chunk;                   // that chunk continues this walk: accepted on the next trip
+        cur = src.resume_code;
+    }
+    atomicAdd(failcount + 1, walks);   // chunks rewritten
 }
 
 // ---- host side ---------------------------------------------------------------------------------------------------------
@@ -479,42 +575,93 @@ void launch_seq(const SweepArgs &args, const FibreGeom &g, hipStream_t stream) {
     PTV_HIP(hipGetLastError());
 }
 
-// persistent per-thread scratch of the chunked path: link codes, fail flags, fail counter
+// persistent per-thread state of the chunked path: link codes, fail flags, counters, and the geometry policy
 struct ChunkScratch {
     std::unique_ptr<Scratch> links, flags;
     size_t link_bytes = 0, flag_count = 0;
-    link_t *link_in = nullptr, *link_out = nullptr;
-    int *failflags = nullptr, *failcount = nullptr;
-    void ensure(long count, int WQ, hipStream_t s) {
-        const size_t need = sizeof(link_t) * (size_t)count * (size_t)WQ * 2;
+    link_t *code_mine = nullptr, *code_next = nullptr;   // [chunk][fibre]
+    int *failflags = nullptr;
+    int *failcount = nullptr;   // [0] fibres that needed repair, [1] chunks rewritten by repair walks (cumulative)
+
+    // Geometry policy.  mode 0: H = 16 (noisy data, small lambda) ; mode 1: H = 64 (pieces of ~10 samples) ;
+    // mode 2: sequential kernel (pieces far longer than a chunk: speculation cannot pay).
+    // The repair kernel's counters are read back lazily (pinned memory + event, never a stall except once per solve)
+    // and the mode escalates when too many chunks need repair.  Every solve starts one level below where the
+    // previous one ended (chunk_stats_reset), so an easy problem after a hard one recovers within two solves.
+    int mode = 0;
+    long sweeps = 0;              // chunked sweeps launched since the last stats reset (= solve start)
+    int *h_counts = nullptr;      // pinned: [slot][2]
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool pending[4] = {false, false, false, false};
+    long pending_chunks[4] = {0, 0, 0, 0};   // chunks processed (cumulative) when the slot's read-back was enqueued
+    long chunks_done = 0, last_chunks = 0;
+    int last_rewritten = 0;
+    int next_slot = 0;
+
+    void ensure(long count, int NC, hipStream_t s) {
+        const size_t need = sizeof(link_t) * (size_t)count * (size_t)NC * 2;
         if (need > link_bytes) {
             links.reset(new Scratch(need));
             link_bytes = need;
         }
-        link_in = links->as<link_t>();
-        link_out = link_in + (size_t)count * (size_t)WQ;
-        if ((size_t)count + 1 > flag_count) {
-            flags.reset(new Scratch(sizeof(int) * ((size_t)count + 1)));
-            flag_count = (size_t)count + 1;
+        code_mine = links->as<link_t>();
+        code_next = code_mine + (size_t)count * (size_t)NC;
+        if ((size_t)count + 2 > flag_count) {
+            flags.reset(new Scratch(sizeof(int) * ((size_t)count + 2)));
+            flag_count = (size_t)count + 2;
             PTV_HIP(hipMemsetAsync(flags->as<int>(), 0, sizeof(int) * flag_count, s));
+            last_rewritten = 0;
         }
         failcount = flags->as<int>();
-        failflags = failcount + 1;
+        failflags = failcount + 2;
+        if (!h_counts) {
+            PTV_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_counts), sizeof(int) * 8, hipHostMallocDefault));
+            for (auto &e : ev) PTV_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        }
+    }
+
+    // fraction of chunks that repair walks had to rewrite over the most recent completed read-back interval, or -1
+    double poll(bool wait, hipStream_t s) {
+        double frac = -1.0;
+        for (int k = 0; k < 4; k++) {
+            const int slot = (next_slot + k) & 3;   // oldest first
+            if (!pending[slot]) continue;
+            if (wait) PTV_HIP(hipEventSynchronize(ev[slot]));
+            else if (hipEventQuery(ev[slot]) != hipSuccess) continue;
+            pending[slot] = false;
+            const long dchunks = pending_chunks[slot] - last_chunks;
+            const int rewritten = h_counts[2 * slot + 1];
+            if (dchunks > 0) frac = (double)(rewritten - last_rewritten) / (double)dchunks;
+            last_chunks = pending_chunks[slot];
+            last_rewritten = rewritten;
+        }
+        (void)s;
+        return frac;
+    }
+
+    void enqueue_readback(hipStream_t s) {
+        const int slot = next_slot;
+        if (pending[slot]) return;   // ring full: skip this sample
+        PTV_HIP(hipMemcpyAsync(h_counts + 2 * slot, failcount, sizeof(int) * 2, hipMemcpyDeviceToHost, s));
+        PTV_HIP(hipEventRecord(ev[slot], s));
+        pending[slot] = true;
+        pending_chunks[slot] = chunks_done;
+        next_slot = (slot + 1) & 3;
     }
 };
 static thread_local ChunkScratch g_chunk;
 
 // Chunk geometry: C = 16 samples per chunk, 8 waves (chunks) per block of 128 samples.  LDS per workgroup = one window
-// of 16 + 128 + 8 rows x 512 B ~ 77 KiB (twice that with the penalty window of weighted sweeps): two workgroups
-// = 16 waves per CU unweighted, one (8 waves) weighted.
-template <int OP, bool WEIGHTED, bool TRANSPOSED>
-void launch_chunk(const SweepArgs &args, const FibreGeom &g, hipStream_t stream) {
+// of H + 128 + 8 rows x 512 B: ~77 KiB for H = 16 -> two workgroups = 16 waves per CU; ~101 KiB for H = 64 -> one.
+// Weighted sweeps carry a second (penalty) window and exist for H = 16 only.
+template <int OP, bool WEIGHTED, bool TRANSPOSED, int H>
+void launch_chunk_h(const SweepArgs &args, const FibreGeom &g, hipStream_t stream) {
     constexpr int C = 16, NW = 8;
     constexpr int PITCH = TRANSPOSED ? 65 : 64;
-    constexpr int ROWS = kWarm + NW * C + kTail;
+    constexpr int ROWS = H + NW * C + tail_rows(H);
     ChunkPlan plan;
     plan.Q = (g.len + NW * C - 1) / (NW * C);
-    // blocks per workgroup: enough workgroups to fill the chip a few times over, then as deep a pipeline as possible
+    // blocks per workgroup: enough workgroups to fill the chip a few times over
     const long groups = (g.count + 63) / 64;
     int qpw = options().blocks_per_wg;
     if (qpw <= 0) {
@@ -526,8 +673,9 @@ void launch_chunk(const SweepArgs &args, const FibreGeom &g, hipStream_t stream)
     const int WQ = (plan.Q + plan.qpw - 1) / plan.qpw;
     constexpr size_t lds = sizeof(double) * PITCH * (size_t)ROWS * (WEIGHTED ? 2 : 1) + sizeof(link_t) * (NW + 1) * 64;
     static_assert(lds <= 160 * 1024, "chunk geometry does not fit the LDS of a CU");
-    g_chunk.ensure(g.count, WQ, stream);
-    auto kern = sweep_chunk_kernel<OP, WEIGHTED, TRANSPOSED, C, NW>;
+    const int NC = (g.len + C - 1) / C;
+    g_chunk.ensure(g.count, NC, stream);
+    auto kern = sweep_chunk_kernel<OP, WEIGHTED, TRANSPOSED, C, NW, H>;
     static thread_local bool attr_set = false;
     if (!attr_set) {
         PTV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -535,12 +683,45 @@ void launch_chunk(const SweepArgs &args, const FibreGeom &g, hipStream_t stream)
         attr_set = true;
     }
     const dim3 grid((unsigned)groups, (unsigned)WQ);
-    hipLaunchKernelGGL(kern, grid, dim3(64 * NW), lds, stream, args, g, plan, g_chunk.link_in, g_chunk.link_out,
+    hipLaunchKernelGGL(kern, grid, dim3(64 * NW), lds, stream, args, g, plan, g_chunk.code_mine, g_chunk.code_next,
                        g_chunk.failflags);
     if (!plan.ablate)
-        hipLaunchKernelGGL((sweep_fix_kernel<OP, WEIGHTED>), dim3((unsigned)groups), dim3(64), 0, stream, args, g, WQ,
-                           g_chunk.link_in, g_chunk.link_out, g_chunk.failflags, g_chunk.failcount);
+        hipLaunchKernelGGL((sweep_repair_kernel<OP, WEIGHTED>), dim3((unsigned)groups), dim3(64), 0, stream, args, g, C,
+                           H, plan.qpw * NW, g_chunk.code_mine, g_chunk.code_next, g_chunk.failflags,
+                           g_chunk.failcount);
     PTV_HIP(hipGetLastError());
+    g_chunk.chunks_done += (long)NC * g.count;
+}
+
+template <int OP, bool WEIGHTED, bool TRANSPOSED>
+void launch_chunk(const SweepArgs &args, const FibreGeom &g, hipStream_t stream) {
+    ChunkScratch &st = g_chunk;
+    if (options().chunk_mode >= 0) st.mode = options().chunk_mode;   // forced by the user / tests
+    else if (st.h_counts) {
+        // The host enqueues a whole solve long before the device finishes its first sweep, so a decision needs a
+        // stall: the first read-back of a solve is always waited for (one short stall per solve), and while the
+        // policy sits in the long-zone mode the next few are too (those sweeps are slow anyway).
+        const bool wait = (st.sweeps == 1) || (st.mode == 1 && st.sweeps <= 4);
+        const double frac = st.poll(wait, stream);
+        if (frac >= 0) {
+            if (st.mode == 0 && frac > 0.002) st.mode = 1;
+            else if (st.mode == 1 && frac > 0.10) st.mode = 2;
+        }
+    }
+    int mode = st.mode;
+    if (WEIGHTED && mode == 1) mode = 0;   // no long-zone geometry for weighted sweeps (LDS): repairs take the load
+    if (mode >= 2) {
+        launch_seq<OP, WEIGHTED>(args, g, stream);
+        return;
+    }
+    if constexpr (!WEIGHTED) {
+        if (mode == 1) launch_chunk_h<OP, false, TRANSPOSED, kWarmLong>(args, g, stream);
+        else           launch_chunk_h<OP, false, TRANSPOSED, kWarm>(args, g, stream);
+    } else {
+        launch_chunk_h<OP, true, TRANSPOSED, kWarm>(args, g, stream);
+    }
+    st.sweeps++;
+    if (options().chunk_mode < 0) st.enqueue_readback(stream);
 }
 
 template <int OP, bool WEIGHTED>
@@ -555,16 +736,26 @@ void launch_op_w(const SweepArgs &args, const FibreGeom &g, hipStream_t stream, 
 }  // namespace
 
 void chunk_stats_reset(hipStream_t s) {
-    if (g_chunk.failcount) PTV_HIP(hipMemsetAsync(g_chunk.failcount, 0, sizeof(int), s));
+    ChunkScratch &st = g_chunk;
+    if (!st.failcount) return;
+    // drain read-backs of the previous solve so that the counters can restart from zero
+    if (st.h_counts) st.poll(true, s);
+    PTV_HIP(hipMemsetAsync(st.failcount, 0, sizeof(int) * 2, s));
+    st.sweeps = 0;
+    st.chunks_done = st.last_chunks = 0;
+    st.last_rewritten = 0;
+    if (st.mode > 0) st.mode--;   // probe one level down once per solve
 }
 
 long chunk_stats_fixups(hipStream_t s) {
     if (!g_chunk.failcount) return 0;
-    int h = 0;
-    PTV_HIP(hipMemcpyAsync(&h, g_chunk.failcount, sizeof(int), hipMemcpyDeviceToHost, s));
+    int h[2] = {0, 0};
+    PTV_HIP(hipMemcpyAsync(h, g_chunk.failcount, sizeof(int) * 2, hipMemcpyDeviceToHost, s));
     PTV_HIP(hipStreamSynchronize(s));
-    return h;
+    return h[0];
 }
+
+int chunk_stats_mode() { return g_chunk.mode; }
 
 void launch_sweep(OpId op, bool weighted, const SweepArgs &args, const FibreGeom &g, hipStream_t stream, int fam,
                   bool allow_chunked) {

@@ -52,6 +52,44 @@ __device__ __forceinline__ void walker_start(Walker &w, S &src, int at, double l
     w.i = at;
 }
 
+// Put the walker in the state it has right after a bend of `type` whose new piece starts at sample `at` (0 < at < n).
+// This is the whole point of the chunked kernels: that state depends on nothing but (at, type).  For at < n-1 it is
+// the closed-form first sample used by walker_run's interior branch (a bend met at the last sample, which restarts
+// without stepping, reaches the very same state one trip later); for at == n-1 the no-step form applies.
+template <bool WEIGHTED, class S>
+__device__ __forceinline__ void walker_restart(Walker &w, S &src, int at, int type, int n, double lam) {
+    const int last = n - 1;
+    const bool cv = (type == BEND_CEIL);
+    const double yn = src.y(at);
+    w.k0 = at - 1;
+    w.klo = w.khi = at;
+    if (at < last) {
+        if (WEIGHTED) {
+            const double wp = src.r(at - 1), wc = src.r(at);
+            if (cv) { w.lo = yn + wp - wc; w.hi = yn + wp + wc; }
+            else    { w.hi = yn - wp + wc; w.lo = yn - wp - wc; }
+            w.hhi = wc;
+            w.hlo = -wc;
+        } else {
+            if (cv) { w.lo = yn; w.hi = 2 * lam + yn; }
+            else    { w.hi = yn; w.lo = 2 * (-lam) + yn; }
+            w.hhi = lam;
+            w.hlo = -lam;
+        }
+        w.i = at + 1;
+    } else {
+        if (WEIGHTED) {
+            const double wp = src.r(at - 1);
+            if (cv) { w.lo = yn + wp; w.hi = yn + wp; w.hhi = w.hlo = -wp; }
+            else    { w.hi = yn - wp; w.lo = yn - wp; w.hhi = w.hlo = wp; }
+        } else {
+            if (cv) { w.lo = yn; w.hi = 2 * lam + yn; w.hhi = w.hlo = -lam; }
+            else    { w.hi = yn; w.lo = 2 * (-lam) + yn; w.hhi = w.hlo = lam; }
+        }
+        w.i = at;
+    }
+}
+
 // Run until the fibre end (sample n-1 closed) or until src.keep_going() says stop.
 // Returns true when the fibre end was reached and the closing piece was emitted.
 template <bool WEIGHTED, class S>

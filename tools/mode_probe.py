@@ -1,0 +1,19 @@
+#!/usr/bin/env python3
+"""Time one DR solve (4096^2 N(0,1)) for a given lambda under each pinned chunk-geometry mode; prints repairs."""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from proxtv_amd import _lib, device
+lib = _lib.require_device()
+lam = float(sys.argv[1]) if len(sys.argv) > 1 else 1.0
+X = device.to_colmajor(torch.from_numpy(np.random.default_rng(0).standard_normal((4096, 4096))).cuda())
+out = device.colmajor_empty((4096, 4096))
+ref = None
+for mode in (2, 1, 0, -1):
+    lib.proxtv_set_option(b"chunk_mode", mode)
+    device.tv1_2d(X, lam, out=out); torch.cuda.synchronize()
+    t0 = time.perf_counter(); device.tv1_2d(X, lam, out=out); torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    o = out.clone()
+    if ref is None: ref = o
+    print(f"lam={lam} mode={mode:2d}: {dt*1e3:9.2f} ms  fibres repaired={lib.proxtv_last_fixups():7d}  policy now={lib.proxtv_chunk_mode()}  max|diff vs sequential|={float((o-ref).abs().max()):.2e}")
