@@ -129,6 +129,17 @@ def main():
         dom = 0 if fam_ms[0] >= fam_ms[1] else 1
         avg_ms = fam_ms[dom] / max(fam_n[dom], 1)
         achieved = per_px[dom] * M * N / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        # HBM bytes per launch from the committed PMC run of this same command (tools/pmc_traffic.py: FETCH_SIZE +
+        # WRITE_SIZE, separate passes, calibrated on an 8-B/lane copy of known size).  bench.py cannot run under the
+        # profiler itself, so the figure is read from profiles/; null if that run has not been made for this build.
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+                pmc = json.load(f)
+            label = ["column sweep (DR_COL)", "row sweep (DR_ROW)"][dom]
+            traffic = pmc["kernels"][label]["hbm_total"]
+        except (OSError, KeyError, ValueError):
+            pass
         line = {
             "metric": "Mpixel/s on 2D TV-L1 DR (4096x4096 f64, lambda=0.1); % HBM roofline",
             "value": value, "unit": "Mpixel/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -139,7 +150,7 @@ def main():
                        "parallelism": f"independent images, {world} rank(s), no data-path collective"},
             "roofline": {"bound": "hbm", "kernel": ["column sweep (DR_COL)", "row sweep (DR_ROW, fused reflections+combiner)"][dom],
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "avg_launch_ms": avg_ms, "launches": fam_n[dom],
+                         "traffic": traffic, "avg_launch_ms": avg_ms, "launches": fam_n[dom],
                          "algorithmic_bytes_per_launch": per_px[dom] * M * N,
                          "family_ms_per_solve": {"col": fam_ms[0] / args.steps, "row": fam_ms[1] / args.steps,
                                                  "other": fam_ms[2] / args.steps}},

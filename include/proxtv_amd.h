@@ -157,6 +157,9 @@ long   proxtv_last_fixups(void);
 /* Geometry policy the adaptive chunk kernel currently uses on this thread: 0 = 16-sample warm-up zones (noisy data,
    small lambda), 1 = 64-sample zones (pieces of ~10 samples), 2 = sequential kernel (very long pieces). */
 int    proxtv_chunk_mode(void);
+/* dst = src with the 8-bytes-per-lane access width of the sweep kernels: a known byte count against which the
+   rocprofv3 FETCH_SIZE / WRITE_SIZE counters are calibrated (tools/pmc_traffic.py).  Device pointers. */
+int    proxtv_calib_copy_dev(const double *src, double *dst, long n, void *stream);
 long   proxtv_last_kernel_launches(int which);
 
 #ifdef __cplusplus

@@ -54,6 +54,7 @@ SIGNATURES = {
     "proxtv_DR2_TV_batch": (C.c_int, [C.c_size_t, C.c_size_t, C.c_size_t, _dp, C.c_double, C.c_double, _dp, C.c_int, _dp]),
     "proxtv_last_fixups": (C.c_long, []),
     "proxtv_chunk_mode": (C.c_int, []),
+    "proxtv_calib_copy_dev": (C.c_int, [_dp, _dp, C.c_long, C.c_void_p]),
     "proxtv_last_kernel_ms": (C.c_double, [C.c_int]),
     "proxtv_last_kernel_launches": (C.c_long, [C.c_int]),
 }

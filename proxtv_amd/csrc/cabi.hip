@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "solvers.hpp"
+#include "pointwise.hpp"
 #include "sweep.hpp"
 
 using namespace ptv;
@@ -452,6 +453,14 @@ int proxtv_tv1_fibres_dev(const double *in, double *out, const int *ns, int nds,
         tv1_fibres(in, out, ns, nds, dim, lambda, weights, st);
         PTV_HIP(hipStreamSynchronize(st));
         scope.finish();
+    });
+}
+
+int proxtv_calib_copy_dev(const double *src, double *dst, long n, void *stream) {
+    return guarded("proxtv_calib_copy_dev", nullptr, 1, [&] {
+        hipStream_t st = pick(stream);
+        calib_copy(src, dst, n, st);
+        PTV_HIP(hipStreamSynchronize(st));
     });
 }
 

@@ -58,6 +58,12 @@ __global__ __launch_bounds__(kThreads) void dr_fill_kernel(double *t, long n, co
     for (long i = (long)blockIdx.x * kThreads + threadIdx.x; i < n; i += (long)gridDim.x * kThreads) seg[i] = v;
 }
 
+// Plain 8-bytes-per-lane stream copy: the access width of every sweep kernel.  Used to calibrate the rocprofv3
+// FETCH_SIZE / WRITE_SIZE counters against a known byte count (tools/pmc_traffic.sh), nothing else.
+__global__ __launch_bounds__(kThreads) void calib_copy_kernel(const double *src, double *dst, long n) {
+    for (long i = (long)blockIdx.x * kThreads + threadIdx.x; i < n; i += (long)gridDim.x * kThreads) dst[i] = src[i];
+}
+
 __global__ __launch_bounds__(kThreads) void scale_kernel(const double *y, double *x, double divisor, long n) {
     for (long i = (long)blockIdx.x * kThreads + threadIdx.x; i < n; i += (long)gridDim.x * kThreads) x[i] = y[i] / divisor;
 }
@@ -144,6 +150,11 @@ void pdr_combine(const PtrPack &p, const PtrPack &z, const double *x, double *xo
                  double *out, hipStream_t s) {
     hipLaunchKernelGGL(pdr_combine_kernel, dim3(kReduceBlocks), dim3(kThreads), 0, s, p, z, x, xo, P, n, partials);
     hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(kThreads), 0, s, partials, kReduceBlocks, out);
+    PTV_HIP(hipGetLastError());
+}
+
+void calib_copy(const double *src, double *dst, long n, hipStream_t s) {
+    hipLaunchKernelGGL(calib_copy_kernel, dim3(grid_for(n, 8192)), dim3(kThreads), 0, s, src, dst, n);
     PTV_HIP(hipGetLastError());
 }
 

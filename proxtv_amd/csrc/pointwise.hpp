@@ -28,6 +28,8 @@ void pdr_combine(const PtrPack &p, const PtrPack &z, const double *x, double *xo
                  double *out, hipStream_t s);
 // x = y / P                                                 (PDR initialisation, src/TVNDopt.cpp:362-367)
 void scale_to(const double *y, double *x, double divisor, long n, hipStream_t s);
+// dst = src, 8 bytes per lane (counter calibration only)
+void calib_copy(const double *src, double *dst, long n, hipStream_t s);
 // Yang X update (src/TV2Dopt.cpp:832-833 ; src/TVNDopt.cpp:729-730): X = (Y + sum U_k + rho sum Z_k) / (1 + D rho)
 void yang_x(const double *Y, const PtrPack &U, const PtrPack &Z, double *X, int D, double rho, long n, hipStream_t s);
 

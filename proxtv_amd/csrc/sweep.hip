@@ -721,7 +721,8 @@ void launch_chunk(const SweepArgs &args, const FibreGeom &g, hipStream_t stream)
         launch_chunk_h<OP, true, TRANSPOSED, kWarm>(args, g, stream);
     }
     st.sweeps++;
-    if (options().chunk_mode < 0) st.enqueue_readback(stream);
+    // only the read-backs that a later launch of this solve will wait for are worth a copy on the stream
+    if (options().chunk_mode < 0 && st.sweeps <= 4) st.enqueue_readback(stream);
 }
 
 template <int OP, bool WEIGHTED>
