@@ -1,0 +1,108 @@
+"""The speculative-chunk machinery under stress: data whose walks do NOT meet inside the warm-up zone, so links stay
+unproven, windows overflow and the repair kernel / geometry policy must keep the result exact.  Every case is
+checked against the CPU oracle and across the three pinned geometry modes (0: 16-sample zones, 1: 64-sample zones,
+2: sequential kernel)."""
+import numpy as np
+import pytest
+
+from conftest import assert_close
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def modes(clib):
+    def set_mode(m):
+        clib.proxtv_set_option(b"chunk_mode", m)
+    yield set_mode
+    clib.proxtv_set_option(b"chunk_mode", -1)
+
+
+def _signals(rng, n):
+    yield "randn", rng.standard_normal(n)
+    yield "blocks", np.repeat(rng.standard_normal(n // 50 + 1), 50)[:n] + 0.2 * rng.standard_normal(n)
+    yield "walk", np.cumsum(rng.standard_normal(n)) * 0.3
+    yield "ramp+noise", np.linspace(-5, 5, n) + 0.05 * rng.standard_normal(n)
+    yield "constant", np.full(n, 1.25)
+    yield "sparse spikes", (rng.random(n) < 0.01) * 10.0 * rng.standard_normal(n)
+
+
+def test_long_fibres_all_modes_vs_oracle(ptv, clib, oracle, modes):
+    """Single long fibres (many chunks per fibre) over lambdas from 'every sample bends' to 'one flat piece'."""
+    rng = np.random.default_rng(41)
+    for name, x in _signals(rng, 5000):
+        for lam in (0.05, 0.5, 3.0, 40.0):
+            want = oracle.tv1_hybrid(x, lam)
+            for m in (0, 1, 2):
+                modes(m)
+                got = ptv.tv1_1d(x, lam)
+                assert_close(got, want, tol=1e-11, what=f"{name} lam={lam} mode={m}")
+
+
+def test_repairs_happen_and_are_exact(ptv, clib, oracle, modes):
+    """lambda = 1 on unit noise: walks need ~10-70 samples to meet, so 16-sample zones leave many links unproven."""
+    rng = np.random.default_rng(42)
+    X = rng.standard_normal((700, 900))
+    want = oracle.dr2(X, 1.0)[0]
+    modes(0)
+    got0 = ptv.tv1_2d(X, 1.0)
+    fix0 = clib.proxtv_last_fixups()
+    assert fix0 > 0, "expected unproven links with 16-sample zones at lambda = 1"
+    assert_close(got0, want, tol=1e-11, what="mode 0")
+    modes(1)
+    got1 = ptv.tv1_2d(X, 1.0)
+    assert clib.proxtv_last_fixups() < fix0            # longer zones prove (almost) every link
+    assert_close(got1, want, tol=1e-11, what="mode 1")
+    modes(2)
+    assert_close(ptv.tv1_2d(X, 1.0), want, tol=1e-11, what="mode 2")
+    assert clib.proxtv_last_fixups() == 0
+
+
+def test_policy_escalates_and_recovers(ptv, clib, oracle, modes):
+    """Adaptive policy: easy data stays in mode 0; moderate lambda moves to the long zones; an easy problem afterwards
+    comes back down.  Results are exact throughout."""
+    modes(-1)
+    rng = np.random.default_rng(43)
+    X = rng.standard_normal((600, 640))
+    assert_close(ptv.tv1_2d(X, 0.1), oracle.dr2(X, 0.1)[0], tol=1e-11)
+    assert_close(ptv.tv1_2d(X, 0.1), oracle.dr2(X, 0.1)[0], tol=1e-11)
+    assert clib.proxtv_chunk_mode() == 0 and clib.proxtv_last_fixups() == 0
+    assert_close(ptv.tv1_2d(X, 1.0), oracle.dr2(X, 1.0)[0], tol=1e-11)
+    assert clib.proxtv_chunk_mode() >= 1
+    assert_close(ptv.tv1_2d(X, 30.0), oracle.dr2(X, 30.0)[0], tol=1e-11)       # one piece per fibre: hopeless for chunks
+    for _ in range(3):
+        assert_close(ptv.tv1_2d(X, 0.1), oracle.dr2(X, 0.1)[0], tol=1e-11)
+    assert clib.proxtv_chunk_mode() == 0
+
+
+def test_weighted_and_nd_under_repair(ptv, clib, oracle, modes):
+    rng = np.random.default_rng(44)
+    X = rng.standard_normal((520, 300))
+    W1, W2 = rng.uniform(0.5, 1.5, (519, 300)), rng.uniform(0.5, 1.5, (520, 299))
+    want = oracle.dr2w(X, W1, W2)[0]
+    for m in (0, 2, -1):
+        modes(m)
+        assert_close(ptv.tv1w_2d(X, W1, W2), want, tol=1e-11, what=f"weighted mode {m}")
+    V = rng.standard_normal((300, 280, 6))
+    wantv = oracle.pd(V, [0.8, 0.9, 0.2], [1, 2, 3])[0]
+    for m in (0, 1, 2, -1):
+        modes(m)
+        assert_close(ptv.tvgen(V, [0.8, 0.9, 0.2], [1, 2, 3], [1, 1, 1]), wantv, tol=1e-10, what=f"pd mode {m}")
+
+
+def test_fibre_lengths_around_chunk_and_block_edges(ptv, clib, oracle, modes):
+    """Lengths that are not multiples of the chunk (16) / block (128) sizes, for both sweep orientations."""
+    rng = np.random.default_rng(45)
+    torch = pytest.importorskip("torch")
+    from proxtv_amd import device
+    for n in (256, 257, 271, 272, 383, 384, 385, 511, 1000):
+        A = rng.standard_normal((n, 70))
+        for lam, m in ((0.1, 0), (0.7, 0), (0.7, 1)):
+            modes(m)
+            ad = device.to_colmajor(torch.from_numpy(A).cuda())
+            got = device.tv1_fibres(ad, lam, 0).cpu().numpy()                       # contiguous fibres of length n
+            want = np.apply_along_axis(lambda f: oracle.tv1_hybrid(f, lam), 0, A)
+            assert_close(got, want, tol=1e-11, what=f"dim0 n={n} lam={lam} mode={m}")
+            bd = device.to_colmajor(torch.from_numpy(np.ascontiguousarray(A.T)).cuda())
+            got = device.tv1_fibres(bd, lam, 1).cpu().numpy()                       # strided fibres of length n
+            assert_close(got, want.T, tol=1e-11, what=f"dim1 n={n} lam={lam} mode={m}")
