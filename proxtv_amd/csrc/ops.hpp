@@ -69,22 +69,42 @@ struct InAplusB {
     __device__ static __forceinline__ double load_y(const SweepArgs &p, long idx) { return p.a[idx] + p.b[idx]; }
 };
 
+// An op whose single output is a function of (y, x) alone is FUSED: the chunk kernel evaluates fuse(y, x) in LDS while
+// it still holds y, and streams the result out with no operand fetch at all (store_fused).  The others get x and
+// fetch what they need (fetch / finish).
+struct NotFused {
+    static constexpr bool FUSED = false;
+    __device__ static __forceinline__ double fuse(double, double x) { return x; }
+    __device__ static __forceinline__ void store_fused(const SweepArgs &, long, double) {}
+};
+
 // o0 = prox(a)                                  (PD_TV :164-209, PDR_TV :405-458, batched tv1_1d)
 template <> struct Op<OP_PROX> : InA {
+    static constexpr bool FUSED = true;
+    __device__ static __forceinline__ double fuse(double, double x) { return x; }
+    __device__ static __forceinline__ void store_fused(const SweepArgs &p, long idx, double v) { p.o0[idx] = v; }
     __device__ static __forceinline__ Ext fetch(const SweepArgs &, long) { return Ext{0, 0}; }
     __device__ static __forceinline__ void finish(const SweepArgs &p, long idx, const Ext &, double x) { p.o0[idx] = x; }
 };
 
 // DR, columns (a = t): s = t - prox(t) ; s' = 2 s - t          (src/TV2Dopt.cpp:408-411, 539-547)
 template <> struct Op<OP_DR_COL> : InA {
+    static constexpr bool FUSED = true;
+    __device__ static __forceinline__ double fuse(double y, double x) {
+        const double s = y - x;
+        return 2 * s - y;
+    }
+    __device__ static __forceinline__ void store_fused(const SweepArgs &p, long idx, double v) { p.o0[idx] = v; }
     __device__ static __forceinline__ Ext fetch(const SweepArgs &p, long idx) { return Ext{p.a[idx], 0}; }
     __device__ static __forceinline__ void finish(const SweepArgs &p, long idx, const Ext &e, double x) {
-        const double s = e.e0 - x;
-        p.o0[idx] = 2 * s - e.e0;
+        p.o0[idx] = fuse(e.e0, x);
     }
 };
 // final projection: s = t - prox(t)                              (src/TV2Dopt.cpp:427)
 template <> struct Op<OP_DR_COL_FINAL> : InA {
+    static constexpr bool FUSED = true;
+    __device__ static __forceinline__ double fuse(double y, double x) { return y - x; }
+    __device__ static __forceinline__ void store_fused(const SweepArgs &p, long idx, double v) { p.o0[idx] = v; }
     __device__ static __forceinline__ Ext fetch(const SweepArgs &p, long idx) { return Ext{p.a[idx], 0}; }
     __device__ static __forceinline__ void finish(const SweepArgs &p, long idx, const Ext &e, double x) { p.o0[idx] = e.e0 - x; }
 };
@@ -94,7 +114,7 @@ template <> struct Op<OP_DR_COL_FINAL> : InA {
 // and, weighted (src/TV2DWopt.cpp:114-119, 218): tbw = (v - prox(v)) - U ; tb' = -2 tbw - s' ; same t.
 // Both are t = 0.5 (t + (s' + 2 prox(v))) once U - v is replaced by s' (it IS s' up to the rounding of v): evaluated
 // in that form, which needs s' and t but not U at the epilogue -- a few ulps of |U| away from the reference's order.
-template <> struct Op<OP_DR_ROW> : InBminusA {
+template <> struct Op<OP_DR_ROW> : InBminusA, NotFused {
     __device__ static __forceinline__ Ext fetch(const SweepArgs &p, long idx) { return Ext{p.a[idx], p.c[idx]}; }
     __device__ static __forceinline__ void finish(const SweepArgs &p, long idx, const Ext &e, double x) {
         const double tb = e.e0 + 2 * x;
@@ -102,7 +122,7 @@ template <> struct Op<OP_DR_ROW> : InBminusA {
     }
 };
 // recovery (a = s, b = unary): out = (U - (v - prox(v))) - s                         (src/TV2Dopt.cpp:429-430)
-template <> struct Op<OP_DR_ROW_FINAL> : InBminusA {
+template <> struct Op<OP_DR_ROW_FINAL> : InBminusA, NotFused {
     __device__ static __forceinline__ Ext fetch(const SweepArgs &p, long idx) { return Ext{p.b[idx], p.a[idx]}; }
     __device__ static __forceinline__ void finish(const SweepArgs &p, long idx, const Ext &e, double x) {
         const double y = e.e0 - e.e1;
@@ -111,7 +131,7 @@ template <> struct Op<OP_DR_ROW_FINAL> : InBminusA {
     }
 };
 // weighted recovery: tbw = (v - prox(v)) - U ; out = -s - tbw                          (src/TV2DWopt.cpp:124-126, 218)
-template <> struct Op<OP_DRW_ROW_FINAL> : InBminusA {
+template <> struct Op<OP_DRW_ROW_FINAL> : InBminusA, NotFused {
     __device__ static __forceinline__ Ext fetch(const SweepArgs &p, long idx) { return Ext{p.b[idx], p.a[idx]}; }
     __device__ static __forceinline__ void finish(const SweepArgs &p, long idx, const Ext &e, double x) {
         const double y = e.e0 - e.e1;
@@ -121,7 +141,7 @@ template <> struct Op<OP_DRW_ROW_FINAL> : InBminusA {
 };
 
 // Dykstra term 1 (a = x, b = p_in, o0 = z, o1 = p_out): z = prox(x + p) ; p += x - z   (src/TV2Dopt.cpp:187-213)
-template <> struct Op<OP_PD2_A> : InAplusB {
+template <> struct Op<OP_PD2_A> : InAplusB, NotFused {
     __device__ static __forceinline__ Ext fetch(const SweepArgs &p, long idx) { return Ext{p.a[idx], p.b[idx]}; }
     __device__ static __forceinline__ void finish(const SweepArgs &p, long idx, const Ext &e, double x) {
         p.o0[idx] = x;
@@ -129,7 +149,7 @@ template <> struct Op<OP_PD2_A> : InAplusB {
     }
 };
 // Dykstra term 2 (a = z, b = q_in, o0 = x, o1 = q_out): x = prox(z + q) ; q += z - x    (src/TV2Dopt.cpp:234-263)
-template <> struct Op<OP_PD2_B> : InAplusB {
+template <> struct Op<OP_PD2_B> : InAplusB, NotFused {
     __device__ static __forceinline__ Ext fetch(const SweepArgs &p, long idx) { return Ext{p.a[idx], p.b[idx]}; }
     __device__ static __forceinline__ void finish(const SweepArgs &p, long idx, const Ext &e, double x) {
         p.o0[idx] = x;
@@ -139,7 +159,7 @@ template <> struct Op<OP_PD2_B> : InAplusB {
 
 // Yang ADMM (a = X, b = U_in, o0 = Z, o1 = U_out, s0 = rho):
 //   Z = prox_{lambda/rho}(-1/rho U + X) ; U += rho (Z - X)          (src/TV2Dopt.cpp:836-862 ; src/TVNDopt.cpp:733-788)
-template <> struct Op<OP_YANG> {
+template <> struct Op<OP_YANG> : NotFused {
     static constexpr int NIN = 2;
     __device__ static __forceinline__ void fetch_in(const SweepArgs &p, long idx, double &i0, double &i1) { i0 = p.a[idx]; i1 = p.b[idx]; }
     __device__ static __forceinline__ double y_of(const SweepArgs &p, double i0, double i1) { return -1. / p.s0 * i1 + i0; }

@@ -221,14 +221,17 @@ constexpr int tail_rows(int H) { return H > kWarm ? H : kTail; }
 // piece [a, b] therefore gives   v = ( sum_{a..b} y + h_b - h_{a-1} ) / (b - a + 1).
 // For one-sample pieces this is bit-for-bit the walker's closed-form restart value (y, y +- 2 lambda); for longer
 // pieces it agrees with the walker's running slope to a few ulps (checked on the host: < 1e-15 relative).
-// Pass A walks forward from the start `a0` of the piece that straddles the chunk start (the restart index of the
-// lane's last bend at-or-before cs, i.e. its `mine` code) and leaves each piece's value at the piece's END row, in
-// place in the window; pass B (after a barrier) fills backwards so that row k of the chunk holds x_k.
-// In-place is safe: a row is read by another lane only inside a piece that straddles a chunk boundary, and proven
-// links guarantee no piece END lies inside such a stretch (unproven fibres are re-solved anyway).
-template <bool WEIGHTED, int PITCH>
-__device__ __forceinline__ void rebuild_piece_ends(double *Ycol, const double *Wcol, int lo, int cs, int ce, int start,
-                                                   unsigned mine, unsigned ends, unsigned types, double lam) {
+// rebuild_chunk does this for one lane's chunk, in place in the window, in ONE forward pass: it accumulates y over the
+// current piece and, when the piece ends, goes back over the piece's rows (still holding y) and replaces each by
+// Op::fuse(y, v) -- the prox value itself, or directly the sweep's output when the op's output depends on (y, x) only.
+// The piece that straddles the chunk start is the previous lane's closing piece: for waves > 0 its value arrives
+// through LDS (`v_prev`, the walker's own value), so no lane ever reads a row another lane of the block rewrites;
+// the first wave of a block sums the warm-up rows instead (nobody writes those).  The piece covering the chunk's
+// last sample takes `v_close`, the value the lane's own walk ended with.
+template <int OP, bool WEIGHTED, int PITCH>
+__device__ __forceinline__ void rebuild_chunk(double *Ycol, const double *Wcol, int lo, int cs, int ce, int start,
+                                              unsigned mine, unsigned ends, unsigned types, double v_close,
+                                              double v_prev, bool prev_in_block, double lam) {
     int a0 = cs;
     double hprev = 0.0;
     if (mine != 0) {
@@ -238,22 +241,33 @@ __device__ __forceinline__ void rebuild_piece_ends(double *Ycol, const double *W
     } else if (start == 0) {
         a0 = 0;   // no bend yet and the walk began at the fibre start: the first piece starts at sample 0, height 0
     }
+    bool from_prev = prev_in_block && a0 < cs;
     double s = 0.0;
     int cnt = 0;
-    for (int k = a0; k <= ce - 2; k++) {
+    if (!from_prev)
+        for (int k = a0; k < cs; k++) {
+            s += Ycol[(k - lo) * PITCH];
+            cnt++;
+        }
+    int first = cs;   // first row of the current piece inside the chunk
+    for (int k = cs; k <= ce - 2; k++) {
         s += Ycol[(k - lo) * PITCH];
         cnt++;
         const int e = k - cs;
-        if (e >= 0 && ((ends >> e) & 1u)) {
+        if ((ends >> e) & 1u) {
             const double r = WEIGHTED ? Wcol[(k - lo) * PITCH] : lam;
             const double hk = ((types >> e) & 1u) ? r : -r;
             const double sc = (double)cnt;
-            Ycol[(k - lo) * PITCH] = div_by(s + (hk - hprev), sc, refined_rcp(sc));
+            const double v = from_prev ? v_prev : div_by(s + (hk - hprev), sc, refined_rcp(sc));
+            for (int jj = first; jj <= k; jj++) Ycol[(jj - lo) * PITCH] = Op<OP>::fuse(Ycol[(jj - lo) * PITCH], v);
+            from_prev = false;
+            first = k + 1;
             s = 0.0;
             cnt = 0;
             hprev = hk;
         }
     }
+    for (int jj = first; jj <= ce - 1; jj++) Ycol[(jj - lo) * PITCH] = Op<OP>::fuse(Ycol[(jj - lo) * PITCH], v_close);
 }
 
 // One workgroup = NW waves = NW consecutive chunks (a "block" of NW*C samples) of the same 64 fibres; it processes
@@ -261,9 +275,9 @@ __device__ __forceinline__ void rebuild_piece_ends(double *Ycol, const double *W
 //   1. stage the window [block start - H, block end + T) into LDS through the op's input functor: all loads of a
 //      thread are issued before the first is waited for; for dimension-0 sweeps the tile is transposed on the way;
 //   2. every wave walks its chunk speculatively (LDS only), recording piece ends, bend types and link codes;
-//   3. links between consecutive chunks are proven through LDS (and, across workgroups, by sweep_fix_kernel);
-//   4. piece values are rebuilt in place (pass A, barrier, pass B), then the block's rows are streamed out through
-//      the op's output functor with the operand fetches of UL rows in flight.
+//   3. links between consecutive chunks are proven through LDS (and, across workgroups, by sweep_repair_kernel);
+//   4. piece values are rebuilt in place (rebuild_chunk), then the block's rows are streamed out: straight from LDS
+//      for fused ops, otherwise through the op's output functor with the operand fetches of UL rows in flight.
 // LDS carve (dynamic, 16-byte aligned base): Y window | Wt window (weighted) | link codes.
 template <int OP, bool WEIGHTED, bool TRANSPOSED, int C, int NW, int H>
 __global__ __launch_bounds__(64 * NW, ((WEIGHTED || H > 16) ? 2 : 4)) void sweep_chunk_kernel(SweepArgs p, FibreGeom g, ChunkPlan plan,
@@ -271,6 +285,7 @@ __global__ __launch_bounds__(64 * NW, ((WEIGHTED || H > 16) ? 2 : 4)) void sweep
                                                                                    int *failflags) {
     constexpr int PITCH = TRANSPOSED ? 65 : 64;
     constexpr int T = tail_rows(H), ROWS = H + NW * C + T;
+    static_assert(T >= NW, "the look-ahead rows double as the closing-value slots of the NW waves");
     constexpr int RB = (ROWS + 63) / 64;                                      // transposed: 64-row blocks per fibre
     constexpr int NST = TRANSPOSED ? (64 / NW) * RB : (ROWS + NW - 1) / NW;   // staged window elements per thread
     constexpr int UL = 8;                                                     // epilogue rows in flight per lane
@@ -388,18 +403,17 @@ __global__ __launch_bounds__(64 * NW, ((WEIGHTED || H > 16) ? 2 : 4)) void sweep
             const long slot = (long)(q * NW + wave) * g.count + j;
             code_mine[slot] = src.mine;
             code_next[slot] = src.next;
-            // pass A: piece values at the piece-end rows
-            rebuild_piece_ends<WEIGHTED, PITCH>(Yp + lane, Wp + lane, lo, cs, ce, start, src.mine, src.ends, src.types, p.lam);
         }
+        // The walks are over, so the look-ahead rows are free: tail row `wave` carries this lane's closing value to
+        // the lane of the next chunk (T >= NW).
+        double *vslot = Yp + (size_t)(H + NW * C) * PITCH;
+        vslot[wave * PITCH + lane] = src.vclose;
         __syncthreads();
         if (wave == NW - 1) codes[NW * 64 + lane] = src.next;   // carried to the next block's first chunk
-        // pass B: every row of the chunk gets its prox value
         if (has_chunk) {
-            double cur = src.vclose;
-            for (int k = ce - 1; k >= cs; k--) {
-                if (k < ce - 1 && ((src.ends >> (k - cs)) & 1u)) cur = Yp[(k - lo) * PITCH + lane];
-                Yp[(k - lo) * PITCH + lane] = cur;
-            }
+            const double v_prev = (wave > 0) ? vslot[(wave - 1) * PITCH + lane] : 0.0;
+            rebuild_chunk<OP, WEIGHTED, PITCH>(Yp + lane, Wp + lane, lo, cs, ce, start, src.mine, src.ends, src.types,
+                                               src.vclose, v_prev, wave > 0, p.lam);
         }
         __syncthreads();
 
@@ -413,12 +427,16 @@ __global__ __launch_bounds__(64 * NW, ((WEIGHTED || H > 16) ? 2 : 4)) void sweep
 #pragma unroll
                         for (int u = 0; u < UL; u++) {
                             const int k = min(k0 + u, ce_wg - 1);
-                            ex[u] = Op<OP>::fetch(p, base + (long)k * g.inc);
+                            if (!Op<OP>::FUSED) ex[u] = Op<OP>::fetch(p, base + (long)k * g.inc);
                         }
 #pragma unroll
                         for (int u = 0; u < UL; u++) {
                             const int k = k0 + u;
-                            if (k < ce_wg) Op<OP>::finish(p, base + (long)k * g.inc, ex[u], Yp[(k - lo) * PITCH + lane]);
+                            if (k < ce_wg) {
+                                const double v = Yp[(k - lo) * PITCH + lane];
+                                if (Op<OP>::FUSED) Op<OP>::store_fused(p, base + (long)k * g.inc, v);
+                                else               Op<OP>::finish(p, base + (long)k * g.inc, ex[u], v);
+                            }
                         }
                     }
                 }
@@ -434,15 +452,18 @@ __global__ __launch_bounds__(64 * NW, ((WEIGHTED || H > 16) ? 2 : 4)) void sweep
                         const long jf = j0 + wave + NW * (t / ERB);
                         const int k = cs_wg + (t % ERB) * 64 + lane;
                         const bool ok = t < items && jf < g.count && k < ce_wg;
-                        ex[u] = ok ? Op<OP>::fetch(p, jf * len + k) : Ext{0, 0};
+                        ex[u] = (ok && !Op<OP>::FUSED) ? Op<OP>::fetch(p, jf * len + k) : Ext{0, 0};
                     }
 #pragma unroll
                     for (int u = 0; u < UL; u++) {
                         const int t = t0 + u;
                         const int f = wave + NW * (t / ERB);
                         const int k = cs_wg + (t % ERB) * 64 + lane;
-                        if (t < items && j0 + f < g.count && k < ce_wg)
-                            Op<OP>::finish(p, (j0 + f) * len + k, ex[u], Yp[(k - lo) * PITCH + f]);
+                        if (t < items && j0 + f < g.count && k < ce_wg) {
+                            const double v = Yp[(k - lo) * PITCH + f];
+                            if (Op<OP>::FUSED) Op<OP>::store_fused(p, (j0 + f) * len + k, v);
+                            else               Op<OP>::finish(p, (j0 + f) * len + k, ex[u], v);
+                        }
                     }
                 }
             }
