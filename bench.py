@@ -79,9 +79,15 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus}")
-    torch.cuda.set_device(local)
+    # One rank per GPU over RCCL.  (PROXTV_BENCH_SHARED_GPU=1 is a plumbing dry run for boxes with a single GPU: every
+    # rank uses device 0 and the two scalar collectives go over gloo -- never a measurement.)
+    shared = os.environ.get("PROXTV_BENCH_SHARED_GPU") == "1"
+    torch.cuda.set_device(0 if shared else local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if shared:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     from proxtv_amd import _lib, device
     lib = _lib.require_device()
@@ -116,7 +122,7 @@ def main():
     assert int(info[0]) == ITERS, info
 
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if shared else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 

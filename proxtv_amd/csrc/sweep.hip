@@ -280,7 +280,7 @@ __device__ __forceinline__ void rebuild_chunk(double *Ycol, const double *Wcol, 
 //      for fused ops, otherwise through the op's output functor with the operand fetches of UL rows in flight.
 // LDS carve (dynamic, 16-byte aligned base): Y window | Wt window (weighted) | link codes.
 template <int OP, bool WEIGHTED, bool TRANSPOSED, int C, int NW, int H>
-__global__ __launch_bounds__(64 * NW, ((WEIGHTED || H > 16) ? 2 : 4)) void sweep_chunk_kernel(SweepArgs p, FibreGeom g, ChunkPlan plan,
+__global__ __launch_bounds__(64 * NW, ((WEIGHTED || H > 16) ? NW / 4 : NW / 2)) void sweep_chunk_kernel(SweepArgs p, FibreGeom g, ChunkPlan plan,
                                                                                    link_t *code_mine, link_t *code_next,
                                                                                    int *failflags) {
     constexpr int PITCH = TRANSPOSED ? 65 : 64;
@@ -675,9 +675,8 @@ static thread_local ChunkScratch g_chunk;
 // Chunk geometry: C = 16 samples per chunk, 8 waves (chunks) per block of 128 samples.  LDS per workgroup = one window
 // of H + 128 + 8 rows x 512 B: ~77 KiB for H = 16 -> two workgroups = 16 waves per CU; ~101 KiB for H = 64 -> one.
 // Weighted sweeps carry a second (penalty) window and exist for H = 16 only.
-template <int OP, bool WEIGHTED, bool TRANSPOSED, int H>
+template <int OP, bool WEIGHTED, bool TRANSPOSED, int H, int C = 16, int NW = 8>
 void launch_chunk_h(const SweepArgs &args, const FibreGeom &g, hipStream_t stream) {
-    constexpr int C = 16, NW = 8;
     constexpr int PITCH = TRANSPOSED ? 65 : 64;
     constexpr int ROWS = H + NW * C + tail_rows(H);
     ChunkPlan plan;
@@ -736,8 +735,9 @@ void launch_chunk(const SweepArgs &args, const FibreGeom &g, hipStream_t stream)
         return;
     }
     if constexpr (!WEIGHTED) {
-        if (mode == 1) launch_chunk_h<OP, false, TRANSPOSED, kWarmLong>(args, g, stream);
-        else           launch_chunk_h<OP, false, TRANSPOSED, kWarm>(args, g, stream);
+        if (mode == 1)                    launch_chunk_h<OP, false, TRANSPOSED, kWarmLong>(args, g, stream);
+        else if (options().chunk == 32)   launch_chunk_h<OP, false, TRANSPOSED, kWarm, 32, 4>(args, g, stream);   // experiment
+        else                              launch_chunk_h<OP, false, TRANSPOSED, kWarm>(args, g, stream);
     } else {
         launch_chunk_h<OP, true, TRANSPOSED, kWarm>(args, g, stream);
     }
