@@ -30,7 +30,7 @@ double fetch(const double *dev, hipStream_t s) {
     return h;
 }
 
-int fam_of_dim(int d) { return d == 0 ? FAM_COL : FAM_ROW; }
+int fam_of_dim(int d) { return d == 0 ? FAM_COL : d == 1 ? FAM_ROW : FAM_OTHER; }
 
 }  // namespace
 

@@ -28,6 +28,8 @@
 
 #include "walker.hpp"
 
+#include <cstdio>
+
 namespace ptv {
 
 namespace {
@@ -36,26 +38,88 @@ using link_t = unsigned;                 // (restart << 1 | bend type) of a walk
 constexpr link_t kLinkBad = 0xfffffffeu;        // the chunk's walk ran off its LDS window: trust nothing it recorded
 
 // ---- kernel 1: sequential walk straight from / to global memory --------------------------------------------------
+// Global-memory walks fetch their samples kGlobalBlock at a time (walker_run_blocked) and write a piece out the same
+// way: a batch of independent operand fetches, then the batch of stores -- one memory round trip per batch instead of
+// one per sample.
+constexpr int kGlobalBlock = 8;
+
+template <int OP>
+__device__ __forceinline__ void write_run(const SweepArgs &p, long base, long inc, int from, int to, double v) {
+    int k = from;
+    for (; k + kGlobalBlock - 1 <= to; k += kGlobalBlock) {
+        Ext e[kGlobalBlock];
+#pragma unroll
+        for (int u = 0; u < kGlobalBlock; u++) e[u] = Op<OP>::fetch(p, base + (long)(k + u) * inc);
+#pragma unroll
+        for (int u = 0; u < kGlobalBlock; u++) Op<OP>::finish(p, base + (long)(k + u) * inc, e[u], v);
+    }
+    for (; k <= to; k++) {
+        const long idx = base + (long)k * inc;
+        Op<OP>::finish(p, idx, Op<OP>::fetch(p, idx), v);
+    }
+}
+
+// Queue of one piece whose outputs are still to be written: walker_run_blocked drains it kGlobalBlock samples per trip,
+// software-pipelined like the walk itself -- pump() stores the batch whose operands it fetched one trip earlier and
+// issues the fetches of the next.  (The queued samples all lie before the walk's restart point and are never read
+// again, so in-place sweeps stay correct.)
+template <int OP>
+struct LazyRun {
+    int k = 0, to = -1;
+    double v = 0.0;
+    bool inflight = false;   // e[] holds (or is about to receive) the operands of samples k .. k + kGlobalBlock - 1
+    Ext e[kGlobalBlock];
+    __device__ __forceinline__ void store_batch(const SweepArgs &p, long base, long inc) {
+#pragma unroll
+        for (int u = 0; u < kGlobalBlock; u++)
+            if (k + u <= to) Op<OP>::finish(p, base + (long)(k + u) * inc, e[u], v);
+        k = min(k + kGlobalBlock, to + 1);
+    }
+    __device__ __forceinline__ void pump(const SweepArgs &p, long base, long inc) {
+        if (inflight) store_batch(p, base, inc);
+        inflight = (k <= to);
+        if (inflight) {
+#pragma unroll
+            for (int u = 0; u < kGlobalBlock; u++)
+                if (k + u <= to) e[u] = Op<OP>::fetch(p, base + (long)(k + u) * inc);
+        }
+    }
+    __device__ __forceinline__ void flush(const SweepArgs &p, long base, long inc) {
+        if (inflight) store_batch(p, base, inc);
+        inflight = false;
+        write_run<OP>(p, base, inc, k, to, v);
+        k = to + 1;
+    }
+    __device__ __forceinline__ void queue(const SweepArgs &p, long base, long inc, int from, int to_, double v_) {
+        flush(p, base, inc);
+        k = from;
+        to = to_;
+        v = v_;
+    }
+};
+
 template <int OP, bool WEIGHTED>
 struct SeqSource {
     const SweepArgs &p;
     long base, inc, wbase;
+    LazyRun<OP> run;
     __device__ __forceinline__ double y(int i) const { return Op<OP>::load_y(p, base + (long)i * inc); }
     __device__ __forceinline__ double r(int i) const { return p.w[wbase + (long)i * inc]; }
-    __device__ __forceinline__ void piece(int from, int to, double v) const {
-        for (int j = from; j <= to; j++) {
-            const long idx = base + (long)j * inc;
-            Op<OP>::finish(p, idx, Op<OP>::fetch(p, idx), v);
-        }
-    }
+    __device__ __forceinline__ void piece(int from, int to, double v) { run.queue(p, base, inc, from, to, v); }
     __device__ __forceinline__ void bend(int, int) const {}
     __device__ __forceinline__ bool keep_going(int) const { return true; }
+    __device__ __forceinline__ int limit() const { return 1 << 30; }
+    __device__ __forceinline__ void pump() { run.pump(p, base, inc); }
+    __device__ __forceinline__ void flush() { run.flush(p, base, inc); }
 };
 
-template <int OP, bool WEIGHTED>
+// PIPELINED picks the walker: walker_run_blocked when the pieces are known to be long (the policy's sequential mode),
+// the plain per-sample loop otherwise (short fibres, unknown data: with a bend every few samples the pipelined
+// walker's mispredictions cost more than its batching saves).
+template <int OP, bool WEIGHTED, bool PIPELINED>
 __device__ __forceinline__ void solve_fibre_seq(const SweepArgs &p, const FibreGeom &g, long j) {
     const long blk = j / g.inc, off = j % g.inc;
-    SeqSource<OP, WEIGHTED> src{p, blk * g.inc * g.len + off, g.inc, blk * g.inc * (g.len - 1) + off};
+    SeqSource<OP, WEIGHTED> src{p, blk * g.inc * g.len + off, g.inc, blk * g.inc * (g.len - 1) + off, {}};
     if (WEIGHTED && g.len == 1) {  // no edge at all: prox is the identity (the reference reads lambda[0] out of bounds here)
         const double y0 = src.y(0);
         Op<OP>::finish(p, src.base, Op<OP>::fetch(p, src.base), y0);
@@ -63,14 +127,19 @@ __device__ __forceinline__ void solve_fibre_seq(const SweepArgs &p, const FibreG
     }
     Walker w;
     walker_start<WEIGHTED>(w, src, 0, p.lam);
-    walker_run<WEIGHTED>(w, src, g.len, p.lam);
+    if (PIPELINED) {
+        walker_run_blocked<WEIGHTED, kGlobalBlock>(w, src, g.len, p.lam);
+    } else {
+        walker_run<WEIGHTED>(w, src, g.len, p.lam);
+        src.flush();
+    }
 }
 
-template <int OP, bool WEIGHTED>
+template <int OP, bool WEIGHTED, bool PIPELINED>
 __global__ __launch_bounds__(64) void sweep_seq_kernel(SweepArgs p, FibreGeom g) {
     const long j = (long)blockIdx.x * 64 + threadIdx.x;
     if (j >= g.count || g.len <= 0) return;
-    solve_fibre_seq<OP, WEIGHTED>(p, g, j);
+    solve_fibre_seq<OP, WEIGHTED, PIPELINED>(p, g, j);
 }
 
 // ---- kernel 2: speculative chunks over an LDS window -----------------------------------------------------------------
@@ -472,6 +541,69 @@ __global__ __launch_bounds__(64 * NW, ((WEIGHTED || H > 16) ? NW / 4 : NW / 2)) 
     }
 }
 
+// ---- kernel 2b: speculative chunks straight from global memory (long pieces) ---------------------------------------------------
+// Same scheme as kernel 2 -- one lane per (fibre, chunk), warm-up zone, link codes, repairs by kernel 3 -- for data
+// whose pieces are tens to hundreds of samples long (lambda several times the noise).  There the zone a walk needs to
+// meet the true one is hundreds of samples: no LDS window holds that for 64 fibres, so this variant walks global
+// memory like kernel 1 and lets chunk-level parallelism (fibres x chunks lanes instead of fibres) hide the latency.
+// Chunk and zone sizes are run-time values; the lane owns, and writes, exactly the outputs of its chunk.
+template <int OP, bool WEIGHTED>
+struct GlobalChunkSource {
+    const SweepArgs &p;
+    long base, inc, wbase;
+    int cs, ce;                // samples owned by this lane: [cs, ce)
+    int hi;                    // the walk gives up at this sample (pieces far longer than the zone); == len near the fibre end
+    unsigned mine = 0, next = 0;
+    bool done = false, failed = false;
+    LazyRun<OP> run;
+    __device__ __forceinline__ double y(int i) const { return Op<OP>::load_y(p, base + (long)i * inc); }
+    __device__ __forceinline__ double r(int i) const { return p.w[wbase + (long)i * inc]; }
+    __device__ __forceinline__ void piece(int from, int to, double v) {
+        if (to >= cs) run.queue(p, base, inc, max(from, cs), min(to, ce - 1), v);
+        if (to >= ce - 1) done = true;
+    }
+    __device__ __forceinline__ void pump() { run.pump(p, base, inc); }
+    __device__ __forceinline__ void flush() { run.flush(p, base, inc); }
+    __device__ __forceinline__ void bend(int at, int type) {
+        const unsigned code = ((unsigned)at << 1) | (unsigned)type;
+        mine = (at <= cs) ? code : mine;
+        next = (at <= ce) ? code : next;
+    }
+    __device__ __forceinline__ bool keep_going(int i) {
+        if (done) return false;
+        if (i >= hi) {   // hi == len is never reached by a live walk
+            failed = true;
+            return false;
+        }
+        return true;
+    }
+    __device__ __forceinline__ int limit() const { return hi; }
+};
+
+template <int OP, bool WEIGHTED>
+__global__ __launch_bounds__(64) void sweep_gchunk_kernel(SweepArgs p, FibreGeom g, int C, int H, link_t *code_mine,
+                                                           link_t *code_next, int *failflags) {
+    const long j = (long)blockIdx.x * 64 + threadIdx.x;
+    const int c = blockIdx.y;
+    const int len = g.len;
+    const int cs = c * C;
+    if (j >= g.count || cs >= len) return;
+    const int ce = min(cs + C, len);
+    const long blk = j / g.inc, off = j % g.inc;
+    GlobalChunkSource<OP, WEIGHTED> src{p, blk * g.inc * len + off, g.inc, blk * g.inc * (len - 1) + off, cs, ce,
+                                        min(len, ce + H), 0u, 0u, false, false, {}};
+    Walker w;
+    walker_start<WEIGHTED>(w, src, max(0, cs - H), p.lam);
+    walker_run_blocked<WEIGHTED, kGlobalBlock>(w, src, len, p.lam);
+    if (src.failed) {   // nothing this lane recorded may be trusted; the repair walk rewrites its chunk
+        failflags[j] = 1;
+        src.mine = kLinkBad;
+        src.next = 0;
+    }
+    code_mine[(long)c * g.count + j] = src.mine;
+    code_next[(long)c * g.count + j] = src.next;
+}
+
 // ---- kernel 3: local repair of unproven stretches -----------------------------------------------------------------------
 // One lane per fibre.  Fast path (the common case): every link is proven -> return.  Otherwise the lane scans its
 // chunks in order keeping `cur` = the last bend of the TRUE walk (chunk 0 is true by construction; a chunk whose
@@ -499,12 +631,13 @@ struct RepairSource {
 
     __device__ __forceinline__ double y(int i) const { return Op<OP>::load_y(p, base + (long)i * inc); }
     __device__ __forceinline__ double r(int i) const { return p.w[wbase + (long)i * inc]; }
-    __device__ __forceinline__ void piece(int from, int to, double v) const {
-        for (int k = max(from, wfrom); k <= to; k++) {
-            const long idx = base + (long)k * inc;
-            Op<OP>::finish(p, idx, Op<OP>::fetch(p, idx), v);
-        }
+    LazyRun<OP> run;
+    __device__ __forceinline__ void piece(int from, int to, double v) {
+        if (to >= wfrom) run.queue(p, base, inc, max(from, wfrom), to, v);
     }
+    __device__ __forceinline__ int limit() const { return 1 << 30; }
+    __device__ __forceinline__ void pump() { run.pump(p, base, inc); }
+    __device__ __forceinline__ void flush() { run.flush(p, base, inc); }
     __device__ __forceinline__ void bend(int at, int type) {
         const link_t code = ((link_t)at << 1) | (link_t)type;
         while (!stop && boundary < len && at >= boundary) {
@@ -574,11 +707,16 @@ __global__ __launch_bounds__(64) void sweep_repair_kernel(SweepArgs p, FibreGeom
         }
         if (c >= NC) break;
         RepairSource<OP, WEIGHTED> src{p, base, g.inc, wbase, code_mine, g.count, j, C, len, c * C, (c + 1) * C,
-                                       (cur == kFromStart) ? 0u : cur};
+                                       (cur == kFromStart) ? 0u : cur, false, 0, 0u, {}};
         Walker w;
         if (cur == kFromStart) walker_start<WEIGHTED>(w, src, 0, p.lam);
         else walker_restart<WEIGHTED>(w, src, (int)(cur >> 1), (int)(cur & 1u), len, p.lam);
-        walker_run<WEIGHTED>(w, src, len, p.lam);
+        if (H > kWarmLong) {   // global-memory geometries: long pieces
+            walker_run_blocked<WEIGHTED, kGlobalBlock>(w, src, len, p.lam);
+        } else {
+            walker_run<WEIGHTED>(w, src, len, p.lam);
+            src.flush();
+        }
         walks += src.stop ? (src.resume_chunk - c) : (NC - c);   // chunks this walk had to rewrite
         if (!src.stop) break;                   // walked to the fibre end: everything from chunk c on is rewritten
         c = src.resume_chunk;                   // that chunk continues this walk: accepted on the next trip
@@ -589,35 +727,108 @@ __global__ __launch_bounds__(64) void sweep_repair_kernel(SweepArgs p, FibreGeom
 
 // ---- host side ---------------------------------------------------------------------------------------------------------
 template <int OP, bool WEIGHTED>
-void launch_seq(const SweepArgs &args, const FibreGeom &g, hipStream_t stream) {
+void launch_seq(const SweepArgs &args, const FibreGeom &g, hipStream_t stream, bool long_pieces) {
     const unsigned blocks = (unsigned)((g.count + 63) / 64);
     if (blocks == 0) return;
-    hipLaunchKernelGGL((sweep_seq_kernel<OP, WEIGHTED>), dim3(blocks), dim3(64), 0, stream, args, g);
+    if (long_pieces) hipLaunchKernelGGL((sweep_seq_kernel<OP, WEIGHTED, true>), dim3(blocks), dim3(64), 0, stream, args, g);
+    else             hipLaunchKernelGGL((sweep_seq_kernel<OP, WEIGHTED, false>), dim3(blocks), dim3(64), 0, stream, args, g);
     PTV_HIP(hipGetLastError());
 }
 
-// persistent per-thread state of the chunked path: link codes, fail flags, counters, and the geometry policy
+// Geometry ladder (Policy::mode).  The zone must be a few pieces long for a speculative walk to meet the true one,
+// and piece length grows like (lambda / noise)^2:
+//   0  LDS window, 16-sample zones            pieces of a few samples (the headline regime)
+//   1  LDS window, 64-sample zones            pieces of ~10 samples
+//   2  global memory, zone 256 / chunk 64     pieces of ~50 samples
+//   3  global memory, zone 1024 / chunk 256   pieces of a few hundred samples
+//   4  one sequential walk per fibre          pieces comparable to the fibre: speculation cannot pay
+constexpr int kModeSeq = 4;
+constexpr double kTryUp = 5e-4;     // rewritten-chunk fraction above which a longer zone is worth a trial
+constexpr double kClean = 5e-5;     // ... below which a shorter one is
+constexpr double kJump = 0.5;       // ... above which the trial goes straight to the sequential walk
+constexpr double kBetter = 0.9;     // a trial wins if its sweep took less than this times the incumbent's
+constexpr double kDrift = 1.5;      // steady state: re-explore when the sweep time moved by this factor
+constexpr int kMonitorLag = 2;      // family sweeps between a steady-state sample and its evaluation
+constexpr int kHoldSolves = 2;      // solves during which a rejected direction is not tried again
+constexpr int kQuietSolves = 16;    // one-sweep solves between explorations
+
+// persistent per-thread state of the chunked path: link codes, fail flags, repair counters and the geometry policy
 struct ChunkScratch {
     std::unique_ptr<Scratch> links, flags;
     size_t link_bytes = 0, flag_count = 0;
     link_t *code_mine = nullptr, *code_next = nullptr;   // [chunk][fibre]
     int *failflags = nullptr;
-    int *failcount = nullptr;   // [0] fibres that needed repair, [1] chunks rewritten by repair walks (cumulative)
+    int *failcount = nullptr;   // [family][2]: fibres that needed repair, chunks rewritten by repair walks (cumulative per solve)
 
-    // Geometry policy.  mode 0: H = 16 (noisy data, small lambda) ; mode 1: H = 64 (pieces of ~10 samples) ;
-    // mode 2: sequential kernel (pieces far longer than a chunk: speculation cannot pay).
-    // The repair kernel's counters are read back lazily (pinned memory + event, never a stall except once per solve)
-    // and the mode escalates when too many chunks need repair.  Every solve starts one level below where the
-    // previous one ended (chunk_stats_reset), so an easy problem after a hard one recovers within two solves.
-    int mode = 0;
-    long sweeps = 0;              // chunked sweeps launched since the last stats reset (= solve start)
-    int *h_counts = nullptr;      // pinned: [slot][2]
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-    bool pending[4] = {false, false, false, false};
-    long pending_chunks[4] = {0, 0, 0, 0};   // chunks processed (cumulative) when the slot's read-back was enqueued
-    long chunks_done = 0, last_chunks = 0;
-    int last_rewritten = 0;
+    // Geometry policy, one per sweep family (fibres along dim 0 / along the other dims see different data: in a DR
+    // solve at large lambda the column pieces are several times longer than the row pieces).  It is a hill climb on
+    // MEASURED sweep time with the repair counters as the hint for where to look:
+    //   * a solve starts by measuring one sweep at the incumbent mode (hipEvents around the launch, counters read
+    //     back behind it; the family's next launch waits for both -- the host enqueues a whole solve long before the
+    //     device finishes its first sweep, so a decision needs a stall: one per family and solve in the steady state);
+    //   * many rewritten chunks -> trial of the next longer zone (straight to the sequential walk if most chunks
+    //     failed, then back down); none at all -> trial of the next shorter one; a trial replaces the incumbent if
+    //     its sweep was faster, and the climb goes on in that direction until a trial loses;
+    //   * afterwards a sample (time + counters) is taken every few sweeps and looked at kMonitorLag sweeps later,
+    //     when the device has reached it but still has work queued (no bubble): the data of a solve drift -- DR
+    //     iterates at large lambda grow longer pieces sweep after sweep -- and a drift re-opens the exploration.
+    // The mode persists across solves; one-sweep solves (batched 1-D prox calls) explore across calls.
+    struct Policy {
+        int mode = 0;            // incumbent geometry
+        double t_mode = 0.0;     // ms of its last measured sweep
+        int trial = -1;          // >= 0: geometry under trial
+        int dir = 0;
+        int best = 0;            // fastest geometry of the exploration under way, and its sweep time
+        double best_t = 0.0;
+        long count = 0;          // fibres of the last sweep (a different shape = a different workload)
+        int changes = 0;         // workload changes seen in this solve
+        bool explore = true;
+        int hold_up = 0, hold_down = 0, quiet = 0;
+        long sweeps = 0;         // sweeps of this family since the solve started
+        bool weighted = false;   // of the last sweep: no mode 1 for weighted sweeps (two LDS windows)
+        int len = 0;             // fibre length of the last sweep: no mode 3 below 1024
+        // measurement in flight
+        bool meas = false;
+        int meas_mode = 0, meas_slot = -1;
+        long meas_sweep = 0;
+        hipEvent_t t0 = nullptr, t1 = nullptr;
+        long chunks_done = 0;    // chunks processed (host-side count, cumulative per solve)
+        long chunks_seen = 0;    // ... at the last evaluation
+        int rewritten_seen = 0;
+
+        bool available(int m) const { return !(m == 1 && weighted) && !(m == 3 && len < 1024); }
+        int up(int m) const {
+            do m++; while (m < kModeSeq && !available(m));
+            return m;
+        }
+        int down(int m) const {
+            do m--; while (m > 0 && !available(m));
+            return m;
+        }
+        void conclude() {
+            trial = -1;
+            explore = false;
+        }
+    } pol[FAM_COUNT];
+
+    static constexpr int kSlots = 8, kCounters = 2 * FAM_COUNT;
+    int *h_counts = nullptr;    // pinned: [slot][kCounters]
+    hipEvent_t ev[kSlots] = {};
+    bool pending[kSlots] = {};
+    long pending_chunks[kSlots][FAM_COUNT] = {};
     int next_slot = 0;
+    int latest_rewritten[FAM_COUNT] = {0, 0, 0};
+    long latest_chunks[FAM_COUNT] = {0, 0, 0};
+
+    void ensure_host() {
+        if (h_counts) return;
+        PTV_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_counts), sizeof(int) * kSlots * kCounters, hipHostMallocDefault));
+        for (auto &e : ev) PTV_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        for (auto &pl : pol) {
+            PTV_HIP(hipEventCreate(&pl.t0));
+            PTV_HIP(hipEventCreate(&pl.t1));
+        }
+    }
 
     void ensure(long count, int NC, hipStream_t s) {
         const size_t need = sizeof(link_t) * (size_t)count * (size_t)NC * 2;
@@ -627,47 +838,126 @@ struct ChunkScratch {
         }
         code_mine = links->as<link_t>();
         code_next = code_mine + (size_t)count * (size_t)NC;
-        if ((size_t)count + 2 > flag_count) {
-            flags.reset(new Scratch(sizeof(int) * ((size_t)count + 2)));
-            flag_count = (size_t)count + 2;
+        if ((size_t)count + kCounters > flag_count) {
+            poll(true);   // read-backs of the old counters must land before the buffer goes away
+            flags.reset(new Scratch(sizeof(int) * ((size_t)count + kCounters)));
+            flag_count = (size_t)count + kCounters;
             PTV_HIP(hipMemsetAsync(flags->as<int>(), 0, sizeof(int) * flag_count, s));
-            last_rewritten = 0;
+            for (int f = 0; f < FAM_COUNT; f++) {
+                pol[f].rewritten_seen = 0;
+                latest_rewritten[f] = 0;
+            }
         }
         failcount = flags->as<int>();
-        failflags = failcount + 2;
-        if (!h_counts) {
-            PTV_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_counts), sizeof(int) * 8, hipHostMallocDefault));
-            for (auto &e : ev) PTV_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        }
+        failflags = failcount + kCounters;
+        ensure_host();
     }
 
-    // fraction of chunks that repair walks had to rewrite over the most recent completed read-back interval, or -1
-    double poll(bool wait, hipStream_t s) {
-        double frac = -1.0;
-        for (int k = 0; k < 4; k++) {
-            const int slot = (next_slot + k) & 3;   // oldest first
+    // take in read-backs, oldest first: all of them (wait), or up to and including slot `until` (blocking), or those
+    // that have completed
+    void poll(bool wait, int until = -1) {
+        for (int k = 0; k < kSlots; k++) {
+            const int slot = (next_slot + k) % kSlots;
             if (!pending[slot]) continue;
-            if (wait) PTV_HIP(hipEventSynchronize(ev[slot]));
-            else if (hipEventQuery(ev[slot]) != hipSuccess) continue;
+            if (wait || until >= 0) PTV_HIP(hipEventSynchronize(ev[slot]));
+            else if (hipEventQuery(ev[slot]) != hipSuccess) break;
             pending[slot] = false;
-            const long dchunks = pending_chunks[slot] - last_chunks;
-            const int rewritten = h_counts[2 * slot + 1];
-            if (dchunks > 0) frac = (double)(rewritten - last_rewritten) / (double)dchunks;
-            last_chunks = pending_chunks[slot];
-            last_rewritten = rewritten;
+            for (int f = 0; f < FAM_COUNT; f++) {
+                latest_rewritten[f] = h_counts[slot * kCounters + 2 * f + 1];
+                latest_chunks[f] = pending_chunks[slot][f];
+            }
+            if (slot == until) break;
         }
-        (void)s;
-        return frac;
     }
 
-    void enqueue_readback(hipStream_t s) {
+    int enqueue_readback(hipStream_t s) {
         const int slot = next_slot;
-        if (pending[slot]) return;   // ring full: skip this sample
-        PTV_HIP(hipMemcpyAsync(h_counts + 2 * slot, failcount, sizeof(int) * 2, hipMemcpyDeviceToHost, s));
+        if (pending[slot] || !failcount) return -1;   // ring full: skip this sample
+        PTV_HIP(hipMemcpyAsync(h_counts + slot * kCounters, failcount, sizeof(int) * kCounters, hipMemcpyDeviceToHost, s));
         PTV_HIP(hipEventRecord(ev[slot], s));
         pending[slot] = true;
-        pending_chunks[slot] = chunks_done;
-        next_slot = (slot + 1) & 3;
+        for (int f = 0; f < FAM_COUNT; f++) pending_chunks[slot][f] = pol[f].chunks_done;
+        next_slot = (slot + 1) % kSlots;
+        return slot;
+    }
+
+    // the measurement in flight: sweep time in ms, and the fraction of the family's chunks that repair walks rewrote
+    // since its last evaluation (-1: no counters, e.g. after a sequential sweep)
+    void evaluate(int fam, double &t, double &f) {
+        Policy &pl = pol[fam];
+        PTV_HIP(hipEventSynchronize(pl.t1));
+        float ms = 0.f;
+        PTV_HIP(hipEventElapsedTime(&ms, pl.t0, pl.t1));
+        t = ms;
+        f = -1.0;
+        if (pl.meas_slot >= 0) {
+            poll(false, pl.meas_slot);
+            const long d = latest_chunks[fam] - pl.chunks_seen;
+            if (d > 0) {
+                f = (double)(latest_rewritten[fam] - pl.rewritten_seen) / (double)d;
+                pl.chunks_seen = latest_chunks[fam];
+                pl.rewritten_seen = latest_rewritten[fam];
+            }
+        }
+        pl.meas = false;
+        pl.meas_slot = -1;
+    }
+
+    // one step of an exploration: the sweep just measured ran geometry r
+    void step(int fam, int r, double t, double f) {
+        Policy &pl = pol[fam];
+        if (options().verbose)
+            fprintf(stderr, "[proxtv_amd] policy: family %d sweep %ld: mode %d %s took %.3f ms, rewrote %.5f of its chunks (incumbent %d: %.3f ms)\n",
+                    fam, pl.sweeps, r, pl.trial >= 0 ? "(trial)" : "(incumbent)", t, f, pl.mode, pl.t_mode);
+        const bool dirty = f > kTryUp, clean = f < 0 || f <= kClean;
+        int next = -1;
+        if (pl.trial < 0) {   // the incumbent: where to look, if anywhere
+            pl.t_mode = pl.best_t = t;
+            pl.best = r;
+            if (r < kModeSeq && dirty && pl.hold_up == 0) {
+                next = (f > kJump) ? kModeSeq : pl.up(r);
+                pl.dir = (next > pl.up(r)) ? -1 : +1;   // skipped rungs on the way up: look at them from above
+            } else if (r > 0 && clean && pl.hold_down == 0) {
+                next = pl.down(r);
+                pl.dir = -1;
+            }
+        } else {              // a trial: remember the fastest, walk on while the counters say there is something to find
+            if (t < kBetter * pl.best_t) {
+                pl.best = r;
+                pl.best_t = t;
+            }
+            if (t < 3.0 * pl.best_t) {
+                if (pl.dir > 0 && r < kModeSeq && dirty) next = pl.up(r);
+                if (pl.dir < 0 && r > 0 && clean) next = pl.down(r);
+            }
+        }
+        if (next >= 0) {
+            pl.trial = next;
+            return;
+        }
+        if (pl.trial >= 0 && pl.best == pl.mode) {   // looked and found nothing: leave that direction alone for a while
+            if (pl.dir > 0) pl.hold_up = kHoldSolves;
+            else pl.hold_down = kHoldSolves;
+        }
+        pl.mode = pl.best;
+        pl.t_mode = pl.best_t;
+        pl.conclude();
+    }
+
+    // steady-state sample of the incumbent
+    void monitor(int fam, int r, double t, double f) {
+        Policy &pl = pol[fam];
+        const bool dirty = f > kTryUp, clean = f < 0 || f <= kClean;
+        const bool slower = pl.t_mode > 0 && t > kDrift * pl.t_mode;
+        const bool harder = r < kModeSeq && dirty && (pl.hold_up == 0 || slower);
+        const bool easier = r > 0 && clean && pl.t_mode > 0 && t * kDrift < pl.t_mode;
+        if (harder) pl.hold_up = 0;
+        if (easier) pl.hold_down = 0;
+        if (harder || easier) {
+            pl.explore = true;
+            pl.trial = -1;
+            step(fam, r, t, f);
+        }
     }
 };
 static thread_local ChunkScratch g_chunk;
@@ -676,7 +966,7 @@ static thread_local ChunkScratch g_chunk;
 // of H + 128 + 8 rows x 512 B: ~77 KiB for H = 16 -> two workgroups = 16 waves per CU; ~101 KiB for H = 64 -> one.
 // Weighted sweeps carry a second (penalty) window and exist for H = 16 only.
 template <int OP, bool WEIGHTED, bool TRANSPOSED, int H, int C = 16, int NW = 8>
-void launch_chunk_h(const SweepArgs &args, const FibreGeom &g, hipStream_t stream) {
+void launch_chunk_h(const SweepArgs &args, const FibreGeom &g, hipStream_t stream, int fam) {
     constexpr int PITCH = TRANSPOSED ? 65 : 64;
     constexpr int ROWS = H + NW * C + tail_rows(H);
     ChunkPlan plan;
@@ -708,76 +998,149 @@ void launch_chunk_h(const SweepArgs &args, const FibreGeom &g, hipStream_t strea
     if (!plan.ablate)
         hipLaunchKernelGGL((sweep_repair_kernel<OP, WEIGHTED>), dim3((unsigned)groups), dim3(64), 0, stream, args, g, C,
                            H, plan.qpw * NW, g_chunk.code_mine, g_chunk.code_next, g_chunk.failflags,
-                           g_chunk.failcount);
+                           g_chunk.failcount + 2 * fam);
     PTV_HIP(hipGetLastError());
-    g_chunk.chunks_done += (long)NC * g.count;
+    g_chunk.pol[fam].chunks_done += (long)NC * g.count;
+}
+
+// Global-memory chunks (kernel 2b): chunk C and zone H are run-time values; every link is checked by the repair kernel.
+template <int OP, bool WEIGHTED>
+void launch_gchunk(const SweepArgs &args, const FibreGeom &g, int C, int H, hipStream_t stream, int fam) {
+    const long groups = (g.count + 63) / 64;
+    const int NC = (g.len + C - 1) / C;
+    g_chunk.ensure(g.count, NC, stream);
+    hipLaunchKernelGGL((sweep_gchunk_kernel<OP, WEIGHTED>), dim3((unsigned)groups, (unsigned)NC), dim3(64), 0, stream, args,
+                       g, C, H, g_chunk.code_mine, g_chunk.code_next, g_chunk.failflags);
+    hipLaunchKernelGGL((sweep_repair_kernel<OP, WEIGHTED>), dim3((unsigned)groups), dim3(64), 0, stream, args, g, C, H, 1,
+                       g_chunk.code_mine, g_chunk.code_next, g_chunk.failflags, g_chunk.failcount + 2 * fam);
+    PTV_HIP(hipGetLastError());
+    g_chunk.pol[fam].chunks_done += (long)NC * g.count;
 }
 
 template <int OP, bool WEIGHTED, bool TRANSPOSED>
-void launch_chunk(const SweepArgs &args, const FibreGeom &g, hipStream_t stream) {
+void launch_chunk(const SweepArgs &args, const FibreGeom &g, hipStream_t stream, int fam) {
     ChunkScratch &st = g_chunk;
-    if (options().chunk_mode >= 0) st.mode = options().chunk_mode;   // forced by the user / tests
-    else if (st.h_counts) {
-        // The host enqueues a whole solve long before the device finishes its first sweep, so a decision needs a
-        // stall: the first read-back of a solve is always waited for (one short stall per solve), and while the
-        // policy sits in the long-zone mode the next few are too (those sweeps are slow anyway).
-        const bool wait = (st.sweeps == 1) || (st.mode == 1 && st.sweeps <= 4);
-        const double frac = st.poll(wait, stream);
-        if (frac >= 0) {
-            if (st.mode == 0 && frac > 0.002) st.mode = 1;
-            else if (st.mode == 1 && frac > 0.10) st.mode = 2;
+    ChunkScratch::Policy &pl = st.pol[fam];
+    const bool pinned = options().chunk_mode >= 0;
+    // a new workload: explore afresh (unless shapes keep alternating inside one solve: 4-D+ tensors share a family)
+    if ((pl.len != g.len || pl.count != g.count || pl.weighted != WEIGHTED) && pl.changes++ < 4) {
+        if (pl.meas) {
+            double t, f;
+            st.evaluate(fam, t, f);
         }
+        pl.explore = true;
+        pl.trial = -1;
+        pl.hold_up = pl.hold_down = pl.quiet = 0;
     }
-    int mode = st.mode;
-    if (WEIGHTED && mode == 1) mode = 0;   // no long-zone geometry for weighted sweeps (LDS): repairs take the load
-    if (mode >= 2) {
-        launch_seq<OP, WEIGHTED>(args, g, stream);
-        return;
-    }
-    if constexpr (!WEIGHTED) {
-        if (mode == 1)                    launch_chunk_h<OP, false, TRANSPOSED, kWarmLong>(args, g, stream);
-        else if (options().chunk == 32)   launch_chunk_h<OP, false, TRANSPOSED, kWarm, 32, 4>(args, g, stream);   // experiment
-        else                              launch_chunk_h<OP, false, TRANSPOSED, kWarm>(args, g, stream);
+    pl.weighted = WEIGHTED;
+    pl.len = g.len;
+    pl.count = g.count;
+    int mode;
+    bool measure = false;
+    if (pinned) {
+        mode = pl.mode = options().chunk_mode < kModeSeq ? options().chunk_mode : kModeSeq;
+        if (!pl.available(mode)) mode = pl.up(mode);
     } else {
-        launch_chunk_h<OP, true, TRANSPOSED, kWarm>(args, g, stream);
+        st.ensure_host();
+        if (pl.meas && (pl.explore || pl.sweeps - pl.meas_sweep >= kMonitorLag)) {
+            const int r = pl.meas_mode;
+            double t, f;
+            st.evaluate(fam, t, f);
+            if (pl.explore) st.step(fam, r, t, f);
+            else st.monitor(fam, r, t, f);
+        }
+        if (!pl.available(pl.mode)) pl.mode = pl.up(pl.mode);
+        mode = (pl.explore && pl.trial >= 0) ? pl.trial : pl.mode;
+        measure = !pl.meas && (pl.explore || (pl.sweeps > 0 && pl.sweeps % (pl.mode == 0 ? 8 : 4) == 0));
+        if (measure) PTV_HIP(hipEventRecord(pl.t0, stream));
     }
-    st.sweeps++;
-    // only the read-backs that a later launch of this solve will wait for are worth a copy on the stream
-    if (options().chunk_mode < 0 && st.sweeps <= 4) st.enqueue_readback(stream);
+    if (mode >= kModeSeq)  launch_seq<OP, WEIGHTED>(args, g, stream, true);
+    else if (mode == 2)    launch_gchunk<OP, WEIGHTED>(args, g, 64, 256, stream, fam);
+    else if (mode == 3)    launch_gchunk<OP, WEIGHTED>(args, g, 256, 1024, stream, fam);
+    else if constexpr (!WEIGHTED) {
+        if (mode == 1)                    launch_chunk_h<OP, false, TRANSPOSED, kWarmLong>(args, g, stream, fam);
+        else if (options().chunk == 32)   launch_chunk_h<OP, false, TRANSPOSED, kWarm, 32, 4>(args, g, stream, fam);   // experiment
+        else                              launch_chunk_h<OP, false, TRANSPOSED, kWarm>(args, g, stream, fam);
+    } else {
+        launch_chunk_h<OP, true, TRANSPOSED, kWarm>(args, g, stream, fam);
+    }
+    pl.sweeps++;
+    if (measure) {
+        PTV_HIP(hipEventRecord(pl.t1, stream));
+        pl.meas = true;
+        pl.meas_mode = mode;
+        pl.meas_sweep = pl.sweeps;
+        pl.meas_slot = (mode < kModeSeq) ? st.enqueue_readback(stream) : -1;
+    }
 }
 
 template <int OP, bool WEIGHTED>
-void launch_op_w(const SweepArgs &args, const FibreGeom &g, hipStream_t stream, bool allow_chunked) {
+void launch_op_w(const SweepArgs &args, const FibreGeom &g, hipStream_t stream, bool allow_chunked, int fam) {
     // chunking pays once a fibre spans several blocks; short fibres stay sequential
     const bool chunked = allow_chunked && options().chunk > 0 && g.len >= 256;
-    if (!chunked) launch_seq<OP, WEIGHTED>(args, g, stream);
-    else if (g.inc == 1) launch_chunk<OP, WEIGHTED, true>(args, g, stream);
-    else launch_chunk<OP, WEIGHTED, false>(args, g, stream);
+    if (!chunked) launch_seq<OP, WEIGHTED>(args, g, stream, false);
+    else if (g.inc == 1) launch_chunk<OP, WEIGHTED, true>(args, g, stream, fam);
+    else launch_chunk<OP, WEIGHTED, false>(args, g, stream, fam);
 }
 
 }  // namespace
 
+// Called at the start of every solve on this thread's stream.
 void chunk_stats_reset(hipStream_t s) {
     ChunkScratch &st = g_chunk;
-    if (!st.failcount) return;
-    // drain read-backs of the previous solve so that the counters can restart from zero
-    if (st.h_counts) st.poll(true, s);
-    PTV_HIP(hipMemsetAsync(st.failcount, 0, sizeof(int) * 2, s));
-    st.sweeps = 0;
-    st.chunks_done = st.last_chunks = 0;
-    st.last_rewritten = 0;
-    if (st.mode > 0) st.mode--;   // probe one level down once per solve
+    const bool adaptive = options().chunk_mode < 0;
+    if (st.h_counts) st.poll(true);
+    for (int f = 0; f < FAM_COUNT; f++) {
+        ChunkScratch::Policy &pl = st.pol[f];
+        // what the previous solve left behind: for one-sweep solves (batched 1-D prox calls) this is where the
+        // climb advances
+        if (pl.meas) {
+            const int r = pl.meas_mode;
+            double t, fr;
+            st.evaluate(f, t, fr);
+            if (adaptive) {
+                if (pl.explore) st.step(f, r, t, fr);
+                else st.monitor(f, r, t, fr);
+            }
+        }
+        if (pl.hold_up > 0) pl.hold_up--;
+        if (pl.hold_down > 0) pl.hold_down--;
+        if (pl.sweeps > 1) {            // a real solve: every solve opens with a measured sweep of the incumbent
+            pl.explore = true;
+            pl.trial = -1;
+        } else if (!pl.explore) {       // one-sweep solves: an exploration every kQuietSolves calls
+            if (pl.quiet > 0) pl.quiet--;
+            else {
+                pl.explore = true;
+                pl.trial = -1;
+                pl.quiet = kQuietSolves;
+            }
+        }
+        pl.sweeps = 0;
+        pl.changes = 0;
+        pl.chunks_done = pl.chunks_seen = 0;
+        pl.rewritten_seen = 0;
+        st.latest_rewritten[f] = 0;
+        st.latest_chunks[f] = 0;
+    }
+    if (st.failcount) PTV_HIP(hipMemsetAsync(st.failcount, 0, sizeof(int) * ChunkScratch::kCounters, s));
 }
 
 long chunk_stats_fixups(hipStream_t s) {
     if (!g_chunk.failcount) return 0;
-    int h[2] = {0, 0};
-    PTV_HIP(hipMemcpyAsync(h, g_chunk.failcount, sizeof(int) * 2, hipMemcpyDeviceToHost, s));
+    int h[ChunkScratch::kCounters] = {};
+    PTV_HIP(hipMemcpyAsync(h, g_chunk.failcount, sizeof(h), hipMemcpyDeviceToHost, s));
     PTV_HIP(hipStreamSynchronize(s));
-    return h[0];
+    long total = 0;
+    for (int f = 0; f < FAM_COUNT; f++) total += h[2 * f];
+    return total;
 }
 
-int chunk_stats_mode() { return g_chunk.mode; }
+int chunk_stats_mode() {
+    int m = 0;
+    for (int f = 0; f < FAM_COUNT; f++) m = g_chunk.pol[f].mode > m ? g_chunk.pol[f].mode : m;
+    return m;
+}
 
 void launch_sweep(OpId op, bool weighted, const SweepArgs &args, const FibreGeom &g, hipStream_t stream, int fam,
                   bool allow_chunked) {
@@ -785,11 +1148,11 @@ void launch_sweep(OpId op, bool weighted, const SweepArgs &args, const FibreGeom
     FamilyTimer timer(fam, stream);
 #define PTV_CASE(ID)                                                                             \
     case ID:                                                                                     \
-        if (weighted) launch_op_w<ID, true>(args, g, stream, allow_chunked);                     \
-        else          launch_op_w<ID, false>(args, g, stream, allow_chunked);                    \
+        if (weighted) launch_op_w<ID, true>(args, g, stream, allow_chunked, fam);                     \
+        else          launch_op_w<ID, false>(args, g, stream, allow_chunked, fam);                    \
         break;
-#define PTV_CASE_U(ID) case ID: launch_op_w<ID, false>(args, g, stream, allow_chunked); break;
-#define PTV_CASE_W(ID) case ID: launch_op_w<ID, true>(args, g, stream, allow_chunked); break;
+#define PTV_CASE_U(ID) case ID: launch_op_w<ID, false>(args, g, stream, allow_chunked, fam); break;
+#define PTV_CASE_W(ID) case ID: launch_op_w<ID, true>(args, g, stream, allow_chunked, fam); break;
     switch (op) {
         PTV_CASE(OP_PROX)
         PTV_CASE(OP_DR_COL)

@@ -21,7 +21,7 @@ void launch_sweep(OpId op, bool weighted, const SweepArgs &args, const FibreGeom
 // Fibres that the chunked path had to re-solve sequentially (unproven chunk links) since the last reset, on this thread.
 void chunk_stats_reset(hipStream_t s);
 long chunk_stats_fixups(hipStream_t s);
-// current geometry policy of this thread: 0 = short warm-up zone, 1 = long zone, 2 = sequential kernel
+// current geometry policy of this thread: 0 / 1 = LDS windows (16- / 64-sample zones), 2 / 3 = global-memory chunks, 4 = sequential
 int chunk_stats_mode();
 
 }  // namespace ptv

@@ -56,16 +56,16 @@ __device__ __forceinline__ void walker_start(Walker &w, S &src, int at, double l
 // This is the whole point of the chunked kernels: that state depends on nothing but (at, type).  For at < n-1 it is
 // the closed-form first sample used by walker_run's interior branch (a bend met at the last sample, which restarts
 // without stepping, reaches the very same state one trip later); for at == n-1 the no-step form applies.
-template <bool WEIGHTED, class S>
-__device__ __forceinline__ void walker_restart(Walker &w, S &src, int at, int type, int n, double lam) {
+// Operands: yn = y(at); weighted: wp = r(at-1), wc = r(at) (wc unused at the last sample).
+template <bool WEIGHTED>
+__device__ __forceinline__ void walker_restart_with(Walker &w, int at, int type, int n, double lam, double yn, double wp,
+                                                    double wc) {
     const int last = n - 1;
     const bool cv = (type == BEND_CEIL);
-    const double yn = src.y(at);
     w.k0 = at - 1;
     w.klo = w.khi = at;
     if (at < last) {
         if (WEIGHTED) {
-            const double wp = src.r(at - 1), wc = src.r(at);
             if (cv) { w.lo = yn + wp - wc; w.hi = yn + wp + wc; }
             else    { w.hi = yn - wp + wc; w.lo = yn - wp - wc; }
             w.hhi = wc;
@@ -79,7 +79,6 @@ __device__ __forceinline__ void walker_restart(Walker &w, S &src, int at, int ty
         w.i = at + 1;
     } else {
         if (WEIGHTED) {
-            const double wp = src.r(at - 1);
             if (cv) { w.lo = yn + wp; w.hi = yn + wp; w.hhi = w.hlo = -wp; }
             else    { w.hi = yn - wp; w.lo = yn - wp; w.hhi = w.hlo = wp; }
         } else {
@@ -90,9 +89,20 @@ __device__ __forceinline__ void walker_restart(Walker &w, S &src, int at, int ty
     }
 }
 
-// Run until the fibre end (sample n-1 closed) or until src.keep_going() says stop.
-// Returns true when the fibre end was reached and the closing piece was emitted.
 template <bool WEIGHTED, class S>
+__device__ __forceinline__ void walker_restart(Walker &w, S &src, int at, int type, int n, double lam) {
+    const double yn = src.y(at);
+    double wp = 0.0, wc = 0.0;
+    if (WEIGHTED) {
+        wp = src.r(at - 1);
+        if (at < n - 1) wc = src.r(at);
+    }
+    walker_restart_with<WEIGHTED>(w, at, type, n, lam, yn, wp, wc);
+}
+
+// Run until the fibre end (sample n-1 closed) or until src.keep_going() says stop (SINGLE: at most one trip).
+// Returns true when the fibre end was reached and the closing piece was emitted.
+template <bool WEIGHTED, class S, bool SINGLE = false>
 __device__ __forceinline__ bool walker_run(Walker &w, S &src, int n, double lam) {
     const int last = n - 1;
     while (w.i < n) {
@@ -149,28 +159,155 @@ __device__ __forceinline__ bool walker_run(Walker &w, S &src, int n, double lam)
                     }
                 }
             }
+        } else {
+            if (interior) {
+                // pull the pieces back inside the tube where they left it
+                const int span = i - w.k0;
+                if (w.hhi >= r) {
+                    w.hi += (r - w.hhi) / span;
+                    w.hhi = r;
+                    w.khi = i;
+                }
+                if (w.hlo <= -r) {
+                    w.lo += (-r - w.hlo) / span;
+                    w.hlo = -r;
+                    w.klo = i;
+                }
+            } else {
+                if (w.hlo <= 0) w.lo += (-w.hlo) / (i - w.k0);
+            }
+            w.i = i + 1;
+        }
+        if (SINGLE) break;
+    }
+    if (SINGLE && w.i < n) return false;
+    src.piece(w.k0 + 1, last, w.lo);
+    return true;
+}
+
+// a / s for a small positive integer s held as a double.  Device: reciprocal (v_rcp_f64) + one Newton step, then one
+// residual correction of the quotient -- agrees with IEEE division to the last bit in all but rare ties (at most one
+// ulp off) at a third of the instructions of the full v_div_* sequence; both tube pieces share the reciprocal.
+// The host harness divides.
+struct SpanDiv {
+    double s, inv;
+#ifdef PTV_HOST_TEST
+    explicit SpanDiv(double s_) : s(s_), inv(0.0) {}
+    double operator()(double a) const { return a / s; }
+#else
+    __device__ __forceinline__ explicit SpanDiv(double s_) : s(s_) {
+        const double x = __builtin_amdgcn_rcp(s_);
+        inv = __builtin_fma(__builtin_fma(-s_, x, 1.0), x, x);
+    }
+    __device__ __forceinline__ double operator()(double a) const {
+        const double q = a * inv;
+        return __builtin_fma(__builtin_fma(-q, s, a), inv, q);
+    }
+#endif
+};
+
+// Same walk for sources that live in global memory, where every dependent load is a memory round trip and a wave
+// has few neighbours to hide it behind (one lane per fibre: 64 waves for 4096 fibres).  The loop is software-
+// pipelined: each trip of the outer loop first ISSUES the loads the next trip will use -- the K samples that follow
+// the block in hand (the walk is predicted to run straight on) and the operands of the next K queued outputs
+// (src.pump) -- and then works out of registers on the block loaded one trip earlier: the restart after the previous
+// bend, up to K interior trips as straight-line predicated code.  A lane whose prediction failed (it bent and
+// rewound, or just started) issues the right block and sits one trip out instead of stalling its wave for a round
+// trip.  A bend only books the finished piece (src.piece queues it; it drains K samples per trip while the walk
+// goes on) and the restart, whose sample arrives with the lane's next block.  The last sample of the fibre, with its
+// own tests, goes through one trip of walker_run.  Same state machine and operation order as walker_run; the tube
+// updates divide through SpanDiv.
+// Extra source members:
+//   int  limit()   the walk never processes a sample >= limit() (keep_going must refuse those)
+//   void pump()    store the outputs whose operands were fetched one trip ago; fetch the operands of the next K
+//   void flush()   write everything still queued (called before returning)
+template <bool WEIGHTED, int K, class S>
+__device__ __forceinline__ bool walker_run_blocked(Walker &w, S &src, int n, double lam) {
+    const int last = n - 1;
+    int rs = -1;                         // >= 0: a bend of this type happened and the walker has to restart at sample w.i
+    double yn[K], rn[K], rnprev = 0.0;   // block being loaded, for samples nb .. nb + K - 1
+    int nb = w.i;
+#pragma unroll
+    for (int u = 0; u < K; u++) {
+        const int at = nb + u < last ? nb + u : last;
+        yn[u] = src.y(at);
+        if (WEIGHTED) rn[u] = src.r(at < last ? at : last - 1);
+    }
+    while (w.i < n) {
+        if (!src.keep_going(w.i)) {
+            src.flush();
+            return false;
+        }
+        if (rs < 0 && w.i >= last) {
+            if (walker_run<WEIGHTED, S, true>(w, src, n, lam)) {
+                src.flush();
+                return true;
+            }
             continue;
         }
-
-        if (interior) {
-            // pull the pieces back inside the tube where they left it
-            const int span = i - w.k0;
-            if (w.hhi >= r) {
-                w.hi += (r - w.hhi) / span;
-                w.hhi = r;
-                w.khi = i;
-            }
-            if (w.hlo <= -r) {
-                w.lo += (-r - w.hlo) / span;
-                w.hlo = -r;
-                w.klo = i;
-            }
-        } else {
-            if (w.hlo <= 0) w.lo += (-w.hlo) / (i - w.k0);
+        // the block in hand, and the loads for the next one
+        double yb[K], rb[K];
+        const double rprev = rnprev;
+        const int base = nb;
+#pragma unroll
+        for (int u = 0; u < K; u++) {
+            yb[u] = yn[u];
+            if (WEIGHTED) rb[u] = rn[u];
         }
-        w.i = i + 1;
+        const bool useful = (base == w.i);
+        nb = useful ? base + K : w.i;
+        src.pump();
+#pragma unroll
+        for (int u = 0; u < K; u++) {
+            const int at = nb + u < last ? nb + u : last;
+            yn[u] = src.y(at);
+            if (WEIGHTED) rn[u] = src.r(at < last ? at : last - 1);
+        }
+        if (WEIGHTED) rnprev = src.r(nb > 0 ? nb - 1 : 0);
+        if (!useful) continue;
+
+        const int lim = last < src.limit() ? last : src.limit();   // interior trips handle i < lim
+        if (rs >= 0) {   // base < last here: a bend found at an interior sample restarts at or before it
+            walker_restart_with<WEIGHTED>(w, base, rs, n, lam, yb[0], rprev, rb[0]);
+            rs = -1;
+        }
+        int pend = -1;
+#pragma unroll
+        for (int u = 0; u < K; u++) {
+            const int i = base + u;
+            const bool act = (pend < 0) & (w.i == i) & (i < lim);
+            const double yi = yb[u];
+            const double r = WEIGHTED ? rb[u] : lam;
+            const double h1 = w.hlo + (w.lo - yi);
+            const bool cv = r < h1;
+            const double h2 = w.hhi + (w.hi - yi);
+            const bool fv = !cv & (-r > h2);
+            const bool bent = act & (cv | fv);
+            const bool adv = act & !(cv | fv);
+            pend = bent ? (cv ? BEND_CEIL : BEND_FLOOR) : pend;
+            const SpanDiv over((double)(i - w.k0));
+            const bool th = adv & (h2 >= r), tl = adv & (h1 <= -r);
+            const double nhi = w.hi + over(r - h2);
+            const double nlo = w.lo + over(-r - h1);
+            w.hi = th ? nhi : w.hi;
+            w.hhi = th ? r : (adv ? h2 : w.hhi);
+            w.khi = th ? i : w.khi;
+            w.lo = tl ? nlo : w.lo;
+            w.hlo = tl ? -r : (adv ? h1 : w.hlo);
+            w.klo = tl ? i : w.klo;
+            w.i = adv ? i + 1 : w.i;
+        }
+        if (pend >= 0) {
+            const bool cv = (pend == BEND_CEIL);
+            const int brk = cv ? w.klo : w.khi;
+            src.piece(w.k0 + 1, brk, cv ? w.lo : w.hi);
+            src.bend(brk + 1, pend);
+            w.i = brk + 1;
+            rs = pend;
+        }
     }
     src.piece(w.k0 + 1, last, w.lo);
+    src.flush();
     return true;
 }
 

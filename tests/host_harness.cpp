@@ -26,6 +26,9 @@ struct HostSource {
     }
     void bend(int, int) { bends++; }
     bool keep_going(int) const { return !done; }
+    int limit() const { return 1 << 30; }
+    void pump() const {}
+    void flush() const {}
 };
 }  // namespace
 
@@ -39,6 +42,17 @@ int host_walk(const double *y, const double *w, double lam, double *x, int n) {
     Walker wk;
     if (w) { walker_start<true>(wk, s, 0, lam); walker_run<true>(wk, s, n, lam); }
     else   { walker_start<false>(wk, s, 0, lam); walker_run<false>(wk, s, n, lam); }
+    return s.bends;
+}
+
+// the same walk in blocks of K samples, what the global-memory kernels do per lane (walker_run_blocked)
+int host_walk_blocked(const double *y, const double *w, double lam, double *x, int n, int from, int until) {
+    if (n <= 0) return 0;
+    if (w && n == 1) { x[0] = y[0]; return 0; }
+    HostSource s{y, w, x, until};
+    Walker wk;
+    if (w) { walker_start<true>(wk, s, from, lam); walker_run_blocked<true, 8>(wk, s, n, lam); }
+    else   { walker_start<false>(wk, s, from, lam); walker_run_blocked<false, 8>(wk, s, n, lam); }
     return s.bends;
 }
 

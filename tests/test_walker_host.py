@@ -19,6 +19,7 @@ def harness():
     lib = C.CDLL(out)
     lib.host_walk.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_int]
     lib.host_walk_from.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_int, C.c_int, C.c_int]
+    lib.host_walk_blocked.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_int, C.c_int, C.c_int]
     return lib
 
 
@@ -100,3 +101,32 @@ def test_speculative_start_synchronises(harness, oracle):
         bad = idx[~agree[idx]]
         first_ok = (bad.max() + 1) if bad.size else start
         assert first_ok - start <= 32, (trial, first_ok - start)     # synchronised within the warm-up zone
+
+
+def test_blocked_walk_is_bit_identical(harness, oracle):
+    """walker_run_blocked (global-memory kernels: K samples fetched per block) against walker_run: same bits, same
+    bends, for full walks, negative penalties, weighted walks and speculative starts that stop early."""
+    rng = np.random.default_rng(5)
+    for t, x in enumerate(signals(rng, 6000)):
+        n = x.size
+        a, b = np.zeros(n), np.zeros(n)
+        if t % 3 == 2 and n >= 2:
+            w = rng.uniform(0, 2, n - 1) * float(rng.choice([0.0, 0.1, 1, 5]))
+            lam, wp = 0.0, w.ctypes.data
+        else:
+            w = None
+            lam, wp = float(rng.standard_normal() * rng.choice([0.0, 0.1, 1, 3, 30])), None
+            if lam < 0 and n < 3:
+                continue
+        na = harness.host_walk(x.ctypes.data, wp, lam, a.ctypes.data, n)
+        nb = harness.host_walk_blocked(x.ctypes.data, wp, lam, b.ctypes.data, n, 0, -1)
+        np.testing.assert_array_equal(a, b)
+        assert na == nb
+        if n >= 20 and lam >= 0:
+            start = int(rng.integers(1, n - 10))
+            until = min(n - 1, start + 9)
+            a[:], b[:] = np.nan, np.nan
+            na = harness.host_walk_from(x.ctypes.data, wp, lam, a.ctypes.data, n, start, until)
+            nb = harness.host_walk_blocked(x.ctypes.data, wp, lam, b.ctypes.data, n, start, until)
+            np.testing.assert_array_equal(a, b)
+            assert na == nb
