@@ -36,6 +36,7 @@ namespace {
 
 using link_t = unsigned;                 // (restart << 1 | bend type) of a walk's last bend before a chunk boundary
 constexpr link_t kLinkBad = 0xfffffffeu;        // the chunk's walk ran off its LDS window: trust nothing it recorded
+constexpr link_t kLinkCertain = 0x80000000u;    // flag on a published `mine` code: the chunk's walk began AT a bend known a priori
 
 // ---- kernel 1: sequential walk straight from / to global memory --------------------------------------------------
 // Global-memory walks fetch their samples kGlobalBlock at a time (walker_run_blocked) and write a piece out the same
@@ -168,6 +169,8 @@ struct ChunkSource {
     // the following chunk, whose walk started H samples before that boundary).  0 = none.
     unsigned mine = 0, next = 0;
     double vclose = 0.0;       // value of the piece covering sample ce - 1
+    double vfirst = 0.0;       // value of the piece covering sample cs
+    bool have_first = false;
     bool done = false;         // the piece covering ce - 1 is closed
     bool failed = false;       // the walk ran off the LDS window (a piece much longer than a chunk): give the fibre up
 
@@ -176,6 +179,10 @@ struct ChunkSource {
     __device__ __forceinline__ double y(int i) const { return Y[(min(i, hi - 1) - lo) * PITCH]; }
     __device__ __forceinline__ double r(int i) const { return Wt[(min(i, hi - 1) - lo) * PITCH]; }
     __device__ __forceinline__ void piece(int, int to, double v) {
+        if (to >= cs && !have_first) {
+            vfirst = v;
+            have_first = true;
+        }
         if (to >= ce - 1) {
             vclose = v;
             done = true;
@@ -293,14 +300,13 @@ constexpr int tail_rows(int H) { return H > kWarm ? H : kTail; }
 // rebuild_chunk does this for one lane's chunk, in place in the window, in ONE forward pass: it accumulates y over the
 // current piece and, when the piece ends, goes back over the piece's rows (still holding y) and replaces each by
 // Op::fuse(y, v) -- the prox value itself, or directly the sweep's output when the op's output depends on (y, x) only.
-// The piece that straddles the chunk start is the previous lane's closing piece: for waves > 0 its value arrives
-// through LDS (`v_prev`, the walker's own value), so no lane ever reads a row another lane of the block rewrites;
-// the first wave of a block sums the warm-up rows instead (nobody writes those).  The piece covering the chunk's
-// last sample takes `v_close`, the value the lane's own walk ended with.
+// The piece that covers the chunk's first sample may have begun before the chunk (rows that belong to, and are being
+// rewritten by, the previous lane): it takes `v_first`, the value the lane's own walk gave it; likewise the piece
+// covering the chunk's last sample takes `v_close`.  So a lane reads and writes the rows of its own chunk only.
 template <int OP, bool WEIGHTED, int PITCH>
 __device__ __forceinline__ void rebuild_chunk(double *Ycol, const double *Wcol, int lo, int cs, int ce, int start,
                                               unsigned mine, unsigned ends, unsigned types, double v_close,
-                                              double v_prev, bool prev_in_block, double lam) {
+                                              double v_first, double lam) {
     int a0 = cs;
     double hprev = 0.0;
     if (mine != 0) {
@@ -310,14 +316,10 @@ __device__ __forceinline__ void rebuild_chunk(double *Ycol, const double *Wcol, 
     } else if (start == 0) {
         a0 = 0;   // no bend yet and the walk began at the fibre start: the first piece starts at sample 0, height 0
     }
-    bool from_prev = prev_in_block && a0 < cs;
+    bool from_prev = a0 < cs;
+    const double v_prev = v_first;
     double s = 0.0;
     int cnt = 0;
-    if (!from_prev)
-        for (int k = a0; k < cs; k++) {
-            s += Ycol[(k - lo) * PITCH];
-            cnt++;
-        }
     int first = cs;   // first row of the current piece inside the chunk
     for (int k = cs; k <= ce - 2; k++) {
         s += Ycol[(k - lo) * PITCH];
@@ -361,7 +363,7 @@ __global__ __launch_bounds__(64 * NW, ((WEIGHTED || H > 16) ? NW / 4 : NW / 2)) 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double *Yp = reinterpret_cast<double *>(smem);
     double *Wp = Yp + (WEIGHTED ? (size_t)ROWS * PITCH : 0);
-    link_t *codes = reinterpret_cast<link_t *>(Wp + (size_t)ROWS * PITCH);   // [NW + 1][64]; slot NW carries over blocks
+    link_t *codes = reinterpret_cast<link_t *>(Wp + (size_t)ROWS * PITCH);   // [NW + 2][64]; slots NW, NW + 1 carry over blocks
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int len = g.len;
@@ -446,9 +448,48 @@ __global__ __launch_bounds__(64 * NW, ((WEIGHTED || H > 16) ? NW / 4 : NW / 2)) 
         const bool has_chunk = active && cs < len;
         const int start = max(0, cs - H);
         ChunkSource<OP, WEIGHTED, PITCH> src{p, base, g.inc, wbase, Yp + lane, Wp + lane, lo, hi, cs, ce, len};
+        bool certain = false;
         if (has_chunk && !(plan.ablate & 1)) {
             Walker w;
-            walker_start<WEIGHTED>(w, src, start, p.lam);
+            // A bend known without walking: x_k - x_{k-1} = (y_k - y_{k-1}) + (u_k - u_{k-1}) - (u_{k-1} - u_{k-2}) with every
+            // dual |u_j| <= r_j, so a jump |y_k - y_{k-1}| > r_k + 2 r_{k-1} + r_{k-2} (4 lambda) keeps its sign in x: the
+            // string bends there (up-jump: off the floor), and the state after a bend depends on the bend alone.  A lane
+            // that finds one among the kLook edges before its chunk starts its walk AT it -- exact by construction, no
+            // warm-up zone to walk, no link to prove.  On noisy data with small lambda (the headline: 78 % of all edges
+            // qualify) every lane of a wave does; otherwise the lane falls back to the speculative start.
+            constexpr int kLook = 8;
+            static_assert(H >= kLook + 2, "the certain-bend search reads rows of the warm-up zone");
+            int cat = -1, ctype = 0;
+            if (start > 0 && H <= kWarm && p.lam > 0.0) {
+                double yv[kLook + 1], rv[kLook + 2];
+#pragma unroll
+                for (int u = 0; u <= kLook; u++) yv[u] = src.y(cs - u);
+                if (WEIGHTED) {
+#pragma unroll
+                    for (int u = 0; u <= kLook + 1; u++) rv[u] = (cs - u < len - 1) ? src.r(cs - u) : 0.0;
+                }
+#pragma unroll
+                for (int u = kLook - 1; u >= 0; u--) {   // edge (k - 1, k), k = cs - u; the nearest one wins
+                    const double d = yv[u] - yv[u + 1];
+                    double thr = 4.0000001 * p.lam;
+                    bool ok = true;
+                    if (WEIGHTED) {
+                        thr = 1.0000001 * (rv[u] + 2.0 * rv[u + 1] + rv[u + 2]);
+                        ok = (rv[u] >= 0.0) & (rv[u + 1] > 0.0) & (rv[u + 2] >= 0.0);
+                    }
+                    const bool hit = ok & (fabs(d) > thr);
+                    cat = hit ? cs - u : cat;
+                    ctype = hit ? (d > 0 ? BEND_FLOOR : BEND_CEIL) : ctype;
+                }
+            }
+            if (cat >= 0) {
+                certain = true;
+                walker_restart_with<WEIGHTED>(w, cat, ctype, len, p.lam, src.y(cat), WEIGHTED ? src.r(cat - 1) : 0.0,
+                                              (WEIGHTED && cat < len - 1) ? src.r(cat) : 0.0);
+                src.mine = src.next = ((link_t)cat << 1) | (link_t)ctype;
+            } else {
+                walker_start<WEIGHTED>(w, src, start, p.lam);
+            }
             walker_run_interior<WEIGHTED>(w, src, len, p.lam);   // the hot part
             walker_run<WEIGHTED>(w, src, len, p.lam);            // fibre end / window end (no-op for most lanes)
             if (src.failed) {   // ran off the window: nothing this lane recorded may be trusted
@@ -462,28 +503,22 @@ __global__ __launch_bounds__(64 * NW, ((WEIGHTED || H > 16) ? NW / 4 : NW / 2)) 
         codes[wave * 64 + lane] = src.next;
         __syncthreads();   // all walks done: link codes visible, window rows no longer read as walk input
         if (has_chunk) {
-            const bool true_start = (start == 0);
+            const bool true_start = (start == 0) || certain;
             if (wave > 0 || kb > 0) {
-                const link_t prev = (wave > 0) ? codes[(wave - 1) * 64 + lane] : codes[NW * 64 + lane];
+                const link_t prev = (wave > 0) ? codes[(wave - 1) * 64 + lane] : codes[(NW + ((kb + 1) & 1)) * 64 + lane];
                 if (!true_start && (src.mine == 0 || src.mine != prev)) failflags[j] = 1;
             }
             // Every chunk publishes its two codes: sweep_repair_kernel proves the links between workgroups with them
             // and, for a fibre with an unproven link, finds where a repair walk may stop.
             const long slot = (long)(q * NW + wave) * g.count + j;
-            code_mine[slot] = src.mine;
+            code_mine[slot] = (certain && src.mine != kLinkBad) ? (src.mine | kLinkCertain) : src.mine;
             code_next[slot] = src.next;
         }
-        // The walks are over, so the look-ahead rows are free: tail row `wave` carries this lane's closing value to
-        // the lane of the next chunk (T >= NW).
-        double *vslot = Yp + (size_t)(H + NW * C) * PITCH;
-        vslot[wave * PITCH + lane] = src.vclose;
-        __syncthreads();
-        if (wave == NW - 1) codes[NW * 64 + lane] = src.next;   // carried to the next block's first chunk
-        if (has_chunk) {
-            const double v_prev = (wave > 0) ? vslot[(wave - 1) * PITCH + lane] : 0.0;
+        // carried to the next block's first chunk; two slots in turn, so that no barrier is needed before the write
+        if (wave == NW - 1) codes[(NW + (kb & 1)) * 64 + lane] = src.next;
+        if (has_chunk)
             rebuild_chunk<OP, WEIGHTED, PITCH>(Yp + lane, Wp + lane, lo, cs, ce, start, src.mine, src.ends, src.types,
-                                               src.vclose, v_prev, wave > 0, p.lam);
-        }
+                                               src.vclose, src.vfirst, p.lam);
         __syncthreads();
 
         // ---- stream the block's NW*C rows out: coalesced 512-byte rows, UL operand fetches in flight per lane ------------------
@@ -643,7 +678,8 @@ struct RepairSource {
         while (!stop && boundary < len && at >= boundary) {
             const link_t here = (at == boundary) ? code : last;      // this walk's last bend at-or-before `boundary`
             const int c = boundary / C;
-            const link_t m = code_mine[(long)c * count + j];
+            link_t m = code_mine[(long)c * count + j];
+            if (m != kLinkBad) m &= ~kLinkCertain;
             if (m != 0 && m == here) {
                 stop = true;
                 resume_chunk = c;
@@ -680,7 +716,8 @@ __global__ __launch_bounds__(64) void sweep_repair_kernel(SweepArgs p, FibreGeom
 #pragma unroll
         for (int u = 0; u < UB; u++) {
             const int c = c0 + u * chunks_per_wg;
-            if (c < NC && c * C - H > 0 && (in[u] == 0 || in[u] != out[u])) bad = 1;
+            const bool certain = (in[u] & kLinkCertain) && in[u] != kLinkBad;
+            if (c < NC && c * C - H > 0 && !certain && (in[u] == 0 || in[u] != out[u])) bad = 1;
         }
     }
     if (!bad) return;
@@ -697,9 +734,12 @@ __global__ __launch_bounds__(64) void sweep_repair_kernel(SweepArgs p, FibreGeom
     // lanes, each reaching its repair at a different trip).
     while (true) {
         while (c < NC) {
-            const link_t m = code_mine[(long)c * g.count + j];
-            // a chunk whose walk began at sample 0 is the true walk unless it ran off its window (kLinkBad)
-            const bool accept = (c * C - H <= 0) ? (m != kLinkBad) : (m != 0 && m == cur);
+            const link_t mraw = code_mine[(long)c * g.count + j];
+            const bool certain = (mraw & kLinkCertain) && mraw != kLinkBad;
+            const link_t m = certain ? (mraw & ~kLinkCertain) : mraw;
+            // a chunk whose walk began at sample 0 (or at a bend known a priori) is the true walk unless it ran off
+            // its window (kLinkBad)
+            const bool accept = (c * C - H <= 0 || certain) ? (m != kLinkBad) : (m != 0 && m == cur);
             if (!accept) break;
             const link_t nx = code_next[(long)c * g.count + j];
             if (nx != 0) cur = nx;
@@ -981,7 +1021,7 @@ void launch_chunk_h(const SweepArgs &args, const FibreGeom &g, hipStream_t strea
     plan.qpw = qpw < plan.Q ? qpw : plan.Q;
     plan.ablate = options().ablate;
     const int WQ = (plan.Q + plan.qpw - 1) / plan.qpw;
-    constexpr size_t lds = sizeof(double) * PITCH * (size_t)ROWS * (WEIGHTED ? 2 : 1) + sizeof(link_t) * (NW + 1) * 64;
+    constexpr size_t lds = sizeof(double) * PITCH * (size_t)ROWS * (WEIGHTED ? 2 : 1) + sizeof(link_t) * (NW + 2) * 64;
     static_assert(lds <= 160 * 1024, "chunk geometry does not fit the LDS of a CU");
     const int NC = (g.len + C - 1) / C;
     g_chunk.ensure(g.count, NC, stream);
