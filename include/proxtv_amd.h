@@ -40,6 +40,11 @@ extern "C" {
 #define MAX_ITERS_PD 35       /* src/TVopt.h:73 */
 #define MAX_ITERS_DR 35       /* src/TVopt.h:83 */
 #define MAX_ITERS_YANG 35     /* src/TVopt.h:85 */
+#define MAX_ITERS_CONDAT 2500      /* src/TVopt.h:75 ; STOP_CONDAT = 0 (:77) */
+#define MAX_ITERS_KOLMOGOROV 2500  /* src/TVopt.h:79 ; STOP_KOLMOGOROV = 0 (:81) */
+#define ALG_CONDAT 0               /* src/TVopt.h: algorithm selector of CondatChambollePock2_TV */
+#define ALG_CHAMBOLLE_POCK 1
+#define ALG_CHAMBOLLE_POCK_ACC 2
 
 /* Opaque, ABI-only (reference: src/utils.h:20-34).  The HIP path keeps its scratch in HBM and
    ignores workspaces; callers (like the reference's Python layer) pass NULL. */
@@ -84,6 +89,15 @@ int PDR_TV(double *y, double *lambdas, double *norms, double *dims, double *x, d
 int Yang2_TV(size_t M, size_t N, double *Y, double lambda, double *X, int maxit, double *info);
 /* replaces src/TVNDopt.cpp:678 */
 int Yang3_TV(size_t M, size_t N, size_t O, double *Y, double lambda, double *X, int maxit, double *info);
+/* replaces src/TV2Dopt.cpp:907 -- Kolmogorov et al.'s primal-dual splitting of the same 2-D TV-L1 problem; both of
+   its steps are 1-D proxes (columns through Moreau's identity, rows directly) and run on the sweep kernels.
+   maxit <= 0 -> 2500; stops earlier only when X reaches a bitwise fixed point (STOP = 0); info[0] = iterations + 1 */
+int Kolmogorov2_TV(size_t M, size_t N, double *Y, double lambda, double *X, int maxit, double *info);
+/* replaces src/TV2Dopt.cpp:587 -- Condat (alg 0) / Chambolle-Pock (1) / accelerated Chambolle-Pock (2) primal-dual
+   iterations: pointwise stencils, one fused kernel per iteration.  Images with a single row or column are rejected
+   (the reference indexes out of bounds there). */
+int CondatChambollePock2_TV(size_t M, size_t N, double *Y, double lambda, double *X, short alg, int maxit,
+                            double *info);
 
 /* Workspace allocator shims (reference: src/utils.cpp:79-237).  ABI-only: they return / accept
    small host objects so reference callers that create workspaces keep linking. */
@@ -128,6 +142,10 @@ int proxtv_PDR_TV_dev(const double *y, const double *lambdas_scaled /*host*/, co
    when all entries are equal).  order follows the reference: 2-D rows then columns, 3-D dims 1,2,3. */
 int proxtv_Yang_TV_dev(const int *ns /*host*/, int nds, const double *Y, const double *lambdas /*host, nds*/,
                        double *X, int maxit, double *info, void *stream);
+int proxtv_Kolmogorov2_TV_dev(size_t M, size_t N, const double *Y, double lambda, double *X, int maxit, double *info,
+                              void *stream);
+int proxtv_CondatChambollePock2_TV_dev(size_t M, size_t N, const double *Y, double lambda, double *X, short alg,
+                                       int maxit, double *info, void *stream);
 
 /* Batched exact 1-D TV-L1 prox along one dimension of an N-D column-major array (the per-sweep
    kernel of every solver above): out = prox_{lambda}(in) on every fibre along dimension `dim`

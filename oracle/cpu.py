@@ -36,6 +36,8 @@ _SIGS = {
     "PDR_TV": (C.c_int, [_dp, _dp, _dp, _dp, _dp, _dp, _dp, C.c_int, C.c_int, C.c_int, C.c_int]),
     "Yang2_TV": (C.c_int, [C.c_size_t, C.c_size_t, _dp, C.c_double, _dp, C.c_int, _dp]),
     "Yang3_TV": (C.c_int, [C.c_size_t, C.c_size_t, C.c_size_t, _dp, C.c_double, _dp, C.c_int, _dp]),
+    "Kolmogorov2_TV": (C.c_int, [C.c_size_t, C.c_size_t, _dp, C.c_double, _dp, C.c_int, _dp]),
+    "CondatChambollePock2_TV": (C.c_int, [C.c_size_t, C.c_size_t, _dp, C.c_double, _dp, C.c_short, C.c_int, _dp]),
 }
 
 
@@ -136,6 +138,23 @@ class CpuLib:
         out = np.zeros(X.shape, order="F")
         info = np.zeros(3)
         rc = self._fn["Yang2_TV"](X.shape[0], X.shape[1], X.ctypes.data, lam, out.ctypes.data, max_iters, info.ctypes.data)
+        return out, info, rc
+
+    def kolmogorov2(self, X, lam, max_iters=0):
+        X = np.asfortranarray(X, dtype=np.float64)
+        out = np.zeros(X.shape, order="F")
+        info = np.zeros(3)
+        rc = self._fn["Kolmogorov2_TV"](X.shape[0], X.shape[1], X.ctypes.data, lam, out.ctypes.data, max_iters,
+                                        info.ctypes.data)
+        return out, info, rc
+
+    def ccp2(self, X, lam, alg, max_iters=0):
+        """alg 0 = Condat, 1 = Chambolle-Pock, 2 = accelerated Chambolle-Pock"""
+        X = np.asfortranarray(X, dtype=np.float64)
+        out = np.zeros(X.shape, order="F")
+        info = np.zeros(3)
+        rc = self._fn["CondatChambollePock2_TV"](X.shape[0], X.shape[1], X.ctypes.data, lam, out.ctypes.data, alg,
+                                                 max_iters, info.ctypes.data)
         return out, info, rc
 
     def yang3(self, X, lam, max_iters=0):

@@ -129,6 +129,43 @@ def gen_2d(ref):
     print("golden_2d:", len(names), "cases (+ emengd, blocks, multireg)")
 
 
+def gen_2d_primal_dual(ref):
+    """Kolmogorov2_TV and CondatChambollePock2_TV (the other tv1_2d methods): full 2500-iteration runs and truncated ones."""
+    rng = np.random.default_rng(20260928)
+    out = {}
+    names = []
+    for (M, N) in [(2, 2), (2, 3), (3, 2), (5, 7), (16, 16), (24, 31), (64, 48), (65, 130)]:
+        for lam in (0.1, 1.5):
+            name = f"randn_{M}x{N}_l{lam}"
+            names.append(name)
+            X = np.asfortranarray(rng.standard_normal((M, N)))
+            out[f"{name}/X"] = X
+            out[f"{name}/lam"] = np.float64(lam)
+            y, info, rc = ref.kolmogorov2(X, lam)
+            out[f"{name}/kol"], out[f"{name}/kol_info"], out[f"{name}/kol_rc"] = y, info, np.int64(rc)
+            y, info, rc = ref.kolmogorov2(X, lam, max_iters=40)
+            out[f"{name}/kol_it40"], out[f"{name}/kol_it40_info"] = y, info
+            for alg in (0, 1, 2):
+                y, info, rc = ref.ccp2(X, lam, alg)
+                out[f"{name}/ccp{alg}"], out[f"{name}/ccp{alg}_info"], out[f"{name}/ccp{alg}_rc"] = y, info, np.int64(rc)
+                y, info, rc = ref.ccp2(X, lam, alg, max_iters=60)
+                out[f"{name}/ccp{alg}_it60"], out[f"{name}/ccp{alg}_it60_info"] = y, info
+    # a constant image is a fixed point of the first primal step: the loops exit through their `stop > 0` test
+    C = np.asfortranarray(np.full((6, 9), 3.25))
+    out["const/X"] = C
+    for alg in (0, 1, 2):
+        y, info, rc = ref.ccp2(C, 0.7, alg)
+        out[f"const/ccp{alg}"], out[f"const/ccp{alg}_info"] = y, info
+    y, info, rc = ref.kolmogorov2(C, 0.7)
+    out["const/kol"], out["const/kol_info"] = y, info
+    # invalid algorithm selector
+    y, info, rc = ref.ccp2(C, 0.7, 5)
+    out["const/ccp_bad_info"], out["const/ccp_bad_rc"] = info, np.int64(rc)
+    out["names"] = np.array(names)
+    np.savez_compressed(os.path.join(GOLD, "golden_2d_primal_dual.npz"), **out)
+    print("golden_2d_primal_dual:", len(names), "cases (+ const)")
+
+
 def gen_nd(ref):
     rng = np.random.default_rng(20260928)
     out = {}
@@ -239,15 +276,20 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--large", action="store_true")
     ap.add_argument("--only-large", action="store_true")
+    ap.add_argument("--only-primal-dual", action="store_true", help="regenerate golden_2d_primal_dual.npz only")
     ap.add_argument("--threads", type=int, default=os.cpu_count() or 1)
     args = ap.parse_args()
     if not cpu.have_reference():
         cpu.build_reference(quiet=False)
     ref = cpu.reference()
     os.makedirs(GOLD, exist_ok=True)
+    if args.only_primal_dual:
+        gen_2d_primal_dual(ref)
+        return
     if not args.only_large:
         gen_1d(ref)
         gen_2d(ref)
+        gen_2d_primal_dual(ref)
         gen_nd(ref)
     if args.large or args.only_large:
         gen_large(ref, args.threads)

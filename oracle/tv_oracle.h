@@ -37,6 +37,10 @@ extern "C" {
 #define ORC_MAX_ITERS_PD   35
 #define ORC_MAX_ITERS_DR   35
 #define ORC_MAX_ITERS_YANG 35
+#define ORC_MAX_ITERS_CONDAT 2500      /* src/TVopt.h:75 */
+#define ORC_STOP_CONDAT 0              /* src/TVopt.h:77 */
+#define ORC_MAX_ITERS_KOLMOGOROV 2500  /* src/TVopt.h:79 */
+#define ORC_STOP_KOLMOGOROV 0          /* src/TVopt.h:81 */
 /* absolute comparison tolerance: src/general.h:64-67 */
 #define ORC_EPSILON 1e-10
 
@@ -77,6 +81,11 @@ int orc_Yang2_TV(size_t M, size_t N, const double *Y, double lambda, double *X, 
 /* src/TVNDopt.cpp:678-803 */
 int orc_Yang3_TV(size_t M, size_t N, size_t O, const double *Y, double lambda, double *X, int maxit, double *info);
 /* extension used only to check the per-dimension-lambda Yang variant of the product */
+/* 2-D primal-dual baselines of the same problem (src/TVopt.h:129-131) */
+int orc_Kolmogorov2_TV(size_t M, size_t N, const double *Y, double lambda, double *X, int maxit, double *info);
+int orc_CondatChambollePock2_TV(size_t M, size_t N, const double *Y, double lambda, double *X, short alg, int maxit,
+                                double *info);
+
 int orc_Yang3_TV_perdim(size_t M, size_t N, size_t O, const double *Y, const double *lambda3, double *X,
                         int maxit, double *info);
 

@@ -423,3 +423,151 @@ int orc_Yang3_TV_perdim(size_t M, size_t N, size_t O, const double *Y, const dou
     const int order[3] = { 0, 1, 2 };
     return yang_generic("Yang3_TV_perdim", ns, 3, order, lambda3, Y, X, maxit, info);
 }
+
+/* ------------------------------------------------------------------------- */
+/*  Kolmogorov et al.'s primal-dual splitting, 2-D        src/TV2Dopt.cpp:907-1024 */
+/*  Saddle point  min_X max_U <X,U> + TV_rows(X) + 1/2|X-Y|^2 - TV_cols^*(U); the   */
+/*  dual step goes through Moreau's identity, so both steps are 1-D TV-L1 proxes.   */
+/*  Step sizes: theta=1, tau=1/2, sigma=1, then theta=1/sqrt(1+tau), tau*=theta,    */
+/*  sigma/=theta every iteration (:1002-1004).  Stops when the relative change of X */
+/*  is not > STOP_KOLMOGOROV = 0 (i.e. X reached a bitwise fixed point) or after     */
+/*  maxit (default 2500) iterations; info[0] = iterations done + 1.                  */
+/* ------------------------------------------------------------------------- */
+int orc_Kolmogorov2_TV(size_t M, size_t N, const double *Y, double lambda, double *X, int maxit, double *info)
+{
+    const long n = (long)M * (long)N;
+    const int ns[2] = { (int)M, (int)N };
+    double *U = (double *)malloc(sizeof(double) * (size_t)n);
+    double *Xold = (double *)malloc(sizeof(double) * (size_t)n);
+    double *V = (double *)malloc(sizeof(double) * (size_t)n);
+    double *P = (double *)malloc(sizeof(double) * (size_t)n);
+    if (!U || !Xold || !V || !P) {
+        free(U); free(Xold); free(V); free(P);
+        return fail("Kolmogorov2_TV", "insufficient memory", info);
+    }
+    double theta = 1., tau = 1. / 2., sigma = 1.;
+    set_threads(1);   /* the reference's loop is serial (one fibre at a time through TV(..., NULL)) */
+    memcpy(X, Y, sizeof(double) * (size_t)n);
+    memcpy(Xold, Y, sizeof(double) * (size_t)n);
+    memcpy(U, Y, sizeof(double) * (size_t)n);
+    if (maxit <= 0) maxit = ORC_MAX_ITERS_KOLMOGOROV;
+
+    int it;
+    double stop = DBL_MAX;
+    for (it = 1; stop > ORC_STOP_KOLMOGOROV && it <= maxit; it++) {
+        /* dual step along columns: V = (U + sigma (X + theta (X - Xold))) / sigma ; U = sigma (V - colprox_{lambda/sigma} V)   (:963-973) */
+        for (long i = 0; i < n; i++) {
+            double v = U[i] + sigma * (X[i] + theta * (X[i] - Xold[i]));
+            v /= sigma;
+            V[i] = v;
+        }
+        sweep_prox(V, NULL, 0, P, ns, 2, 0, lambda / sigma, 0);
+        for (long i = 0; i < n; i++) U[i] = sigma * (V[i] - P[i]);
+        memcpy(Xold, X, sizeof(double) * (size_t)n);                                   /* :976 */
+        /* primal step along rows: V = 1/(1+1/tau) (Y + 1/tau (X - tau U)) ; X = rowprox_{lambda/(1+1/tau)} V   (:981-996) */
+        for (long i = 0; i < n; i++) {
+            double v = X[i] - tau * U[i];
+            v = 1 / (1 + 1 / tau) * (Y[i] + 1 / tau * v);
+            V[i] = v;
+        }
+        sweep_prox(V, NULL, 0, X, ns, 2, 1, lambda / (1. + 1. / tau), 0);
+        theta = 1. / sqrt(1 + 1 * tau);
+        tau *= theta;
+        sigma /= theta;
+        /* relative change, summed serially in index order (:1007-1013) */
+        double num = 0, den = 0;
+        for (long i = 0; i < n; i++) {
+            den += X[i] * X[i];
+            const double d = Xold[i] - X[i];
+            num += d * d;
+        }
+        stop = sqrt(num / den);
+    }
+    if (info) { info[ORC_INFO_ITERS] = it; info[ORC_INFO_RC] = ORC_RC_OK; }
+    free(U); free(Xold); free(V); free(P);
+    return 1;
+}
+
+/* ------------------------------------------------------------------------- */
+/*  Condat's and Chambolle-Pock's primal-dual iterations, 2-D   src/TV2Dopt.cpp:587-760 */
+/*  Duals U1 ((M-1) x N, vertical differences) and U2 (M x (N-1)), both column-major.  */
+/*  alg 0: Condat (gradient step on the data term), 1: Chambolle-Pock (prox step),      */
+/*  2: accelerated Chambolle-Pock (gamma = 1/lambda; tau, sigma, theta updated after     */
+/*  the extrapolation and BEFORE the dual updates, :697-701).  sigma=10, tau=.9/(8 sigma),*/
+/*  theta=1.  Same stopping rule as above with STOP_CONDAT = 0, default 2500 iterations. */
+/* ------------------------------------------------------------------------- */
+int orc_CondatChambollePock2_TV(size_t M, size_t N, const double *Y, double lambda, double *X, short alg, int maxit,
+                                double *info)
+{
+    if (alg != 0 && alg != 1 && alg != 2)
+        return fail("Condat2_TV", "Algorithm parameter has an invalid value", info);
+    if (M < 2 || N < 2)   /* the reference indexes U1[(M-1)*j] / U2[i+M*(N-2)] regardless: out of bounds for a single row / column */
+        return fail("Condat2_TV", "needs at least two rows and two columns", info);
+    const long m = (long)M, nn = (long)N, n = m * nn;
+    double sigma = 10, tau = .9 / (sigma * 8), theta = 1., gamma = (alg == 2) ? 1. / lambda : 0.;
+    double *U1 = (double *)malloc(sizeof(double) * (size_t)((m - 1) * nn));
+    double *U2 = (double *)malloc(sizeof(double) * (size_t)(m * (nn - 1)));
+    double *Xt = (double *)malloc(sizeof(double) * (size_t)n);
+    double *Z = (double *)malloc(sizeof(double) * (size_t)n);
+    if (!U1 || !U2 || !Xt || !Z) {
+        free(U1); free(U2); free(Xt); free(Z);
+        return fail("Condat2_TV", "insufficient memory", info);
+    }
+    memcpy(X, Y, sizeof(double) * (size_t)n);
+    for (long j = 0; j < nn; j++)
+        for (long i = 0; i < m - 1; i++) U1[i + (m - 1) * j] = Y[i + 1 + m * j] - Y[i + m * j];
+    for (long j = 0; j < nn - 1; j++)
+        for (long i = 0; i < m; i++) U2[i + m * j] = Y[i + m * (j + 1)] - Y[i + m * j];
+    if (maxit <= 0) maxit = ORC_MAX_ITERS_CONDAT;
+
+    int it;
+    double stop = DBL_MAX;
+    for (it = 1; stop > ORC_STOP_CONDAT && it <= maxit; it++) {
+        for (long j = 0; j < nn; j++)
+            for (long i = 0; i < m; i++) {
+                /* adjoint of the two difference operators at (i, j): vertical part first, then "+=" the horizontal part (:656-675) */
+                double g = (i == 0) ? -U1[(m - 1) * j] : (i == m - 1) ? U1[m - 2 + (m - 1) * j]
+                                                                       : U1[i - 1 + (m - 1) * j] - U1[i + (m - 1) * j];
+                if (j == 0)            g += -U2[i];
+                else if (j == nn - 1)  g += U2[i + m * (nn - 2)];
+                else                   g += U2[i + m * (j - 1)] - U2[i + m * j];
+                const long k = i + m * j;
+                if (alg == 0) {
+                    Xt[k] = X[k] - tau * (X[k] - Y[k] + g);                       /* :683 */
+                } else {
+                    const double c = 1. / (1. + tau);
+                    Xt[k] = c * (X[k] + tau * (Y[k] - g));                        /* :691-693 */
+                }
+            }
+        for (long k = 0; k < n; k++) Z[k] = Xt[k] + theta * (Xt[k] - X[k]);       /* :697-698 */
+        if (alg == 2) {
+            tau *= theta;
+            sigma /= theta;
+            theta = 1. / sqrt(1 + 2 * gamma * tau);
+        }
+        double num = 0, den = 0;
+        for (long k = 0; k < n; k++) {
+            den += X[k] * X[k];
+            const double d = Xt[k] - X[k];
+            num += d * d;
+        }
+        stop = sqrt(num / den);
+        memcpy(X, Xt, sizeof(double) * (size_t)n);
+        /* dual ascent + projection onto the l_inf ball of radius lambda (:720-747) */
+        for (long j = 0; j < nn; j++)
+            for (long i = 1; i < m; i++) {
+                double u = U1[i - 1 + (m - 1) * j] + sigma * (Z[i + m * j] - Z[i - 1 + m * j]);
+                if (u < -lambda) u = -lambda; else if (u > lambda) u = lambda;
+                U1[i - 1 + (m - 1) * j] = u;
+            }
+        for (long j = 1; j < nn; j++)
+            for (long i = 0; i < m; i++) {
+                double u = U2[i + m * (j - 1)] + sigma * (Z[i + m * j] - Z[i + m * (j - 1)]);
+                if (u < -lambda) u = -lambda; else if (u > lambda) u = lambda;
+                U2[i + m * (j - 1)] = u;
+            }
+    }
+    if (info) { info[ORC_INFO_ITERS] = it; info[ORC_INFO_RC] = ORC_RC_OK; }
+    free(U1); free(U2); free(Xt); free(Z);
+    return 1;
+}

@@ -123,14 +123,13 @@ def tvp_1d(x, w, p, method="gpfw", max_iters=0):
 def tv1_2d(x, w, n_threads=1, max_iters=0, method="dr"):
     r"""2D proximal operator for :math:`\ell_1` (anisotropic TV), reference: prox_tv/__init__.py:355-407.
 
-    ``method``: 'dr' (Douglas-Rachford, DR2_TV), 'pd' (proximal Dykstra, PD2_TV), 'yang' (Yang2_TV).
+    ``method``: 'dr' (Douglas-Rachford, DR2_TV), 'pd' (proximal Dykstra, PD2_TV), 'yang' (Yang2_TV), 'kolmogorov'
+    (Kolmogorov2_TV), 'condat' / 'chambolle-pock' / 'chambolle-pock-acc' (CondatChambollePock2_TV, algorithm 0 / 1 / 2).
     ``n_threads`` is accepted for compatibility; the GPU path ignores it.
     """
     methods = ("yang", "dr", "pd", "kolmogorov", "condat", "chambolle-pock", "chambolle-pock-acc")
     assert w >= 0
     assert method in methods
-    if method not in ("yang", "dr", "pd"):
-        raise NotImplementedError(f"tv1_2d(method={method!r}): the pointwise 2-D baselines are out of scope")
     x = np.asfortranarray(x, dtype="float64")
     w = force_float_scalar(w)
     y = np.asfortranarray(np.zeros(x.shape))
@@ -145,8 +144,13 @@ def tv1_2d(x, w, n_threads=1, max_iters=0, method="dr"):
         ns = np.array(x.shape, dtype=np.int32)
         lib.PD2_TV(_ptr(x), _ptr(lam), _ptr(norms), _ptr(dims), _ptr(y), _ptr(info), _ptr(ns), 2, 2,
                    int(n_threads), int(max_iters))
-    else:                   # prox_tv/__init__.py:409-411
+    elif method == "yang":  # prox_tv/__init__.py:409-411
         lib.Yang2_TV(x.shape[0], x.shape[1], _ptr(x), w, _ptr(y), int(max_iters), _ptr(info))
+    elif method == "kolmogorov":   # prox_tv/__init__.py:423-426
+        lib.Kolmogorov2_TV(x.shape[0], x.shape[1], _ptr(x), w, _ptr(y), int(max_iters), _ptr(info))
+    else:                   # prox_tv/__init__.py:428-443
+        alg = {"condat": 0, "chambolle-pock": 1, "chambolle-pock-acc": 2}[method]
+        lib.CondatChambollePock2_TV(x.shape[0], x.shape[1], _ptr(x), w, _ptr(y), alg, int(max_iters), _ptr(info))
     _lib.check("tv1_2d")
     return y
 

@@ -31,6 +31,8 @@ SIGNATURES = {
     "PDR_TV": (C.c_int, [_dp, _dp, _dp, _dp, _dp, _dp, _ip, C.c_int, C.c_int, C.c_int, C.c_int]),
     "Yang2_TV": (C.c_int, [C.c_size_t, C.c_size_t, _dp, C.c_double, _dp, C.c_int, _dp]),
     "Yang3_TV": (C.c_int, [C.c_size_t, C.c_size_t, C.c_size_t, _dp, C.c_double, _dp, C.c_int, _dp]),
+    "Kolmogorov2_TV": (C.c_int, [C.c_size_t, C.c_size_t, _dp, C.c_double, _dp, C.c_int, _dp]),
+    "CondatChambollePock2_TV": (C.c_int, [C.c_size_t, C.c_size_t, _dp, C.c_double, _dp, C.c_short, C.c_int, _dp]),
     "newWorkspace": (C.c_void_p, [C.c_int]),
     "resetWorkspace": (None, [C.c_void_p]),
     "freeWorkspace": (None, [C.c_void_p]),
@@ -48,6 +50,9 @@ SIGNATURES = {
     "proxtv_PD_TV_dev": (C.c_int, [_dp, _dp, _dp, _dp, _dp, _ip, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "proxtv_PDR_TV_dev": (C.c_int, [_dp, _dp, _dp, _dp, _dp, _ip, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "proxtv_Yang_TV_dev": (C.c_int, [_ip, C.c_int, _dp, _dp, _dp, C.c_int, _dp, C.c_void_p]),
+    "proxtv_Kolmogorov2_TV_dev": (C.c_int, [C.c_size_t, C.c_size_t, _dp, C.c_double, _dp, C.c_int, _dp, C.c_void_p]),
+    "proxtv_CondatChambollePock2_TV_dev": (C.c_int, [C.c_size_t, C.c_size_t, _dp, C.c_double, _dp, C.c_short, C.c_int, _dp,
+                                                     C.c_void_p]),
     "proxtv_tv1_fibres_dev": (C.c_int, [_dp, _dp, _ip, C.c_int, C.c_int, C.c_double, _dp, C.c_void_p]),
     "proxtv_DR2_TV_batch_dev": (C.c_int, [C.c_size_t, C.c_size_t, C.c_size_t, _dp, C.c_double, C.c_double, _dp,
                                           C.c_int, _dp, C.c_void_p]),

@@ -277,6 +277,32 @@ int Yang3_TV(size_t M, size_t N, size_t O, double *Y, double lambda, double *X, 
     return yang_host("Yang3_TV", ns, 3, order, lambda, Y, X, maxit, info);
 }
 
+int Kolmogorov2_TV(size_t M, size_t N, double *Y, double lambda, double *X, int maxit, double *info) {
+    return guarded("Kolmogorov2_TV", info, 1, [&] {
+        hipStream_t st = thread_stream();
+        SolveScope scope(st);
+        Staged in(Y, M * N, st);
+        Scratch out(sizeof(double) * (M * N ? M * N : 1));
+        const SolveInfo si = kolmogorov2(M, N, in.d(), lambda, out.d(), maxit, st);
+        download(X, out.d(), M * N, st);
+        scope.finish();
+        put_info(info, si);
+    });
+}
+
+int CondatChambollePock2_TV(size_t M, size_t N, double *Y, double lambda, double *X, short alg, int maxit, double *info) {
+    return guarded("Condat2_TV", info, 1, [&] {   // the reference's messages say "Condat2_TV" (src/TV2Dopt.cpp:598)
+        hipStream_t st = thread_stream();
+        SolveScope scope(st);
+        Staged in(Y, M * N, st);
+        Scratch out(sizeof(double) * (M * N ? M * N : 1));
+        const SolveInfo si = ccp2(M, N, in.d(), lambda, out.d(), alg, maxit, st);
+        download(X, out.d(), M * N, st);
+        scope.finish();
+        put_info(info, si);
+    });
+}
+
 // ---- Workspace shims (ABI only) ----
 struct Workspace {
     int n;
@@ -438,6 +464,30 @@ int proxtv_Yang_TV_dev(const int *ns, int nds, const double *Y, const double *la
         double lams[3] = {lambdas[0], lambdas[1], nds == 3 ? lambdas[2] : 0.0};
         if (nds == 2) { order[0] = 1; order[1] = 0; std::swap(lams[0], lams[1]); }   // (Z1,U1) = rows = dim 2
         const SolveInfo si = yang(ns, nds, order, lams, Y, X, maxit, st);
+        PTV_HIP(hipStreamSynchronize(st));
+        scope.finish();
+        put_info(info, si);
+    });
+}
+
+int proxtv_Kolmogorov2_TV_dev(size_t M, size_t N, const double *Y, double lambda, double *X, int maxit, double *info,
+                              void *stream) {
+    return guarded("proxtv_Kolmogorov2_TV_dev", info, 1, [&] {
+        hipStream_t st = pick(stream);
+        SolveScope scope(st);
+        const SolveInfo si = kolmogorov2(M, N, Y, lambda, X, maxit, st);
+        PTV_HIP(hipStreamSynchronize(st));
+        scope.finish();
+        put_info(info, si);
+    });
+}
+
+int proxtv_CondatChambollePock2_TV_dev(size_t M, size_t N, const double *Y, double lambda, double *X, short alg,
+                                       int maxit, double *info, void *stream) {
+    return guarded("proxtv_CondatChambollePock2_TV_dev", info, 1, [&] {
+        hipStream_t st = pick(stream);
+        SolveScope scope(st);
+        const SolveInfo si = ccp2(M, N, Y, lambda, X, alg, maxit, st);
         PTV_HIP(hipStreamSynchronize(st));
         scope.finish();
         put_info(info, si);

@@ -26,6 +26,7 @@ struct SweepArgs {
     double s0 = 0.0;            // scalar (rho for Yang)
     double lam = 0.0;           // uniform penalty
     const double *w = nullptr;  // per-edge penalties (weighted sweeps); same layout as the data with len-1 along the fibre
+    const int *gate = nullptr;  // device flag: the sweep is a no-op when *gate == 0 (loops whose exit test lives on the device)
 };
 
 enum OpId : int {

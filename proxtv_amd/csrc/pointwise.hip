@@ -114,6 +114,97 @@ __global__ __launch_bounds__(kThreads) void yang_x_kernel(const double *Y, PtrPa
     }
 }
 
+__global__ __launch_bounds__(kThreads) void kolmo_dual_in_kernel(const double *D, double su, const double *X, const double *Xold,
+                                                                   double sigma, double theta, double *V, long n,
+                                                                   const int *gate, int *changed) {
+    if (gate && *gate == 0) return;
+    bool any = false;
+    for (long i = (long)blockIdx.x * kThreads + threadIdx.x; i < n; i += (long)gridDim.x * kThreads) {
+        const double x = X[i], xo = Xold[i];
+        const double u = su * D[i];
+        double v = u + sigma * (x + theta * (x - xo));
+        v = v / sigma;
+        V[i] = v;
+        const double d = xo - x;
+        any |= (d * d > 0);
+    }
+    if (changed && any) *changed = 1;
+}
+
+__global__ __launch_bounds__(kThreads) void kolmo_primal_in_kernel(const double *X, const double *D, double su, const double *Y,
+                                                                     double tau, double c1, double c2, double *V, long n,
+                                                                     const int *gate) {
+    if (gate && *gate == 0) return;
+    for (long i = (long)blockIdx.x * kThreads + threadIdx.x; i < n; i += (long)gridDim.x * kThreads) {
+        const double u = su * D[i];
+        const double v = X[i] - tau * u;
+        V[i] = c1 * (Y[i] + c2 * v);
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void ccp_init_kernel(const double *Y, double *U1, double *U2, long M, long N) {
+    const long n = M * N;
+    for (long k = (long)blockIdx.x * kThreads + threadIdx.x; k < n; k += (long)gridDim.x * kThreads) {
+        const long i = k % M, j = k / M;
+        if (i < M - 1) U1[i + (M - 1) * j] = Y[k + 1] - Y[k];
+        if (j < N - 1) U2[k] = Y[k + M] - Y[k];
+    }
+}
+
+__device__ __forceinline__ double clip_to(double u, double lambda) {
+    if (u < -lambda) u = -lambda;
+    else if (u > lambda) u = lambda;
+    return u;
+}
+
+template <bool FIRST>
+__global__ __launch_bounds__(kThreads) void ccp_step_kernel(CcpArgs a) {
+    if (a.gate && *a.gate == 0) return;
+    const long M = a.M, N = a.N, n = M * N;
+    bool any = false;
+    for (long k = (long)blockIdx.x * kThreads + threadIdx.x; k < n; k += (long)gridDim.x * kThreads) {
+        const long i = k % M, j = k / M;
+        // the four duals around pixel (i, j): above / below (U1), left / right (U2)
+        double ua = 0, ub = 0, ul = 0, ur = 0;
+        if (FIRST) {
+            if (i > 0) ua = a.U1o[i - 1 + (M - 1) * j];
+            if (i < M - 1) ub = a.U1o[i + (M - 1) * j];
+            if (j > 0) ul = a.U2o[k - M];
+            if (j < N - 1) ur = a.U2o[k];
+        } else {
+            const double z = a.Zold[k];
+            if (i > 0) ua = clip_to(a.U1o[i - 1 + (M - 1) * j] + a.sigma * (z - a.Zold[k - 1]), a.lambda);
+            if (i < M - 1) {
+                ub = clip_to(a.U1o[i + (M - 1) * j] + a.sigma * (a.Zold[k + 1] - z), a.lambda);
+                a.U1n[i + (M - 1) * j] = ub;
+            }
+            if (j > 0) ul = clip_to(a.U2o[k - M] + a.sigma * (z - a.Zold[k - M]), a.lambda);
+            if (j < N - 1) {
+                ur = clip_to(a.U2o[k] + a.sigma * (a.Zold[k + M] - z), a.lambda);
+                a.U2n[k] = ur;
+            }
+        }
+        // adjoint of the difference operators: vertical part, then "+=" the horizontal part (reference order)
+        double g = (i == 0) ? -ub : (i == M - 1) ? ua : ua - ub;
+        if (j == 0) g += -ur;
+        else if (j == N - 1) g += ul;
+        else g += ul - ur;
+        const double x = a.X[k], y = a.Y[k];
+        double xt;
+        if (a.alg == 0) {
+            xt = x - a.tau * (x - y + g);
+        } else {
+            const double c = 1. / (1. + a.tau);
+            xt = c * (x + a.tau * (y - g));
+        }
+        a.Xn[k] = xt;
+        a.Zn[k] = xt + a.theta * (xt - x);
+        const double d = xt - x;
+        any |= (d * d > 0);
+    }
+    if (a.changed && any) *a.changed = 1;
+}
+
 inline unsigned grid_for(long n, unsigned cap) {
     long b = (n + kThreads - 1) / kThreads;
     if (b < 1) b = 1;
@@ -168,6 +259,32 @@ void yang_x(const double *Y, const PtrPack &U, const PtrPack &Z, double *X, int 
     if (D == 2)      hipLaunchKernelGGL(yang_x_kernel<2>, grid, block, 0, s, Y, U, Z, X, rho, n);
     else if (D == 3) hipLaunchKernelGGL(yang_x_kernel<3>, grid, block, 0, s, Y, U, Z, X, rho, n);
     else { set_error("yang_x: D must be 2 or 3"); throw HipFailure{hipErrorInvalidValue}; }
+    PTV_HIP(hipGetLastError());
+}
+
+void kolmo_dual_in(const double *D, double su, const double *X, const double *Xold, double sigma, double theta, double *V,
+                   long n, const int *gate, int *changed, hipStream_t s) {
+    hipLaunchKernelGGL(kolmo_dual_in_kernel, dim3(grid_for(n, 4096)), dim3(kThreads), 0, s, D, su, X, Xold, sigma, theta, V, n,
+                       gate, changed);
+    PTV_HIP(hipGetLastError());
+}
+
+void kolmo_primal_in(const double *X, const double *D, double su, const double *Y, double tau, double c1, double c2,
+                     double *V, long n, const int *gate, hipStream_t s) {
+    hipLaunchKernelGGL(kolmo_primal_in_kernel, dim3(grid_for(n, 4096)), dim3(kThreads), 0, s, X, D, su, Y, tau, c1, c2, V, n,
+                       gate);
+    PTV_HIP(hipGetLastError());
+}
+
+void ccp_init(const double *Y, double *U1, double *U2, long M, long N, hipStream_t s) {
+    hipLaunchKernelGGL(ccp_init_kernel, dim3(grid_for(M * N, 4096)), dim3(kThreads), 0, s, Y, U1, U2, M, N);
+    PTV_HIP(hipGetLastError());
+}
+
+void ccp_step(const CcpArgs &a, bool first, hipStream_t s) {
+    const dim3 grid(grid_for(a.M * a.N, 8192)), block(kThreads);
+    if (first) hipLaunchKernelGGL(ccp_step_kernel<true>, grid, block, 0, s, a);
+    else       hipLaunchKernelGGL(ccp_step_kernel<false>, grid, block, 0, s, a);
     PTV_HIP(hipGetLastError());
 }
 

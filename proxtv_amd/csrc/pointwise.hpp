@@ -33,4 +33,31 @@ void calib_copy(const double *src, double *dst, long n, hipStream_t s);
 // Yang X update (src/TV2Dopt.cpp:832-833 ; src/TVNDopt.cpp:729-730): X = (Y + sum U_k + rho sum Z_k) / (1 + D rho)
 void yang_x(const double *Y, const PtrPack &U, const PtrPack &Z, double *X, int D, double rho, long n, hipStream_t s);
 
+// ---- Kolmogorov2_TV (src/TV2Dopt.cpp:907-1024).  The dual is kept unscaled: U = su * D with D = V - colprox(V).
+// `gate` (may be null): the kernel is a no-op when *gate == 0.
+// V = (su*D + sigma (X + theta (X - Xold))) / sigma     (:963-966); if `changed`: *changed = 1 when X differs from Xold
+// anywhere ((Xold - X)^2 > 0: the reference's exit test `stop > 0`, :1007-1013)
+void kolmo_dual_in(const double *D, double su, const double *X, const double *Xold, double sigma, double theta, double *V,
+                   long n, const int *gate, int *changed, hipStream_t s);
+// V = c1 (Y + c2 (X - tau su D)),  c1 = 1/(1+1/tau), c2 = 1/tau        (:981-984)
+void kolmo_primal_in(const double *X, const double *D, double su, const double *Y, double tau, double c1, double c2,
+                     double *V, long n, const int *gate, hipStream_t s);
+
+// ---- CondatChambollePock2_TV (src/TV2Dopt.cpp:587-760): M x N column-major image, duals U1 ((M-1) x N), U2 (M x (N-1)).
+void ccp_init(const double *Y, double *U1, double *U2, long M, long N, hipStream_t s);
+// One iteration, fused: (unless `first`) the dual ascent + clip of the PREVIOUS iteration from Zold into U1n/U2n
+// (every thread recomputes the four duals around its pixel, writes the two it owns), then the primal step
+// (alg 0: X - tau (X - Y + g) ; 1, 2: (X + tau (Y - g)) / (1 + tau)) into Xn and the extrapolation
+// Zn = Xn + theta (Xn - X).  *changed = 1 when Xn differs from X anywhere.
+struct CcpArgs {
+    const double *Y, *X, *Zold, *U1o, *U2o;
+    double *Xn, *Zn, *U1n, *U2n;
+    long M, N;
+    double tau, theta, sigma, lambda;
+    int alg;
+    const int *gate;
+    int *changed;
+};
+void ccp_step(const CcpArgs &a, bool first, hipStream_t s);
+
 }  // namespace ptv

@@ -7,8 +7,10 @@
 #include "solvers.hpp"
 
 #include <cfloat>
+#include <cmath>
 #include <memory>
 #include <utility>
+#include <vector>
 
 #include "pointwise.hpp"
 #include "sweep.hpp"
@@ -254,6 +256,134 @@ SolveInfo yang(const int *ns, int nds, const int *order, const double *lambdas, 
         std::swap(Uin, Uout);
     }
     info.iters = maxit + 1;   // the reference reports its loop counter after exit (:867 / :793)
+    return info;
+}
+
+namespace {
+
+// Loops whose exit test is "X changed at all" (STOP = 0 in the reference): the test lives on the device.  flag[k] says
+// "iteration k changed X" (flag[0] = 1); the kernels of iteration k + 1 are no-ops when flag[k] == 0, so the host
+// enqueues all iterations without a round trip and reads the flags once at the end.
+struct ChangeFlags {
+    Scratch buf;
+    int count;
+    ChangeFlags(int n, hipStream_t s) : buf(sizeof(int) * (size_t)(n + 2)), count(n + 2) {
+        PTV_HIP(hipMemsetAsync(buf.as<int>(), 0, sizeof(int) * (size_t)count, s));
+        const int one = 1;
+        PTV_HIP(hipMemcpyAsync(buf.as<int>(), &one, sizeof(int), hipMemcpyHostToDevice, s));
+        PTV_HIP(hipStreamSynchronize(s));   // `one` lives on this stack frame
+    }
+    int *at(int k) const { return buf.as<int>() + k; }
+    // the reference's loop counter at exit: first k in [1, last] with flag[k] == 0 -> k + 1 ; none -> maxit + 1
+    int exit_counter(int last, int maxit, hipStream_t s) const {
+        std::vector<int> h((size_t)count, 0);
+        PTV_HIP(hipMemcpyAsync(h.data(), buf.as<int>(), sizeof(int) * (size_t)count, hipMemcpyDeviceToHost, s));
+        PTV_HIP(hipStreamSynchronize(s));
+        for (int k = 1; k <= last; k++)
+            if (!h[(size_t)k]) return k + 1;
+        return maxit + 1;
+    }
+};
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Kolmogorov et al., "Total variation on a tree", p. 19: reference src/TV2Dopt.cpp:907-1024.
+//   X = Xold = U = Y ; theta = 1, tau = 1/2, sigma = 1 ; repeat:
+//     V = (U + sigma (X + theta (X - Xold))) / sigma ; U = sigma (V - colprox_{lambda/sigma} V)       (Moreau)
+//     Xold = X ; V = (Y + (X - tau U)/tau) / (1 + 1/tau) ; X = rowprox_{lambda/(1+1/tau)} V
+//     theta = 1/sqrt(1+tau) ; tau *= theta ; sigma /= theta ; stop = |X - Xold| / |X|
+// The dual is stored unscaled (D = V - colprox V, the fused output of the column sweep; U = su D is formed where it
+// is used, the same single rounding), X and Xold trade places instead of being copied.
+SolveInfo kolmogorov2(size_t M, size_t N, const double *Y, double lambda, double *X, int maxit, hipStream_t s) {
+    SolveInfo info;
+    if (maxit <= 0) maxit = MAX_ITERS_KOLMOGOROV;
+    const long n = (long)M * (long)N;
+    const size_t bytes = sizeof(double) * (size_t)(n ? n : 1);
+    const int ns[2] = {(int)M, (int)N};
+    Scratch D(bytes), Xa(bytes), Xb(bytes), V(bytes);
+    ChangeFlags flags(maxit, s);
+    double *xcur = Xa.d(), *xold = Xb.d();
+    PTV_HIP(hipMemcpyAsync(xcur, Y, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, s));
+    PTV_HIP(hipMemcpyAsync(xold, Y, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, s));
+    PTV_HIP(hipMemcpyAsync(D.d(), Y, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, s));
+    double theta = 1., tau = 1. / 2., sigma = 1., su = 1.;
+
+    for (int it = 1; it <= maxit; it++) {
+        const int *gate = flags.at(it - 1);
+        {
+            // also settles flag[it - 1] (did iteration it - 1 change X?); itself gated on iteration it - 1 having run
+            FamilyTimer tm(FAM_OTHER, s);
+            kolmo_dual_in(D.d(), su, xcur, xold, sigma, theta, V.d(), n, it > 1 ? flags.at(it - 2) : nullptr,
+                          it > 1 ? flags.at(it - 1) : nullptr, s);
+        }
+        SweepArgs col;
+        col.a = V.d(); col.o0 = D.d(); col.lam = lambda / sigma; col.gate = gate;
+        launch_sweep(OP_DR_COL_FINAL, false, col, fibres_along(ns, 2, 0), s, FAM_COL, true);   // D = V - prox(V)
+        su = sigma;
+        {
+            FamilyTimer tm(FAM_OTHER, s);
+            kolmo_primal_in(xcur, D.d(), su, Y, tau, 1 / (1 + 1 / tau), 1 / tau, V.d(), n, gate, s);
+        }
+        SweepArgs row;
+        row.a = V.d(); row.o0 = xold; row.lam = lambda / (1. + 1. / tau); row.gate = gate;
+        launch_sweep(OP_PROX, false, row, fibres_along(ns, 2, 1), s, FAM_ROW, true);
+        std::swap(xcur, xold);   // the buffer just written is X, the other one Xold
+        theta = 1. / sqrt(1 + 1 * tau);
+        tau *= theta;
+        sigma /= theta;
+    }
+    // flag[maxit - 1] is the last one the loop evaluated (iteration maxit's own change is never tested: it <= maxit ends it)
+    info.iters = flags.exit_counter(maxit - 1, maxit, s);
+    PTV_HIP(hipMemcpyAsync(X, xcur, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, s));
+    return info;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Condat / Chambolle-Pock primal-dual iterations: reference src/TV2Dopt.cpp:587-760.  sigma = 10, tau = .9/(8 sigma),
+// theta = 1; the accelerated variant (gamma = 1/lambda) rescales tau, sigma, theta after the extrapolation and before
+// the dual update (:697-701).  One fused kernel per iteration; every array is double-buffered (neighbours read the
+// previous iterate of Z and of the duals).  The final dual update of the reference does not touch X and is skipped.
+SolveInfo ccp2(size_t M, size_t N, const double *Y, double lambda, double *X, int alg, int maxit, hipStream_t s) {
+    SolveInfo info;
+    if (alg != 0 && alg != 1 && alg != 2) {
+        set_error("Algorithm parameter has an invalid value");
+        throw HipFailure{hipErrorInvalidValue};
+    }
+    if (M < 2 || N < 2) {
+        set_error("needs at least two rows and two columns (the reference indexes out of bounds otherwise)");
+        throw HipFailure{hipErrorInvalidValue};
+    }
+    if (maxit <= 0) maxit = MAX_ITERS_CONDAT;
+    const long m = (long)M, nn = (long)N, n = m * nn;
+    const size_t bytes = sizeof(double) * (size_t)n;
+    Scratch X0(bytes), X1(bytes), Z0(bytes), Z1(bytes), U10(bytes), U11(bytes), U20(bytes), U21(bytes);
+    ChangeFlags flags(maxit, s);
+    double *xc = X0.d(), *xn = X1.d(), *zc = Z0.d(), *zn = Z1.d();
+    double *u1c = U10.d(), *u1n = U11.d(), *u2c = U20.d(), *u2n = U21.d();
+    PTV_HIP(hipMemcpyAsync(xc, Y, bytes, hipMemcpyDeviceToDevice, s));
+    ccp_init(Y, u1c, u2c, m, nn, s);
+    double sigma = 10, tau = .9 / (sigma * 8), theta = 1.;
+    const double gamma = (alg == 2) ? 1. / lambda : 0.;
+
+    for (int it = 1; it <= maxit; it++) {
+        FamilyTimer tm(FAM_OTHER, s);
+        CcpArgs a{Y, xc, zc, u1c, u2c, xn, zn, u1n, u2n, m, nn, tau, theta, sigma, lambda, alg, flags.at(it - 1), flags.at(it)};
+        ccp_step(a, it == 1, s);
+        if (it > 1) {
+            std::swap(u1c, u1n);
+            std::swap(u2c, u2n);
+        }
+        std::swap(xc, xn);
+        std::swap(zc, zn);
+        if (alg == 2) {
+            tau *= theta;
+            sigma /= theta;
+            theta = 1. / sqrt(1 + 2 * gamma * tau);
+        }
+    }
+    info.iters = flags.exit_counter(maxit, maxit, s);
+    PTV_HIP(hipMemcpyAsync(X, xc, bytes, hipMemcpyDeviceToDevice, s));
     return info;
 }
 

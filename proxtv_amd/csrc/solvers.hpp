@@ -32,4 +32,9 @@ SolveInfo pdr(const double *y, const double *lambdas, const double *dims, double
 SolveInfo yang(const int *ns, int nds, const int *order, const double *lambdas, const double *Y, double *X, int maxit,
                hipStream_t s);
 
+// Kolmogorov et al.'s primal-dual splitting, 2-D (src/TV2Dopt.cpp:907-1024)
+SolveInfo kolmogorov2(size_t M, size_t N, const double *Y, double lambda, double *X, int maxit, hipStream_t s);
+// Condat / Chambolle-Pock / accelerated Chambolle-Pock, 2-D (src/TV2Dopt.cpp:587-760); alg = 0 / 1 / 2
+SolveInfo ccp2(size_t M, size_t N, const double *Y, double lambda, double *X, int alg, int maxit, hipStream_t s);
+
 }  // namespace ptv

@@ -140,6 +140,7 @@ template <int OP, bool WEIGHTED, bool PIPELINED>
 __global__ __launch_bounds__(64) void sweep_seq_kernel(SweepArgs p, FibreGeom g) {
     const long j = (long)blockIdx.x * 64 + threadIdx.x;
     if (j >= g.count || g.len <= 0) return;
+    if (p.gate && *p.gate == 0) return;
     solve_fibre_seq<OP, WEIGHTED, PIPELINED>(p, g, j);
 }
 
@@ -365,6 +366,7 @@ __global__ __launch_bounds__(64 * NW, ((WEIGHTED || H > 16) ? NW / 4 : NW / 2)) 
     double *Wp = Yp + (WEIGHTED ? (size_t)ROWS * PITCH : 0);
     link_t *codes = reinterpret_cast<link_t *>(Wp + (size_t)ROWS * PITCH);   // [NW + 2][64]; slots NW, NW + 1 carry over blocks
 
+    if (p.gate && *p.gate == 0) return;   // uniform over the grid
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int len = g.len;
     const long j0 = (long)blockIdx.x * 64;
@@ -623,6 +625,7 @@ __global__ __launch_bounds__(64) void sweep_gchunk_kernel(SweepArgs p, FibreGeom
     const int len = g.len;
     const int cs = c * C;
     if (j >= g.count || cs >= len) return;
+    if (p.gate && *p.gate == 0) return;
     const int ce = min(cs + C, len);
     const long blk = j / g.inc, off = j % g.inc;
     GlobalChunkSource<OP, WEIGHTED> src{p, blk * g.inc * len + off, g.inc, blk * g.inc * (len - 1) + off, cs, ce,
@@ -699,6 +702,7 @@ __global__ __launch_bounds__(64) void sweep_repair_kernel(SweepArgs p, FibreGeom
                                                            int *failflags, int *failcount) {
     const long j = (long)blockIdx.x * 64 + threadIdx.x;
     if (j >= g.count) return;
+    if (p.gate && *p.gate == 0) return;
     const int len = g.len;
     const int NC = (len + C - 1) / C;
     int bad = failflags[j];

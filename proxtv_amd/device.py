@@ -68,6 +68,12 @@ def tv1_2d(x, w, max_iters=0, method="dr", out=None, w_row=None):
         ns = np.array([M, N], dtype=np.int32)
         lib.proxtv_Yang_TV_dev(ns.ctypes.data, 2, x.data_ptr(), lam.ctypes.data, y.data_ptr(), int(max_iters),
                                info.ctypes.data, _stream())
+    elif method == "kolmogorov":
+        lib.proxtv_Kolmogorov2_TV_dev(M, N, x.data_ptr(), float(w), y.data_ptr(), int(max_iters), info.ctypes.data, _stream())
+    elif method in ("condat", "chambolle-pock", "chambolle-pock-acc"):
+        alg = {"condat": 0, "chambolle-pock": 1, "chambolle-pock-acc": 2}[method]
+        lib.proxtv_CondatChambollePock2_TV_dev(M, N, x.data_ptr(), float(w), y.data_ptr(), alg, int(max_iters),
+                                               info.ctypes.data, _stream())
     else:
         raise NotImplementedError(method)
     _lib.check("device.tv1_2d")

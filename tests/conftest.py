@@ -63,6 +63,11 @@ def g2d():
 
 
 @pytest.fixture(scope="session")
+def gpd():
+    return load_golden("golden_2d_primal_dual.npz")
+
+
+@pytest.fixture(scope="session")
 def gnd():
     return load_golden("golden_nd.npz")
 

@@ -109,8 +109,7 @@ def test_python_surface_argument_checks():
         ptv.tvp_2d(x, 1, 1, 0.5, 1)
     # out-of-scope solvers say so instead of silently doing something else
     for call in (lambda: ptv.tv2_1d(np.zeros(5), 1.0), lambda: ptv.tvp_1d(np.zeros(5), 1.0, 1.5),
-                 lambda: ptv.tvp_2d(x, 1, 1, 2, 2), lambda: ptv.tv1_2d(x, 0.1, method="condat"),
-                 lambda: ptv.tv1_2d(x, 0.1, method="kolmogorov"), lambda: ptv.tvgen(x, [1, 1], [1, 2], [1, 2])):
+                 lambda: ptv.tvp_2d(x, 1, 1, 2, 2), lambda: ptv.tvgen(x, [1, 1], [1, 2], [1, 2])):
         with pytest.raises(NotImplementedError):
             call()
 

@@ -99,6 +99,38 @@ def test_yang_perdim_extension_consistent(oracle):
     np.testing.assert_array_equal(oracle.yang3(X, [0.3, 0.3, 0.3])[0], oracle.yang3(X, 0.3)[0])
 
 
+def test_golden_2d_primal_dual(oracle, gpd):
+    """Kolmogorov2_TV / CondatChambollePock2_TV restatements against vectors of the compiled reference."""
+    for name in gpd["names"]:
+        X, lam = gpd[f"{name}/X"], float(gpd[f"{name}/lam"])
+        y, info, rc = oracle.kolmogorov2(X, lam)
+        assert_close(y, gpd[f"{name}/kol"], TIGHT, f"{name}:kol")
+        assert rc == int(gpd[f"{name}/kol_rc"]) == 1
+        np.testing.assert_array_equal(info, gpd[f"{name}/kol_info"])
+        y, info, rc = oracle.kolmogorov2(X, lam, max_iters=40)
+        assert_close(y, gpd[f"{name}/kol_it40"], TIGHT, f"{name}:kol_it40")
+        assert info[0] == gpd[f"{name}/kol_it40_info"][0] == 41
+        for alg in (0, 1, 2):
+            y, info, rc = oracle.ccp2(X, lam, alg)
+            assert_close(y, gpd[f"{name}/ccp{alg}"], TIGHT, f"{name}:ccp{alg}")
+            assert rc == int(gpd[f"{name}/ccp{alg}_rc"]) == 1
+            np.testing.assert_array_equal(info, gpd[f"{name}/ccp{alg}_info"])
+            y, info, rc = oracle.ccp2(X, lam, alg, max_iters=60)
+            assert_close(y, gpd[f"{name}/ccp{alg}_it60"], TIGHT, f"{name}:ccp{alg}_it60")
+            assert info[0] == gpd[f"{name}/ccp{alg}_it60_info"][0] == 61
+    C = gpd["const/X"]
+    for alg in (0, 1, 2):   # a constant image is a fixed point: the loop exits through `stop > 0` after one iteration
+        y, info, rc = oracle.ccp2(C, 0.7, alg)
+        np.testing.assert_array_equal(y, gpd[f"const/ccp{alg}"])
+        np.testing.assert_array_equal(info, gpd[f"const/ccp{alg}_info"])
+        assert info[0] == 2
+    y, info, rc = oracle.kolmogorov2(C, 0.7)
+    assert_close(y, gpd["const/kol"], TIGHT)
+    np.testing.assert_array_equal(info, gpd["const/kol_info"])
+    y, info, rc = oracle.ccp2(C, 0.7, 5)
+    assert rc == int(gpd["const/ccp_bad_rc"]) == 0 and info[2] == gpd["const/ccp_bad_info"][2] == 3
+
+
 def test_bitwise_against_compiled_reference(oracle, reference):
     """Fresh seeded inputs, restatement vs the unmodified reference build: identical to the last bit."""
     rng = np.random.default_rng(99)
@@ -128,6 +160,9 @@ def test_bitwise_against_compiled_reference(oracle, reference):
         np.testing.assert_array_equal(oracle.dr2w(X, W1, W2)[0], reference.dr2w(X, W1, W2)[0])
         np.testing.assert_array_equal(oracle.pd2(X, [lam, lam], [1, 2])[0], reference.pd2(X, [lam, lam], [1, 2])[0])
         np.testing.assert_array_equal(oracle.yang2(X, lam)[0], reference.yang2(X, lam)[0])
+        np.testing.assert_array_equal(oracle.kolmogorov2(X, lam, 150)[0], reference.kolmogorov2(X, lam, 150)[0])
+        for alg in (0, 1, 2):
+            np.testing.assert_array_equal(oracle.ccp2(X, lam, alg, 300)[0], reference.ccp2(X, lam, alg, 300)[0])
         np.testing.assert_array_equal(oracle.pd(V, [lam, lam, lam / 2], [1, 2, 3])[0], reference.pd(V, [lam, lam, lam / 2], [1, 2, 3])[0])
         np.testing.assert_array_equal(oracle.pdr(V, [lam, lam, lam / 2], [1, 2, 3])[0], reference.pdr(V, [lam, lam, lam / 2], [1, 2, 3])[0])
         np.testing.assert_array_equal(oracle.yang3(V, lam)[0], reference.yang3(V, lam)[0])
