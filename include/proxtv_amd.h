@@ -15,7 +15,7 @@
  * callers that already hold data in HBM, plus the batch solver that shards independent images.
  *
  * Only the p = 1 (TV-L1) norm is implemented -- the hot path of BASELINE.json.  The TV-L2 / TV-Lp /
- * projected-Newton / Kolmogorov / Johnson-DP entry points of the reference are out of scope
+ * projected-Newton / 1-D Kolmogorov / Johnson-DP entry points of the reference are out of scope
  * (DESIGN.md "Out of scope") and are not exported.
  */
 #ifndef PROXTV_AMD_H

@@ -44,6 +44,8 @@ def main():
     rows.append(("    tv1_2d PD2 4096^2 lam=.1", timed(lambda: device.tv1_2d(X, 0.1, method="pd", out=out)), 4096 * 4096, lib.proxtv_last_fixups(), lib.proxtv_chunk_mode()))
     rows.append(("    tv1_2d Yang2 4096^2 lam=.1", timed(lambda: device.tv1_2d(X, 0.1, method="yang", out=out)), 4096 * 4096, lib.proxtv_last_fixups(), lib.proxtv_chunk_mode()))
     del W1, W2
+    for m, its in (("kolmogorov", 100), ("condat", 100), ("chambolle-pock-acc", 100)):
+        rows.append((f"    tv1_2d {m} 4096^2, {its} its", timed(lambda: device.tv1_2d(X, 0.1, method=m, max_iters=its, out=out), reps=1), 4096 * 4096, lib.proxtv_last_fixups(), lib.proxtv_chunk_mode()))
     V = dev(rng.standard_normal((512, 512, 64)))
     vout = device.colmajor_empty((512, 512, 64))
     rows.append(("C4  tvgen PD_TV 512x512x64", timed(lambda: device.tvgen(V, [0.1, 0.1, 0.05], [1, 2, 3], out=vout)), 512 * 512 * 64, lib.proxtv_last_fixups(), lib.proxtv_chunk_mode()))
