@@ -382,47 +382,57 @@ __global__ __launch_bounds__(64 * NW, ((WEIGHTED || H > 16) ? NW / 4 : NW / 2)) 
     // Strided sweeps: element u of a thread is row lo + wave + NW*u of its own fibre (each wave instruction = one
     // coalesced 512-byte row).  Dimension-0 sweeps (fibres contiguous): lanes run ALONG the fibre, element u is row
     // lo + 64*(u % RB) + lane of fibre wave + NW*(u / RB), and the tile is transposed on its way into LDS (pitch 65).
+    // The loads of a batch of NB elements are all issued before the first is waited for.  NB = NST (the whole window
+    // share of the thread) unless that would not fit the register budget: two-operand inputs of a transposed sweep go
+    // in three batches (48 live doubles spill otherwise).
+    constexpr int NB = (TRANSPOSED && Op<OP>::NIN > 1) ? (NST + 2) / 3 : NST;
     auto stage = [&](int q) {
         const int cs_wg = q * NW * C;
         const int lo = max(0, cs_wg - H), hi = min(len, cs_wg + NW * C + T);
-        double s0[NST], s1[NST], sw[NST];
 #pragma unroll
-        for (int u = 0; u < NST; u++) {
-            int r;
-            long idx, widx;
-            bool ok;
-            if (!TRANSPOSED) {
-                r = lo + wave + NW * u;
-                ok = active && r < hi;
-                idx = base + (long)r * g.inc;
-                widx = wbase + (long)r * g.inc;
-            } else {
-                const long jf = j0 + wave + NW * (u / RB);
-                r = lo + (u % RB) * 64 + lane;
-                ok = jf < g.count && r < hi;
-                idx = jf * len + r;
-                widx = jf * (len - 1) + r;
-            }
-            s0[u] = s1[u] = 0.0;
-            if (ok) Op<OP>::fetch_in(p, idx, s0[u], s1[u]);
-            if (WEIGHTED) sw[u] = (ok && r < len - 1) ? p.w[widx] : 0.0;
-        }
+        for (int u0 = 0; u0 < NST; u0 += NB) {
+            double s0[NB], s1[NB], sw[NB];
 #pragma unroll
-        for (int u = 0; u < NST; u++) {
-            int r, col;
-            bool ok;
-            if (!TRANSPOSED) {
-                r = lo + wave + NW * u;
-                col = lane;
-                ok = active && r < hi;
-            } else {
-                col = wave + NW * (u / RB);
-                r = lo + (u % RB) * 64 + lane;
-                ok = j0 + col < g.count && r < hi;
+            for (int v = 0; v < NB; v++) {
+                const int u = u0 + v;
+                int r;
+                long idx, widx;
+                bool ok;
+                if (!TRANSPOSED) {
+                    r = lo + wave + NW * u;
+                    ok = active && r < hi;
+                    idx = base + (long)r * g.inc;
+                    widx = wbase + (long)r * g.inc;
+                } else {
+                    const long jf = j0 + wave + NW * (u / RB);
+                    r = lo + (u % RB) * 64 + lane;
+                    ok = jf < g.count && r < hi;
+                    idx = jf * len + r;
+                    widx = jf * (len - 1) + r;
+                }
+                ok = ok && u < NST;
+                s0[v] = s1[v] = 0.0;
+                if (ok) Op<OP>::fetch_in(p, idx, s0[v], s1[v]);
+                if (WEIGHTED) sw[v] = (ok && r < len - 1) ? p.w[widx] : 0.0;
             }
-            if (ok) {
-                Yp[(r - lo) * PITCH + col] = Op<OP>::y_of(p, s0[u], s1[u]);
-                if (WEIGHTED) Wp[(r - lo) * PITCH + col] = sw[u];
+#pragma unroll
+            for (int v = 0; v < NB; v++) {
+                const int u = u0 + v;
+                int r, col;
+                bool ok;
+                if (!TRANSPOSED) {
+                    r = lo + wave + NW * u;
+                    col = lane;
+                    ok = active && r < hi;
+                } else {
+                    col = wave + NW * (u / RB);
+                    r = lo + (u % RB) * 64 + lane;
+                    ok = j0 + col < g.count && r < hi;
+                }
+                if (ok && u < NST) {
+                    Yp[(r - lo) * PITCH + col] = Op<OP>::y_of(p, s0[v], s1[v]);
+                    if (WEIGHTED) Wp[(r - lo) * PITCH + col] = sw[v];
+                }
             }
         }
     };
@@ -1121,7 +1131,7 @@ void launch_chunk(const SweepArgs &args, const FibreGeom &g, hipStream_t stream,
 template <int OP, bool WEIGHTED>
 void launch_op_w(const SweepArgs &args, const FibreGeom &g, hipStream_t stream, bool allow_chunked, int fam) {
     // chunking pays once a fibre spans several blocks; short fibres stay sequential
-    const bool chunked = allow_chunked && options().chunk > 0 && g.len >= 256;
+    const bool chunked = allow_chunked && options().chunk > 0 && g.len >= options().chunk_min_len;
     if (!chunked) launch_seq<OP, WEIGHTED>(args, g, stream, false);
     else if (g.inc == 1) launch_chunk<OP, WEIGHTED, true>(args, g, stream, fam);
     else launch_chunk<OP, WEIGHTED, false>(args, g, stream, fam);

@@ -120,11 +120,12 @@ def test_weighted_and_nd_under_repair(ptv, clib, oracle, modes):
 
 
 def test_fibre_lengths_around_chunk_and_block_edges(ptv, clib, oracle, modes):
-    """Lengths that are not multiples of the chunk (16) / block (128) sizes, for both sweep orientations."""
+    """Lengths from the chunked path's lower bound (96) up, not multiples of the chunk (16) / block (128) sizes, for both
+    sweep orientations."""
     rng = np.random.default_rng(45)
     torch = pytest.importorskip("torch")
     from proxtv_amd import device
-    for n in (256, 257, 271, 272, 383, 384, 385, 511, 1000):
+    for n in (96, 97, 111, 112, 127, 128, 129, 200, 255, 256, 257, 271, 272, 383, 384, 385, 511, 1000):
         A = rng.standard_normal((n, 70))
         for lam, m in ((0.1, 0), (0.7, 0), (0.7, 1), (0.7, 2)):
             modes(m)
