@@ -58,6 +58,16 @@ class CpuLib:
             f = getattr(self._lib, prefix + name)
             f.restype, f.argtypes = res, args
             self._fn[name] = f
+        if not prefix:  # the reference's other tv1_1d methods (no restatement: used to generate / check golden vectors only)
+            for name, (res, args) in {
+                "PN_TV1": (C.c_int, [_dp, C.c_double, _dp, _dp, C.c_int, C.c_double, _dp]),
+                "SolveTVConvexQuadratic_a1_nw": (None, [C.c_int, _dp, C.c_double, _dp]),
+                "TV1D_denoise_tautstring": (None, [_dp, _dp, C.c_int, C.c_double]),
+                "dp": (None, [C.c_int, _dp, C.c_double, _dp]),
+            }.items():
+                f = getattr(self._lib, name)
+                f.restype, f.argtypes = res, args
+                self._fn[name] = f
         if prefix:  # oracle-only extension
             f = self._lib.orc_Yang3_TV_perdim
             f.restype = C.c_int
@@ -86,6 +96,24 @@ class CpuLib:
 
     def tv1_condat(self, x, lam):
         return self._run1d(lambda a, o: self._fn["TV1D_denoise"](a.ctypes.data, o.ctypes.data, a.size, lam), x)
+
+    def tv1_other_method(self, x, lam, method, sigma=0.05):
+        """reference() only: 'pn' | 'kolmogorov' | 'condattautstring' | 'dp' (prox_tv/__init__.py:197-216)"""
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        out = np.zeros(x.size)
+        n = int(x.size)
+        if method == "pn":
+            info = np.zeros(3)
+            self._fn["PN_TV1"](x.ctypes.data, lam, out.ctypes.data, info.ctypes.data, n, sigma, None)
+        elif method == "kolmogorov":
+            self._fn["SolveTVConvexQuadratic_a1_nw"](n, x.ctypes.data, lam, out.ctypes.data)
+        elif method == "condattautstring":
+            self._fn["TV1D_denoise_tautstring"](x.ctypes.data, out.ctypes.data, n, lam)
+        elif method == "dp":
+            self._fn["dp"](n, x.ctypes.data, lam, out.ctypes.data)
+        else:
+            raise ValueError(method)
+        return out
 
     def tv1_weighted(self, x, w):
         w = np.ascontiguousarray(w, dtype=np.float64).ravel()

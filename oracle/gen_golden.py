@@ -129,6 +129,29 @@ def gen_2d(ref):
     print("golden_2d:", len(names), "cases (+ emengd, blocks, multireg)")
 
 
+def gen_1d_other_methods(ref):
+    """What the reference returns for tv1_1d's other method names ('pn', 'kolmogorov', 'condattautstring', 'dp'):
+    the HIP surface serves them with the exact solver, these vectors show how close that is."""
+    rng = np.random.default_rng(20260929)
+    out = {}
+    names = []
+    cases = {"ka_zigzag": (np.array([0.0, 10.0, 0.0, 10.0, 0.0]), 2.0), "ka_pair": (np.array([1.0, 5.0]), 1.0)}
+    for n in (3, 17, 100, 257, 1000):
+        cases[f"randn_n{n}"] = (rng.standard_normal(n), 0.5)
+    cases["scaled_like_ref_tests"] = (100 * rng.standard_normal(29), 13.7)
+    cases["blocks_noise"] = (np.repeat(rng.standard_normal(12), 40) + 0.2 * rng.standard_normal(480), 0.5)
+    cases["walk"] = (np.cumsum(rng.standard_normal(500)), 2.0)
+    for name, (x, lam) in cases.items():
+        names.append(name)
+        out[f"{name}/x"], out[f"{name}/lam"] = x, np.float64(lam)
+        out[f"{name}/hybrid"] = ref.tv1_hybrid(x, lam)
+        for m in ("pn", "kolmogorov", "condattautstring", "dp"):
+            out[f"{name}/{m}"] = ref.tv1_other_method(x, lam, m)
+    out["names"] = np.array(names)
+    np.savez_compressed(os.path.join(GOLD, "golden_1d_other_methods.npz"), **out)
+    print("golden_1d_other_methods:", len(names), "cases")
+
+
 def gen_2d_primal_dual(ref):
     """Kolmogorov2_TV and CondatChambollePock2_TV (the other tv1_2d methods): full 2500-iteration runs and truncated ones."""
     rng = np.random.default_rng(20260928)
@@ -284,11 +307,13 @@ def main():
     ref = cpu.reference()
     os.makedirs(GOLD, exist_ok=True)
     if args.only_primal_dual:
+        gen_1d_other_methods(ref)
         gen_2d_primal_dual(ref)
         return
     if not args.only_large:
         gen_1d(ref)
         gen_2d(ref)
+        gen_1d_other_methods(ref)
         gen_2d_primal_dual(ref)
         gen_nd(ref)
     if args.large or args.only_large:

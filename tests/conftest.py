@@ -63,6 +63,11 @@ def g2d():
 
 
 @pytest.fixture(scope="session")
+def g1dm():
+    return load_golden("golden_1d_other_methods.npz")
+
+
+@pytest.fixture(scope="session")
 def gpd():
     return load_golden("golden_2d_primal_dual.npz")
 

@@ -41,6 +41,14 @@ def test_golden_alias_methods(ptv, g1d):
             assert_close(ptv.tv1_1d(x, lam, method=method), g1d[f"{name}/hybrid"], what=f"{name}:{method}")
 
 
+def test_other_methods_against_the_references_own_outputs(ptv, g1dm):
+    """Same method names, against what the compiled reference returns for each of them (not for its hybrid solver)."""
+    for name in g1dm["names"]:
+        x, lam = g1dm[f"{name}/x"], float(g1dm[f"{name}/lam"])
+        for method in ("pn", "kolmogorov", "condattautstring", "dp"):
+            assert_close(ptv.tv1_1d(x, lam, method=method), g1dm[f"{name}/{method}"], what=f"{name}:{method}")
+
+
 def test_golden_weighted(ptv, g1d):
     for name in g1d["names"]:
         if f"{name}/weighted" not in g1d:
