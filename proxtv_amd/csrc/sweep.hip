@@ -663,29 +663,24 @@ __global__ __launch_bounds__(64) void sweep_gchunk_kernel(SweepArgs p, FibreGeom
 // the fibre.  Data with pieces much longer than a chunk fail everywhere and degrade to one sequential walk per fibre.
 constexpr link_t kFromStart = 1;   // "no bend yet: the true walk is still in its first piece" (real codes are >= 2)
 
-template <int OP, bool WEIGHTED>
-struct RepairSource {
-    const SweepArgs &p;
-    long base, inc, wbase;
+// what a repair walk keeps track of, whatever it reads its samples from
+struct RepairBook {
     const link_t *code_mine;   // [chunk][fibre]
     long count, j;
     int C, len;
-    int wfrom;                 // outputs are (re)written from this sample on
-    int boundary;              // next chunk boundary whose chunk may take over
-    link_t last;               // last bend of this walk so far
+    int wfrom = 0;             // outputs are (re)written from this sample on
+    int boundary = 0;          // next chunk boundary whose chunk may take over
+    link_t last = 0;           // last bend of this walk so far
     bool stop = false;
     int resume_chunk = 0;
     link_t resume_code = 0;
 
-    __device__ __forceinline__ double y(int i) const { return Op<OP>::load_y(p, base + (long)i * inc); }
-    __device__ __forceinline__ double r(int i) const { return p.w[wbase + (long)i * inc]; }
-    LazyRun<OP> run;
-    __device__ __forceinline__ void piece(int from, int to, double v) {
-        if (to >= wfrom) run.queue(p, base, inc, max(from, wfrom), to, v);
+    __device__ __forceinline__ void begin(int chunk, link_t cur) {
+        wfrom = chunk * C;
+        boundary = (chunk + 1) * C;
+        last = cur;
+        stop = false;
     }
-    __device__ __forceinline__ int limit() const { return 1 << 30; }
-    __device__ __forceinline__ void pump() { run.pump(p, base, inc); }
-    __device__ __forceinline__ void flush() { run.flush(p, base, inc); }
     __device__ __forceinline__ void bend(int at, int type) {
         const link_t code = ((link_t)at << 1) | (link_t)type;
         while (!stop && boundary < len && at >= boundary) {
@@ -704,12 +699,108 @@ struct RepairSource {
         last = code;
     }
     __device__ __forceinline__ bool keep_going(int) const { return !stop; }
+    __device__ __forceinline__ int limit() const { return 1 << 30; }
+};
+
+// repair walk straight from global memory (the global-memory geometries: long stretches, pipelined walker)
+template <int OP, bool WEIGHTED>
+struct RepairSource : RepairBook {
+    const SweepArgs &p;
+    long base, inc, wbase;
+    LazyRun<OP> run;
+    __device__ __forceinline__ RepairSource(const RepairBook &b, const SweepArgs &p_, long base_, long inc_, long wbase_)
+        : RepairBook(b), p(p_), base(base_), inc(inc_), wbase(wbase_) {}
+    __device__ __forceinline__ double y(int i) const { return Op<OP>::load_y(p, base + (long)i * inc); }
+    __device__ __forceinline__ double r(int i) const { return p.w[wbase + (long)i * inc]; }
+    __device__ __forceinline__ void piece(int from, int to, double v) {
+        if (to >= wfrom) run.queue(p, base, inc, max(from, wfrom), to, v);
+    }
+    __device__ __forceinline__ void pump() { run.pump(p, base, inc); }
+    __device__ __forceinline__ void flush() { run.flush(p, base, inc); }
+};
+
+// Repair walk through a per-lane LDS window (the LDS geometries: short stretches of short pieces, where a dependent
+// global access per sample AND per piece is all the cost -- 200 us for a 100-sample repair).  The lane fetches
+// kRepairWindow samples of its fibre in batches of 16 independent loads, walks them out of LDS, parks the piece values
+// in a second LDS plane and writes the outputs of the whole stretch at the end, 8 operand fetches in flight.
+constexpr int kRepairWindow = 64;
+constexpr int kRepairBack = 8;   // samples kept before the one that triggered a refill (short rewinds stay inside)
+
+template <int OP, bool WEIGHTED>
+struct WindowRepairSource : RepairBook {
+    const SweepArgs &p;
+    long base, inc, wbase;
+    double *Yw, *Xw, *Rw;      // this lane's columns of the LDS planes: window slot s at [s * 64]
+    int wlo = 0, whi = 0;      // samples in the window: [wlo, whi)
+    int xlo = 0, xhi = 0;      // samples whose outputs wait in Xw: [xlo, xhi)
+    __device__ __forceinline__ WindowRepairSource(const RepairBook &b, const SweepArgs &p_, long base_, long inc_,
+                                                  long wbase_, double *lds, int lane)
+        : RepairBook(b), p(p_), base(base_), inc(inc_), wbase(wbase_), Yw(lds + lane),
+          Xw(lds + kRepairWindow * 64 + lane), Rw(lds + 2 * kRepairWindow * 64 + lane) {}
+
+    __device__ __forceinline__ void flush() {
+        int k = xlo;
+        for (; k + 8 <= xhi; k += 8) {
+            Ext e[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) e[u] = Op<OP>::fetch(p, base + (long)(k + u) * inc);
+#pragma unroll
+            for (int u = 0; u < 8; u++) Op<OP>::finish(p, base + (long)(k + u) * inc, e[u], Xw[(k + u - wlo) * 64]);
+        }
+        for (; k < xhi; k++) {
+            const long idx = base + (long)k * inc;
+            Op<OP>::finish(p, idx, Op<OP>::fetch(p, idx), Xw[(k - wlo) * 64]);
+        }
+        xlo = xhi = 0;
+    }
+    __device__ __forceinline__ void refill(int i) {
+        flush();   // the parked outputs are addressed relative to the window
+        wlo = max(0, i - kRepairBack);
+        whi = min(len, wlo + kRepairWindow);
+        for (int b = 0; b < kRepairWindow; b += 16) {
+            double t[16], rr[16];
+#pragma unroll
+            for (int u = 0; u < 16; u++) {
+                const int k = wlo + b + u;
+                t[u] = (k < whi) ? Op<OP>::load_y(p, base + (long)k * inc) : 0.0;
+                if (WEIGHTED) rr[u] = (k < whi && k < len - 1) ? p.w[wbase + (long)k * inc] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 16; u++) {
+                Yw[(b + u) * 64] = t[u];
+                if (WEIGHTED) Rw[(b + u) * 64] = rr[u];
+            }
+        }
+    }
+    __device__ __forceinline__ double y(int i) {
+        if (i < wlo || i >= whi) refill(i);
+        return Yw[(i - wlo) * 64];
+    }
+    __device__ __forceinline__ double r(int i) {
+        if (i < wlo || i >= whi) refill(i);
+        return Rw[(i - wlo) * 64];
+    }
+    __device__ __forceinline__ void piece(int from, int to, double v) {
+        from = max(from, wfrom);
+        if (from > to) return;
+        if (from < wlo || to >= whi) {   // (partly) outside the window -- a piece longer than the look-back: write it directly
+            const int a = (to >= whi) ? to : min(to, wlo - 1);
+            if (to >= whi) flush();
+            write_run<OP>(p, base, inc, from, a, v);
+            from = a + 1;
+            if (from > to) return;
+        }
+        for (int k = from; k <= to; k++) Xw[(k - wlo) * 64] = v;
+        if (xlo == xhi) xlo = from;
+        xhi = to + 1;
+    }
 };
 
 template <int OP, bool WEIGHTED>
 __global__ __launch_bounds__(64) void sweep_repair_kernel(SweepArgs p, FibreGeom g, int C, int H, int chunks_per_wg,
                                                            const link_t *code_mine, const link_t *code_next,
                                                            int *failflags, int *failcount) {
+    extern __shared__ __attribute__((aligned(16))) double repair_lds[];   // (2 + WEIGHTED) planes of kRepairWindow x 64 (LDS geometries only)
     const long j = (long)blockIdx.x * 64 + threadIdx.x;
     if (j >= g.count) return;
     if (p.gate && *p.gate == 0) return;
@@ -741,40 +832,70 @@ __global__ __launch_bounds__(64) void sweep_repair_kernel(SweepArgs p, FibreGeom
 
     const long blk = j / g.inc, off = j % g.inc;
     const long base = blk * g.inc * len + off, wbase = blk * g.inc * (len - 1) + off;
+    const RepairBook book{code_mine, g.count, j, C, len};
+    const bool windowed = H <= kWarmLong;
+    RepairSource<OP, WEIGHTED> gsrc(book, p, base, g.inc, wbase);
+    WindowRepairSource<OP, WEIGHTED> wsrc(book, p, base, g.inc, wbase, repair_lds, (int)threadIdx.x);
     link_t cur = kFromStart;
     int c = 0;
     // Two-phase loop so that the lanes of a wave repair TOGETHER: first every lane scans ahead to its next unproven
     // chunk, then all lanes that found one walk at the same time (a walk nested inside the scan would serialise the
     // lanes, each reaching its repair at a different trip).
     while (true) {
-        while (c < NC) {
-            const link_t mraw = code_mine[(long)c * g.count + j];
-            const bool certain = (mraw & kLinkCertain) && mraw != kLinkBad;
-            const link_t m = certain ? (mraw & ~kLinkCertain) : mraw;
-            // a chunk whose walk began at sample 0 (or at a bend known a priori) is the true walk unless it ran off
-            // its window (kLinkBad)
-            const bool accept = (c * C - H <= 0 || certain) ? (m != kLinkBad) : (m != 0 && m == cur);
-            if (!accept) break;
-            const link_t nx = code_next[(long)c * g.count + j];
-            if (nx != 0) cur = nx;
-            c++;
+        // the scan reads the codes of UB chunks at a time (2 UB independent loads), then goes through them in registers:
+        // one memory round trip per UB chunks instead of two per chunk
+        bool rejected = false;
+        while (c < NC && !rejected) {
+            link_t mm[UB], nn[UB];
+#pragma unroll
+            for (int u = 0; u < UB; u++) {
+                const int cc = min(c + u, NC - 1);
+                mm[u] = code_mine[(long)cc * g.count + j];
+                nn[u] = code_next[(long)cc * g.count + j];
+            }
+            const int c0 = c;
+#pragma unroll
+            for (int u = 0; u < UB; u++) {
+                if (!rejected && c == c0 + u && c < NC) {
+                    const link_t mraw = mm[u];
+                    const bool certain = (mraw & kLinkCertain) && mraw != kLinkBad;
+                    const link_t m = certain ? (mraw & ~kLinkCertain) : mraw;
+                    // a chunk whose walk began at sample 0 (or at a bend known a priori) is the true walk unless it
+                    // ran off its window (kLinkBad)
+                    const bool accept = (c * C - H <= 0 || certain) ? (m != kLinkBad) : (m != 0 && m == cur);
+                    if (accept) {
+                        if (nn[u] != 0) cur = nn[u];
+                        c++;
+                    } else {
+                        rejected = true;
+                    }
+                }
+            }
         }
         if (c >= NC) break;
-        RepairSource<OP, WEIGHTED> src{p, base, g.inc, wbase, code_mine, g.count, j, C, len, c * C, (c + 1) * C,
-                                       (cur == kFromStart) ? 0u : cur, false, 0, 0u, {}};
+        const link_t from = (cur == kFromStart) ? 0u : cur;
+        bool stopped;
+        int resume_chunk;
+        link_t resume_code;
         Walker w;
-        if (cur == kFromStart) walker_start<WEIGHTED>(w, src, 0, p.lam);
-        else walker_restart<WEIGHTED>(w, src, (int)(cur >> 1), (int)(cur & 1u), len, p.lam);
-        if (H > kWarmLong) {   // global-memory geometries: long pieces
-            walker_run_blocked<WEIGHTED, kGlobalBlock>(w, src, len, p.lam);
-        } else {
-            walker_run<WEIGHTED>(w, src, len, p.lam);
-            src.flush();
+        if (windowed) {
+            wsrc.begin(c, from);
+            if (cur == kFromStart) walker_start<WEIGHTED>(w, wsrc, 0, p.lam);
+            else walker_restart<WEIGHTED>(w, wsrc, (int)(cur >> 1), (int)(cur & 1u), len, p.lam);
+            walker_run<WEIGHTED>(w, wsrc, len, p.lam);
+            wsrc.flush();
+            stopped = wsrc.stop; resume_chunk = wsrc.resume_chunk; resume_code = wsrc.resume_code;
+        } else {   // global-memory geometries: long pieces
+            gsrc.begin(c, from);
+            if (cur == kFromStart) walker_start<WEIGHTED>(w, gsrc, 0, p.lam);
+            else walker_restart<WEIGHTED>(w, gsrc, (int)(cur >> 1), (int)(cur & 1u), len, p.lam);
+            walker_run_blocked<WEIGHTED, kGlobalBlock>(w, gsrc, len, p.lam);
+            stopped = gsrc.stop; resume_chunk = gsrc.resume_chunk; resume_code = gsrc.resume_code;
         }
-        walks += src.stop ? (src.resume_chunk - c) : (NC - c);   // chunks this walk had to rewrite
-        if (!src.stop) break;                   // walked to the fibre end: everything from chunk c on is rewritten
-        c = src.resume_chunk;                   // that chunk continues this walk: accepted on the next trip
-        cur = src.resume_code;
+        walks += stopped ? (resume_chunk - c) : (NC - c);   // chunks this walk had to rewrite
+        if (!stopped) break;                    // walked to the fibre end: everything from chunk c on is rewritten
+        c = resume_chunk;                       // that chunk continues this walk: accepted on the next trip
+        cur = resume_code;
     }
     atomicAdd(failcount + 1, walks);   // chunks rewritten
 }
@@ -1049,10 +1170,18 @@ void launch_chunk_h(const SweepArgs &args, const FibreGeom &g, hipStream_t strea
     const dim3 grid((unsigned)groups, (unsigned)WQ);
     hipLaunchKernelGGL(kern, grid, dim3(64 * NW), lds, stream, args, g, plan, g_chunk.code_mine, g_chunk.code_next,
                        g_chunk.failflags);
-    if (!plan.ablate)
-        hipLaunchKernelGGL((sweep_repair_kernel<OP, WEIGHTED>), dim3((unsigned)groups), dim3(64), 0, stream, args, g, C,
-                           H, plan.qpw * NW, g_chunk.code_mine, g_chunk.code_next, g_chunk.failflags,
-                           g_chunk.failcount + 2 * fam);
+    if (!plan.ablate) {
+        constexpr size_t rlds = sizeof(double) * (2 + (WEIGHTED ? 1 : 0)) * kRepairWindow * 64;
+        auto rkern = sweep_repair_kernel<OP, WEIGHTED>;
+        static thread_local bool rattr_set = false;
+        if (!rattr_set) {
+            PTV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(rkern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)rlds));
+            rattr_set = true;
+        }
+        hipLaunchKernelGGL(rkern, dim3((unsigned)groups), dim3(64), rlds, stream, args, g, C, H, plan.qpw * NW,
+                           g_chunk.code_mine, g_chunk.code_next, g_chunk.failflags, g_chunk.failcount + 2 * fam);
+    }
     PTV_HIP(hipGetLastError());
     g_chunk.pol[fam].chunks_done += (long)NC * g.count;
 }

@@ -20,6 +20,11 @@ elif which in ("c4", "c4y"):
     out = device.colmajor_empty((512, 512, 64))
     run = (lambda: device.tvgen(V, [0.1, 0.1, 0.05], [1, 2, 3], out=out)) if which == "c4" else \
           (lambda: device.tvgen(V, [0.1, 0.1, 0.1], [1, 2, 3], method="yang", out=out))
+elif which.startswith("dr"):      # dr0.3 -> DR 4096^2 at lambda 0.3
+    lam = float(which[2:])
+    X = dev(rng.standard_normal((4096, 4096)))
+    out = device.colmajor_empty((4096, 4096))
+    run = lambda: device.tv1_2d(X, lam, out=out)
 else:
     X = dev(rng.standard_normal((4096, 4096)))
     out = device.colmajor_empty((4096, 4096))
