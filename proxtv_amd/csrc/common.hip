@@ -23,6 +23,7 @@ Options &options() {
         if (const char *e = getenv("PROXTV_ABLATE")) v.ablate = atoi(e);
         if (const char *e = getenv("PROXTV_BLOCKS_PER_WG")) v.blocks_per_wg = atoi(e);
         if (const char *e = getenv("PROXTV_CHUNK_MIN_LEN")) v.chunk_min_len = atoi(e);
+        if (const char *e = getenv("PROXTV_ROUNDS")) v.rounds = atoi(e);
         if (const char *e = getenv("PROXTV_CHUNK_MODE")) v.chunk_mode = atoi(e);
         return v;
     }();

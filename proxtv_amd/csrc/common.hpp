@@ -38,8 +38,9 @@ struct HipFailure {
 struct Options {
     int chunk = 16;     // non-zero: speculative-chunk kernels (16-sample chunks); 0 = sequential lane-per-fibre kernels only
     int warmup = 16;    // (reserved) warm-up zone in samples; the chunk kernels are built for kWarm = 16
-    int chunk_mode = -1;    // -1 = adaptive (see ChunkScratch); 0..4 pin the chunk geometry policy
+    int chunk_mode = -1;    // -1 = adaptive (see ChunkScratch); 0..5 pin the chunk geometry policy
     int blocks_per_wg = 0;  // blocks pipelined per workgroup in the chunk kernel; 0 = pick from the problem size
+    int rounds = 0;         // second-chance rounds of geometry mode 1 (0 = the built-in default)
     int chunk_min_len = 96;   // fibres shorter than this take the sequential kernel (measured crossover: 512x512xL volumes, L ~ 96)
     int verbose = 0;
     int profile = 0;    // per-kernel-family hipEvent timing

@@ -149,6 +149,7 @@ struct ChunkPlan {
     int Q;      // blocks (NW chunks each) per fibre
     int qpw;    // consecutive blocks of one fibre group processed (software-pipelined) by one workgroup
     int ablate; // profiling aid (option "ablate"): 1 = skip the walk, 2 = skip the epilogue, 4 = skip the window loads
+    int rounds; // second-chance rounds inside a block (0 = none): see the link-proof step of sweep_chunk_kernel
 };
 
 template <int OP, bool WEIGHTED, int PITCH>
@@ -175,10 +176,21 @@ struct ChunkSource {
     bool done = false;         // the piece covering ce - 1 is closed
     bool failed = false;       // the walk ran off the LDS window (a piece much longer than a chunk): give the fibre up
 
-    // The speculative walk never leaves the LDS window: a lane that would (a long flat piece) marks its fibre for the
-    // sequential kernel instead -- this bounds the cost of a chunk by its window whatever the data.
-    __device__ __forceinline__ double y(int i) const { return Y[(min(i, hi - 1) - lo) * PITCH]; }
-    __device__ __forceinline__ double r(int i) const { return Wt[(min(i, hi - 1) - lo) * PITCH]; }
+    // Past the end of the LDS window (the last chunk of a block, when the piece covering its last sample runs on for
+    // more than the T look-ahead rows) the walk reads global memory, one dependent access per sample, for at most
+    // kOverflow samples; a lane that needs more (a long flat piece) marks its fibre for the repair kernel instead --
+    // this bounds the cost of a chunk whatever the data.
+    static constexpr int kOverflow = 48;
+    __device__ __forceinline__ double y_window(int i) const { return Y[(min(i, hi - 1) - lo) * PITCH]; }   // hot loop: i < hi
+    __device__ __forceinline__ double r_window(int i) const { return Wt[(min(i, hi - 1) - lo) * PITCH]; }
+    __device__ __forceinline__ double y(int i) const {
+        if (i < hi) return Y[(i - lo) * PITCH];
+        return Op<OP>::load_y(p, base + (long)min(i, len - 1) * inc);
+    }
+    __device__ __forceinline__ double r(int i) const {
+        if (i < hi) return Wt[(i - lo) * PITCH];
+        return (i < len - 1) ? p.w[wbase + (long)i * inc] : 0.0;
+    }
     __device__ __forceinline__ void piece(int, int to, double v) {
         if (to >= cs && !have_first) {
             vfirst = v;
@@ -200,11 +212,16 @@ struct ChunkSource {
     }
     __device__ __forceinline__ bool keep_going(int i) {
         if (done) return false;
-        if (i >= hi) {   // hi == len for the windows that reach the fibre end, so this is never the true end
+        if (i >= hi + kOverflow) {   // (a walk that reaches the fibre end never gets here: i < len <= hi + kOverflow then)
             failed = true;
             return false;
         }
         return true;
+    }
+    // take over what another walk of the same chunk recorded
+    __device__ __forceinline__ void adopt(const ChunkSource &o) {
+        ends = o.ends; types = o.types; mine = o.mine; next = o.next;
+        vclose = o.vclose; vfirst = o.vfirst; have_first = o.have_first; done = o.done; failed = o.failed;
     }
 };
 
@@ -233,13 +250,13 @@ __device__ __forceinline__ void walker_run_interior(Walker &w, S &src, int n, do
     const int last = n - 1;
     const int lim = min(last, src.hi);   // handle i < lim only
     if (w.i >= lim || src.done) return;
-    double yi = src.y(w.i);
+    double yi = src.y_window(w.i);
     while (true) {
         const int i = w.i;
         const bool live = !src.done && i < lim;
         if (!live) break;
-        const double ynext = src.y(i + 1);               // speculative: most steps advance by one
-        const double r = WEIGHTED ? src.r(i) : lam;
+        const double ynext = src.y_window(i + 1);        // speculative: most steps advance by one (LDS only)
+        const double r = WEIGHTED ? src.r_window(i) : lam;
         const double h1 = w.hlo + (w.lo - yi);
         const bool cv = r < h1;
         const double h2 = w.hhi + (w.hi - yi);
@@ -249,9 +266,9 @@ __device__ __forceinline__ void walker_run_interior(Walker &w, S &src, int n, do
             src.piece(w.k0 + 1, brk, cv ? w.lo : w.hi);
             const int at = brk + 1;                       // at <= i < last: the restart is an interior sample
             src.bend(at, cv ? BEND_CEIL : BEND_FLOOR);
-            const double yn = (at == i) ? yi : src.y(at);
+            const double yn = (at == i) ? yi : src.y_window(at);
             if (WEIGHTED) {
-                const double wp = src.r(at - 1), wc = (at == i) ? r : src.r(at);
+                const double wp = src.r_window(at - 1), wc = (at == i) ? r : src.r_window(at);
                 if (cv) { w.lo = yn + wp - wc; w.hi = yn + wp + wc; }
                 else    { w.hi = yn - wp + wc; w.lo = yn - wp - wc; }
                 w.hhi = wc;
@@ -265,7 +282,7 @@ __device__ __forceinline__ void walker_run_interior(Walker &w, S &src, int n, do
             w.k0 = brk;
             w.klo = w.khi = at;
             w.i = at + 1;
-            yi = (at == i) ? ynext : src.y(at + 1);
+            yi = (at == i) ? ynext : src.y_window(at + 1);
         } else {
             const double s = (double)(i - w.k0);
             const double inv = refined_rcp(s);
@@ -351,7 +368,7 @@ __device__ __forceinline__ void rebuild_chunk(double *Ycol, const double *Wcol, 
 //   4. piece values are rebuilt in place (rebuild_chunk), then the block's rows are streamed out: straight from LDS
 //      for fused ops, otherwise through the op's output functor with the operand fetches of UL rows in flight.
 // LDS carve (dynamic, 16-byte aligned base): Y window | Wt window (weighted) | link codes.
-template <int OP, bool WEIGHTED, bool TRANSPOSED, int C, int NW, int H>
+template <int OP, bool WEIGHTED, bool TRANSPOSED, int C, int NW, int H, bool ROUNDS>
 __global__ __launch_bounds__(64 * NW, ((WEIGHTED || H > 16) ? NW / 4 : NW / 2)) void sweep_chunk_kernel(SweepArgs p, FibreGeom g, ChunkPlan plan,
                                                                                    link_t *code_mine, link_t *code_next,
                                                                                    int *failflags) {
@@ -365,6 +382,8 @@ __global__ __launch_bounds__(64 * NW, ((WEIGHTED || H > 16) ? NW / 4 : NW / 2)) 
     double *Yp = reinterpret_cast<double *>(smem);
     double *Wp = Yp + (WEIGHTED ? (size_t)ROWS * PITCH : 0);
     link_t *codes = reinterpret_cast<link_t *>(Wp + (size_t)ROWS * PITCH);   // [NW + 2][64]; slots NW, NW + 1 carry over blocks
+    // (bit 31 of a slot -- never part of a code: restart indices are below 2^30 -- says "this lane's link is proven")
+    int *anybad = reinterpret_cast<int *>(codes + (NW + 2) * 64);            // [2], by round parity: some lane of the block has an unproven link
 
     if (p.gate && *p.gate == 0) return;   // uniform over the grid
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -504,22 +523,57 @@ __global__ __launch_bounds__(64 * NW, ((WEIGHTED || H > 16) ? NW / 4 : NW / 2)) 
             }
             walker_run_interior<WEIGHTED>(w, src, len, p.lam);   // the hot part
             walker_run<WEIGHTED>(w, src, len, p.lam);            // fibre end / window end (no-op for most lanes)
-            if (src.failed) {   // ran off the window: nothing this lane recorded may be trusted
-                failflags[j] = 1;
-                src.mine = kLinkBad;
-                src.next = 0;
-            }
+            if (src.failed) src.next = 0;   // ran off the window: nothing this lane recorded may be trusted
         }
 
         // ---- prove the links between consecutive chunks ------------------------------------------------------------------
         codes[wave * 64 + lane] = src.next;
+        if (ROUNDS && tid == 0) anybad[0] = anybad[1] = 0;
         __syncthreads();   // all walks done: link codes visible, window rows no longer read as walk input
-        if (has_chunk) {
-            const bool true_start = (start == 0) || certain;
-            if (wave > 0 || kb > 0) {
-                const link_t prev = (wave > 0) ? codes[(wave - 1) * 64 + lane] : codes[(NW + ((kb + 1) & 1)) * 64 + lane];
-                if (!true_start && (src.mine == 0 || src.mine != prev)) failflags[j] = 1;
+        const int prev_slot = (wave > 0) ? (wave - 1) * 64 + lane : (NW + ((kb + 1) & 1)) * 64 + lane;
+        bool bad = false;
+        // Second chances inside the block (plan.rounds > 0; data whose walks need more than the zone to meet): a lane
+        // whose link fails, while its predecessor's holds, walks its chunk again from the predecessor's last bend -- a
+        // bend of the true walk if the predecessor is true.  Every round moves the proven frontier of a failing run one
+        // chunk on; links are re-examined after every round (a predecessor that walked again may have changed its
+        // code), and what is still unproven after the last round goes to the repair kernel as usual.
+        for (int round = 0; ; round++) {
+            const bool linked = has_chunk && !(start == 0 || certain) && (wave > 0 || kb > 0);   // hangs on its predecessor
+            bad = has_chunk && (src.failed || (linked && (src.mine == 0 || src.mine != (codes[prev_slot] & ~kLinkCertain))));
+            if (!ROUNDS || round >= plan.rounds) break;
+            if (has_chunk) codes[wave * 64 + lane] = bad ? src.next : (src.next | kLinkCertain);   // same code, plus the flag
+            if (bad) anybad[round & 1] = 1;
+            __syncthreads();
+            if (!anybad[round & 1]) break;               // uniform
+            if (tid == 0) anybad[(round + 1) & 1] = 0;   // set again only after the barrier below
+            if (bad && (wave > 0 || kb > 0)) {
+                const link_t praw = codes[prev_slot];
+                const link_t prev = praw & ~kLinkCertain;
+                const int at = (int)(prev >> 1);
+                if ((praw & kLinkCertain) && prev != 0 && at > lo) {
+                    ChunkSource<OP, WEIGHTED, PITCH> again{p, base, g.inc, wbase, Yp + lane, Wp + lane, lo, hi, cs, ce, len};
+                    Walker w;
+                    walker_restart_with<WEIGHTED>(w, at, (int)(prev & 1u), len, p.lam, again.y(at),
+                                                  WEIGHTED ? again.r(at - 1) : 0.0,
+                                                  (WEIGHTED && at < len - 1) ? again.r(at) : 0.0);
+                    again.mine = again.next = prev;
+                    walker_run_interior<WEIGHTED>(w, again, len, p.lam);
+                    walker_run<WEIGHTED>(w, again, len, p.lam);
+                    if (!again.failed) {
+                        src.adopt(again);
+                        certain = false;   // from now on the chunk hangs on its predecessor like any other
+                        codes[wave * 64 + lane] = src.next;
+                    }
+                }
             }
+            __syncthreads();
+        }
+        if (has_chunk) {
+            if (src.failed) {
+                src.mine = kLinkBad;
+                src.next = 0;
+            }
+            if (bad) failflags[j] = 1;
             // Every chunk publishes its two codes: sweep_repair_kernel proves the links between workgroups with them
             // and, for a fibre with an unproven link, finds where a repair walk may stop.
             const long slot = (long)(q * NW + wave) * g.count + j;
@@ -527,7 +581,7 @@ __global__ __launch_bounds__(64 * NW, ((WEIGHTED || H > 16) ? NW / 4 : NW / 2)) 
             code_next[slot] = src.next;
         }
         // carried to the next block's first chunk; two slots in turn, so that no barrier is needed before the write
-        if (wave == NW - 1) codes[(NW + (kb & 1)) * 64 + lane] = src.next;
+        if (wave == NW - 1) codes[(NW + (kb & 1)) * 64 + lane] = (bad || !has_chunk) ? src.next : (src.next | kLinkCertain);
         if (has_chunk)
             rebuild_chunk<OP, WEIGHTED, PITCH>(Yp + lane, Wp + lane, lo, cs, ce, start, src.mine, src.ends, src.types,
                                                src.vclose, src.vfirst, p.lam);
@@ -913,11 +967,13 @@ void launch_seq(const SweepArgs &args, const FibreGeom &g, hipStream_t stream, b
 // Geometry ladder (Policy::mode).  The zone must be a few pieces long for a speculative walk to meet the true one,
 // and piece length grows like (lambda / noise)^2:
 //   0  LDS window, 16-sample zones            pieces of a few samples (the headline regime)
-//   1  LDS window, 64-sample zones            pieces of ~10 samples
-//   2  global memory, zone 256 / chunk 64     pieces of ~50 samples
-//   3  global memory, zone 1024 / chunk 256   pieces of a few hundred samples
-//   4  one sequential walk per fibre          pieces comparable to the fibre: speculation cannot pay
-constexpr int kModeSeq = 4;
+//   1  the same + second-chance rounds        pieces of ~5 samples: failed links are walked again inside the block
+//   2  LDS window, 64-sample zones            pieces of ~10 samples
+//   3  global memory, zone 256 / chunk 64     pieces of ~50 samples
+//   4  global memory, zone 1024 / chunk 256   pieces of a few hundred samples
+//   5  one sequential walk per fibre          pieces comparable to the fibre: speculation cannot pay
+constexpr int kModeSeq = 5;
+constexpr int kRounds = 4;          // second-chance rounds of mode 1 (option "rounds" overrides)
 constexpr double kTryUp = 5e-4;     // rewritten-chunk fraction above which a longer zone is worth a trial
 constexpr double kClean = 5e-5;     // ... below which a shorter one is
 constexpr double kJump = 0.5;       // ... above which the trial goes straight to the sequential walk
@@ -971,7 +1027,7 @@ struct ChunkScratch {
         long chunks_seen = 0;    // ... at the last evaluation
         int rewritten_seen = 0;
 
-        bool available(int m) const { return !(m == 1 && weighted) && !(m == 3 && len < 1024); }
+        bool available(int m) const { return !(m == 2 && weighted) && !(m == 4 && len < 1024); }
         int up(int m) const {
             do m++; while (m < kModeSeq && !available(m));
             return m;
@@ -1097,7 +1153,9 @@ struct ChunkScratch {
                 pl.dir = -1;
             }
         } else {              // a trial: remember the fastest, walk on while the counters say there is something to find
-            if (t < kBetter * pl.best_t) {
+            // going up a trial must win clearly; going down a clean one only has to be no slower (noise on small
+            // problems must not leave the policy on a heavier geometry than the data need)
+            if (t < (pl.dir < 0 && clean ? 1.05 : kBetter) * pl.best_t) {
                 pl.best = r;
                 pl.best_t = t;
             }
@@ -1141,7 +1199,7 @@ static thread_local ChunkScratch g_chunk;
 // of H + 128 + 8 rows x 512 B: ~77 KiB for H = 16 -> two workgroups = 16 waves per CU; ~101 KiB for H = 64 -> one.
 // Weighted sweeps carry a second (penalty) window and exist for H = 16 only.
 template <int OP, bool WEIGHTED, bool TRANSPOSED, int H, int C = 16, int NW = 8>
-void launch_chunk_h(const SweepArgs &args, const FibreGeom &g, hipStream_t stream, int fam) {
+void launch_chunk_h(const SweepArgs &args, const FibreGeom &g, hipStream_t stream, int fam, int rounds_wanted) {
     constexpr int PITCH = TRANSPOSED ? 65 : 64;
     constexpr int ROWS = H + NW * C + tail_rows(H);
     ChunkPlan plan;
@@ -1155,21 +1213,30 @@ void launch_chunk_h(const SweepArgs &args, const FibreGeom &g, hipStream_t strea
     }
     plan.qpw = qpw < plan.Q ? qpw : plan.Q;
     plan.ablate = options().ablate;
+    plan.rounds = rounds_wanted;
     const int WQ = (plan.Q + plan.qpw - 1) / plan.qpw;
-    constexpr size_t lds = sizeof(double) * PITCH * (size_t)ROWS * (WEIGHTED ? 2 : 1) + sizeof(link_t) * (NW + 2) * 64;
+    constexpr size_t lds = sizeof(double) * PITCH * (size_t)ROWS * (WEIGHTED ? 2 : 1) + sizeof(link_t) * ((NW + 2) * 64 + 16);
+    static_assert(WEIGHTED || H > kWarm || 2 * lds <= 160 * 1024, "the short-zone geometry is meant to run two workgroups per CU");
     static_assert(lds <= 160 * 1024, "chunk geometry does not fit the LDS of a CU");
     const int NC = (g.len + C - 1) / C;
     g_chunk.ensure(g.count, NC, stream);
-    auto kern = sweep_chunk_kernel<OP, WEIGHTED, TRANSPOSED, C, NW, H>;
+    // the second-chance rounds are a separate instantiation: their live state costs the plain kernel registers it
+    // does not have (it sits at the 128-VGPR budget of two workgroups per CU)
+    constexpr bool kCanRound = (H <= kWarm) && C == 16;
+    const bool rounds = kCanRound && plan.rounds > 0;
+    auto kern = sweep_chunk_kernel<OP, WEIGHTED, TRANSPOSED, C, NW, H, false>;
+    auto kern_r = sweep_chunk_kernel<OP, WEIGHTED, TRANSPOSED, C, NW, H, kCanRound>;
     static thread_local bool attr_set = false;
     if (!attr_set) {
         PTV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     160 * 1024));
+        PTV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern_r), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    160 * 1024));
         attr_set = true;
     }
     const dim3 grid((unsigned)groups, (unsigned)WQ);
-    hipLaunchKernelGGL(kern, grid, dim3(64 * NW), lds, stream, args, g, plan, g_chunk.code_mine, g_chunk.code_next,
-                       g_chunk.failflags);
+    hipLaunchKernelGGL(rounds ? kern_r : kern, grid, dim3(64 * NW), lds, stream, args, g, plan, g_chunk.code_mine,
+                       g_chunk.code_next, g_chunk.failflags);
     if (!plan.ablate) {
         constexpr size_t rlds = sizeof(double) * (2 + (WEIGHTED ? 1 : 0)) * kRepairWindow * 64;
         auto rkern = sweep_repair_kernel<OP, WEIGHTED>;
@@ -1237,15 +1304,16 @@ void launch_chunk(const SweepArgs &args, const FibreGeom &g, hipStream_t stream,
         measure = !pl.meas && (pl.explore || (pl.sweeps > 0 && pl.sweeps % (pl.mode == 0 ? 8 : 4) == 0));
         if (measure) PTV_HIP(hipEventRecord(pl.t0, stream));
     }
+    const int rounds = (mode == 1) ? (options().rounds > 0 ? options().rounds : kRounds) : 0;
     if (mode >= kModeSeq)  launch_seq<OP, WEIGHTED>(args, g, stream, true);
-    else if (mode == 2)    launch_gchunk<OP, WEIGHTED>(args, g, 64, 256, stream, fam);
-    else if (mode == 3)    launch_gchunk<OP, WEIGHTED>(args, g, 256, 1024, stream, fam);
+    else if (mode == 3)    launch_gchunk<OP, WEIGHTED>(args, g, 64, 256, stream, fam);
+    else if (mode == 4)    launch_gchunk<OP, WEIGHTED>(args, g, 256, 1024, stream, fam);
     else if constexpr (!WEIGHTED) {
-        if (mode == 1)                    launch_chunk_h<OP, false, TRANSPOSED, kWarmLong>(args, g, stream, fam);
-        else if (options().chunk == 32)   launch_chunk_h<OP, false, TRANSPOSED, kWarm, 32, 4>(args, g, stream, fam);   // experiment
-        else                              launch_chunk_h<OP, false, TRANSPOSED, kWarm>(args, g, stream, fam);
+        if (mode == 2)                    launch_chunk_h<OP, false, TRANSPOSED, kWarmLong>(args, g, stream, fam, 0);
+        else if (options().chunk == 32)   launch_chunk_h<OP, false, TRANSPOSED, kWarm, 32, 4>(args, g, stream, fam, 0);   // experiment
+        else                              launch_chunk_h<OP, false, TRANSPOSED, kWarm>(args, g, stream, fam, rounds);
     } else {
-        launch_chunk_h<OP, true, TRANSPOSED, kWarm>(args, g, stream, fam);
+        launch_chunk_h<OP, true, TRANSPOSED, kWarm>(args, g, stream, fam, rounds);
     }
     pl.sweeps++;
     if (measure) {

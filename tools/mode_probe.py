@@ -7,10 +7,11 @@ import torch
 from proxtv_amd import _lib, device
 lib = _lib.require_device()
 lam = float(sys.argv[1]) if len(sys.argv) > 1 else 1.0
+if len(sys.argv) > 3: lib.proxtv_set_option(b"rounds", int(sys.argv[3]))
 X = device.to_colmajor(torch.from_numpy(np.random.default_rng(0).standard_normal((4096, 4096))).cuda())
 out = device.colmajor_empty((4096, 4096))
 ref = None
-for mode in [int(m) for m in (sys.argv[2].split(',') if len(sys.argv) > 2 else '4,3,2,1,0,-1'.split(','))]:
+for mode in [int(m) for m in (sys.argv[2].split(',') if len(sys.argv) > 2 else '5,4,3,2,1,0,-1'.split(','))]:
     lib.proxtv_set_option(b"chunk_mode", mode)
     device.tv1_2d(X, lam, out=out); torch.cuda.synchronize()
     t0 = time.perf_counter(); device.tv1_2d(X, lam, out=out); torch.cuda.synchronize(); dt = time.perf_counter() - t0

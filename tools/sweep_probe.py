@@ -7,7 +7,7 @@ import torch
 from proxtv_amd import _lib, device
 lib = _lib.require_device()
 lams = [float(v) for v in (sys.argv[1].split(',') if len(sys.argv) > 1 else ['0.1', '1', '3', '10', '30'])]
-modes = [int(v) for v in (sys.argv[2].split(',') if len(sys.argv) > 2 else ['0', '1', '2', '3', '4'])]
+modes = [int(v) for v in (sys.argv[2].split(',') if len(sys.argv) > 2 else ['0', '1', '2', '3', '4', '5'])]
 kind = sys.argv[3] if len(sys.argv) > 3 else "randn"
 rng = np.random.default_rng(0)
 A = rng.standard_normal((4096, 4096))
