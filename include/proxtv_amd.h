@@ -173,8 +173,8 @@ double proxtv_last_kernel_ms(int which);
    either way. */
 long   proxtv_last_fixups(void);
 /* Geometry policy the adaptive chunk kernel currently uses on this thread (the highest over the sweep families):
-   0 = 16-sample warm-up zones (noisy data, small lambda), 1 = the same with second-chance rounds inside a block
-   (pieces of ~5 samples), 2 = 64-sample zones (pieces of ~10 samples), 3 / 4 = chunks walked straight from global
+   0 = 16-sample warm-up zones (noisy data, small lambda), 1 = the same, robust instantiation (walks may run past
+   the window, second-chance rounds inside a block: pieces of ~5 samples), 2 = 64-sample zones (pieces of ~10 samples), 3 / 4 = chunks walked straight from global
    memory with 256- / 1024-sample zones (pieces of tens / hundreds of samples), 5 = one sequential walk per fibre. */
 int    proxtv_chunk_mode(void);
 /* dst = src with the 8-bytes-per-lane access width of the sweep kernels: a known byte count against which the

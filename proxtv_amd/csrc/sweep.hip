@@ -152,7 +152,7 @@ struct ChunkPlan {
     int rounds; // second-chance rounds inside a block (0 = none): see the link-proof step of sweep_chunk_kernel
 };
 
-template <int OP, bool WEIGHTED, int PITCH>
+template <int OP, bool WEIGHTED, int PITCH, bool PAST>
 struct ChunkSource {
     const SweepArgs &p;
     long base, inc, wbase;     // this lane's fibre in global memory
@@ -180,15 +180,17 @@ struct ChunkSource {
     // more than the T look-ahead rows) the walk reads global memory, one dependent access per sample, for at most
     // kOverflow samples; a lane that needs more (a long flat piece) marks its fibre for the repair kernel instead --
     // this bounds the cost of a chunk whatever the data.
-    static constexpr int kOverflow = 48;
+    // (PAST: only the robust instantiation of the kernel -- geometry mode 1 -- carries this; inlined into the plain one it
+    // costs the headline 2 %, out of line far more.)
+    static constexpr int kOverflow = PAST ? 48 : 0;
     __device__ __forceinline__ double y_window(int i) const { return Y[(min(i, hi - 1) - lo) * PITCH]; }   // hot loop: i < hi
     __device__ __forceinline__ double r_window(int i) const { return Wt[(min(i, hi - 1) - lo) * PITCH]; }
     __device__ __forceinline__ double y(int i) const {
-        if (i < hi) return Y[(i - lo) * PITCH];
+        if (!PAST || i < hi) return Y[(min(i, hi - 1) - lo) * PITCH];
         return Op<OP>::load_y(p, base + (long)min(i, len - 1) * inc);
     }
     __device__ __forceinline__ double r(int i) const {
-        if (i < hi) return Wt[(i - lo) * PITCH];
+        if (!PAST || i < hi) return Wt[(min(i, hi - 1) - lo) * PITCH];
         return (i < len - 1) ? p.w[wbase + (long)i * inc] : 0.0;
     }
     __device__ __forceinline__ void piece(int, int to, double v) {
@@ -478,7 +480,7 @@ __global__ __launch_bounds__(64 * NW, ((WEIGHTED || H > 16) ? NW / 4 : NW / 2)) 
         const int ce = min(cs + C, len);
         const bool has_chunk = active && cs < len;
         const int start = max(0, cs - H);
-        ChunkSource<OP, WEIGHTED, PITCH> src{p, base, g.inc, wbase, Yp + lane, Wp + lane, lo, hi, cs, ce, len};
+        ChunkSource<OP, WEIGHTED, PITCH, ROUNDS> src{p, base, g.inc, wbase, Yp + lane, Wp + lane, lo, hi, cs, ce, len};
         bool certain = false;
         if (has_chunk && !(plan.ablate & 1)) {
             Walker w;
@@ -551,7 +553,7 @@ __global__ __launch_bounds__(64 * NW, ((WEIGHTED || H > 16) ? NW / 4 : NW / 2)) 
                 const link_t prev = praw & ~kLinkCertain;
                 const int at = (int)(prev >> 1);
                 if ((praw & kLinkCertain) && prev != 0 && at > lo) {
-                    ChunkSource<OP, WEIGHTED, PITCH> again{p, base, g.inc, wbase, Yp + lane, Wp + lane, lo, hi, cs, ce, len};
+                    ChunkSource<OP, WEIGHTED, PITCH, ROUNDS> again{p, base, g.inc, wbase, Yp + lane, Wp + lane, lo, hi, cs, ce, len};
                     Walker w;
                     walker_restart_with<WEIGHTED>(w, at, (int)(prev & 1u), len, p.lam, again.y(at),
                                                   WEIGHTED ? again.r(at - 1) : 0.0,
@@ -967,15 +969,19 @@ void launch_seq(const SweepArgs &args, const FibreGeom &g, hipStream_t stream, b
 // Geometry ladder (Policy::mode).  The zone must be a few pieces long for a speculative walk to meet the true one,
 // and piece length grows like (lambda / noise)^2:
 //   0  LDS window, 16-sample zones            pieces of a few samples (the headline regime)
-//   1  the same + second-chance rounds        pieces of ~5 samples: failed links are walked again inside the block
+//   1  the same, robust instantiation         pieces of ~5 samples: walks may run past the window (global reads), failed
+//                                             links are walked again inside the block (second-chance rounds)
 //   2  LDS window, 64-sample zones            pieces of ~10 samples
 //   3  global memory, zone 256 / chunk 64     pieces of ~50 samples
 //   4  global memory, zone 1024 / chunk 256   pieces of a few hundred samples
 //   5  one sequential walk per fibre          pieces comparable to the fibre: speculation cannot pay
 constexpr int kModeSeq = 5;
 constexpr int kRounds = 4;          // second-chance rounds of mode 1 (option "rounds" overrides)
-constexpr double kTryUp = 5e-4;     // rewritten-chunk fraction above which a longer zone is worth a trial
-constexpr double kClean = 5e-5;     // ... below which a shorter one is
+// rewritten-chunk fraction above which the next rung is worth a trial, per rung (from mode 0 the next rung is the same
+// geometry made robust: a handful of repaired fibres per sweep already costs more than that), and below which the rung
+// below is
+constexpr double kTryUpAt[kModeSeq + 1] = {4e-6, 2e-4, 5e-4, 5e-4, 5e-4, 1.0};
+constexpr double kCleanAt[kModeSeq + 1] = {1e-6, 1e-6, 5e-5, 5e-5, 5e-5, 1.0};
 constexpr double kJump = 0.5;       // ... above which the trial goes straight to the sequential walk
 constexpr double kBetter = 0.9;     // a trial wins if its sweep took less than this times the incumbent's
 constexpr double kDrift = 1.5;      // steady state: re-explore when the sweep time moved by this factor
@@ -1140,7 +1146,8 @@ struct ChunkScratch {
         if (options().verbose)
             fprintf(stderr, "[proxtv_amd] policy: family %d sweep %ld: mode %d %s took %.3f ms, rewrote %.5f of its chunks (incumbent %d: %.3f ms)\n",
                     fam, pl.sweeps, r, pl.trial >= 0 ? "(trial)" : "(incumbent)", t, f, pl.mode, pl.t_mode);
-        const bool dirty = f > kTryUp, clean = f < 0 || f <= kClean;
+        const int rr = r < kModeSeq ? r : kModeSeq;
+        const bool dirty = f > kTryUpAt[rr], clean = f < 0 || f <= kCleanAt[rr];
         int next = -1;
         if (pl.trial < 0) {   // the incumbent: where to look, if anywhere
             pl.t_mode = pl.best_t = t;
@@ -1180,7 +1187,8 @@ struct ChunkScratch {
     // steady-state sample of the incumbent
     void monitor(int fam, int r, double t, double f) {
         Policy &pl = pol[fam];
-        const bool dirty = f > kTryUp, clean = f < 0 || f <= kClean;
+        const int rr = r < kModeSeq ? r : kModeSeq;
+        const bool dirty = f > kTryUpAt[rr], clean = f < 0 || f <= kCleanAt[rr];
         const bool slower = pl.t_mode > 0 && t > kDrift * pl.t_mode;
         const bool harder = r < kModeSeq && dirty && (pl.hold_up == 0 || slower);
         const bool easier = r > 0 && clean && pl.t_mode > 0 && t * kDrift < pl.t_mode;
