@@ -1317,9 +1317,8 @@ void launch_chunk(const SweepArgs &args, const FibreGeom &g, hipStream_t stream,
     else if (mode == 3)    launch_gchunk<OP, WEIGHTED>(args, g, 64, 256, stream, fam);
     else if (mode == 4)    launch_gchunk<OP, WEIGHTED>(args, g, 256, 1024, stream, fam);
     else if constexpr (!WEIGHTED) {
-        if (mode == 2)                    launch_chunk_h<OP, false, TRANSPOSED, kWarmLong>(args, g, stream, fam, 0);
-        else if (options().chunk == 32)   launch_chunk_h<OP, false, TRANSPOSED, kWarm, 32, 4>(args, g, stream, fam, 0);   // experiment
-        else                              launch_chunk_h<OP, false, TRANSPOSED, kWarm>(args, g, stream, fam, rounds);
+        if (mode == 2) launch_chunk_h<OP, false, TRANSPOSED, kWarmLong>(args, g, stream, fam, 0);
+        else           launch_chunk_h<OP, false, TRANSPOSED, kWarm>(args, g, stream, fam, rounds);
     } else {
         launch_chunk_h<OP, true, TRANSPOSED, kWarm>(args, g, stream, fam, rounds);
     }
