@@ -263,7 +263,7 @@ __device__ __forceinline__ bool walker_run_blocked(Walker &w, S &src, int n, dou
             yn[u] = src.y(at);
             if (WEIGHTED) rn[u] = src.r(at < last ? at : last - 1);
         }
-        if (WEIGHTED) rnprev = src.r(nb > 0 ? nb - 1 : 0);
+        if (WEIGHTED) rnprev = src.r(nb > 0 ? (nb - 1 < last ? nb - 1 : last - 1) : 0);   // (nb may lie past the fibre end)
         if (!useful) continue;
 
         const int lim = last < src.limit() ? last : src.limit();   // interior trips handle i < lim

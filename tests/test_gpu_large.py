@@ -49,6 +49,22 @@ def test_c3_weighted_dr_4096(ptv, glarge):
     assert abs(y.mean() - X.mean()) < 1e-9
 
 
+def test_c3_weighted_dr_4096_global_memory_walks(ptv, clib, glarge):
+    """The same solve through the geometries that walk global memory (chunks with 256-sample zones, one sequential walk
+    per fibre).  Exactly-sized device buffers: an index one past the last fibre's weights is a GPU memory fault, not a
+    silently wrong read -- the regression this test pins (the pipelined walker fetched r[n - 1] of the last fibre)."""
+    rng = np.random.default_rng(0)
+    X = np.asfortranarray(rng.standard_normal((4096, 4096)))
+    W1 = np.asfortranarray(rng.uniform(0.05, 0.15, (4095, 4096)))
+    W2 = np.asfortranarray(rng.uniform(0.05, 0.15, (4096, 4095)))
+    try:
+        for mode in (3, 5):
+            clib.proxtv_set_option(b"chunk_mode", mode)
+            _check_digest(ptv.tv1w_2d(X, W1, W2), glarge, "c3/dr2w")
+    finally:
+        clib.proxtv_set_option(b"chunk_mode", -1)
+
+
 def test_c4_volume(ptv, clib, glarge):
     """Config #4: 512x512x64 volume (float32 up-cast like the reference surface does), lambda = [0.1, 0.1, 0.05].
     tvgen runs PD_TV (35 iterations, RC_ITERS) -- plus scalar-lambda Yang3_TV, the C entry point BASELINE names."""
