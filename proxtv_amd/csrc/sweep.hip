@@ -38,6 +38,13 @@ using link_t = unsigned;                 // (restart << 1 | bend type) of a walk
 constexpr link_t kLinkBad = 0xfffffffeu;        // the chunk's walk ran off its LDS window: trust nothing it recorded
 constexpr link_t kLinkCertain = 0x80000000u;    // flag on a published `mine` code: the chunk's walk began AT a bend known a priori
 
+// Per fibre, two words tell the repair kernel where the chunk kernels left work: the first and the last chunk with an
+// unproven link (both as maxima, so that 0 = none: NC - first and last + 1).  Only failing lanes touch them.
+__device__ __forceinline__ void flag_chunk(int *failflags, long j, int chunk, int NC) {
+    atomicMax(failflags + 2 * j, NC - chunk);
+    atomicMax(failflags + 2 * j + 1, chunk + 1);
+}
+
 // ---- kernel 1: sequential walk straight from / to global memory --------------------------------------------------
 // Global-memory walks fetch their samples kGlobalBlock at a time (walker_run_blocked) and write a piece out the same
 // way: a batch of independent operand fetches, then the batch of stores -- one memory round trip per batch instead of
@@ -575,7 +582,7 @@ __global__ __launch_bounds__(64 * NW, ((WEIGHTED || H > 16) ? NW / 4 : NW / 2)) 
                 src.mine = kLinkBad;
                 src.next = 0;
             }
-            if (bad) failflags[j] = 1;
+            if (bad) flag_chunk(failflags, j, q * NW + wave, (len + C - 1) / C);
             // Every chunk publishes its two codes: sweep_repair_kernel proves the links between workgroups with them
             // and, for a fibre with an unproven link, finds where a repair walk may stop.
             const long slot = (long)(q * NW + wave) * g.count + j;
@@ -700,7 +707,7 @@ __global__ __launch_bounds__(64) void sweep_gchunk_kernel(SweepArgs p, FibreGeom
     walker_start<WEIGHTED>(w, src, max(0, cs - H), p.lam);
     walker_run_blocked<WEIGHTED, kGlobalBlock>(w, src, len, p.lam);
     if (src.failed) {   // nothing this lane recorded may be trusted; the repair walk rewrites its chunk
-        failflags[j] = 1;
+        flag_chunk(failflags, j, c, (len + C - 1) / C);
         src.mine = kLinkBad;
         src.next = 0;
     }
@@ -862,7 +869,13 @@ __global__ __launch_bounds__(64) void sweep_repair_kernel(SweepArgs p, FibreGeom
     if (p.gate && *p.gate == 0) return;
     const int len = g.len;
     const int NC = (len + C - 1) / C;
-    int bad = failflags[j];
+    // first / last chunk with an unproven link: what the chunk kernel flagged, widened below by the links between workgroups
+    int first = NC, lastbad = -1;
+    {
+        const int f0 = failflags[2 * j], f1 = failflags[2 * j + 1];
+        if (f0 > 0) first = NC - f0;
+        if (f1 > 0) lastbad = f1 - 1;
+    }
     // links between workgroups (inside a workgroup they were checked through LDS): 16 boundaries = 32 independent
     // loads in flight per lane -- the cost of the common case is the latency of these reads
     constexpr int UB = 16;
@@ -878,11 +891,14 @@ __global__ __launch_bounds__(64) void sweep_repair_kernel(SweepArgs p, FibreGeom
         for (int u = 0; u < UB; u++) {
             const int c = c0 + u * chunks_per_wg;
             const bool certain = (in[u] & kLinkCertain) && in[u] != kLinkBad;
-            if (c < NC && c * C - H > 0 && !certain && (in[u] == 0 || in[u] != out[u])) bad = 1;
+            if (c < NC && c * C - H > 0 && !certain && (in[u] == 0 || in[u] != out[u])) {
+                first = min(first, c);
+                lastbad = max(lastbad, c);
+            }
         }
     }
-    if (!bad) return;
-    failflags[j] = 0;
+    if (lastbad < 0) return;
+    failflags[2 * j] = failflags[2 * j + 1] = 0;
     atomicAdd(failcount, 1);       // fibres that needed a repair
     int walks = 0;
 
@@ -892,8 +908,16 @@ __global__ __launch_bounds__(64) void sweep_repair_kernel(SweepArgs p, FibreGeom
     const bool windowed = H <= kWarmLong;
     RepairSource<OP, WEIGHTED> gsrc(book, p, base, g.inc, wbase);
     WindowRepairSource<OP, WEIGHTED> wsrc(book, p, base, g.inc, wbase, repair_lds, (int)threadIdx.x);
+    // every chunk before `first` is proven: the true walk's last bend there is the last non-zero `next` code before it
     link_t cur = kFromStart;
-    int c = 0;
+    for (int b = first - 1; b >= 0; b--) {
+        const link_t nx = code_next[(long)b * g.count + j];
+        if (nx != 0) {
+            cur = nx;
+            break;
+        }
+    }
+    int c = first;
     // Two-phase loop so that the lanes of a wave repair TOGETHER: first every lane scans ahead to its next unproven
     // chunk, then all lanes that found one walk at the same time (a walk nested inside the scan would serialise the
     // lanes, each reaching its repair at a different trip).
@@ -901,7 +925,7 @@ __global__ __launch_bounds__(64) void sweep_repair_kernel(SweepArgs p, FibreGeom
         // the scan reads the codes of UB chunks at a time (2 UB independent loads), then goes through them in registers:
         // one memory round trip per UB chunks instead of two per chunk
         bool rejected = false;
-        while (c < NC && !rejected) {
+        while (c < NC && c <= lastbad && !rejected) {   // (everything after the last flagged chunk is proven)
             link_t mm[UB], nn[UB];
 #pragma unroll
             for (int u = 0; u < UB; u++) {
@@ -928,7 +952,7 @@ __global__ __launch_bounds__(64) void sweep_repair_kernel(SweepArgs p, FibreGeom
                 }
             }
         }
-        if (c >= NC) break;
+        if (c >= NC || !rejected) break;
         const link_t from = (cur == kFromStart) ? 0u : cur;
         bool stopped;
         int resume_chunk;
@@ -1075,10 +1099,10 @@ struct ChunkScratch {
         }
         code_mine = links->as<link_t>();
         code_next = code_mine + (size_t)count * (size_t)NC;
-        if ((size_t)count + kCounters > flag_count) {
+        if (2 * (size_t)count + kCounters > flag_count) {
             poll(true);   // read-backs of the old counters must land before the buffer goes away
-            flags.reset(new Scratch(sizeof(int) * ((size_t)count + kCounters)));
-            flag_count = (size_t)count + kCounters;
+            flags.reset(new Scratch(sizeof(int) * (2 * (size_t)count + kCounters)));
+            flag_count = 2 * (size_t)count + kCounters;
             PTV_HIP(hipMemsetAsync(flags->as<int>(), 0, sizeof(int) * flag_count, s));
             for (int f = 0; f < FAM_COUNT; f++) {
                 pol[f].rewritten_seen = 0;
