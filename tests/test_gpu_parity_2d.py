@@ -214,6 +214,22 @@ def test_random_shapes_vs_oracle(ptv, oracle):
             assert_close(ptv.tv1_2d(X, lam, method="yang"), oracle.yang2(X, lam)[0], what=f"yang2 {M}x{N}")
 
 
+def test_extreme_aspect_ratios_vs_oracle(ptv, oracle):
+    """Very long against very short fibres in the same solve: one sweep direction goes through the chunked kernels
+    (and their geometry policy), the other through the sequential one; lengths around the 96-sample switch."""
+    rng = np.random.default_rng(29)
+    for M, N in [(2, 6000), (6000, 3), (95, 2100), (96, 97), (1500, 96), (5, 100000)]:
+        X = rng.standard_normal((M, N))
+        for lam in (0.1, 0.6, 4.0):
+            assert_close(ptv.tv1_2d(X, lam), oracle.dr2(X, lam)[0], what=f"dr2 {M}x{N} {lam}")
+        W1, W2 = rng.uniform(0, 0.5, (M - 1, N)), rng.uniform(0, 0.5, (M, N - 1))
+        assert_close(ptv.tv1w_2d(X, W1, W2), oracle.dr2w(X, W1, W2)[0], what=f"dr2w {M}x{N}")
+        assert_close(ptv.tv1_2d(X, 0.3, method="pd"), oracle.pd2(X, [0.3, 0.3], [1, 2])[0], what=f"pd2 {M}x{N}")
+        assert_close(ptv.tv1_2d(X, 0.3, method="kolmogorov", max_iters=30), oracle.kolmogorov2(X, 0.3, 30)[0],
+                     what=f"kolmogorov {M}x{N}")
+        assert_close(ptv.tv1_2d(X, 0.3, method="condat", max_iters=30), oracle.ccp2(X, 0.3, 0, 30)[0], what=f"condat {M}x{N}")
+
+
 def test_input_coercions(ptv, oracle):
     """C-ordered, float32 and integer inputs are converted like the reference (F-order float64)."""
     rng = np.random.default_rng(24)
