@@ -1,0 +1,180 @@
+// policy.hpp -- which geometry a sweep family runs: pure host logic, no HIP (tests/host_harness.cpp drives it on the CPU).
+//
+// Geometry ladder.  The zone must be a few pieces long for a speculative walk to meet the true one, and piece length
+// grows like (lambda / noise)^2:
+//   0  LDS window, 16-sample zones            pieces of a few samples (the headline regime)
+//   1  the same, robust instantiation         pieces of ~5 samples: walks may run past the window (global reads), failed
+//                                             links are walked again inside the block (second-chance rounds)
+//   2  LDS window, 64-sample zones            pieces of ~10 samples
+//   3  global memory, zone 256 / chunk 64     pieces of ~50 samples
+//   4  global memory, zone 1024 / chunk 256   pieces of a few hundred samples
+//   5  one sequential walk per fibre          pieces comparable to the fibre: speculation cannot pay
+//
+// The policy is a hill climb on MEASURED sweep time with the repair kernel's counters as the hint for where to look:
+//   * a solve starts by measuring one sweep at the incumbent mode (the family's next launch waits for the
+//     measurement -- the host enqueues a whole solve long before the device finishes its first sweep, so a decision
+//     needs a stall: one per family and solve in the steady state);
+//   * many rewritten chunks -> trial of the next rung up (straight to the sequential walk if most chunks failed, then
+//     back down); none at all -> trial of the next rung down; the fastest of the modes tried wins, and the climb
+//     goes on in that direction while the counters say there is something to find;
+//   * afterwards a sample (time + counters) is taken every few sweeps and looked at kMonitorLag sweeps later, when
+//     the device has reached it but still has work queued (no bubble): the data of a solve drift -- DR iterates at
+//     large lambda grow longer pieces sweep after sweep -- and a drift re-opens the exploration.
+// The mode persists across solves; one-sweep solves (batched 1-D prox calls) explore across calls.
+#pragma once
+
+namespace ptv {
+
+constexpr int kModeSeq = 5;
+constexpr int kRounds = 4;          // second-chance rounds of mode 1 (option "rounds" overrides)
+// rewritten-chunk fraction above which the next rung is worth a trial, per rung (from mode 0 the next rung is the same
+// geometry made robust: a handful of repaired fibres per sweep already costs more than that), and below which the rung
+// below is
+constexpr double kTryUpAt[kModeSeq + 1] = {4e-6, 2e-4, 5e-4, 5e-4, 5e-4, 1.0};
+constexpr double kCleanAt[kModeSeq + 1] = {1e-6, 1e-6, 5e-5, 5e-5, 5e-5, 1.0};
+constexpr double kJump = 0.5;       // ... above which the trial goes straight to the sequential walk
+constexpr double kBetter = 0.9;     // a trial wins if its sweep took less than this times the incumbent's
+constexpr double kDrift = 1.5;      // steady state: re-explore when the sweep time moved by this factor
+constexpr int kMonitorLag = 2;      // family sweeps between a steady-state sample and its evaluation
+constexpr int kHoldSolves = 2;      // solves during which a rejected direction is not tried again
+constexpr int kQuietSolves = 16;    // one-sweep solves between explorations
+
+struct GeometryPolicy {
+    int mode = 0;            // incumbent geometry
+    double t_mode = 0.0;     // ms of its last measured sweep
+    int trial = -1;          // >= 0: geometry under trial
+    int dir = 0;
+    int best = 0;            // fastest geometry of the exploration under way, and its sweep time
+    double best_t = 0.0;
+    bool explore = true;
+    int hold_up = 0, hold_down = 0, quiet = 0;
+    long sweeps = 0;         // sweeps of this family since the solve started
+    // the workload of the last sweep (a different shape = a different workload)
+    bool weighted = false;   // no mode 2 for weighted sweeps (two LDS windows)
+    int len = 0;             // no mode 4 below 1024 samples
+    long count = 0;
+    int changes = 0;         // workload changes seen in this solve
+
+    bool available(int m) const { return !(m == 2 && weighted) && !(m == 4 && len < 1024); }
+    int up(int m) const {
+        do m++; while (m < kModeSeq && !available(m));
+        return m;
+    }
+    int down(int m) const {
+        do m--; while (m > 0 && !available(m));
+        return m;
+    }
+    void conclude() {
+        trial = -1;
+        explore = false;
+    }
+
+    // A sweep of this shape is about to be launched.  Returns true when the workload differs from the last one's
+    // (explore afresh -- unless shapes keep alternating inside one solve: 4-D+ tensors share a family).
+    bool workload(int len_, long count_, bool weighted_) {
+        const bool fresh = (len != len_ || count != count_ || weighted != weighted_) && changes++ < 4;
+        if (fresh) {
+            explore = true;
+            trial = -1;
+            hold_up = hold_down = quiet = 0;
+        }
+        len = len_;
+        count = count_;
+        weighted = weighted_;
+        return fresh;
+    }
+
+    // geometry of the next sweep
+    int choose() {
+        if (!available(mode)) mode = up(mode);
+        return (explore && trial >= 0) ? trial : mode;
+    }
+    // should the next sweep be measured?  (`pending`: a measurement is still in flight)
+    bool wants_measurement(bool pending) const {
+        return !pending && (explore || (sweeps > 0 && sweeps % (mode == 0 ? 8 : 4) == 0));
+    }
+
+    // one step of an exploration: the sweep just measured ran geometry r in t ms and had the fraction f of its chunks
+    // rewritten by repair walks (f < 0: no counters, e.g. the sequential kernel)
+    void step(int r, double t, double f) {
+        const int rr = r < kModeSeq ? r : kModeSeq;
+        const bool dirty = f > kTryUpAt[rr], clean = f < 0 || f <= kCleanAt[rr];
+        int next = -1;
+        if (trial < 0) {   // the incumbent: where to look, if anywhere
+            t_mode = best_t = t;
+            best = r;
+            if (r < kModeSeq && dirty && hold_up == 0) {
+                next = (f > kJump) ? kModeSeq : up(r);
+                dir = (next > up(r)) ? -1 : +1;   // skipped rungs on the way up: look at them from above
+            } else if (r > 0 && clean && hold_down == 0) {
+                next = down(r);
+                dir = -1;
+            }
+        } else {           // a trial: remember the fastest, walk on while the counters say there is something to find
+            // going up a trial must win clearly; going down a clean one only has to be no slower (noise on small
+            // problems must not leave the policy on a heavier geometry than the data need)
+            if (t < (dir < 0 && clean ? 1.05 : kBetter) * best_t) {
+                best = r;
+                best_t = t;
+            }
+            if (t < 3.0 * best_t) {
+                if (dir > 0 && r < kModeSeq && dirty) next = up(r);
+                if (dir < 0 && r > 0 && clean) next = down(r);
+            }
+        }
+        if (next >= 0) {
+            trial = next;
+            return;
+        }
+        if (trial >= 0 && best == mode) {   // looked and found nothing: leave that direction alone for a while
+            if (dir > 0) hold_up = kHoldSolves;
+            else hold_down = kHoldSolves;
+        }
+        mode = best;
+        t_mode = best_t;
+        conclude();
+    }
+
+    // steady-state sample of the incumbent
+    void monitor(int r, double t, double f) {
+        const int rr = r < kModeSeq ? r : kModeSeq;
+        const bool dirty = f > kTryUpAt[rr], clean = f < 0 || f <= kCleanAt[rr];
+        const bool slower = t_mode > 0 && t > kDrift * t_mode;
+        const bool harder = r < kModeSeq && dirty && (hold_up == 0 || slower);
+        const bool easier = r > 0 && clean && t_mode > 0 && t * kDrift < t_mode;
+        if (harder) hold_up = 0;
+        if (easier) hold_down = 0;
+        if (harder || easier) {
+            explore = true;
+            trial = -1;
+            step(r, t, f);
+        }
+    }
+
+    // a measurement arrived: exploration step or steady-state sample
+    void measured(int r, double t, double f) {
+        if (explore) step(r, t, f);
+        else monitor(r, t, f);
+    }
+
+    // a new solve starts (after the previous solve's last measurement, if any, went through measured())
+    void begin_solve() {
+        if (hold_up > 0) hold_up--;
+        if (hold_down > 0) hold_down--;
+        if (sweeps > 1) {            // a real solve: every solve opens with a measured sweep of the incumbent
+            explore = true;
+            trial = -1;
+        } else if (!explore) {       // one-sweep solves: an exploration every kQuietSolves calls
+            if (quiet > 0) quiet--;
+            else {
+                explore = true;
+                trial = -1;
+                quiet = kQuietSolves;
+            }
+        }
+        sweeps = 0;
+        changes = 0;
+    }
+};
+
+}  // namespace ptv

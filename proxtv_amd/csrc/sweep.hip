@@ -26,6 +26,7 @@
 
 #include <memory>
 
+#include "policy.hpp"
 #include "walker.hpp"
 
 #include <cstdio>
@@ -990,29 +991,6 @@ void launch_seq(const SweepArgs &args, const FibreGeom &g, hipStream_t stream, b
     PTV_HIP(hipGetLastError());
 }
 
-// Geometry ladder (Policy::mode).  The zone must be a few pieces long for a speculative walk to meet the true one,
-// and piece length grows like (lambda / noise)^2:
-//   0  LDS window, 16-sample zones            pieces of a few samples (the headline regime)
-//   1  the same, robust instantiation         pieces of ~5 samples: walks may run past the window (global reads), failed
-//                                             links are walked again inside the block (second-chance rounds)
-//   2  LDS window, 64-sample zones            pieces of ~10 samples
-//   3  global memory, zone 256 / chunk 64     pieces of ~50 samples
-//   4  global memory, zone 1024 / chunk 256   pieces of a few hundred samples
-//   5  one sequential walk per fibre          pieces comparable to the fibre: speculation cannot pay
-constexpr int kModeSeq = 5;
-constexpr int kRounds = 4;          // second-chance rounds of mode 1 (option "rounds" overrides)
-// rewritten-chunk fraction above which the next rung is worth a trial, per rung (from mode 0 the next rung is the same
-// geometry made robust: a handful of repaired fibres per sweep already costs more than that), and below which the rung
-// below is
-constexpr double kTryUpAt[kModeSeq + 1] = {4e-6, 2e-4, 5e-4, 5e-4, 5e-4, 1.0};
-constexpr double kCleanAt[kModeSeq + 1] = {1e-6, 1e-6, 5e-5, 5e-5, 5e-5, 1.0};
-constexpr double kJump = 0.5;       // ... above which the trial goes straight to the sequential walk
-constexpr double kBetter = 0.9;     // a trial wins if its sweep took less than this times the incumbent's
-constexpr double kDrift = 1.5;      // steady state: re-explore when the sweep time moved by this factor
-constexpr int kMonitorLag = 2;      // family sweeps between a steady-state sample and its evaluation
-constexpr int kHoldSolves = 2;      // solves during which a rejected direction is not tried again
-constexpr int kQuietSolves = 16;    // one-sweep solves between explorations
-
 // persistent per-thread state of the chunked path: link codes, fail flags, repair counters and the geometry policy
 struct ChunkScratch {
     std::unique_ptr<Scratch> links, flags;
@@ -1021,55 +999,17 @@ struct ChunkScratch {
     int *failflags = nullptr;
     int *failcount = nullptr;   // [family][2]: fibres that needed repair, chunks rewritten by repair walks (cumulative per solve)
 
-    // Geometry policy, one per sweep family (fibres along dim 0 / along the other dims see different data: in a DR
-    // solve at large lambda the column pieces are several times longer than the row pieces).  It is a hill climb on
-    // MEASURED sweep time with the repair counters as the hint for where to look:
-    //   * a solve starts by measuring one sweep at the incumbent mode (hipEvents around the launch, counters read
-    //     back behind it; the family's next launch waits for both -- the host enqueues a whole solve long before the
-    //     device finishes its first sweep, so a decision needs a stall: one per family and solve in the steady state);
-    //   * many rewritten chunks -> trial of the next longer zone (straight to the sequential walk if most chunks
-    //     failed, then back down); none at all -> trial of the next shorter one; a trial replaces the incumbent if
-    //     its sweep was faster, and the climb goes on in that direction until a trial loses;
-    //   * afterwards a sample (time + counters) is taken every few sweeps and looked at kMonitorLag sweeps later,
-    //     when the device has reached it but still has work queued (no bubble): the data of a solve drift -- DR
-    //     iterates at large lambda grow longer pieces sweep after sweep -- and a drift re-opens the exploration.
-    // The mode persists across solves; one-sweep solves (batched 1-D prox calls) explore across calls.
-    struct Policy {
-        int mode = 0;            // incumbent geometry
-        double t_mode = 0.0;     // ms of its last measured sweep
-        int trial = -1;          // >= 0: geometry under trial
-        int dir = 0;
-        int best = 0;            // fastest geometry of the exploration under way, and its sweep time
-        double best_t = 0.0;
-        long count = 0;          // fibres of the last sweep (a different shape = a different workload)
-        int changes = 0;         // workload changes seen in this solve
-        bool explore = true;
-        int hold_up = 0, hold_down = 0, quiet = 0;
-        long sweeps = 0;         // sweeps of this family since the solve started
-        bool weighted = false;   // of the last sweep: no mode 1 for weighted sweeps (two LDS windows)
-        int len = 0;             // fibre length of the last sweep: no mode 3 below 1024
-        // measurement in flight
-        bool meas = false;
+    // Geometry policy (policy.hpp), one per sweep family -- fibres along dim 0 / along the other dims see different
+    // data: in a DR solve at large lambda the column pieces are several times longer than the row pieces -- plus the
+    // plumbing of its measurements: hipEvents around the measured launch, the repair counters read back behind it.
+    struct Policy : GeometryPolicy {
+        bool meas = false;       // a measurement is in flight
         int meas_mode = 0, meas_slot = -1;
         long meas_sweep = 0;
         hipEvent_t t0 = nullptr, t1 = nullptr;
         long chunks_done = 0;    // chunks processed (host-side count, cumulative per solve)
         long chunks_seen = 0;    // ... at the last evaluation
         int rewritten_seen = 0;
-
-        bool available(int m) const { return !(m == 2 && weighted) && !(m == 4 && len < 1024); }
-        int up(int m) const {
-            do m++; while (m < kModeSeq && !available(m));
-            return m;
-        }
-        int down(int m) const {
-            do m--; while (m > 0 && !available(m));
-            return m;
-        }
-        void conclude() {
-            trial = -1;
-            explore = false;
-        }
     } pol[FAM_COUNT];
 
     static constexpr int kSlots = 8, kCounters = 2 * FAM_COUNT;
@@ -1164,65 +1104,17 @@ struct ChunkScratch {
         pl.meas_slot = -1;
     }
 
-    // one step of an exploration: the sweep just measured ran geometry r
-    void step(int fam, int r, double t, double f) {
+    // hand the measurement in flight to the policy
+    void settle(int fam, bool adaptive) {
         Policy &pl = pol[fam];
+        const int r = pl.meas_mode;
+        double t, f;
+        evaluate(fam, t, f);
+        if (!adaptive) return;
         if (options().verbose)
             fprintf(stderr, "[proxtv_amd] policy: family %d sweep %ld: mode %d %s took %.3f ms, rewrote %.5f of its chunks (incumbent %d: %.3f ms)\n",
-                    fam, pl.sweeps, r, pl.trial >= 0 ? "(trial)" : "(incumbent)", t, f, pl.mode, pl.t_mode);
-        const int rr = r < kModeSeq ? r : kModeSeq;
-        const bool dirty = f > kTryUpAt[rr], clean = f < 0 || f <= kCleanAt[rr];
-        int next = -1;
-        if (pl.trial < 0) {   // the incumbent: where to look, if anywhere
-            pl.t_mode = pl.best_t = t;
-            pl.best = r;
-            if (r < kModeSeq && dirty && pl.hold_up == 0) {
-                next = (f > kJump) ? kModeSeq : pl.up(r);
-                pl.dir = (next > pl.up(r)) ? -1 : +1;   // skipped rungs on the way up: look at them from above
-            } else if (r > 0 && clean && pl.hold_down == 0) {
-                next = pl.down(r);
-                pl.dir = -1;
-            }
-        } else {              // a trial: remember the fastest, walk on while the counters say there is something to find
-            // going up a trial must win clearly; going down a clean one only has to be no slower (noise on small
-            // problems must not leave the policy on a heavier geometry than the data need)
-            if (t < (pl.dir < 0 && clean ? 1.05 : kBetter) * pl.best_t) {
-                pl.best = r;
-                pl.best_t = t;
-            }
-            if (t < 3.0 * pl.best_t) {
-                if (pl.dir > 0 && r < kModeSeq && dirty) next = pl.up(r);
-                if (pl.dir < 0 && r > 0 && clean) next = pl.down(r);
-            }
-        }
-        if (next >= 0) {
-            pl.trial = next;
-            return;
-        }
-        if (pl.trial >= 0 && pl.best == pl.mode) {   // looked and found nothing: leave that direction alone for a while
-            if (pl.dir > 0) pl.hold_up = kHoldSolves;
-            else pl.hold_down = kHoldSolves;
-        }
-        pl.mode = pl.best;
-        pl.t_mode = pl.best_t;
-        pl.conclude();
-    }
-
-    // steady-state sample of the incumbent
-    void monitor(int fam, int r, double t, double f) {
-        Policy &pl = pol[fam];
-        const int rr = r < kModeSeq ? r : kModeSeq;
-        const bool dirty = f > kTryUpAt[rr], clean = f < 0 || f <= kCleanAt[rr];
-        const bool slower = pl.t_mode > 0 && t > kDrift * pl.t_mode;
-        const bool harder = r < kModeSeq && dirty && (pl.hold_up == 0 || slower);
-        const bool easier = r > 0 && clean && pl.t_mode > 0 && t * kDrift < pl.t_mode;
-        if (harder) pl.hold_up = 0;
-        if (easier) pl.hold_down = 0;
-        if (harder || easier) {
-            pl.explore = true;
-            pl.trial = -1;
-            step(fam, r, t, f);
-        }
+                    fam, pl.sweeps, r, !pl.explore ? "(sample)" : pl.trial >= 0 ? "(trial)" : "(incumbent)", t, f, pl.mode, pl.t_mode);
+        pl.measured(r, t, f);
     }
 };
 static thread_local ChunkScratch g_chunk;
@@ -1304,19 +1196,10 @@ void launch_chunk(const SweepArgs &args, const FibreGeom &g, hipStream_t stream,
     ChunkScratch &st = g_chunk;
     ChunkScratch::Policy &pl = st.pol[fam];
     const bool pinned = options().chunk_mode >= 0;
-    // a new workload: explore afresh (unless shapes keep alternating inside one solve: 4-D+ tensors share a family)
-    if ((pl.len != g.len || pl.count != g.count || pl.weighted != WEIGHTED) && pl.changes++ < 4) {
-        if (pl.meas) {
-            double t, f;
-            st.evaluate(fam, t, f);
-        }
-        pl.explore = true;
-        pl.trial = -1;
-        pl.hold_up = pl.hold_down = pl.quiet = 0;
+    if (pl.workload(g.len, g.count, WEIGHTED) && pl.meas) {   // a new workload: the measurement in flight is of the old one
+        double t, f;
+        st.evaluate(fam, t, f);
     }
-    pl.weighted = WEIGHTED;
-    pl.len = g.len;
-    pl.count = g.count;
     int mode;
     bool measure = false;
     if (pinned) {
@@ -1324,16 +1207,9 @@ void launch_chunk(const SweepArgs &args, const FibreGeom &g, hipStream_t stream,
         if (!pl.available(mode)) mode = pl.up(mode);
     } else {
         st.ensure_host();
-        if (pl.meas && (pl.explore || pl.sweeps - pl.meas_sweep >= kMonitorLag)) {
-            const int r = pl.meas_mode;
-            double t, f;
-            st.evaluate(fam, t, f);
-            if (pl.explore) st.step(fam, r, t, f);
-            else st.monitor(fam, r, t, f);
-        }
-        if (!pl.available(pl.mode)) pl.mode = pl.up(pl.mode);
-        mode = (pl.explore && pl.trial >= 0) ? pl.trial : pl.mode;
-        measure = !pl.meas && (pl.explore || (pl.sweeps > 0 && pl.sweeps % (pl.mode == 0 ? 8 : 4) == 0));
+        if (pl.meas && (pl.explore || pl.sweeps - pl.meas_sweep >= kMonitorLag)) st.settle(fam, true);
+        mode = pl.choose();
+        measure = pl.wants_measurement(pl.meas);
         if (measure) PTV_HIP(hipEventRecord(pl.t0, stream));
     }
     const int rounds = (mode == 1) ? (options().rounds > 0 ? options().rounds : kRounds) : 0;
@@ -1375,31 +1251,9 @@ void chunk_stats_reset(hipStream_t s) {
     for (int f = 0; f < FAM_COUNT; f++) {
         ChunkScratch::Policy &pl = st.pol[f];
         // what the previous solve left behind: for one-sweep solves (batched 1-D prox calls) this is where the
-        // climb advances
-        if (pl.meas) {
-            const int r = pl.meas_mode;
-            double t, fr;
-            st.evaluate(f, t, fr);
-            if (adaptive) {
-                if (pl.explore) st.step(f, r, t, fr);
-                else st.monitor(f, r, t, fr);
-            }
-        }
-        if (pl.hold_up > 0) pl.hold_up--;
-        if (pl.hold_down > 0) pl.hold_down--;
-        if (pl.sweeps > 1) {            // a real solve: every solve opens with a measured sweep of the incumbent
-            pl.explore = true;
-            pl.trial = -1;
-        } else if (!pl.explore) {       // one-sweep solves: an exploration every kQuietSolves calls
-            if (pl.quiet > 0) pl.quiet--;
-            else {
-                pl.explore = true;
-                pl.trial = -1;
-                pl.quiet = kQuietSolves;
-            }
-        }
-        pl.sweeps = 0;
-        pl.changes = 0;
+        // exploration advances
+        if (pl.meas) st.settle(f, adaptive);
+        pl.begin_solve();
         pl.chunks_done = pl.chunks_seen = 0;
         pl.rewritten_seen = 0;
         st.latest_rewritten[f] = 0;

@@ -6,6 +6,7 @@
 #define __forceinline__ inline
 #include <cstring>
 
+#include "../proxtv_amd/csrc/policy.hpp"
 #include "../proxtv_amd/csrc/walker.hpp"
 
 using namespace ptv;
@@ -65,5 +66,50 @@ int host_walk_from(const double *y, const double *w, double lam, double *x, int 
     if (w) { walker_start<true>(wk, s, from, lam); walker_run<true>(wk, s, n, lam); }
     else   { walker_start<false>(wk, s, from, lam); walker_run<false>(wk, s, n, lam); }
     return s.bends;
+}
+
+// The geometry policy (policy.hpp) under a cost model: `cost` / `frac` hold, for two phases of a solve (before / from
+// sweep `switch_at` on), the sweep time in ms and the rewritten-chunk fraction of each of the 6 modes (frac < 0: no
+// counters).  The loop mirrors launch_chunk / chunk_stats_reset in sweep.hip: measurements are looked at before the
+// family's next launch while exploring, kMonitorLag sweeps later in the steady state, and at the next solve's start.
+// Returns the incumbent mode at the end; total_ms = time of the LAST solve; trace (if not null) = mode of every sweep
+// of the last solve.
+int policy_sim(const double *cost, const double *frac, int switch_at, int solves, int sweeps, int len, int weighted,
+               int start_mode, double *total_ms, int *trace) {
+    GeometryPolicy pl;
+    pl.mode = start_mode;
+    bool meas = false;
+    int meas_mode = 0, meas_phase = 0;
+    long meas_sweep = 0;
+    double total = 0;
+    for (int s = 0; s < solves; s++) {
+        if (meas) {
+            pl.measured(meas_mode, cost[6 * meas_phase + meas_mode], frac[6 * meas_phase + meas_mode]);
+            meas = false;
+        }
+        pl.begin_solve();
+        total = 0;
+        for (int k = 0; k < sweeps; k++) {
+            const int phase = k >= switch_at ? 1 : 0;
+            if (pl.workload(len, 4096, weighted != 0)) meas = false;
+            if (meas && (pl.explore || pl.sweeps - meas_sweep >= kMonitorLag)) {
+                pl.measured(meas_mode, cost[6 * meas_phase + meas_mode], frac[6 * meas_phase + meas_mode]);
+                meas = false;
+            }
+            const int mode = pl.choose();
+            const bool measure = pl.wants_measurement(meas);
+            total += cost[6 * phase + mode];
+            if (trace) trace[k] = mode;
+            pl.sweeps++;
+            if (measure) {
+                meas = true;
+                meas_mode = mode;
+                meas_phase = phase;
+                meas_sweep = pl.sweeps;
+            }
+        }
+    }
+    if (total_ms) *total_ms = total;
+    return pl.mode;
 }
 }

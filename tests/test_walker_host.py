@@ -20,6 +20,7 @@ def harness():
     lib.host_walk.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_int]
     lib.host_walk_from.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_int, C.c_int, C.c_int]
     lib.host_walk_blocked.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_int, C.c_int, C.c_int]
+    lib.policy_sim.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     return lib
 
 
@@ -130,3 +131,70 @@ def test_blocked_walk_is_bit_identical(harness, oracle):
             nb = harness.host_walk_blocked(x.ctypes.data, wp, lam, b.ctypes.data, n, start, until)
             np.testing.assert_array_equal(a, b)
             assert na == nb
+
+
+# ---- the geometry policy (proxtv_amd/csrc/policy.hpp) under a cost model ---------------------------------------------------
+def _simulate(lib, cost, frac, solves=4, sweeps=35, switch_at=10**6, length=4096, weighted=False, start=0, cost2=None, frac2=None):
+    table_c = np.array(list(cost) + list(cost2 if cost2 is not None else cost), dtype=np.float64)
+    table_f = np.array(list(frac) + list(frac2 if frac2 is not None else frac), dtype=np.float64)
+    total = np.zeros(1)
+    trace = np.zeros(sweeps, dtype=np.int32)
+    mode = lib.policy_sim(table_c.ctypes.data, table_f.ctypes.data, switch_at, solves, sweeps, length, int(weighted), start,
+                          total.ctypes.data, trace.ctypes.data)
+    return mode, float(total[0]), trace
+
+
+# sweep time (ms, chunk + repair kernels) and rewritten-chunk fraction per mode, as measured on 4096^2 DR iterates
+REGIMES = {
+    # name: (cost[0..5], frac[0..5], best mode)
+    "headline lam=0.1": ([0.15, 0.16, 0.45, 1.5, 2.0, 6.0], [0, 0, 0, 0, 0, -1], 0),
+    "lam=0.3": ([0.24, 0.17, 0.5, 1.5, 2.0, 6.0], [1.5e-5, 1e-7, 0, 0, 0, -1], 1),
+    "lam=0.7": ([0.85, 0.57, 0.75, 1.3, 1.6, 6.0], [0.02, 3e-3, 1e-5, 0, 0, -1], 1),
+    "lam=1": ([7.0, 3.7, 1.25, 1.2, 1.6, 6.0], [0.3, 0.1, 4e-4, 0, 0, -1], 3),
+    "lam=3 columns": ([14.0, 12.0, 9.0, 12.0, 8.0, 4.3], [1.0, 1.0, 0.9, 0.9, 0.13, -1], 5),
+    "lam=30": ([10.4, 10.4, 11.5, 9.0, 15.0, 4.3], [1.0, 1.0, 1.0, 1.0, 1.0, -1], 5),
+}
+
+
+def test_policy_finds_the_fastest_geometry_from_anywhere(harness):
+    for name, (cost, frac, best) in REGIMES.items():
+        for start in range(6):
+            mode, total, trace = _simulate(harness, cost, frac, solves=5, start=start)
+            assert cost[mode] <= 1.12 * cost[best], (name, start, mode, best)
+            # steady state: a solve costs little more than 35 sweeps of the best mode (one trial sweep at most)
+            assert total <= 35 * cost[mode] + 2 * max(cost) and total <= 1.5 * 35 * cost[best] + max(cost), (name, start, total)
+
+
+def test_policy_headline_pays_nothing(harness):
+    cost, frac, _ = REGIMES["headline lam=0.1"]
+    mode, total, trace = _simulate(harness, cost, frac, solves=3)
+    assert mode == 0 and (trace == 0).all() and abs(total - 35 * cost[0]) < 1e-12
+
+
+def test_policy_follows_a_drift_inside_a_solve(harness):
+    """DR iterates at large lambda grow longer pieces sweep after sweep: what is best early in the solve is not later."""
+    early = ([14.0, 12.0, 5.3, 4.9, 5.5, 5.9], [0.6, 0.3, 1e-3, 3e-4, 0, -1])
+    late = ([14.0, 12.0, 14.0, 12.0, 8.5, 7.5], [1.0, 1.0, 0.3, 0.06, 0.1, -1])
+    mode, total, trace = _simulate(harness, early[0], early[1], solves=3, switch_at=12, cost2=late[0], frac2=late[1])
+    assert trace[-1] == 5 and (trace[-10:] == 5).all(), trace          # the late phase ends on the sequential walk
+    assert set(trace[4:10]) <= {2, 3, 4, 5}, trace                        # ... after running a chunked geometry early on
+    assert total <= 1.35 * (12 * 4.9 + 23 * 7.5), total
+
+
+def test_policy_respects_unavailable_geometries(harness):
+    cost, frac, _ = REGIMES["lam=1"]
+    cost_w = list(cost); cost_w[2] = 0.01                                 # would win if it existed for weighted sweeps
+    mode, total, trace = _simulate(harness, cost_w, frac, weighted=True, solves=4)
+    assert mode != 2 and 2 not in trace
+    cost_s = [14.0, 12.0, 9.0, 12.0, 0.01, 4.3]                            # 1024-sample zones need 1024-sample fibres
+    mode, total, trace = _simulate(harness, cost_s, [1, 1, 0.9, 0.9, 0.1, -1], length=700, solves=4)
+    assert mode != 4 and 4 not in trace
+
+
+def test_policy_one_sweep_solves_explore_across_calls(harness):
+    cost, frac, best = REGIMES["lam=0.3"]
+    mode, total, trace = _simulate(harness, cost, frac, solves=6, sweeps=1, start=0)
+    assert mode == best
+    cost, frac, best = REGIMES["headline lam=0.1"]
+    mode, total, trace = _simulate(harness, cost, frac, solves=8, sweeps=1, start=5)
+    assert mode == best
