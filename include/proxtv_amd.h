@@ -117,8 +117,15 @@ const char *proxtv_last_error(void);
 /* free every cached HBM scratch block held by the calling thread's pool */
 void proxtv_release_scratch(void);
 
-/* Knobs (returns previous value).  key: "chunk" (samples per speculative chunk, 0 = sequential
-   lane-per-fibre kernels only), "warmup", "verbose". */
+/* Knobs (process-wide; returns the previous value, -1 for an unknown key).  Each also has an environment variable
+   PROXTV_<KEY> read at load time.
+     "chunk"          non-zero: speculative-chunk kernels ; 0: sequential lane-per-fibre kernels only
+     "chunk_mode"     -1: adaptive geometry policy (default) ; 0..5: pin a rung of the ladder (see proxtv_chunk_mode)
+     "chunk_min_len"  fibres shorter than this take the sequential kernel (default 96)
+     "rounds"         second-chance rounds of geometry mode 1 (0 = built-in default, 4)
+     "verbose"        1: log every decision of the geometry policy to stderr
+     "profile"        1: hipEvent pair around every sweep launch (proxtv_last_kernel_ms / _launches)
+     "ablate", "blocks_per_wg", "warmup"   profiling aids (tools/) */
 int proxtv_set_option(const char *key, int value);
 
 /* Device-pointer solvers: every double* is an HBM pointer valid on the current device, `stream` is
