@@ -13,10 +13,14 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture()
 def modes(clib):
+    """Pin a geometry mode for the duration of a test; what was set before (PROXTV_CHUNK_MODE pins the whole run) returns."""
+    before = clib.proxtv_set_option(b"chunk_mode", -1)
+    clib.proxtv_set_option(b"chunk_mode", before)
+
     def set_mode(m):
         clib.proxtv_set_option(b"chunk_mode", m)
     yield set_mode
-    clib.proxtv_set_option(b"chunk_mode", -1)
+    clib.proxtv_set_option(b"chunk_mode", before)
 
 
 def _signals(rng, n):

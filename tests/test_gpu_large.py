@@ -57,12 +57,13 @@ def test_c3_weighted_dr_4096_global_memory_walks(ptv, clib, glarge):
     X = np.asfortranarray(rng.standard_normal((4096, 4096)))
     W1 = np.asfortranarray(rng.uniform(0.05, 0.15, (4095, 4096)))
     W2 = np.asfortranarray(rng.uniform(0.05, 0.15, (4096, 4095)))
+    before = clib.proxtv_set_option(b"chunk_mode", 3)
     try:
         for mode in (3, 5):
             clib.proxtv_set_option(b"chunk_mode", mode)
             _check_digest(ptv.tv1w_2d(X, W1, W2), glarge, "c3/dr2w")
     finally:
-        clib.proxtv_set_option(b"chunk_mode", -1)
+        clib.proxtv_set_option(b"chunk_mode", before)
 
 
 def test_c4_volume(ptv, clib, glarge):
