@@ -21,7 +21,13 @@
 // from the last proven bend, so the result is exact for every input; for noisy data the two walks coincide within a
 // handful of samples and nothing needs repair.
 // A workgroup = NW wavefronts = NW consecutive chunks of the same 64 fibres, sharing one LDS window
-// [first chunk - H, last chunk + T) of the fibre samples; the walk itself touches only LDS.
+// [first chunk - H, last chunk + T) of the fibre samples; the walk itself touches only LDS.  A lane that finds a bend
+// known a priori (|dy| > 4 lambda) just before its chunk starts there instead: exact by construction, nothing to prove.
+// A second, "robust" instantiation lets walks run past the window and gives failed links second chances in the block.
+//
+// Kernel 2b, `sweep_gchunk_kernel`: the same scheme straight from global memory with run-time chunk / zone sizes, for
+// pieces of tens to hundreds of samples.  Kernel 3, `sweep_repair_kernel`, finishes what kernels 2 / 2b left unproven.
+// Which of these a sweep runs is the geometry policy's business (policy.hpp; plumbing in ChunkScratch below).
 #include "sweep.hpp"
 
 #include <memory>
