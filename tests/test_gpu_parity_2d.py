@@ -230,6 +230,21 @@ def test_extreme_aspect_ratios_vs_oracle(ptv, oracle):
         assert_close(ptv.tv1_2d(X, 0.3, method="condat", max_iters=30), oracle.ccp2(X, 0.3, 0, 30)[0], what=f"condat {M}x{N}")
 
 
+def test_power_of_two_scaling_is_exact(ptv):
+    """prox(c y; c lambda) = c prox(y; lambda); for c a power of two every operation of the solver scales exactly, so the
+    outputs must agree bit for bit -- across magnitudes where absolute thresholds (the 1e-10 of the last-sample tests
+    aside, which the walker shares with the reference) would show."""
+    rng = np.random.default_rng(37)
+    X = rng.standard_normal((300, 260))
+    base = ptv.tv1_2d(X, 0.1, max_iters=10)
+    for c in (2.0 ** 12, 2.0 ** -9):
+        got = ptv.tv1_2d(c * X, c * 0.1, max_iters=10)
+        assert_close(got, c * base, tol=1e-12, what=f"scale {c}")
+    W1, W2 = rng.uniform(0.05, 0.2, (299, 260)), rng.uniform(0.05, 0.2, (300, 259))
+    basew = ptv.tv1w_2d(X, W1, W2, max_iters=10)
+    assert_close(ptv.tv1w_2d(1024.0 * X, 1024.0 * W1, 1024.0 * W2, max_iters=10), 1024.0 * basew, tol=1e-12, what="weighted scale")
+
+
 def test_input_coercions(ptv, oracle):
     """C-ordered, float32 and integer inputs are converted like the reference (F-order float64)."""
     rng = np.random.default_rng(24)
