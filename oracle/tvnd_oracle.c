@@ -377,6 +377,7 @@ static int yang_generic(const char *who, const int *ns, int nds, const int *orde
     }
     memcpy(X, Y, sizeof(double) * (size_t)n);
     if (maxit <= 0) maxit = ORC_MAX_ITERS_YANG;
+    set_threads(1);   /* the reference's Yang loops are serial (one Workspace) */
 
     int it;
     for (it = 1; it <= maxit; it++) {

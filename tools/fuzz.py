@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""Randomised differential test of the HIP path against the CPU oracle: shapes, data families, penalties over five
+decades, every geometry mode pinned or adaptive, weighted / unweighted, every 2-D solver and both sweep directions.
+
+    python tools/fuzz.py [seconds] [seed]
+"""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import proxtv_amd as ptv
+from proxtv_amd import _lib
+from oracle import cpu
+
+
+def data(rng, kind, shape):
+    M, N = shape
+    if kind == 0: return rng.standard_normal(shape)
+    if kind == 1: return np.kron(rng.standard_normal((M // 16 + 1, N // 16 + 1)), np.ones((16, 16)))[:M, :N] + 0.2 * rng.standard_normal(shape)
+    if kind == 2: return np.add.outer(np.linspace(-3, 3, M), np.linspace(2, -2, N)) + 0.05 * rng.standard_normal(shape)
+    if kind == 3: return np.full(shape, 1.5) + (rng.random(shape) < 0.01) * 8.0
+    if kind == 4: return np.cumsum(rng.standard_normal(shape), axis=int(rng.integers(0, 2))) * 0.3
+    return np.round(rng.standard_normal(shape) * 3)          # many exact ties
+
+
+def rel(a, b):
+    return float(np.max(np.abs(a - b))) / max(float(np.max(np.abs(b))), 1e-300)
+
+
+def run(budget=60.0, seed=0, tol=1e-9, sizes=(2, 3, 17, 95, 96, 97, 130, 257, 400, 700, 1100)):
+    """Returns (cases, worst relative error, description of the worst case); raises AssertionError on a mismatch."""
+    lib = _lib.require_device()
+    orc = cpu.oracle()
+    rng = np.random.default_rng(seed)
+    t_end = time.time() + budget
+    cases, worst, worst_case = 0, 0.0, ""
+    before = lib.proxtv_set_option(b"chunk_mode", -1)
+    try:
+        while time.time() < t_end:
+            M, N = (int(v) for v in rng.choice(list(sizes), 2))
+            X = data(rng, int(rng.integers(0, 6)), (M, N))
+            lam = float(10 ** rng.uniform(-3, 2))
+            mode = int(rng.integers(-1, 6))
+            lib.proxtv_set_option(b"chunk_mode", mode)
+            what = int(rng.integers(0, 6))
+            if what == 0:
+                got, want, name = ptv.tv1_2d(X, lam), orc.dr2(X, lam)[0], "dr2"
+            elif what == 1:
+                W1, W2 = rng.uniform(0, 2 * lam, (M - 1, N)), rng.uniform(0, 2 * lam, (M, N - 1))
+                got, want, name = ptv.tv1w_2d(X, W1, W2), orc.dr2w(X, W1, W2)[0], "dr2w"
+            elif what == 2:
+                got, want, name = ptv.tv1_2d(X, lam, method="pd"), orc.pd2(X, [lam, lam], [1, 2])[0], "pd2"
+            elif what == 3:
+                got, want, name = ptv.tv1_2d(X, lam, method="yang"), orc.yang2(X, lam)[0], "yang2"
+            elif what == 4:
+                its = int(rng.integers(1, 40))
+                got, want, name = ptv.tv1_2d(X, lam, method="kolmogorov", max_iters=its), orc.kolmogorov2(X, lam, its)[0], "kolmogorov"
+            else:
+                d = int(rng.integers(1, 3))
+                got = ptv.tvgen(X, [lam], [d], [1])
+                want = np.apply_along_axis(lambda f: orc.tv1_hybrid(np.ascontiguousarray(f), lam), d - 1, X)
+                name = f"prox dim {d}"
+            e = rel(got, want)
+            desc = f"{name} {M}x{N} lam={lam:.4g} mode={mode}"
+            if e > worst:
+                worst, worst_case = e, desc
+            cases += 1
+            assert e <= tol, f"MISMATCH {desc}: relative error {e:.3e}"
+    finally:
+        lib.proxtv_set_option(b"chunk_mode", before)
+    return cases, worst, worst_case
+
+
+if __name__ == "__main__":
+    n, w, where = run(float(sys.argv[1]) if len(sys.argv) > 1 else 60.0, int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+    print(f"fuzz: {n} cases, worst relative error {w:.2e} ({where})")
