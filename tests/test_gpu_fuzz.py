@@ -15,3 +15,10 @@ def test_fuzz_against_oracle(ptv, oracle):
     cases, worst, where = fuzz.run(budget=12.0, seed=2026, sizes=(2, 3, 17, 95, 96, 97, 130, 257, 400))
     assert cases > 50
     assert worst <= 1e-9, where
+
+
+def test_fuzz_volumes_against_oracle(ptv, oracle):
+    import fuzz
+    cases, worst, where = fuzz.run_nd(budget=10.0, seed=2027, sizes=(2, 5, 33, 96, 130))
+    assert cases > 10
+    assert worst <= 1e-9, where

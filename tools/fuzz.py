@@ -70,6 +70,62 @@ def run(budget=60.0, seed=0, tol=1e-9, sizes=(2, 3, 17, 95, 96, 97, 130, 257, 40
     return cases, worst, worst_case
 
 
+def run_nd(budget=30.0, seed=0, tol=1e-9, sizes=(2, 5, 33, 96, 130, 210)):
+    """The same for 3-D volumes: tvgen (PD_TV with 1-4 penalty terms on random dimensions), PDR_TV, Yang3_TV through the C-ABI."""
+    import ctypes as C
+    lib = _lib.require_device()
+    orc = cpu.oracle()
+    rng = np.random.default_rng(seed)
+    t_end = time.time() + budget
+    cases, worst, worst_case = 0, 0.0, ""
+    before = lib.proxtv_set_option(b"chunk_mode", -1)
+    try:
+        while time.time() < t_end:
+            shape = tuple(int(v) for v in rng.choice(list(sizes), 3))
+            if np.prod(shape) > 3_000_000:
+                continue
+            V = np.asfortranarray(rng.standard_normal(shape) if rng.random() < 0.6 else
+                                  np.cumsum(rng.standard_normal(shape), axis=int(rng.integers(0, 3))) * 0.2)
+            mode = int(rng.integers(-1, 6))
+            lib.proxtv_set_option(b"chunk_mode", mode)
+            what = int(rng.integers(0, 3))
+            if what == 0:
+                npen = int(rng.integers(1, 5))
+                lams = [float(10 ** rng.uniform(-2, 1)) for _ in range(npen)]
+                dims = [int(rng.integers(1, 4)) for _ in range(npen)]
+                got = ptv.tvgen(V, list(lams), dims, [1] * npen)
+                want = (orc.pd2(V, lams, dims)[0] if npen == 2 else orc.pd(V, lams, dims)[0])   # tvgen's dispatch
+                name = f"tvgen {npen} terms dims {dims}"
+            elif what == 1:
+                lams = np.array([float(10 ** rng.uniform(-2, 1)) for _ in range(3)])
+                want = orc.pdr(V, lams, [1, 2, 3])[0]
+                out, info = np.zeros(shape, order="F"), np.zeros(3)
+                l2, nrm, dm, ns = lams.copy(), np.ones(3), np.array([1.0, 2.0, 3.0]), np.array(shape, dtype=np.int32)
+                lib.PDR_TV(V.ctypes.data, l2.ctypes.data, nrm.ctypes.data, dm.ctypes.data, out.ctypes.data, info.ctypes.data,
+                           ns.ctypes.data, 3, 3, 1, 0)
+                got, name = out, "PDR_TV"
+            else:
+                lam = float(10 ** rng.uniform(-2, 1))
+                its = int(rng.integers(1, 36))
+                want = orc.yang3(V, lam, its)[0]
+                out, info = np.zeros(shape, order="F"), np.zeros(3)
+                lib.Yang3_TV(shape[0], shape[1], shape[2], V.ctypes.data, lam, out.ctypes.data, its, info.ctypes.data)
+                got, name = out, f"Yang3_TV {its} its"
+            e = rel(got, want)
+            desc = f"{name} {shape} mode={mode}"
+            if e > worst:
+                worst, worst_case = e, desc
+            cases += 1
+            assert e <= tol, f"MISMATCH {desc}: relative error {e:.3e}"
+    finally:
+        lib.proxtv_set_option(b"chunk_mode", before)
+    return cases, worst, worst_case
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 3 and sys.argv[3] == "nd":
+        n, w, where = run_nd(float(sys.argv[1]), int(sys.argv[2]))
+        print(f"fuzz nd: {n} cases, worst relative error {w:.2e} ({where})")
+        sys.exit(0)
     n, w, where = run(float(sys.argv[1]) if len(sys.argv) > 1 else 60.0, int(sys.argv[2]) if len(sys.argv) > 2 else 0)
     print(f"fuzz: {n} cases, worst relative error {w:.2e} ({where})")
