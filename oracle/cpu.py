@@ -68,6 +68,10 @@ class CpuLib:
                 f = getattr(self._lib, name)
                 f.restype, f.argtypes = res, args
                 self._fn[name] = f
+        if prefix:  # restated here as well: Johnson's dynamic programme
+            f = self._lib.orc_dp
+            f.restype, f.argtypes = None, [C.c_int, _dp, C.c_double, _dp]
+            self._fn["dp"] = f
         if prefix:  # oracle-only extension
             f = self._lib.orc_Yang3_TV_perdim
             f.restype = C.c_int
@@ -96,6 +100,13 @@ class CpuLib:
 
     def tv1_condat(self, x, lam):
         return self._run1d(lambda a, o: self._fn["TV1D_denoise"](a.ctypes.data, o.ctypes.data, a.size, lam), x)
+
+    def tv1_dp(self, x, lam):
+        """Johnson's dynamic programme (both libraries)."""
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        out = np.zeros(x.size)
+        self._fn["dp"](int(x.size), x.ctypes.data, lam, out.ctypes.data)
+        return out
 
     def tv1_other_method(self, x, lam, method, sigma=0.05):
         """reference() only: 'pn' | 'kolmogorov' | 'condattautstring' | 'dp' (prox_tv/__init__.py:197-216)"""

@@ -427,3 +427,81 @@ int orc_TV(const double *y, double lambda, double *x, double *info, int n, doubl
     }
     return 1;
 }
+
+/* ------------------------------------------------------------------------- */
+/*  Johnson's dynamic programme for the 1-D fused lasso (tv1_1d method 'dp')  */
+/*  src/johnsonRyanTV.cpp:9-116                                               */
+/*  Forward pass: the derivative of the k-th "message" (a convex piecewise    */
+/*  quadratic) is piecewise linear; it is kept as a deque of knots with the   */
+/*  increments (da, db) of slope and intercept that become active to the right */
+/*  (left end) / left (right end) of each knot.  Clipping it to [-lambda,      */
+/*  lambda] yields the two back-pointer knots tm[k] <= tp[k].  Backward pass:  */
+/*  x[k] = clamp(x[k+1], tm[k], tp[k]).  Same arithmetic order as the          */
+/*  reference, so results are bit-identical.                                   */
+/* ------------------------------------------------------------------------- */
+void orc_dp(int n, const double *y, double lam, double *beta)
+{
+    if (n == 0) return;
+    if (n == 1 || lam == 0) {                                   /* :12-15 */
+        for (int i = 0; i < n; i++) beta[i] = y[i];
+        return;
+    }
+    /* deque storage: positions n-1 and n are the first two knots, it grows outwards by one per side and step */
+    double *knot = (double *)malloc(sizeof(double) * 2 * (size_t)n);
+    double *da = (double *)malloc(sizeof(double) * 2 * (size_t)n);
+    double *db = (double *)malloc(sizeof(double) * 2 * (size_t)n);
+    double *tm = (double *)malloc(sizeof(double) * (size_t)(n - 1));
+    double *tp = (double *)malloc(sizeof(double) * (size_t)(n - 1));
+    int head = n - 1, tail = n;
+    tm[0] = -lam + y[0];                                        /* first message, by hand (:30-43) */
+    tp[0] = lam + y[0];
+    knot[head] = tm[0]; da[head] = 1;  db[head] = -y[0] + lam;
+    knot[tail] = tp[0]; da[tail] = -1; db[tail] = y[0] + lam;
+    double a_left = 1, b_left = -lam - y[1];                    /* derivative left of every knot ... */
+    double a_right = -1, b_right = -lam + y[1];                 /* ... and (negated) right of every knot */
+
+    for (int k = 1; k < n - 1; k++) {                           /* :48-87 */
+        /* walk in from the left until the derivative exceeds -lambda */
+        double a = a_left, b = b_left;
+        int pos;
+        for (pos = head; pos <= tail; pos++) {
+            if (a * knot[pos] + b > -lam) break;
+            a += da[pos];
+            b += db[pos];
+        }
+        tm[k] = (-lam - b) / a;
+        head = pos - 1;
+        knot[head] = tm[k];
+        /* walk in from the right until it drops below lambda */
+        double ar = a_right, br = b_right;
+        for (pos = tail; pos >= head; pos--) {
+            if (-ar * knot[pos] - br < lam) break;
+            ar += da[pos];
+            br += db[pos];
+        }
+        tp[k] = (lam + br) / (-ar);
+        tail = pos + 1;
+        knot[tail] = tp[k];
+        da[head] = a;  db[head] = b + lam;
+        da[tail] = ar; db[tail] = br + lam;
+        a_left = 1;   b_left = -lam - y[k + 1];
+        a_right = -1; b_right = -lam + y[k + 1];
+    }
+    /* last coefficient: the zero of the derivative (:92-99) */
+    {
+        double a = a_left, b = b_left;
+        for (int pos = head; pos <= tail; pos++) {
+            if (a * knot[pos] + b > 0) break;
+            a += da[pos];
+            b += db[pos];
+        }
+        beta[n - 1] = -b / a;
+    }
+    for (int k = n - 2; k >= 0; k--) {                          /* back-pointers (:103-107) */
+        if (beta[k + 1] > tp[k]) beta[k] = tp[k];
+        else if (beta[k + 1] < tm[k]) beta[k] = tm[k];
+        else beta[k] = beta[k + 1];
+    }
+    free(knot); free(da); free(db); free(tm); free(tp);
+}
+

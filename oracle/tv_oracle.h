@@ -57,6 +57,8 @@ int  orc_classicTautString_TV1_offset(const double *signal, int n, double lam, d
 int  orc_tautString_TV1_Weighted(const double *y, const double *lambda, double *x, int n);
 /* src/condat_fast_tv.cpp:78-121 */
 void orc_TV1D_denoise(const double *input, double *output, int width, double lambda);
+/* src/johnsonRyanTV.cpp:9-116 -- Johnson's dynamic programme (tv1_1d method 'dp'), an independent exact algorithm */
+void orc_dp(int n, const double *y, double lam, double *beta);
 /* src/TVgenopt.cpp:30-57 (p==1 arm only; other p -> RC_ERROR, the oracle does not cover them) */
 int  orc_TV(const double *y, double lambda, double *x, double *info, int n, double p);
 

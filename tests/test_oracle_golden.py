@@ -113,6 +113,22 @@ def test_other_1d_methods_of_the_reference_agree_with_the_exact_solver(oracle, g
             assert_close(mine, g1dm[f"{name}/{m}"], 1e-7 if m == "condattautstring" else 1e-12, f"{name}:{m} (tight)")
 
 
+def test_johnson_dp_restatement(oracle, g1dm):
+    """orc_dp -- an exact algorithm of a different kind (dynamic programming on piecewise-linear derivatives) -- against
+    what the compiled reference's `dp` returned, bit for bit, and against the taut-string solvers."""
+    for name in g1dm["names"]:
+        x, lam = g1dm[f"{name}/x"], float(g1dm[f"{name}/lam"])
+        got = oracle.tv1_dp(x, lam)
+        np.testing.assert_array_equal(got, g1dm[f"{name}/dp"])
+        assert_close(got, oracle.tv1_hybrid(x, lam), 1e-12, f"{name}: dp vs taut string")
+    rng = np.random.default_rng(5)
+    for _ in range(300):
+        n = int(rng.integers(1, 120))
+        x = rng.standard_normal(n) * float(rng.choice([1, 100]))
+        lam = float(rng.choice([0, 0.05, 0.7, 5, 300]))
+        assert_close(oracle.tv1_dp(x, lam), oracle.tv1_linearized(x, lam), 1e-11, f"n={n} lam={lam}")
+
+
 def test_golden_2d_primal_dual(oracle, gpd):
     """Kolmogorov2_TV / CondatChambollePock2_TV restatements against vectors of the compiled reference."""
     for name in gpd["names"]:
@@ -162,6 +178,7 @@ def test_bitwise_against_compiled_reference(oracle, reference):
                        (oracle.tv1_classic, reference.tv1_classic), (oracle.tv1_condat, reference.tv1_condat)):
             np.testing.assert_array_equal(fo(x, lam), fr(x, lam))
         np.testing.assert_array_equal(oracle.tv1_hybrid(x, lam, 0.5), reference.tv1_hybrid(x, lam, 0.5))
+        np.testing.assert_array_equal(oracle.tv1_dp(x, lam), reference.tv1_dp(x, lam))
         if n >= 2:
             w = rng.uniform(0, 2 * lam + 0.01, n - 1)
             np.testing.assert_array_equal(oracle.tv1_weighted(x, w), reference.tv1_weighted(x, w))
