@@ -179,6 +179,10 @@ double proxtv_last_kernel_ms(int which);
    thread's stream (0 for noisy data; large when lambda dwarfs the noise).  Diagnostic only: results are exact
    either way. */
 long   proxtv_last_fixups(void);
+/* Profiling aid (option "trace" = 1): per-workgroup record of the last speculative-chunk kernel launched by this thread,
+   8 words each: [0] = XCC_ID << 32 | HW_ID (where it ran), [1..5] = 100 MHz timestamps at start, window staged, walk
+   done, rebuild done, end.  Returns the number of workgroups copied to `dst` (at most max_wgs). */
+long   proxtv_debug_trace(unsigned long long *dst, long max_wgs);
 /* Geometry policy the adaptive chunk kernel currently uses on this thread (the highest over the sweep families):
    0 = 16-sample warm-up zones (noisy data, small lambda), 1 = the same, robust instantiation (walks may run past
    the window, second-chance rounds inside a block: pieces of ~5 samples), 2 = 64-sample zones (pieces of ~10 samples), 3 / 4 = chunks walked straight from global

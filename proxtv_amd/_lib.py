@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libproxtv_amd.so")
+# PROXTV_LIB: an alternative build of the library for A/B measurements (tools/); never set in production
+LIB_PATH = os.environ.get("PROXTV_LIB") or os.path.join(_HERE, "libproxtv_amd.so")
 
 _dp = C.c_void_p      # double* (host or device, per entry point)
 _ip = C.c_void_p      # int*
@@ -59,6 +60,7 @@ SIGNATURES = {
     "proxtv_DR2_TV_batch": (C.c_int, [C.c_size_t, C.c_size_t, C.c_size_t, _dp, C.c_double, C.c_double, _dp, C.c_int, _dp]),
     "proxtv_last_fixups": (C.c_long, []),
     "proxtv_chunk_mode": (C.c_int, []),
+    "proxtv_debug_trace": (C.c_long, [C.c_void_p, C.c_long]),
     "proxtv_calib_copy_dev": (C.c_int, [_dp, _dp, C.c_long, C.c_void_p]),
     "proxtv_last_kernel_ms": (C.c_double, [C.c_int]),
     "proxtv_last_kernel_launches": (C.c_long, [C.c_int]),

@@ -355,6 +355,7 @@ int proxtv_set_option(const char *key, int value) {
     else if (!strcmp(key, "profile")) slot = &o.profile;
     else if (!strcmp(key, "ablate")) slot = &o.ablate;
     else if (!strcmp(key, "blocks_per_wg")) slot = &o.blocks_per_wg;
+    else if (!strcmp(key, "trace")) slot = &o.trace;
     else if (!strcmp(key, "chunk_min_len")) slot = &o.chunk_min_len;
     else if (!strcmp(key, "rounds")) slot = &o.rounds;
     else if (!strcmp(key, "chunk_mode")) slot = &o.chunk_mode;
@@ -371,6 +372,9 @@ long proxtv_last_fixups(void) {
 }
 
 double proxtv_last_kernel_ms(int which) { return timing_ms(which); }
+long proxtv_debug_trace(unsigned long long *dst, long max_wgs) {
+    try { return chunk_trace_fetch(dst, max_wgs, thread_stream()); } catch (...) { return -1; }
+}
 long proxtv_last_kernel_launches(int which) { return timing_launches(which); }
 
 int proxtv_DR2_TV_batch_dev(size_t M, size_t N, size_t B, const double *unary, double W1, double W2, double *s,

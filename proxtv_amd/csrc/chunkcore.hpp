@@ -1,0 +1,318 @@
+// chunkcore.hpp -- what ONE lane of the speculative-chunk kernels does with its chunk: find a start, walk, rebuild.
+//
+// Host-testable like walker.hpp (tests/host_harness.cpp compiles it with g++ and emulates the lanes of a workgroup one
+// after the other; tests/test_chunk_host.py checks the result against the oracle).  Everything here works on a
+// *window* of the lane's fibre through a small accessor (concept `Win`):
+//     double y(int i)            sample i            (rows [lo, hi) of the fibre are present; reading row hi is allowed
+//     double r(int i)            edge penalty i       and yields an unspecified value)
+//     void   put(int i, double)  replace row i (rebuild only)
+//
+// The walk (walk_interior) is the state machine of walker.hpp -- same arithmetic, same operation order -- written as
+// ONE branch-free trip per sample: the no-bend update and the post-bend state are both computed and selected, the two
+// "pull back inside the tube" updates are a min / max and an unconditional add (a zero correction is an exact no-op),
+// and a bend that rewinds costs two extra window reads instead of a divergent region.  The walk records no piece
+// values: a piece end costs two bits (end, bend type); values are rebuilt from the window afterwards in closed form.
+//
+// Ownership of outputs (rebuild_owned).  A piece is rewritten by the lane in whose chunk it ENDS -- that lane reads
+// and replaces all rows of the piece, including rows that lie in earlier chunks.  The lane of an earlier chunk leaves
+// the rows after its last piece end alone, so every row has exactly one writer as long as consecutive walks agree
+// (proven links).  Exceptions: rows outside the block are never written (the zone before the first chunk and the
+// look-ahead after the last are read-only copies), so the block's last lane also writes the part inside the block of
+// the piece that covers the block's last sample, and the first lane writes its first piece from the block start only;
+// a lane whose link is unproven keeps to its own rows (its output is rewritten by the repair kernel anyway, from the
+// last proven bend on).
+#pragma once
+
+#include "walker.hpp"
+
+#ifdef PTV_HOST_TEST
+#include <cmath>
+#endif
+
+namespace ptv {
+
+#ifdef PTV_HOST_TEST
+inline double ptv_min(double a, double b) { return a < b ? a : b; }
+inline double ptv_max(double a, double b) { return a > b ? a : b; }
+#else
+// plain compare-and-select: no NaN canonicalisation around v_min_f64 / v_max_f64 (inputs are finite)
+__device__ __forceinline__ double ptv_min(double a, double b) { return __builtin_fmin(a, b); }
+__device__ __forceinline__ double ptv_max(double a, double b) { return __builtin_fmax(a, b); }
+#endif
+
+constexpr unsigned kCodeCertain = 0x80000000u;   // flag on a published `mine` code: the walk began AT a bend known a priori
+constexpr unsigned kCodeBad = 0xfffffffeu;       // the walk ran off its window: trust nothing it recorded
+
+// What a chunk's walk leaves behind.
+struct ChunkRec {
+    unsigned ends = 0;     // bit u: a piece ends at sample cs + u (0 <= u < ce - cs)
+    unsigned types = 0;    // bit u: that piece was ended by a FLOOR bend (0: CEIL bend, or the fibre end)
+    unsigned mine = 0;     // (restart << 1 | type) of the last bend at or before cs; 0 = none
+    unsigned next = 0;     // ... at or before ce (read by the lane of the following chunk)
+    unsigned last = 0;     // the walk's most recent bend (once done: the one that closed the piece covering ce - 1)
+    double vclose = 0.0;   // value of the piece covering ce - 1, when the slow tail of the walk closed it (have_vclose)
+    bool have_vclose = false;
+    bool done = false;     // the piece covering ce - 1 is closed
+    bool failed = false;   // the walk ran off its window
+};
+
+// A bend known without walking: x_k - x_{k-1} = (y_k - y_{k-1}) + (u_k - u_{k-1}) - (u_{k-1} - u_{k-2}) with every dual
+// |u_j| <= r_j, so a jump |y_k - y_{k-1}| > r_k + 2 r_{k-1} + r_{k-2} (4 lambda) keeps its sign in x: the string bends
+// there (up-jump: off the floor), and the state after a bend depends on the bend alone.  Looks at the LOOK edges
+// (k - 1, k), k = cs - LOOK + 1 .. cs; the nearest one to cs wins.  Returns the restart sample (-1: none) and the type.
+template <bool WEIGHTED, int LOOK, class Win>
+__device__ __forceinline__ int certain_bend_before(const Win &win, int cs, int len, double lam, int &type) {
+    double yv[LOOK + 1], rv[LOOK + 2];
+#pragma unroll
+    for (int u = 0; u <= LOOK; u++) yv[u] = win.y(cs - u);
+    if (WEIGHTED) {
+#pragma unroll
+        for (int u = 0; u <= LOOK + 1; u++) rv[u] = (cs - u < len - 1) ? win.r(cs - u) : 0.0;
+    }
+    int cat = -1;
+    type = 0;
+#pragma unroll
+    for (int u = LOOK - 1; u >= 0; u--) {   // edge (k - 1, k), k = cs - u
+        const double d = yv[u] - yv[u + 1];
+        double thr = 4.0000001 * lam;
+        bool ok = true;
+        if (WEIGHTED) {
+            thr = 1.0000001 * (rv[u] + 2.0 * rv[u + 1] + rv[u + 2]);
+            ok = (rv[u] >= 0.0) & (rv[u + 1] > 0.0) & (rv[u + 2] >= 0.0);
+        }
+        const bool hit = ok & (fabs(d) > thr);
+        cat = hit ? cs - u : cat;
+        type = hit ? (d > 0 ? BEND_FLOOR : BEND_CEIL) : type;
+    }
+    return cat;
+}
+
+// The interior steps of a chunk's walk: samples i < lim, where lim <= len - 1 (the fibre's last sample has its own
+// tests: walker_run) and lim <= the window end.  Leaves the walker at the first sample it does not handle.
+template <bool WEIGHTED, class Win>
+__device__ __forceinline__ void walk_interior(Walker &w, ChunkRec &rec, const Win &win, int lim, int cs, int ce, double lam) {
+    if (w.i >= lim || rec.done) return;
+    const unsigned span_own = (unsigned)(ce - cs);
+    double yi = win.y(w.i);
+    while (!rec.done && w.i < lim) {
+        const int i = w.i;
+        const double ynx = win.y(i + 1);   // speculative: most trips advance by one
+        const double r = WEIGHTED ? win.r(i) : lam;
+        const double h1 = w.hlo + (w.lo - yi);
+        const double h2 = w.hhi + (w.hi - yi);
+        const bool cv = r < h1;
+        const bool fv = !cv && (-r > h2);
+        const bool bend = cv || fv;
+        const int brk = cv ? w.klo : w.khi;
+        const int at = brk + 1;            // at <= i < len - 1: the restart is an interior sample
+        const double yat = win.y(at), yat1 = win.y(at + 1);
+
+        // no bend: pull the pieces back inside the tube where they left it
+        const SpanDiv over((double)(i - w.k0));
+        const double d2 = ptv_min(r - h2, 0.0), d1 = ptv_max(-r - h1, 0.0);
+        const double nhi = w.hi + over(d2), nlo = w.lo + over(d1);
+        const double nhhi = ptv_min(h2, r), nhlo = ptv_max(h1, -r);
+        const int nkhi = (h2 >= r) ? i : w.khi, nklo = (h1 <= -r) ? i : w.klo;
+
+        // bend: closed-form first sample of the new piece (walker_restart_with, at < len - 1)
+        double blo, bhi, bhhi, bhlo;
+        if (WEIGHTED) {
+            const double wp = win.r(brk), wc = win.r(at);
+            const double a = cv ? yat + wp : yat - wp;
+            blo = a - wc;
+            bhi = a + wc;
+            bhhi = wc;
+            bhlo = -wc;
+        } else {
+            blo = cv ? yat : 2 * (-lam) + yat;
+            bhi = cv ? 2 * lam + yat : yat;
+            bhhi = lam;
+            bhlo = -lam;
+        }
+
+        w.lo = bend ? blo : nlo;
+        w.hi = bend ? bhi : nhi;
+        w.hlo = bend ? bhlo : nhlo;
+        w.hhi = bend ? bhhi : nhhi;
+        w.k0 = bend ? brk : w.k0;
+        w.klo = bend ? at : nklo;
+        w.khi = bend ? at : nkhi;
+        w.i = (bend ? at : i) + 1;
+        yi = bend ? yat1 : ynx;
+
+        // what the bend leaves behind
+        const unsigned code = ((unsigned)at << 1) | (unsigned)fv;
+        const int sh = brk - cs;
+        const bool own = bend && (unsigned)sh < span_own;
+        const unsigned bit = 1u << (sh & 31);
+        rec.ends |= own ? bit : 0u;
+        rec.types |= (own && fv) ? bit : 0u;
+        rec.mine = (bend && at <= cs) ? code : rec.mine;
+        rec.next = (bend && at <= ce) ? code : rec.next;
+        rec.last = bend ? code : rec.last;
+        rec.done = bend && brk >= ce - 1;
+    }
+}
+
+// Source for walker_run (walker.hpp) over the same window and record: the slow tail of a chunk's walk -- the fibre's
+// last sample, or (PAST) samples beyond the window, fetched one at a time through `far` (double far_y(int), far_r(int)).
+template <bool WEIGHTED, bool PAST, int OVERFLOW, class Win, class Far>
+struct TailSource {
+    const Win &win;
+    const Far &far;
+    ChunkRec &rec;
+    int cs, ce, hi, len;
+    __device__ __forceinline__ double y(int i) const {
+        if (!PAST || i < hi) return win.y(i < hi ? i : hi - 1);
+        return far.far_y(i < len ? i : len - 1);
+    }
+    __device__ __forceinline__ double r(int i) const {
+        if (!PAST || i < hi) return win.r(i < hi ? i : hi - 1);
+        return (i < len - 1) ? far.far_r(i) : 0.0;
+    }
+    __device__ __forceinline__ void piece(int, int to, double v) {
+        if (to >= cs && to < ce) rec.ends |= 1u << (to - cs);
+        if (to >= ce - 1) {
+            rec.vclose = v;
+            rec.have_vclose = true;
+            rec.done = true;
+        }
+    }
+    __device__ __forceinline__ void bend(int at, int type) {
+        const unsigned code = ((unsigned)at << 1) | (unsigned)type;
+        rec.mine = (at <= cs) ? code : rec.mine;
+        rec.next = (at <= ce) ? code : rec.next;
+        rec.last = code;
+        const int e = at - 1 - cs;   // the piece that this bend ended, relative to the chunk
+        if (e >= 0 && e < ce - cs) rec.types |= (unsigned)type << e;
+    }
+    __device__ __forceinline__ bool keep_going(int i) {
+        if (rec.done) return false;
+        if (i >= hi + (PAST ? OVERFLOW : 0)) {   // (a walk that reaches the fibre end never gets here: i < len <= hi + OVERFLOW then)
+            rec.failed = true;
+            return false;
+        }
+        return true;
+    }
+};
+
+struct NoFar {
+    __device__ __forceinline__ double far_y(int) const { return 0.0; }
+    __device__ __forceinline__ double far_r(int) const { return 0.0; }
+};
+
+// Piece values from piece ends.  Between two knots of the taut string the prox is constant, and the string's height
+// above the tube centre at a knot is -r after a CEIL bend (the knot sits on the tube floor), +r after a FLOOR bend,
+// 0 at the fibre ends (r = the tube half-width there: lambda, or the edge's own penalty).  Summing x - y over a
+// piece [a, b] therefore gives   v = ( sum_{a..b} y + h_b - h_{a-1} ) / (b - a + 1).
+// For one-sample pieces this is bit-for-bit the walker's closed-form restart value (y, y +- 2 lambda); for longer
+// pieces it agrees with the walker's running slope to a few ulps (checked on the host: < 1e-15 relative).
+//
+// One lane, its chunk [cs, ce), C = the compile-time chunk length (ce - cs <= C).  `wlo`: first row of the block (rows
+// before it are read-only); `block_last`: this is the last chunk of its block (or of the fibre); `link_ok`: the lane's
+// walk is known to continue its predecessor's (or began at the fibre start / at a bend known a priori).
+// Rows are replaced by F::fuse(y, v): the prox value itself, or directly the sweep's output when it depends on (y, x) only.
+template <class F, bool WEIGHTED, int C, class Win>
+__device__ __forceinline__ void rebuild_owned(Win &win, const ChunkRec &rec, int cs, int ce, int len, int start, bool link_ok,
+                                              int wlo, bool block_last, double lam) {
+    // An unproven lane keeps to its own rows -- but if its own walk bent exactly at the chunk start, the piece that
+    // begins there must still come out right: a repair walk that arrives at that very bend hands over to this chunk.
+    int a0 = cs;
+    double hprev = 0.0;
+    if (rec.mine != 0 && rec.mine != kCodeBad) {
+        const int at = (int)(rec.mine >> 1);
+        const double r = WEIGHTED ? win.r(at - 1) : lam;
+        hprev = (rec.mine & 1u) ? r : -r;
+        a0 = link_ok ? at : cs;
+    } else if (link_ok && start == 0) {
+        a0 = 0;   // no bend yet and the walk began at the fibre start: the first piece starts at sample 0, height 0
+    }
+    double s = 0.0, cnt = 0.0;
+    for (int k = a0; k < cs; k++) {   // rows of earlier chunks that belong to the piece ending here (usually none or a few)
+        s += win.y(k);
+        cnt += 1.0;
+    }
+    // One forward step of the piece recurrence at own row u: returns the value of the piece if it ends there.
+    auto step = [&](int u, double yu, double &s_, double &cnt_, double &hprev_, bool divide) {
+        s_ += yu;
+        cnt_ += 1.0;
+        const bool e = (rec.ends >> u) & 1u;
+        const double r = WEIGHTED ? ((cs + u < len - 1) ? win.r(cs + u) : 0.0) : lam;
+        const double hk = (cs + u == len - 1) ? 0.0 : (((rec.types >> u) & 1u) ? r : -r);
+        double v = 0.0;
+        if (divide) {
+            const SpanDiv over(cnt_);
+            v = over(s_ + (hk - hprev_));
+        }
+        s_ = e ? 0.0 : s_;
+        cnt_ = e ? 0.0 : cnt_;
+        hprev_ = e ? hk : hprev_;
+        return v;
+    };
+    // the piece that covers ce - 1 and ends beyond it: the block's last lane writes its rows inside the block
+    auto tail_value = [&](double s_, double cnt_, double hprev_, double &cur_) {
+        if (!(block_last && rec.done && !((rec.ends >> (ce - 1 - cs)) & 1u))) return false;
+        if (rec.have_vclose) {
+            cur_ = rec.vclose;
+        } else {
+            const int brk = (int)(rec.last >> 1) - 1;   // inside the window: the bend was found by the interior walk
+            for (int k = ce; k <= brk; k++) {
+                s_ += win.y(k);
+                cnt_ += 1.0;
+            }
+            const double r = WEIGHTED ? win.r(brk) : lam;
+            const double hk = (rec.last & 1u) ? r : -r;
+            const SpanDiv over(cnt_);
+            cur_ = over(s_ + (hk - hprev_));
+        }
+        return true;
+    };
+    double cur = 0.0;
+    bool have = false;
+    if (!F::USES_Y) {
+        // The output does not depend on the row's own sample: the value of a piece is parked in the row where the piece
+        // ends (forward pass), then every other row takes the value of the next piece end after it (backward pass).
+#pragma unroll 1
+        for (int u = 0; u < C; u++) {
+            const bool in = cs + u < ce;
+            const double v = step(u, in ? win.y(cs + u) : 0.0, s, cnt, hprev, true);
+            if (in && ((rec.ends >> u) & 1u)) win.put(cs + u, F::fuse(0.0, v));
+        }
+        have = tail_value(s, cnt, hprev, cur);
+        if (have) cur = F::fuse(0.0, cur);
+#pragma unroll 1
+        for (int u = C - 1; u >= 0; u--) {
+            const bool e = (rec.ends >> u) & 1u;
+            const bool in = cs + u < ce;
+            const double here = in ? win.y(cs + u) : 0.0;
+            cur = e ? here : cur;
+            if (have && !e && in) win.put(cs + u, cur);
+            have = have || e;
+        }
+    } else {
+        // The output needs the row's own sample too: when a piece ends its rows are replaced there and then, last row
+        // first (it is in a register), the earlier ones -- none for a one-sample piece -- in a short loop.  No second pass,
+        // nothing waits in registers (sixteen parked values spill at the 128-VGPR budget of two workgroups per CU).
+        int first = a0 > wlo ? a0 : wlo;
+#pragma unroll 1
+        for (int u = 0; u < C; u++) {
+            const bool in = cs + u < ce;
+            const double yu = in ? win.y(cs + u) : 0.0;
+            const double v = step(u, yu, s, cnt, hprev, true);
+            if (in && ((rec.ends >> u) & 1u)) {
+                win.put(cs + u, F::fuse(yu, v));
+                for (int k = cs + u - 1; k >= first; k--) win.put(k, F::fuse(win.y(k), v));
+                first = cs + u + 1;
+            }
+        }
+        if (tail_value(s, cnt, hprev, cur))
+            for (int k = ce - 1; k >= first; k--) win.put(k, F::fuse(win.y(k), cur));
+        return;
+    }
+    if (have) {
+        const int from = a0 > wlo ? a0 : wlo;
+        for (int k = cs - 1; k >= from; k--) win.put(k, F::fuse(win.y(k), cur));
+    }
+}
+
+}  // namespace ptv

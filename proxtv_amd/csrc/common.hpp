@@ -44,6 +44,7 @@ struct Options {
     int chunk_min_len = 96;   // fibres shorter than this take the sequential kernel (measured crossover: 512x512xL volumes, L ~ 96)
     int verbose = 0;
     int profile = 0;    // per-kernel-family hipEvent timing
+    int trace = 0;      // profiling aid: per-workgroup phase timestamps of the chunk kernel (proxtv_debug_trace)
     int ablate = 0;     // profiling aid, see ChunkPlan::ablate (results are WRONG when non-zero)
 };
 Options &options();

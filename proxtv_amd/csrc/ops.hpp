@@ -46,24 +46,31 @@ struct Ext {
     double e0, e1;
 };
 
+// An op whose epilogue needs again an operand that was staged for the walk (second input of fetch_in) sets KEEP: the
+// chunk kernel keeps that operand of the block's own rows in registers and asks only for the rest (fetch_rest).
+struct NoKeep {
+    static constexpr bool KEEP = false;
+    __device__ static __forceinline__ Ext fetch_rest(const SweepArgs &, long, double) { return Ext{0, 0}; }
+};
+
 template <int ID> struct Op;
 
 // ---- one-operand inputs: y = a ---------------------------------------------------------------------------------------
-struct InA {
+struct InA : NoKeep {
     static constexpr int NIN = 1;
     __device__ static __forceinline__ void fetch_in(const SweepArgs &p, long idx, double &i0, double &i1) { i0 = p.a[idx]; i1 = 0.0; }
     __device__ static __forceinline__ double y_of(const SweepArgs &, double i0, double) { return i0; }
     __device__ static __forceinline__ double load_y(const SweepArgs &p, long idx) { return p.a[idx]; }
 };
 // ---- y = b - a  (DR rows: unary - s') ----------------------------------------------------------------------------------
-struct InBminusA {
+struct InBminusA : NoKeep {
     static constexpr int NIN = 2;
     __device__ static __forceinline__ void fetch_in(const SweepArgs &p, long idx, double &i0, double &i1) { i0 = p.b[idx]; i1 = p.a[idx]; }
     __device__ static __forceinline__ double y_of(const SweepArgs &, double i0, double i1) { return i0 - i1; }
     __device__ static __forceinline__ double load_y(const SweepArgs &p, long idx) { return p.b[idx] - p.a[idx]; }
 };
 // ---- y = a + b  (Dykstra: iterate + correction) ------------------------------------------------------------------------
-struct InAplusB {
+struct InAplusB : NoKeep {
     static constexpr int NIN = 2;
     __device__ static __forceinline__ void fetch_in(const SweepArgs &p, long idx, double &i0, double &i1) { i0 = p.a[idx]; i1 = p.b[idx]; }
     __device__ static __forceinline__ double y_of(const SweepArgs &, double i0, double i1) { return i0 + i1; }
@@ -73,8 +80,10 @@ struct InAplusB {
 // An op whose single output is a function of (y, x) alone is FUSED: the chunk kernel evaluates fuse(y, x) in LDS while
 // it still holds y, and streams the result out with no operand fetch at all (store_fused).  The others get x and
 // fetch what they need (fetch / finish).
+// (USES_Y: fuse() really looks at y -- the chunk kernel's rebuild then has to hold on to the sample until the value is known)
 struct NotFused {
     static constexpr bool FUSED = false;
+    static constexpr bool USES_Y = false;
     __device__ static __forceinline__ double fuse(double, double x) { return x; }
     __device__ static __forceinline__ void store_fused(const SweepArgs &, long, double) {}
 };
@@ -82,6 +91,7 @@ struct NotFused {
 // o0 = prox(a)                                  (PD_TV :164-209, PDR_TV :405-458, batched tv1_1d)
 template <> struct Op<OP_PROX> : InA {
     static constexpr bool FUSED = true;
+    static constexpr bool USES_Y = false;
     __device__ static __forceinline__ double fuse(double, double x) { return x; }
     __device__ static __forceinline__ void store_fused(const SweepArgs &p, long idx, double v) { p.o0[idx] = v; }
     __device__ static __forceinline__ Ext fetch(const SweepArgs &, long) { return Ext{0, 0}; }
@@ -91,6 +101,7 @@ template <> struct Op<OP_PROX> : InA {
 // DR, columns (a = t): s = t - prox(t) ; s' = 2 s - t          (src/TV2Dopt.cpp:408-411, 539-547)
 template <> struct Op<OP_DR_COL> : InA {
     static constexpr bool FUSED = true;
+    static constexpr bool USES_Y = true;
     __device__ static __forceinline__ double fuse(double y, double x) {
         const double s = y - x;
         return 2 * s - y;
@@ -104,6 +115,7 @@ template <> struct Op<OP_DR_COL> : InA {
 // final projection: s = t - prox(t)                              (src/TV2Dopt.cpp:427)
 template <> struct Op<OP_DR_COL_FINAL> : InA {
     static constexpr bool FUSED = true;
+    static constexpr bool USES_Y = true;
     __device__ static __forceinline__ double fuse(double y, double x) { return y - x; }
     __device__ static __forceinline__ void store_fused(const SweepArgs &p, long idx, double v) { p.o0[idx] = v; }
     __device__ static __forceinline__ Ext fetch(const SweepArgs &p, long idx) { return Ext{p.a[idx], 0}; }
@@ -116,6 +128,12 @@ template <> struct Op<OP_DR_COL_FINAL> : InA {
 // Both are t = 0.5 (t + (s' + 2 prox(v))) once U - v is replaced by s' (it IS s' up to the rounding of v): evaluated
 // in that form, which needs s' and t but not U at the epilogue -- a few ulps of |U| away from the reference's order.
 template <> struct Op<OP_DR_ROW> : InBminusA, NotFused {
+#ifdef PTV_NO_KEEP
+    static constexpr bool KEEP = false;
+#else
+    static constexpr bool KEEP = true;   // s' is staged for the walk (y = U - s') and needed again here: 4 array passes, not 5
+#endif
+    __device__ static __forceinline__ Ext fetch_rest(const SweepArgs &p, long idx, double sp) { return Ext{sp, p.c[idx]}; }
     __device__ static __forceinline__ Ext fetch(const SweepArgs &p, long idx) { return Ext{p.a[idx], p.c[idx]}; }
     __device__ static __forceinline__ void finish(const SweepArgs &p, long idx, const Ext &e, double x) {
         const double tb = e.e0 + 2 * x;
@@ -160,7 +178,7 @@ template <> struct Op<OP_PD2_B> : InAplusB, NotFused {
 
 // Yang ADMM (a = X, b = U_in, o0 = Z, o1 = U_out, s0 = rho):
 //   Z = prox_{lambda/rho}(-1/rho U + X) ; U += rho (Z - X)          (src/TV2Dopt.cpp:836-862 ; src/TVNDopt.cpp:733-788)
-template <> struct Op<OP_YANG> : NotFused {
+template <> struct Op<OP_YANG> : NotFused, NoKeep {
     static constexpr int NIN = 2;
     __device__ static __forceinline__ void fetch_in(const SweepArgs &p, long idx, double &i0, double &i1) { i0 = p.a[idx]; i1 = p.b[idx]; }
     __device__ static __forceinline__ double y_of(const SweepArgs &p, double i0, double i1) { return -1. / p.s0 * i1 + i0; }

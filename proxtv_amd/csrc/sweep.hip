@@ -32,6 +32,7 @@
 
 #include <memory>
 
+#include "chunkcore.hpp"
 #include "policy.hpp"
 #include "walker.hpp"
 
@@ -164,159 +165,35 @@ struct ChunkPlan {
     int qpw;    // consecutive blocks of one fibre group processed (software-pipelined) by one workgroup
     int ablate; // profiling aid (option "ablate"): 1 = skip the walk, 2 = skip the epilogue, 4 = skip the window loads
     int rounds; // second-chance rounds inside a block (0 = none): see the link-proof step of sweep_chunk_kernel
+    unsigned long long *trace;   // option "trace": 8 words per workgroup -- where it ran and when its phases ended (100 MHz clock)
 };
 
-template <int OP, bool WEIGHTED, int PITCH, bool PAST>
-struct ChunkSource {
+__device__ __forceinline__ void trace_mark(const ChunkPlan &plan, int slot) {
+    if (plan.trace && threadIdx.x == 0)
+        plan.trace[8 * (size_t)(blockIdx.x + gridDim.x * blockIdx.y) + slot] = wall_clock64();
+}
+
+// The LDS window as chunkcore.hpp sees it from one lane: row i of the lane's fibre at Y[(i - lo) * PITCH] (`lo` may be
+// negative at the fibre start: rows below 0 are never touched).  32-bit LDS addressing throughout.
+typedef __attribute__((address_space(3))) double lds_double;
+template <bool WEIGHTED, int PITCH>
+struct LdsWin {
+    lds_double *Y;     // already offset to this lane's column
+    lds_double *Wt;    // per-edge penalties, same addressing (weighted sweeps)
+    int lo;
+    __device__ __forceinline__ double y(int i) const { return Y[(i - lo) * PITCH]; }
+    __device__ __forceinline__ double r(int i) const { return Wt[(i - lo) * PITCH]; }
+    __device__ __forceinline__ void put(int i, double v) const { Y[(i - lo) * PITCH] = v; }
+};
+
+// samples beyond the window, one dependent global access each (robust instantiation only)
+template <int OP>
+struct FarFibre {
     const SweepArgs &p;
-    long base, inc, wbase;     // this lane's fibre in global memory
-    const double *Y;           // LDS window, already offset to this lane's column; row r of the fibre at Y[(r - lo) * PITCH]
-    const double *Wt;          // LDS per-edge penalties, same addressing (weighted sweeps)
-    int lo, hi;                // window rows present in LDS
-    int cs, ce;                // samples owned by this lane: [cs, ce)
-    int len;                   // fibre length
-    // The walk stores no piece VALUES: it records where pieces end inside the chunk and with which bend type; the
-    // values are rebuilt afterwards from the window in closed form (see rebuild_pieces).
-    unsigned ends = 0;         // bit k: a piece ends at sample cs + k (k < ce - 1 - cs; chunks are at most 32 samples)
-    unsigned types = 0;        // bit k: bend type (BEND_FLOOR = 1) of the bend that ended that piece
-    // Link proof.  Two walks that share one bend are identical from it on, so inside the zone before a chunk boundary
-    // they either share their LAST bend or share none: it is enough to remember, as (restart << 1 | type), the last
-    // bend at or before the own chunk start (`mine`) and at or before the own chunk end (`next`, read by the lane of
-    // the following chunk, whose walk started H samples before that boundary).  0 = none.
-    unsigned mine = 0, next = 0;
-    double vclose = 0.0;       // value of the piece covering sample ce - 1
-    double vfirst = 0.0;       // value of the piece covering sample cs
-    bool have_first = false;
-    bool done = false;         // the piece covering ce - 1 is closed
-    bool failed = false;       // the walk ran off the LDS window (a piece much longer than a chunk): give the fibre up
-
-    // Past the end of the LDS window (the last chunk of a block, when the piece covering its last sample runs on for
-    // more than the T look-ahead rows) the walk reads global memory, one dependent access per sample, for at most
-    // kOverflow samples; a lane that needs more (a long flat piece) marks its fibre for the repair kernel instead --
-    // this bounds the cost of a chunk whatever the data.
-    // (PAST: only the robust instantiation of the kernel -- geometry mode 1 -- carries this; inlined into the plain one it
-    // costs the headline 2 %, out of line far more.)
-    static constexpr int kOverflow = PAST ? 48 : 0;
-    __device__ __forceinline__ double y_window(int i) const { return Y[(min(i, hi - 1) - lo) * PITCH]; }   // hot loop: i < hi
-    __device__ __forceinline__ double r_window(int i) const { return Wt[(min(i, hi - 1) - lo) * PITCH]; }
-    __device__ __forceinline__ double y(int i) const {
-        if (!PAST || i < hi) return Y[(min(i, hi - 1) - lo) * PITCH];
-        return Op<OP>::load_y(p, base + (long)min(i, len - 1) * inc);
-    }
-    __device__ __forceinline__ double r(int i) const {
-        if (!PAST || i < hi) return Wt[(min(i, hi - 1) - lo) * PITCH];
-        return (i < len - 1) ? p.w[wbase + (long)i * inc] : 0.0;
-    }
-    __device__ __forceinline__ void piece(int, int to, double v) {
-        if (to >= cs && !have_first) {
-            vfirst = v;
-            have_first = true;
-        }
-        if (to >= ce - 1) {
-            vclose = v;
-            done = true;
-        } else if (to >= cs) {
-            ends |= 1u << (to - cs);
-        }
-    }
-    __device__ __forceinline__ void bend(int at, int type) {
-        const unsigned code = ((unsigned)at << 1) | (unsigned)type;
-        mine = (at <= cs) ? code : mine;
-        next = (at <= ce) ? code : next;
-        const int e = at - 1 - cs;                       // the piece that this bend ended, relative to the chunk
-        if (e >= 0 && at < ce) types |= (unsigned)type << e;
-    }
-    __device__ __forceinline__ bool keep_going(int i) {
-        if (done) return false;
-        if (i >= hi + kOverflow) {   // (a walk that reaches the fibre end never gets here: i < len <= hi + kOverflow then)
-            failed = true;
-            return false;
-        }
-        return true;
-    }
-    // take over what another walk of the same chunk recorded
-    __device__ __forceinline__ void adopt(const ChunkSource &o) {
-        ends = o.ends; types = o.types; mine = o.mine; next = o.next;
-        vclose = o.vclose; vfirst = o.vfirst; have_first = o.have_first; done = o.done; failed = o.failed;
-    }
+    long base, inc, wbase;
+    __device__ __forceinline__ double far_y(int i) const { return Op<OP>::load_y(p, base + (long)i * inc); }
+    __device__ __forceinline__ double far_r(int i) const { return p.w[wbase + (long)i * inc]; }
 };
-
-// a / s for a small positive integer s held as a double: reciprocal (v_rcp_f64) + one Newton step, then one
-// residual correction of the quotient.  Agrees with IEEE division to the last bit in all but rare ties (at most
-// one ulp off) at a third of the instructions of the full v_div_* sequence; both tube pieces share `inv`.
-__device__ __forceinline__ double refined_rcp(double s) {
-    double inv = __builtin_amdgcn_rcp(s);
-    inv = __builtin_fma(__builtin_fma(-s, inv, 1.0), inv, inv);
-    return inv;
-}
-__device__ __forceinline__ double div_by(double a, double s, double inv) {
-    const double q = a * inv;
-    return __builtin_fma(__builtin_fma(-q, s, a), inv, q);
-}
-
-// Hot loop of the chunked kernel: the interior steps of the walk (sample index below the last sample of the fibre
-// and inside the LDS window), same state machine and arithmetic order as walker_run, hand-shaped for the wave:
-//   * y of the next sample is requested before the current one is processed (the dependent LDS latency hides
-//     behind the step); a bend that rewinds re-reads;
-//   * both "pull back inside the tube" updates are branch-free selects sharing one reciprocal;
-//   * only the bend path is a divergent region.
-// Leaves the walker at the first sample it does not handle (i == len - 1, window exhausted, or done).
-template <bool WEIGHTED, class S>
-__device__ __forceinline__ void walker_run_interior(Walker &w, S &src, int n, double lam) {
-    const int last = n - 1;
-    const int lim = min(last, src.hi);   // handle i < lim only
-    if (w.i >= lim || src.done) return;
-    double yi = src.y_window(w.i);
-    while (true) {
-        const int i = w.i;
-        const bool live = !src.done && i < lim;
-        if (!live) break;
-        const double ynext = src.y_window(i + 1);        // speculative: most steps advance by one (LDS only)
-        const double r = WEIGHTED ? src.r_window(i) : lam;
-        const double h1 = w.hlo + (w.lo - yi);
-        const bool cv = r < h1;
-        const double h2 = w.hhi + (w.hi - yi);
-        const bool fv = !cv && (-r > h2);
-        if (cv || fv) {
-            const int brk = cv ? w.klo : w.khi;
-            src.piece(w.k0 + 1, brk, cv ? w.lo : w.hi);
-            const int at = brk + 1;                       // at <= i < last: the restart is an interior sample
-            src.bend(at, cv ? BEND_CEIL : BEND_FLOOR);
-            const double yn = (at == i) ? yi : src.y_window(at);
-            if (WEIGHTED) {
-                const double wp = src.r_window(at - 1), wc = (at == i) ? r : src.r_window(at);
-                if (cv) { w.lo = yn + wp - wc; w.hi = yn + wp + wc; }
-                else    { w.hi = yn - wp + wc; w.lo = yn - wp - wc; }
-                w.hhi = wc;
-                w.hlo = -wc;
-            } else {
-                if (cv) { w.lo = yn; w.hi = 2 * lam + yn; }
-                else    { w.hi = yn; w.lo = 2 * (-lam) + yn; }
-                w.hhi = lam;
-                w.hlo = -lam;
-            }
-            w.k0 = brk;
-            w.klo = w.khi = at;
-            w.i = at + 1;
-            yi = (at == i) ? ynext : src.y_window(at + 1);
-        } else {
-            const double s = (double)(i - w.k0);
-            const double inv = refined_rcp(s);
-            const bool th = h2 >= r, tl = h1 <= -r;
-            const double nhi = w.hi + div_by(r - h2, s, inv);
-            const double nlo = w.lo + div_by(-r - h1, s, inv);
-            w.hi = th ? nhi : w.hi;
-            w.hhi = th ? r : h2;
-            w.khi = th ? i : w.khi;
-            w.lo = tl ? nlo : w.lo;
-            w.hlo = tl ? -r : h1;
-            w.klo = tl ? i : w.klo;
-            w.i = i + 1;
-            yi = ynext;
-        }
-    }
-}
-
 
 constexpr int kWarm = 16;       // H: samples a speculative walk starts before its chunk (its synchronisation zone)
 constexpr int kWarmLong = 64;   // ... for data whose walks need longer to meet (moderate lambda: pieces of ~10 samples)
@@ -324,55 +201,17 @@ constexpr int kTail = 8;    // T: look-ahead rows kept in LDS past the last chun
 // The last chunk of a block must see the end of the piece that covers its last sample: the look-ahead has to scale
 // with the piece length the geometry is meant for, like the warm-up zone does.
 constexpr int tail_rows(int H) { return H > kWarm ? H : kTail; }
+constexpr int kOverflow = 48;   // samples a walk of the robust instantiation may read past its window (global memory)
 
-// Piece values from piece ends.  Between two knots of the taut string the prox is constant, and the string's height
-// above the tube centre at a knot is -r after a CEIL bend (the knot sits on the tube floor), +r after a FLOOR bend,
-// 0 at the fibre ends (r = the tube half-width there: lambda, or the edge's own penalty).  Summing x - y over a
-// piece [a, b] therefore gives   v = ( sum_{a..b} y + h_b - h_{a-1} ) / (b - a + 1).
-// For one-sample pieces this is bit-for-bit the walker's closed-form restart value (y, y +- 2 lambda); for longer
-// pieces it agrees with the walker's running slope to a few ulps (checked on the host: < 1e-15 relative).
-// rebuild_chunk does this for one lane's chunk, in place in the window, in ONE forward pass: it accumulates y over the
-// current piece and, when the piece ends, goes back over the piece's rows (still holding y) and replaces each by
-// Op::fuse(y, v) -- the prox value itself, or directly the sweep's output when the op's output depends on (y, x) only.
-// The piece that covers the chunk's first sample may have begun before the chunk (rows that belong to, and are being
-// rewritten by, the previous lane): it takes `v_first`, the value the lane's own walk gave it; likewise the piece
-// covering the chunk's last sample takes `v_close`.  So a lane reads and writes the rows of its own chunk only.
-template <int OP, bool WEIGHTED, int PITCH>
-__device__ __forceinline__ void rebuild_chunk(double *Ycol, const double *Wcol, int lo, int cs, int ce, int start,
-                                              unsigned mine, unsigned ends, unsigned types, double v_close,
-                                              double v_first, double lam) {
-    int a0 = cs;
-    double hprev = 0.0;
-    if (mine != 0) {
-        a0 = (int)(mine >> 1);
-        const double r = WEIGHTED ? Wcol[(a0 - 1 - lo) * PITCH] : lam;
-        hprev = (mine & 1u) ? r : -r;
-    } else if (start == 0) {
-        a0 = 0;   // no bend yet and the walk began at the fibre start: the first piece starts at sample 0, height 0
-    }
-    bool from_prev = a0 < cs;
-    const double v_prev = v_first;
-    double s = 0.0;
-    int cnt = 0;
-    int first = cs;   // first row of the current piece inside the chunk
-    for (int k = cs; k <= ce - 2; k++) {
-        s += Ycol[(k - lo) * PITCH];
-        cnt++;
-        const int e = k - cs;
-        if ((ends >> e) & 1u) {
-            const double r = WEIGHTED ? Wcol[(k - lo) * PITCH] : lam;
-            const double hk = ((types >> e) & 1u) ? r : -r;
-            const double sc = (double)cnt;
-            const double v = from_prev ? v_prev : div_by(s + (hk - hprev), sc, refined_rcp(sc));
-            for (int jj = first; jj <= k; jj++) Ycol[(jj - lo) * PITCH] = Op<OP>::fuse(Ycol[(jj - lo) * PITCH], v);
-            from_prev = false;
-            first = k + 1;
-            s = 0.0;
-            cnt = 0;
-            hprev = hk;
-        }
-    }
-    for (int jj = first; jj <= ce - 1; jj++) Ycol[(jj - lo) * PITCH] = Op<OP>::fuse(Ycol[(jj - lo) * PITCH], v_close);
+// One chunk's walk from a given walker state: the branch-free interior loop (chunkcore.hpp), then walker_run for what
+// is left -- the fibre's last sample, the window's end (PAST: up to kOverflow samples beyond it from global memory).
+template <int OP, bool WEIGHTED, int PITCH, bool PAST>
+__device__ __forceinline__ void walk_chunk(Walker &w, ChunkRec &rec, const LdsWin<WEIGHTED, PITCH> &win, const FarFibre<OP> &far,
+                                           int hi, int cs, int ce, int len, double lam) {
+    walk_interior<WEIGHTED>(w, rec, win, min(len - 1, hi), cs, ce, lam);
+    TailSource<WEIGHTED, PAST, kOverflow, LdsWin<WEIGHTED, PITCH>, FarFibre<OP>> tail{win, far, rec, cs, ce, hi, len};
+    walker_run<WEIGHTED>(w, tail, len, lam);
+    if (rec.failed) rec.next = 0;   // ran off the window: nothing this lane recorded may be trusted
 }
 
 // One workgroup = NW waves = NW consecutive chunks (a "block" of NW*C samples) of the same 64 fibres; it processes
@@ -381,8 +220,9 @@ __device__ __forceinline__ void rebuild_chunk(double *Ycol, const double *Wcol, 
 //      thread are issued before the first is waited for; for dimension-0 sweeps the tile is transposed on the way;
 //   2. every wave walks its chunk speculatively (LDS only), recording piece ends, bend types and link codes;
 //   3. links between consecutive chunks are proven through LDS (and, across workgroups, by sweep_repair_kernel);
-//   4. piece values are rebuilt in place (rebuild_chunk), then the block's rows are streamed out: straight from LDS
-//      for fused ops, otherwise through the op's output functor with the operand fetches of UL rows in flight.
+//   4. piece values are rebuilt in place (rebuild_owned: a piece is rewritten by the lane in whose chunk it ends), then
+//      the block's rows are streamed out: straight from LDS for fused ops, otherwise through the op's output functor
+//      (an operand that was staged for the walk and is needed again stays in registers: Op::KEEP).
 // LDS carve (dynamic, 16-byte aligned base): Y window | Wt window (weighted) | link codes.
 template <int OP, bool WEIGHTED, bool TRANSPOSED, int C, int NW, int H, bool ROUNDS>
 __global__ __launch_bounds__(64 * NW, ((WEIGHTED || H > 16) ? NW / 4 : NW / 2)) void sweep_chunk_kernel(SweepArgs p, FibreGeom g, ChunkPlan plan,
@@ -390,19 +230,35 @@ __global__ __launch_bounds__(64 * NW, ((WEIGHTED || H > 16) ? NW / 4 : NW / 2)) 
                                                                                    int *failflags) {
     constexpr int PITCH = TRANSPOSED ? 65 : 64;
     constexpr int T = tail_rows(H), ROWS = H + NW * C + T;
-    static_assert(T >= NW, "the look-ahead rows double as the closing-value slots of the NW waves");
+    static_assert(H % NW == 0 && T % NW == 0, "the staging shares of the waves are whole rows");
     constexpr int RB = (ROWS + 63) / 64;                                      // transposed: 64-row blocks per fibre
-    constexpr int NST = TRANSPOSED ? (64 / NW) * RB : (ROWS + NW - 1) / NW;   // staged window elements per thread
+    constexpr int NST = TRANSPOSED ? (64 / NW) * RB : ROWS / NW;              // staged window elements per thread
     constexpr int UL = 8;                                                     // epilogue rows in flight per lane
+    constexpr bool KEEP = !TRANSPOSED && Op<OP>::KEEP;                        // a staged operand is reused by the epilogue
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double *Yp = reinterpret_cast<double *>(smem);
     double *Wp = Yp + (WEIGHTED ? (size_t)ROWS * PITCH : 0);
+    // (the walk's look-ahead read of row `hi` lands in whatever follows the Y window -- allocated LDS, value never used)
     link_t *codes = reinterpret_cast<link_t *>(Wp + (size_t)ROWS * PITCH);   // [NW + 2][64]; slots NW, NW + 1 carry over blocks
     // (bit 31 of a slot -- never part of a code: restart indices are below 2^30 -- says "this lane's link is proven")
     int *anybad = reinterpret_cast<int *>(codes + (NW + 2) * 64);            // [2], by round parity: some lane of the block has an unproven link
+    // A lane rewrites the rows of a piece that ends in its chunk even where they lie in earlier chunks; its walk reaches
+    // back H rows (second-chance walks: anywhere in the block).  With H <= C that is the chunk before at most, and if
+    // that chunk's lane is unproven its rows are rewritten by the repair kernel anyway.  Further back there may be
+    // PROVEN chunks before an unproven one -- rows the repair kernel will not touch -- so those instantiations stop a
+    // lane's writes at the nearest unproven chunk before it (GUARD: one flag per lane through LDS, one more barrier).
+    constexpr bool GUARD = ROUNDS || H > C;
+    unsigned long long *unproven = reinterpret_cast<unsigned long long *>(anybad + 2);   // [NW] lane masks (GUARD); NW <= 14
 
     if (p.gate && *p.gate == 0) return;   // uniform over the grid
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (plan.trace && tid == 0) {
+        unsigned hwid, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        plan.trace[8 * (size_t)(blockIdx.x + gridDim.x * blockIdx.y)] = ((unsigned long long)xcc << 32) | hwid;
+    }
+    trace_mark(plan, 1);
     const int len = g.len;
     const long j0 = (long)blockIdx.x * 64;
     const long j = j0 + lane;
@@ -413,17 +269,23 @@ __global__ __launch_bounds__(64 * NW, ((WEIGHTED || H > 16) ? NW / 4 : NW / 2)) 
         base = blk * g.inc * len + off;
         wbase = blk * g.inc * (len - 1) + off;
     }
+    const FarFibre<OP> far{p, base, g.inc, wbase};
 
+    // Window rows are addressed relative to lo = block start - H (negative for the first block: those rows do not
+    // exist and are never touched), so that the share of a thread is the same set of slots in every block.
     // Strided sweeps: element u of a thread is row lo + wave + NW*u of its own fibre (each wave instruction = one
-    // coalesced 512-byte row).  Dimension-0 sweeps (fibres contiguous): lanes run ALONG the fibre, element u is row
-    // lo + 64*(u % RB) + lane of fibre wave + NW*(u / RB), and the tile is transposed on its way into LDS (pitch 65).
+    // coalesced 512-byte row); elements H/NW .. H/NW + C - 1 are rows of the block itself -- the ones the same thread
+    // streams out at the end, so an operand staged here can wait in registers for the epilogue (Op::KEEP).
+    // Dimension-0 sweeps (fibres contiguous): lanes run ALONG the fibre, element u is row lo + 64*(u % RB) + lane of
+    // fibre wave + NW*(u / RB), and the tile is transposed on its way into LDS (pitch 65).
     // The loads of a batch of NB elements are all issued before the first is waited for.  NB = NST (the whole window
-    // share of the thread) unless that would not fit the register budget: two-operand inputs of a transposed sweep go
-    // in three batches (48 live doubles spill otherwise).
-    constexpr int NB = (TRANSPOSED && Op<OP>::NIN > 1) ? (NST + 2) / 3 : NST;
+    // share of the thread) unless that would not fit the register budget: transposed sweeps stage in two batches (three
+    // for two-operand inputs: 48 live doubles spill otherwise), two-operand strided sweeps in two.
+    constexpr int NB = TRANSPOSED ? (Op<OP>::NIN > 1 ? (NST + 2) / 3 : (NST + 1) / 2) : (Op<OP>::NIN > 1 ? (NST + 1) / 2 : NST);
+    double kept[KEEP ? C : 1];
     auto stage = [&](int q) {
         const int cs_wg = q * NW * C;
-        const int lo = max(0, cs_wg - H), hi = min(len, cs_wg + NW * C + T);
+        const int lo = cs_wg - H, hi = min(len, cs_wg + NW * C + T);
 #pragma unroll
         for (int u0 = 0; u0 < NST; u0 += NB) {
             double s0[NB], s1[NB], sw[NB];
@@ -435,13 +297,13 @@ __global__ __launch_bounds__(64 * NW, ((WEIGHTED || H > 16) ? NW / 4 : NW / 2)) 
                 bool ok;
                 if (!TRANSPOSED) {
                     r = lo + wave + NW * u;
-                    ok = active && r < hi;
+                    ok = active && r >= 0 && r < hi;
                     idx = base + (long)r * g.inc;
                     widx = wbase + (long)r * g.inc;
                 } else {
                     const long jf = j0 + wave + NW * (u / RB);
                     r = lo + (u % RB) * 64 + lane;
-                    ok = jf < g.count && r < hi;
+                    ok = jf < g.count && r >= 0 && r < hi;
                     idx = jf * len + r;
                     widx = jf * (len - 1) + r;
                 }
@@ -458,16 +320,17 @@ __global__ __launch_bounds__(64 * NW, ((WEIGHTED || H > 16) ? NW / 4 : NW / 2)) 
                 if (!TRANSPOSED) {
                     r = lo + wave + NW * u;
                     col = lane;
-                    ok = active && r < hi;
+                    ok = active && r >= 0 && r < hi;
                 } else {
                     col = wave + NW * (u / RB);
                     r = lo + (u % RB) * 64 + lane;
-                    ok = j0 + col < g.count && r < hi;
+                    ok = j0 + col < g.count && r >= 0 && r < hi;
                 }
                 if (ok && u < NST) {
                     Yp[(r - lo) * PITCH + col] = Op<OP>::y_of(p, s0[v], s1[v]);
                     if (WEIGHTED) Wp[(r - lo) * PITCH + col] = sw[v];
                 }
+                if (KEEP && u >= H / NW && u < H / NW + C) kept[KEEP ? u - H / NW : 0] = s1[v];
             }
         }
     };
@@ -484,9 +347,10 @@ __global__ __launch_bounds__(64 * NW, ((WEIGHTED || H > 16) ? NW / 4 : NW / 2)) 
             stage(q);
         }
         __syncthreads();
+        if (kb == 0) trace_mark(plan, 2);
 
         const int cs_wg = q * NW * C;
-        const int lo = max(0, cs_wg - H);
+        const int lo = cs_wg - H;
         const int hi = min(len, cs_wg + NW * C + T);
 
         // ---- speculative walk of this wave's chunk --------------------------------------------------------------------
@@ -494,58 +358,35 @@ __global__ __launch_bounds__(64 * NW, ((WEIGHTED || H > 16) ? NW / 4 : NW / 2)) 
         const int ce = min(cs + C, len);
         const bool has_chunk = active && cs < len;
         const int start = max(0, cs - H);
-        ChunkSource<OP, WEIGHTED, PITCH, ROUNDS> src{p, base, g.inc, wbase, Yp + lane, Wp + lane, lo, hi, cs, ce, len};
+        const LdsWin<WEIGHTED, PITCH> win{(lds_double *)Yp + lane, (lds_double *)Wp + lane, lo};
+        ChunkRec rec;
         bool certain = false;
         if (has_chunk && !(plan.ablate & 1)) {
             Walker w;
-            // A bend known without walking: x_k - x_{k-1} = (y_k - y_{k-1}) + (u_k - u_{k-1}) - (u_{k-1} - u_{k-2}) with every
-            // dual |u_j| <= r_j, so a jump |y_k - y_{k-1}| > r_k + 2 r_{k-1} + r_{k-2} (4 lambda) keeps its sign in x: the
-            // string bends there (up-jump: off the floor), and the state after a bend depends on the bend alone.  A lane
-            // that finds one among the kLook edges before its chunk starts its walk AT it -- exact by construction, no
-            // warm-up zone to walk, no link to prove.  On noisy data with small lambda (the headline: 78 % of all edges
-            // qualify) every lane of a wave does; otherwise the lane falls back to the speculative start.
+            // A lane that finds a bend known a priori (chunkcore.hpp) among the kLook edges before its chunk starts its
+            // walk AT it -- exact by construction, no warm-up zone to walk, no link to prove.  On noisy data with small
+            // lambda (the headline: 78 % of all edges qualify) every lane of a wave does; otherwise the lane falls back to
+            // the speculative start.
             constexpr int kLook = 8;
             static_assert(H >= kLook + 2, "the certain-bend search reads rows of the warm-up zone");
             int cat = -1, ctype = 0;
-            if (start > 0 && H <= kWarm && p.lam > 0.0) {
-                double yv[kLook + 1], rv[kLook + 2];
-#pragma unroll
-                for (int u = 0; u <= kLook; u++) yv[u] = src.y(cs - u);
-                if (WEIGHTED) {
-#pragma unroll
-                    for (int u = 0; u <= kLook + 1; u++) rv[u] = (cs - u < len - 1) ? src.r(cs - u) : 0.0;
-                }
-#pragma unroll
-                for (int u = kLook - 1; u >= 0; u--) {   // edge (k - 1, k), k = cs - u; the nearest one wins
-                    const double d = yv[u] - yv[u + 1];
-                    double thr = 4.0000001 * p.lam;
-                    bool ok = true;
-                    if (WEIGHTED) {
-                        thr = 1.0000001 * (rv[u] + 2.0 * rv[u + 1] + rv[u + 2]);
-                        ok = (rv[u] >= 0.0) & (rv[u + 1] > 0.0) & (rv[u + 2] >= 0.0);
-                    }
-                    const bool hit = ok & (fabs(d) > thr);
-                    cat = hit ? cs - u : cat;
-                    ctype = hit ? (d > 0 ? BEND_FLOOR : BEND_CEIL) : ctype;
-                }
-            }
+            if (start > 0 && H <= kWarm && p.lam > 0.0) cat = certain_bend_before<WEIGHTED, kLook>(win, cs, len, p.lam, ctype);
             if (cat >= 0) {
                 certain = true;
-                walker_restart_with<WEIGHTED>(w, cat, ctype, len, p.lam, src.y(cat), WEIGHTED ? src.r(cat - 1) : 0.0,
-                                              (WEIGHTED && cat < len - 1) ? src.r(cat) : 0.0);
-                src.mine = src.next = ((link_t)cat << 1) | (link_t)ctype;
+                walker_restart_with<WEIGHTED>(w, cat, ctype, len, p.lam, win.y(cat), WEIGHTED ? win.r(cat - 1) : 0.0,
+                                              (WEIGHTED && cat < len - 1) ? win.r(cat) : 0.0);
+                rec.mine = rec.next = rec.last = ((link_t)cat << 1) | (link_t)ctype;
             } else {
-                walker_start<WEIGHTED>(w, src, start, p.lam);
+                walker_start<WEIGHTED>(w, win, start, p.lam);
             }
-            walker_run_interior<WEIGHTED>(w, src, len, p.lam);   // the hot part
-            walker_run<WEIGHTED>(w, src, len, p.lam);            // fibre end / window end (no-op for most lanes)
-            if (src.failed) src.next = 0;   // ran off the window: nothing this lane recorded may be trusted
+            walk_chunk<OP, WEIGHTED, PITCH, ROUNDS>(w, rec, win, far, hi, cs, ce, len, p.lam);
         }
 
         // ---- prove the links between consecutive chunks ------------------------------------------------------------------
-        codes[wave * 64 + lane] = src.next;
+        codes[wave * 64 + lane] = rec.next;
         if (ROUNDS && tid == 0) anybad[0] = anybad[1] = 0;
         __syncthreads();   // all walks done: link codes visible, window rows no longer read as walk input
+        if (kb == 0) trace_mark(plan, 3);
         const int prev_slot = (wave > 0) ? (wave - 1) * 64 + lane : (NW + ((kb + 1) & 1)) * 64 + lane;
         bool bad = false;
         // Second chances inside the block (plan.rounds > 0; data whose walks need more than the zone to meet): a lane
@@ -555,9 +396,9 @@ __global__ __launch_bounds__(64 * NW, ((WEIGHTED || H > 16) ? NW / 4 : NW / 2)) 
         // code), and what is still unproven after the last round goes to the repair kernel as usual.
         for (int round = 0; ; round++) {
             const bool linked = has_chunk && !(start == 0 || certain) && (wave > 0 || kb > 0);   // hangs on its predecessor
-            bad = has_chunk && (src.failed || (linked && (src.mine == 0 || src.mine != (codes[prev_slot] & ~kLinkCertain))));
+            bad = has_chunk && (rec.failed || (linked && (rec.mine == 0 || rec.mine != (codes[prev_slot] & ~kLinkCertain))));
             if (!ROUNDS || round >= plan.rounds) break;
-            if (has_chunk) codes[wave * 64 + lane] = bad ? src.next : (src.next | kLinkCertain);   // same code, plus the flag
+            if (has_chunk) codes[wave * 64 + lane] = bad ? rec.next : (rec.next | kLinkCertain);   // same code, plus the flag
             if (bad) anybad[round & 1] = 1;
             __syncthreads();
             if (!anybad[round & 1]) break;               // uniform
@@ -566,58 +407,70 @@ __global__ __launch_bounds__(64 * NW, ((WEIGHTED || H > 16) ? NW / 4 : NW / 2)) 
                 const link_t praw = codes[prev_slot];
                 const link_t prev = praw & ~kLinkCertain;
                 const int at = (int)(prev >> 1);
-                if ((praw & kLinkCertain) && prev != 0 && at > lo) {
-                    ChunkSource<OP, WEIGHTED, PITCH, ROUNDS> again{p, base, g.inc, wbase, Yp + lane, Wp + lane, lo, hi, cs, ce, len};
+                if ((praw & kLinkCertain) && prev != 0 && at > max(lo, 0)) {
+                    ChunkRec again;
                     Walker w;
-                    walker_restart_with<WEIGHTED>(w, at, (int)(prev & 1u), len, p.lam, again.y(at),
-                                                  WEIGHTED ? again.r(at - 1) : 0.0,
-                                                  (WEIGHTED && at < len - 1) ? again.r(at) : 0.0);
-                    again.mine = again.next = prev;
-                    walker_run_interior<WEIGHTED>(w, again, len, p.lam);
-                    walker_run<WEIGHTED>(w, again, len, p.lam);
+                    walker_restart_with<WEIGHTED>(w, at, (int)(prev & 1u), len, p.lam, win.y(at), WEIGHTED ? win.r(at - 1) : 0.0,
+                                                  (WEIGHTED && at < len - 1) ? win.r(at) : 0.0);
+                    again.mine = again.next = again.last = prev;
+                    walk_chunk<OP, WEIGHTED, PITCH, ROUNDS>(w, again, win, far, hi, cs, ce, len, p.lam);
                     if (!again.failed) {
-                        src.adopt(again);
+                        rec = again;
                         certain = false;   // from now on the chunk hangs on its predecessor like any other
-                        codes[wave * 64 + lane] = src.next;
+                        codes[wave * 64 + lane] = rec.next;
                     }
                 }
             }
             __syncthreads();
         }
         if (has_chunk) {
-            if (src.failed) {
-                src.mine = kLinkBad;
-                src.next = 0;
+            if (rec.failed) {
+                rec.mine = kLinkBad;
+                rec.next = 0;
             }
             if (bad) flag_chunk(failflags, j, q * NW + wave, (len + C - 1) / C);
             // Every chunk publishes its two codes: sweep_repair_kernel proves the links between workgroups with them
             // and, for a fibre with an unproven link, finds where a repair walk may stop.
             const long slot = (long)(q * NW + wave) * g.count + j;
-            code_mine[slot] = (certain && src.mine != kLinkBad) ? (src.mine | kLinkCertain) : src.mine;
-            code_next[slot] = src.next;
+            code_mine[slot] = (certain && rec.mine != kLinkBad) ? (rec.mine | kLinkCertain) : rec.mine;
+            code_next[slot] = rec.next;
         }
         // carried to the next block's first chunk; two slots in turn, so that no barrier is needed before the write
-        if (wave == NW - 1) codes[(NW + (kb & 1)) * 64 + lane] = (bad || !has_chunk) ? src.next : (src.next | kLinkCertain);
-        if (has_chunk)
-            rebuild_chunk<OP, WEIGHTED, PITCH>(Yp + lane, Wp + lane, lo, cs, ce, start, src.mine, src.ends, src.types,
-                                               src.vclose, src.vfirst, p.lam);
+        if (wave == NW - 1) codes[(NW + (kb & 1)) * 64 + lane] = (bad || !has_chunk) ? rec.next : (rec.next | kLinkCertain);
+        int wlo = cs_wg;   // first row this lane may write
+        if (GUARD) {
+            const unsigned long long mask = __ballot(bad);
+            if (lane == 0) unproven[wave] = mask;
+            __syncthreads();
+            for (int k = wave - 1; k >= 0; k--)
+                if ((unproven[k] >> lane) & 1ull) {
+                    wlo = cs_wg + k * C;
+                    break;
+                }
+        }
+        if (has_chunk && !(plan.ablate & 1))
+            rebuild_owned<Op<OP>, WEIGHTED, C>(win, rec, cs, ce, len, start, !bad, wlo, wave == NW - 1 || ce == len, p.lam);
         __syncthreads();
+        if (kb == 0) trace_mark(plan, 4);
 
         // ---- stream the block's NW*C rows out: coalesced 512-byte rows, UL operand fetches in flight per lane ------------------
         const int ce_wg = min(len, cs_wg + NW * C);
         if (!(plan.ablate & 2)) {
             if (!TRANSPOSED) {
                 if (active) {
-                    for (int k0 = cs_wg + wave * UL; k0 < ce_wg; k0 += NW * UL) {
+                    // the thread that staged rows cs_wg + wave + NW*m streams them out (Op::KEEP: with the staged operand)
+#pragma unroll
+                    for (int m0 = 0; m0 < C; m0 += UL) {
                         Ext ex[UL];
 #pragma unroll
                         for (int u = 0; u < UL; u++) {
-                            const int k = min(k0 + u, ce_wg - 1);
-                            if (!Op<OP>::FUSED) ex[u] = Op<OP>::fetch(p, base + (long)k * g.inc);
+                            const int k = min(cs_wg + wave + NW * (m0 + u), ce_wg - 1);
+                            if (KEEP) ex[u] = Op<OP>::fetch_rest(p, base + (long)k * g.inc, kept[KEEP ? m0 + u : 0]);
+                            else if (!Op<OP>::FUSED) ex[u] = Op<OP>::fetch(p, base + (long)k * g.inc);
                         }
 #pragma unroll
                         for (int u = 0; u < UL; u++) {
-                            const int k = k0 + u;
+                            const int k = cs_wg + wave + NW * (m0 + u);
                             if (k < ce_wg) {
                                 const double v = Yp[(k - lo) * PITCH + lane];
                                 if (Op<OP>::FUSED) Op<OP>::store_fused(p, base + (long)k * g.inc, v);
@@ -656,6 +509,7 @@ __global__ __launch_bounds__(64 * NW, ((WEIGHTED || H > 16) ? NW / 4 : NW / 2)) 
         }
         if (kb + 1 < nblk) __syncthreads();   // every wave is done reading this block's window
     }
+    trace_mark(plan, 5);
 }
 
 // ---- kernel 2b: speculative chunks straight from global memory (long pieces) ---------------------------------------------------
@@ -745,8 +599,11 @@ struct RepairBook {
     int resume_chunk = 0;
     link_t resume_code = 0;
 
+    // `cur`: the last bend of the true walk at or before the chunk (0: none, the walk starts at sample 0).  The chunk
+    // kernels leave the rows of a piece to the lane in whose chunk it ends, and an unproven lane keeps to its own rows:
+    // the rows between that bend and the chunk belong to the repair walk as well.
     __device__ __forceinline__ void begin(int chunk, link_t cur) {
-        wfrom = chunk * C;
+        wfrom = cur ? (int)(cur >> 1) : 0;
         boundary = (chunk + 1) * C;
         last = cur;
         stop = false;
@@ -1003,6 +860,13 @@ struct ChunkScratch {
     size_t link_bytes = 0, flag_count = 0;
     link_t *code_mine = nullptr, *code_next = nullptr;   // [chunk][fibre]
     int *failflags = nullptr;
+    std::unique_ptr<Scratch> trace;   // option "trace": phase timestamps of the last chunk-kernel launch
+    size_t trace_wgs = 0;
+    unsigned long long *trace_buffer(size_t wgs) {
+        if (!trace || trace->bytes() < wgs * 64) trace.reset(new Scratch(wgs * 64));
+        trace_wgs = wgs;
+        return trace->as<unsigned long long>();
+    }
     int *failcount = nullptr;   // [family][2]: fibres that needed repair, chunks rewritten by repair walks (cumulative per solve)
 
     // Geometry policy (policy.hpp), one per sweep family -- fibres along dim 0 / along the other dims see different
@@ -1144,8 +1008,9 @@ void launch_chunk_h(const SweepArgs &args, const FibreGeom &g, hipStream_t strea
     plan.qpw = qpw < plan.Q ? qpw : plan.Q;
     plan.ablate = options().ablate;
     plan.rounds = rounds_wanted;
+    plan.trace = options().trace ? g_chunk.trace_buffer((size_t)groups * (size_t)((plan.Q + plan.qpw - 1) / plan.qpw)) : nullptr;
     const int WQ = (plan.Q + plan.qpw - 1) / plan.qpw;
-    constexpr size_t lds = sizeof(double) * PITCH * (size_t)ROWS * (WEIGHTED ? 2 : 1) + sizeof(link_t) * ((NW + 2) * 64 + 16);
+    constexpr size_t lds = sizeof(double) * PITCH * (size_t)ROWS * (WEIGHTED ? 2 : 1) + sizeof(link_t) * ((NW + 2) * 64 + 32);
     static_assert(WEIGHTED || H > kWarm || 2 * lds <= 160 * 1024, "the short-zone geometry is meant to run two workgroups per CU");
     static_assert(lds <= 160 * 1024, "chunk geometry does not fit the LDS of a CU");
     const int NC = (g.len + C - 1) / C;
@@ -1278,6 +1143,15 @@ long chunk_stats_fixups(hipStream_t s) {
     return total;
 }
 
+// option "trace": copy the phase timestamps of the last chunk-kernel launch of this thread (8 words per workgroup) to the host
+long chunk_trace_fetch(unsigned long long *dst, long max_wgs, hipStream_t s) {
+    if (!g_chunk.trace) return 0;
+    const long n = (long)g_chunk.trace_wgs < max_wgs ? (long)g_chunk.trace_wgs : max_wgs;
+    PTV_HIP(hipMemcpyAsync(dst, g_chunk.trace->as<unsigned long long>(), (size_t)n * 64, hipMemcpyDeviceToHost, s));
+    PTV_HIP(hipStreamSynchronize(s));
+    return n;
+}
+
 int chunk_stats_mode() {
     int m = 0;
     for (int f = 0; f < FAM_COUNT; f++) m = g_chunk.pol[f].mode > m ? g_chunk.pol[f].mode : m;
@@ -1296,6 +1170,11 @@ void launch_sweep(OpId op, bool weighted, const SweepArgs &args, const FibreGeom
 #define PTV_CASE_U(ID) case ID: launch_op_w<ID, false>(args, g, stream, allow_chunked, fam); break;
 #define PTV_CASE_W(ID) case ID: launch_op_w<ID, true>(args, g, stream, allow_chunked, fam); break;
     switch (op) {
+#ifdef PTV_FAST_BUILD   // experiments only: the headline's three unweighted sweeps (a full build takes two minutes)
+        PTV_CASE_U(OP_PROX)
+        PTV_CASE_U(OP_DR_COL)
+        PTV_CASE_U(OP_DR_ROW)
+#else
         PTV_CASE(OP_PROX)
         PTV_CASE(OP_DR_COL)
         PTV_CASE(OP_DR_COL_FINAL)
@@ -1305,6 +1184,7 @@ void launch_sweep(OpId op, bool weighted, const SweepArgs &args, const FibreGeom
         PTV_CASE_U(OP_PD2_A)
         PTV_CASE_U(OP_PD2_B)
         PTV_CASE_U(OP_YANG)
+#endif
         default:
             set_error("launch_sweep: unknown op %d", (int)op);
             throw HipFailure{hipErrorInvalidValue};

@@ -24,5 +24,6 @@ long chunk_stats_fixups(hipStream_t s);
 // current geometry policy of this thread (highest over the sweep families): 0 / 1 / 2 = LDS windows (16-sample zones, the
 // same with second-chance rounds, 64-sample zones), 3 / 4 = global-memory chunks, 5 = sequential
 int chunk_stats_mode();
+long chunk_trace_fetch(unsigned long long *dst, long max_wgs, hipStream_t s);
 
 }  // namespace ptv

@@ -6,8 +6,14 @@
 #define __forceinline__ inline
 #include <cstring>
 
+#include <algorithm>
+#include <cmath>
+#include <random>
+#include <vector>
+
 #include "../proxtv_amd/csrc/policy.hpp"
 #include "../proxtv_amd/csrc/walker.hpp"
+#include "../proxtv_amd/csrc/chunkcore.hpp"
 
 using namespace ptv;
 
@@ -33,7 +39,149 @@ struct HostSource {
 };
 }  // namespace
 
+namespace {
+// the LDS window of one workgroup, one fibre's column of it: rows [lo, hi) of the fibre (+ one slack row)
+struct HostWin {
+    std::vector<double> yy, ww;
+    std::vector<int> writes;
+    int lo = 0, hi = 0;
+    double y(int i) const { return yy[(size_t)(i - lo)]; }
+    double r(int i) const { return ww[(size_t)(i - lo)]; }
+    void put(int i, double v) {
+        yy[(size_t)(i - lo)] = v;
+        writes[(size_t)(i - lo)]++;
+    }
+};
+struct HostFar {
+    const double *y, *w;
+    double far_y(int i) const { return y[i]; }
+    double far_r(int i) const { return w[i]; }
+};
+// an op whose output depends on the input sample as well (like DR_COL): a row that is read after another lane replaced
+// it, or replaced twice, shows
+struct Reflect {
+    static constexpr bool USES_Y = true;
+    static double fuse(double y, double x) { return y - 2.0 * x; }
+};
+struct Identity {
+    static constexpr bool USES_Y = false;
+    static double fuse(double, double x) { return x; }
+};
+
+template <bool WEIGHTED, bool PAST, class F>
+int chunk_fibre(const double *y, const double *w, double lam, int len, int H, int T, int NW, int seed, double *x,
+                int *first_bad, int *write_errors) {
+    constexpr int C = 16, LOOK = 8;
+    std::mt19937 rng((unsigned)seed);
+    const int Q = (len + NW * C - 1) / (NW * C);
+    *first_bad = -1;
+    *write_errors = 0;
+    unsigned carried = 0;       // `next` code of the previous block's last lane
+    int cur = 0;                // restart of the true walk's last bend so far (what the repair kernel would restart from)
+    int bends = 0;
+    for (int q = 0; q < Q; q++) {
+        const int cs_wg = q * NW * C;
+        const int ce_wg = std::min(len, cs_wg + NW * C);
+        HostWin win;
+        win.lo = std::max(0, cs_wg - H);
+        win.hi = std::min(len, cs_wg + NW * C + T);
+        win.yy.assign(y + win.lo, y + win.hi);
+        win.yy.push_back(1e300);   // the slack row: never used for anything that matters
+        win.yy.push_back(1e300);
+        if (WEIGHTED) {
+            win.ww.assign((size_t)(win.hi - win.lo) + 2, 0.0);
+            for (int k = win.lo; k < win.hi && k < len - 1; k++) win.ww[(size_t)(k - win.lo)] = w[k];
+        }
+        win.writes.assign(win.yy.size(), 0);
+        HostFar far{y, w};
+        std::vector<ChunkRec> recs((size_t)NW);
+        std::vector<int> starts((size_t)NW, 0);
+        std::vector<char> has((size_t)NW, 0), certain((size_t)NW, 0), bad((size_t)NW, 0);
+        for (int wave = 0; wave < NW; wave++) {
+            const int cs = cs_wg + wave * C, ce = std::min(cs + C, len);
+            if (cs >= len) continue;
+            has[(size_t)wave] = 1;
+            const int start = std::max(0, cs - H);
+            starts[(size_t)wave] = start;
+            ChunkRec &rec = recs[(size_t)wave];
+            Walker wk;
+            int cat = -1, ctype = 0;
+            if (start > 0 && H <= 16 && lam > 0.0) cat = certain_bend_before<WEIGHTED, LOOK>(win, cs, len, lam, ctype);
+            if (cat >= 0) {
+                certain[(size_t)wave] = 1;
+                walker_restart_with<WEIGHTED>(wk, cat, ctype, len, lam, win.y(cat), WEIGHTED ? win.r(cat - 1) : 0.0,
+                                              (WEIGHTED && cat < len - 1) ? win.r(cat) : 0.0);
+                rec.mine = rec.next = rec.last = ((unsigned)cat << 1) | (unsigned)ctype;
+            } else {
+                walker_start<WEIGHTED>(wk, win, start, lam);
+            }
+            walk_interior<WEIGHTED>(wk, rec, win, std::min(len - 1, win.hi), cs, ce, lam);
+            TailSource<WEIGHTED, PAST, 48, HostWin, HostFar> tail{win, far, rec, cs, ce, win.hi, len};
+            walker_run<WEIGHTED>(wk, tail, len, lam);
+            if (rec.failed) rec.next = 0;
+            bends += __builtin_popcount(rec.ends);
+        }
+        // links (kernel: through LDS inside the block, by the repair kernel between blocks)
+        for (int wave = 0; wave < NW; wave++) {
+            if (!has[(size_t)wave]) continue;
+            const ChunkRec &rec = recs[(size_t)wave];
+            const bool linked = !(starts[(size_t)wave] == 0 || certain[(size_t)wave]) && (wave > 0 || q > 0);
+            const unsigned prev = wave > 0 ? recs[(size_t)wave - 1].next : carried;
+            bad[(size_t)wave] = rec.failed || (linked && (rec.mine == 0 || rec.mine != prev));
+            if (bad[(size_t)wave] && *first_bad < 0) *first_bad = cur;
+            if (*first_bad < 0 && rec.next != 0) cur = (int)(rec.next >> 1);
+        }
+        // rebuild, lanes in random order (they run concurrently on the device)
+        std::vector<int> order;
+        for (int wave = 0; wave < NW; wave++)
+            if (has[(size_t)wave]) order.push_back(wave);
+        std::shuffle(order.begin(), order.end(), rng);
+        for (int wave : order) {
+            const int cs = cs_wg + wave * C, ce = std::min(cs + C, len);
+            rebuild_owned<F, WEIGHTED, C>(win, recs[(size_t)wave], cs, ce, len, starts[(size_t)wave], !bad[(size_t)wave], cs_wg,
+                                                 wave == NW - 1 || ce == len, lam);
+        }
+        bool clean = true;
+        for (int wave = 0; wave < NW; wave++) clean = clean && !bad[(size_t)wave];
+        for (int k = cs_wg; k < ce_wg; k++) {
+            // undo the reflection (exact only if the row was fused once, from its own sample)
+            x[k] = F::USES_Y ? 0.5 * (y[k] - win.y(k)) : win.y(k);
+            if (clean && *first_bad < 0 && win.writes[(size_t)(k - win.lo)] != 1) (*write_errors)++;
+        }
+        for (int k = win.lo; k < cs_wg; k++)
+            if (win.writes[(size_t)(k - win.lo)] != 0) (*write_errors)++;
+        for (int k = ce_wg; k < win.hi; k++)
+            if (win.writes[(size_t)(k - win.lo)] != 0) (*write_errors)++;
+        int lastw = NW - 1;
+        while (lastw > 0 && !has[(size_t)lastw]) lastw--;
+        carried = recs[(size_t)lastw].next;
+    }
+    return bends;
+}
+}  // namespace
+
 extern "C" {
+
+// One fibre through the speculative-chunk scheme exactly as a workgroup column does it (chunkcore.hpp): blocks of NW
+// chunks of 16 samples, window [block - H, block + T), certain-bend starts, branch-free interior walk + walker_run
+// tail, links, ownership rebuild with the lanes in random order.  first_bad = -1 when every link is proven, else the
+// sample from which the repair kernel would rewrite (the restart of the last proven bend before the first unproven
+// chunk): outputs before it are final.  write_errors counts rows of clean blocks that were not
+// written exactly once, and rows outside a block that were written at all.
+int host_chunk_fibre(const double *y, const double *w, double lam, int len, int H, int T, int NW, int past, int seed,
+                     double *x, int *first_bad, int *write_errors) {
+    const bool refl = seed & 1;   // both rebuild flavours: outputs that depend on the row's own sample, and that do not
+    if (w) {
+        if (refl) return past ? chunk_fibre<true, true, Reflect>(y, w, lam, len, H, T, NW, seed, x, first_bad, write_errors)
+                              : chunk_fibre<true, false, Reflect>(y, w, lam, len, H, T, NW, seed, x, first_bad, write_errors);
+        return past ? chunk_fibre<true, true, Identity>(y, w, lam, len, H, T, NW, seed, x, first_bad, write_errors)
+                    : chunk_fibre<true, false, Identity>(y, w, lam, len, H, T, NW, seed, x, first_bad, write_errors);
+    }
+    if (refl) return past ? chunk_fibre<false, true, Reflect>(y, w, lam, len, H, T, NW, seed, x, first_bad, write_errors)
+                          : chunk_fibre<false, false, Reflect>(y, w, lam, len, H, T, NW, seed, x, first_bad, write_errors);
+    return past ? chunk_fibre<false, true, Identity>(y, w, lam, len, H, T, NW, seed, x, first_bad, write_errors)
+                : chunk_fibre<false, false, Identity>(y, w, lam, len, H, T, NW, seed, x, first_bad, write_errors);
+}
 
 // full sequential walk, what sweep_seq_kernel does per lane
 int host_walk(const double *y, const double *w, double lam, double *x, int n) {

@@ -1,0 +1,51 @@
+"""Per-workgroup phase timeline of the chunk kernels (option "trace"): where every workgroup of a sweep ran and when
+its phases ended.  Answers: do the workgroups sharing a CU run in lockstep?  which phase is the long one?
+
+    python tools/wg_trace.py [lambda] > gpurun_out/wg_trace.txt
+"""
+import sys, os
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from proxtv_amd import _lib, device
+
+lam = float(sys.argv[1]) if len(sys.argv) > 1 else 0.1
+lib = _lib.require_device()
+x = device.to_colmajor(torch.from_numpy(np.random.default_rng(0).standard_normal((4096, 4096))).cuda())
+y = device.colmajor_empty((4096, 4096))
+device.tv1_2d(x, lam, out=y)
+
+
+def report(title, rows=16):
+    buf = np.zeros((8192, 8), dtype=np.uint64)
+    n = lib.proxtv_debug_trace(buf.ctypes.data, 8192)
+    buf = buf[:n]
+    hw = buf[:, 0]
+    hwid = (hw & np.uint64(0xffffffff)).astype(np.int64)
+    xcc = (hw >> np.uint64(32)).astype(np.int64) & 0xf
+    cu = (hwid >> 8) & 0xf; sh = (hwid >> 12) & 1; se = (hwid >> 13) & 7; tg = (hwid >> 16) & 0xf
+    t = buf[:, 1:6].astype(np.int64)
+    t = (t - t[:, 0].min()) * 0.01     # microseconds (100 MHz)
+    print(f"## {title}: {n} workgroups; kernel span {t[:, 4].max():.1f} us")
+    print("#    wg xcc se sh cu tg | start staged walked rebuilt end (us)")
+    cuid = ((xcc * 8 + se) * 2 + sh) * 16 + cu
+    order = np.lexsort((t[:, 0], cuid))
+    for i in order[:rows]:
+        print(f"{i:5d} {xcc[i]} {se[i]} {sh[i]} {cu[i]:2d} {tg[i]:2d} | " + " ".join(f"{v:7.2f}" for v in t[i]))
+    ph = np.diff(t, axis=1)
+    later = t[:, 0] > 1.0
+    print("# distinct CUs:", len(set(cuid.tolist())), " tg values:", sorted(set(tg.tolist())))
+    print("# mean phase lengths (us), all:          stage %.2f walk %.2f link+rebuild %.2f stream-out %.2f" % tuple(ph.mean(axis=0)))
+    if later.any():
+        print("# mean phase lengths (us), after round 1: stage %.2f walk %.2f link+rebuild %.2f stream-out %.2f" % tuple(ph[later].mean(axis=0)))
+    print("# mean workgroup latency %.2f us; workgroups per CU slot %.1f" % ((t[:, 4] - t[:, 0]).mean(), n / 512.0))
+
+
+lib.proxtv_set_option(b"trace", 1)
+device.tv1_2d(x, lam, out=y)     # the last launch of a DR solve is the final row sweep (OP_DR_ROW_FINAL: two-operand input, epilogue fetches)
+report("row sweep, DR_ROW_FINAL")
+device.tv1_fibres(x, lam, 0, out=y)
+report("column sweep (transposed tile), OP_PROX")
+device.tv1_fibres(x, lam, 1, out=y)
+report("row sweep, OP_PROX")
+lib.proxtv_set_option(b"trace", 0)
