@@ -24,6 +24,8 @@ Options &options() {
         if (const char *e = getenv("PROXTV_BLOCKS_PER_WG")) v.blocks_per_wg = atoi(e);
         if (const char *e = getenv("PROXTV_CHUNK_MIN_LEN")) v.chunk_min_len = atoi(e);
         if (const char *e = getenv("PROXTV_ROUNDS")) v.rounds = atoi(e);
+        if (const char *e = getenv("PROXTV_ALONG")) v.along = atoi(e);
+        if (const char *e = getenv("PROXTV_ALONG_MIN_LEN")) v.along_min_len = atoi(e);
         if (const char *e = getenv("PROXTV_CHUNK_MODE")) v.chunk_mode = atoi(e);
         return v;
     }();

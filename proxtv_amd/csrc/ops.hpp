@@ -128,10 +128,13 @@ template <> struct Op<OP_DR_COL_FINAL> : InA {
 // Both are t = 0.5 (t + (s' + 2 prox(v))) once U - v is replaced by s' (it IS s' up to the rounding of v): evaluated
 // in that form, which needs s' and t but not U at the epilogue -- a few ulps of |U| away from the reference's order.
 template <> struct Op<OP_DR_ROW> : InBminusA, NotFused {
-#ifdef PTV_NO_KEEP
-    static constexpr bool KEEP = false;
+    // s' is staged for the walk (y = U - s') and needed again here.  Keeping it (4 array passes instead of 5) costs the
+    // kernel 32 VGPRs it does not have at two workgroups per CU -- measured 4 % slower than fetching it again, and
+    // the second read is served by the memory-side cache; the switch stays for builds with a roomier register budget.
+#ifdef PTV_KEEP_STAGED
+    static constexpr bool KEEP = true;
 #else
-    static constexpr bool KEEP = true;   // s' is staged for the walk (y = U - s') and needed again here: 4 array passes, not 5
+    static constexpr bool KEEP = false;
 #endif
     __device__ static __forceinline__ Ext fetch_rest(const SweepArgs &p, long idx, double sp) { return Ext{sp, p.c[idx]}; }
     __device__ static __forceinline__ Ext fetch(const SweepArgs &p, long idx) { return Ext{p.a[idx], p.c[idx]}; }

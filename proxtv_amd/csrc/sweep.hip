@@ -33,6 +33,7 @@
 #include <memory>
 
 #include "chunkcore.hpp"
+#include "walk_asm.hpp"
 #include "policy.hpp"
 #include "walker.hpp"
 
@@ -208,7 +209,11 @@ constexpr int kOverflow = 48;   // samples a walk of the robust instantiation ma
 template <int OP, bool WEIGHTED, int PITCH, bool PAST>
 __device__ __forceinline__ void walk_chunk(Walker &w, ChunkRec &rec, const LdsWin<WEIGHTED, PITCH> &win, const FarFibre<OP> &far,
                                            int hi, int cs, int ce, int len, double lam) {
-    walk_interior<WEIGHTED>(w, rec, win, min(len - 1, hi), cs, ce, lam);
+#ifndef PTV_NO_ASM_WALK
+    if constexpr (!WEIGHTED) walk_interior_asm<PITCH>(w, rec, win, min(len - 1, hi), cs, ce, lam);
+    else
+#endif
+        walk_interior<WEIGHTED>(w, rec, win, min(len - 1, hi), cs, ce, lam);
     TailSource<WEIGHTED, PAST, kOverflow, LdsWin<WEIGHTED, PITCH>, FarFibre<OP>> tail{win, far, rec, cs, ce, hi, len};
     walker_run<WEIGHTED>(w, tail, len, lam);
     if (rec.failed) rec.next = 0;   // ran off the window: nothing this lane recorded may be trusted
@@ -437,6 +442,23 @@ __global__ __launch_bounds__(64 * NW, ((WEIGHTED || H > 16) ? NW / 4 : NW / 2)) 
         }
         // carried to the next block's first chunk; two slots in turn, so that no barrier is needed before the write
         if (wave == NW - 1) codes[(NW + (kb & 1)) * 64 + lane] = (bad || !has_chunk) ? rec.next : (rec.next | kLinkCertain);
+        // Non-fused ops: the operand fetches of the epilogue's first batch of rows go out now and fly while the rebuild
+        // runs (the walk's registers are free by now); the second batch is fetched while the first is stored.
+        const int ce_wg = min(len, cs_wg + NW * C);
+#ifdef PTV_PREFETCH_EPILOGUE   // measured: the 32 VGPRs it holds across the rebuild spill at two workgroups per CU, 14 % slower
+        constexpr bool PREFETCH = !TRANSPOSED && !Op<OP>::FUSED && !KEEP;
+#else
+        constexpr bool PREFETCH = false;
+#endif
+        constexpr int NPRE = UL;   // (all C rows would not fit the register budget next to the rebuild)
+        Ext pre[PREFETCH ? NPRE : 1];
+        if (PREFETCH && active && !(plan.ablate & 2)) {
+#pragma unroll
+            for (int m = 0; m < NPRE; m++) {
+                const int k = min(cs_wg + wave + NW * m, ce_wg - 1);
+                pre[PREFETCH ? m : 0] = Op<OP>::fetch(p, base + (long)k * g.inc);
+            }
+        }
         int wlo = cs_wg;   // first row this lane may write
         if (GUARD) {
             const unsigned long long mask = __ballot(bad);
@@ -454,7 +476,6 @@ __global__ __launch_bounds__(64 * NW, ((WEIGHTED || H > 16) ? NW / 4 : NW / 2)) 
         if (kb == 0) trace_mark(plan, 4);
 
         // ---- stream the block's NW*C rows out: coalesced 512-byte rows, UL operand fetches in flight per lane ------------------
-        const int ce_wg = min(len, cs_wg + NW * C);
         if (!(plan.ablate & 2)) {
             if (!TRANSPOSED) {
                 if (active) {
@@ -466,6 +487,7 @@ __global__ __launch_bounds__(64 * NW, ((WEIGHTED || H > 16) ? NW / 4 : NW / 2)) 
                         for (int u = 0; u < UL; u++) {
                             const int k = min(cs_wg + wave + NW * (m0 + u), ce_wg - 1);
                             if (KEEP) ex[u] = Op<OP>::fetch_rest(p, base + (long)k * g.inc, kept[KEEP ? m0 + u : 0]);
+                            else if (PREFETCH && m0 == 0) ex[u] = pre[PREFETCH ? u : 0];
                             else if (!Op<OP>::FUSED) ex[u] = Op<OP>::fetch(p, base + (long)k * g.inc);
                         }
 #pragma unroll
@@ -510,6 +532,143 @@ __global__ __launch_bounds__(64 * NW, ((WEIGHTED || H > 16) ? NW / 4 : NW / 2)) 
         if (kb + 1 < nblk) __syncthreads();   // every wave is done reading this block's window
     }
     trace_mark(plan, 5);
+}
+
+// ---- kernel 2a: speculative chunks ALONG the fibre (dimension-0 sweeps, unweighted) -------------------------------------
+// Fibres of dimension 0 are contiguous in memory, so 64 consecutive chunks of ONE fibre can share a wavefront: lane l
+// owns chunk l of a 64-chunk segment.  The segment (+ zone and look-ahead rows) is copied into LDS as it lies in
+// memory -- 512-byte coalesced loads, no transposition -- and everything after that stays inside the wave: the walks
+// read the shared copy (a lane's zone IS its neighbour's chunk: no row is staged twice but the H + T rows at the two
+// ends of a 1088-sample segment, 2 %), a link is proven with one lane shuffle, the rebuild follows the same ownership
+// rule, the outputs leave as 512-byte rows.  No workgroup barrier anywhere: the four waves of a workgroup are only
+// scheduled together, so the memory phases of one wave overlap the walks of the others on the same CU.
+// Chunks are 17 samples long, not 16: lane l walks rows 17 l + t of the linear LDS copy, and 17 is odd, so the 64 lanes
+// of a read hit 32 different bank pairs -- the floor for 8-byte accesses -- without any padding (with 16 they would
+// hit two).
+constexpr int kAlongC = 17;
+constexpr int kAlongSeg = 64 * kAlongC;
+constexpr int kAlongWaves = 4;
+
+template <int OP, int H>
+__global__ __launch_bounds__(64 * kAlongWaves) void sweep_along_kernel(SweepArgs p, FibreGeom g, ChunkPlan plan, link_t *code_mine,
+                                                                        link_t *code_next, int *failflags) {
+    constexpr int C = kAlongC, SEG = kAlongSeg, T = tail_rows(H), ROWS = H + SEG + T;
+    constexpr int NU = (ROWS + 63) / 64;     // staged elements per lane
+    constexpr int NO = SEG / 64;             // output elements per lane
+    constexpr int UL = 8;                    // epilogue operand fetches in flight per lane
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (p.gate && *p.gate == 0) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double *Yp = reinterpret_cast<double *>(smem) + (size_t)wave * (ROWS + 2);
+    const int len = g.len;
+    const int nseg = (len + SEG - 1) / SEG, NC = (len + C - 1) / C;
+    const long wid = (long)blockIdx.x * kAlongWaves + wave;   // one wave = one segment of one fibre
+    const long j = wid / nseg;
+    const int sg = (int)(wid % nseg);
+    if (j >= g.count) return;                // (wave-uniform; nothing in this kernel synchronises across waves)
+    if (plan.trace && lane == 0) {
+        unsigned hwid, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        plan.trace[8 * (size_t)wid] = ((unsigned long long)xcc << 32) | hwid;
+        plan.trace[8 * (size_t)wid + 1] = wall_clock64();
+    }
+    const long fbase = j * len;
+    const int seg_s = sg * SEG, seg_e = min(len, seg_s + SEG);
+    const int lo = seg_s - H, hi = min(len, seg_s + SEG + T);
+
+    // ---- stage: the segment as it lies in memory ---------------------------------------------------------------------------
+    if (!(plan.ablate & 4)) {
+        double s0[NU], s1[NU];
+#pragma unroll
+        for (int u = 0; u < NU; u++) {
+            const int r = lo + 64 * u + lane;
+            s0[u] = s1[u] = 0.0;
+            if (r >= 0 && r < hi) Op<OP>::fetch_in(p, fbase + r, s0[u], s1[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < NU; u++) {
+            const int r = lo + 64 * u + lane;
+            if (r >= 0 && r < hi) Yp[r - lo] = Op<OP>::y_of(p, s0[u], s1[u]);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (plan.trace && lane == 0) plan.trace[8 * (size_t)wid + 2] = wall_clock64();
+
+    // ---- speculative walk of this lane's chunk ---------------------------------------------------------------------------------
+    const int cs = seg_s + lane * C;
+    const int ce = min(cs + C, len);
+    const bool has_chunk = cs < seg_e;
+    const int start = max(0, cs - H);
+    const LdsWin<false, 1> win{(lds_double *)Yp, (lds_double *)Yp, lo};
+    const FarFibre<OP> far{p, fbase, 1, 0};
+    ChunkRec rec;
+    bool certain = false;
+    if (has_chunk && !(plan.ablate & 1)) {
+        Walker w;
+        constexpr int kLook = 8;
+        int cat = -1, ctype = 0;
+        if (start > 0 && H <= kWarm && p.lam > 0.0) cat = certain_bend_before<false, kLook>(win, cs, len, p.lam, ctype);
+        if (cat >= 0) {
+            certain = true;
+            walker_restart_with<false>(w, cat, ctype, len, p.lam, win.y(cat), 0.0, 0.0);
+            rec.mine = rec.next = rec.last = ((link_t)cat << 1) | (link_t)ctype;
+        } else {
+            walker_start<false>(w, win, start, p.lam);
+        }
+        walk_chunk<OP, false, 1, false>(w, rec, win, far, hi, cs, ce, len, p.lam);
+    }
+    if (plan.trace && lane == 0) plan.trace[8 * (size_t)wid + 3] = wall_clock64();
+
+    // ---- links: the predecessor is the lane before (lane 0's is in another wave: left to the repair kernel) ---------------------
+    const link_t prev_next = (link_t)__shfl_up((int)rec.next, 1);
+    const bool linked = has_chunk && !(start == 0 || certain) && lane > 0;
+    const bool bad = has_chunk && (rec.failed || (linked && (rec.mine == 0 || rec.mine != prev_next)));
+    if (has_chunk) {
+        if (rec.failed) {
+            rec.mine = kLinkBad;
+            rec.next = 0;
+        }
+        const int chunk = sg * 64 + lane;
+        if (bad) flag_chunk(failflags, j, chunk, NC);
+        code_mine[j * NC + chunk] = (certain && rec.mine != kLinkBad) ? (rec.mine | kLinkCertain) : rec.mine;
+        code_next[j * NC + chunk] = rec.next;
+    }
+    // a lane's writes stop at the nearest unproven chunk before it (see GUARD in sweep_chunk_kernel; needed for H > C)
+    int wlo = seg_s;
+    if (H > C) {
+        const unsigned long long below = __ballot(bad) & ((1ull << lane) - 1ull);
+        if (below) wlo = seg_s + (63 - __clzll((long long)below)) * C;
+    }
+    if (has_chunk && !(plan.ablate & 1))
+        rebuild_owned<Op<OP>, false, C>(win, rec, cs, ce, len, start, !bad, wlo, lane == 63 || ce == len, p.lam);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (plan.trace && lane == 0) plan.trace[8 * (size_t)wid + 4] = wall_clock64();
+
+    // ---- stream the segment out ---------------------------------------------------------------------------------------------------
+    if (!(plan.ablate & 2)) {
+#pragma unroll
+        for (int t0 = 0; t0 < NO; t0 += UL) {
+            Ext ex[UL];
+#pragma unroll
+            for (int u = 0; u < UL; u++) {
+                const int k = seg_s + 64 * (t0 + u) + lane;
+                ex[u] = (t0 + u < NO && k < seg_e && !Op<OP>::FUSED) ? Op<OP>::fetch(p, fbase + k) : Ext{0, 0};
+            }
+#pragma unroll
+            for (int u = 0; u < UL; u++) {
+                const int k = seg_s + 64 * (t0 + u) + lane;
+                if (t0 + u < NO && k < seg_e) {
+                    const double v = Yp[k - lo];
+                    if (Op<OP>::FUSED) Op<OP>::store_fused(p, fbase + k, v);
+                    else               Op<OP>::finish(p, fbase + k, ex[u], v);
+                }
+            }
+        }
+    }
+    if (plan.trace && lane == 0) plan.trace[8 * (size_t)wid + 5] = wall_clock64();
 }
 
 // ---- kernel 2b: speculative chunks straight from global memory (long pieces) ---------------------------------------------------
@@ -589,8 +748,8 @@ constexpr link_t kFromStart = 1;   // "no bend yet: the true walk is still in it
 
 // what a repair walk keeps track of, whatever it reads its samples from
 struct RepairBook {
-    const link_t *code_mine;   // [chunk][fibre]
-    long count, j;
+    const link_t *code_mine;   // code of (chunk c, fibre j) at [c * cstride + j * fstride]
+    long cstride, fstride, j;
     int C, len;
     int wfrom = 0;             // outputs are (re)written from this sample on
     int boundary = 0;          // next chunk boundary whose chunk may take over
@@ -613,7 +772,7 @@ struct RepairBook {
         while (!stop && boundary < len && at >= boundary) {
             const link_t here = (at == boundary) ? code : last;      // this walk's last bend at-or-before `boundary`
             const int c = boundary / C;
-            link_t m = code_mine[(long)c * count + j];
+            link_t m = code_mine[(long)c * cstride + j * fstride];
             if (m != kLinkBad) m &= ~kLinkCertain;
             if (m != 0 && m == here) {
                 stop = true;
@@ -726,7 +885,7 @@ struct WindowRepairSource : RepairBook {
 template <int OP, bool WEIGHTED>
 __global__ __launch_bounds__(64) void sweep_repair_kernel(SweepArgs p, FibreGeom g, int C, int H, int chunks_per_wg,
                                                            const link_t *code_mine, const link_t *code_next,
-                                                           int *failflags, int *failcount) {
+                                                           int *failflags, int *failcount, long cstride, long fstride) {
     extern __shared__ __attribute__((aligned(16))) double repair_lds[];   // (2 + WEIGHTED) planes of kRepairWindow x 64 (LDS geometries only)
     const long j = (long)blockIdx.x * 64 + threadIdx.x;
     if (j >= g.count) return;
@@ -748,8 +907,8 @@ __global__ __launch_bounds__(64) void sweep_repair_kernel(SweepArgs p, FibreGeom
 #pragma unroll
         for (int u = 0; u < UB; u++) {
             const int c = min(c0 + u * chunks_per_wg, NC - 1);
-            in[u] = code_mine[(long)c * g.count + j];
-            out[u] = code_next[(long)(c - 1) * g.count + j];
+            in[u] = code_mine[(long)c * cstride + j * fstride];
+            out[u] = code_next[(long)(c - 1) * cstride + j * fstride];
         }
 #pragma unroll
         for (int u = 0; u < UB; u++) {
@@ -768,14 +927,14 @@ __global__ __launch_bounds__(64) void sweep_repair_kernel(SweepArgs p, FibreGeom
 
     const long blk = j / g.inc, off = j % g.inc;
     const long base = blk * g.inc * len + off, wbase = blk * g.inc * (len - 1) + off;
-    const RepairBook book{code_mine, g.count, j, C, len};
+    const RepairBook book{code_mine, cstride, fstride, j, C, len};
     const bool windowed = H <= kWarmLong;
     RepairSource<OP, WEIGHTED> gsrc(book, p, base, g.inc, wbase);
     WindowRepairSource<OP, WEIGHTED> wsrc(book, p, base, g.inc, wbase, repair_lds, (int)threadIdx.x);
     // every chunk before `first` is proven: the true walk's last bend there is the last non-zero `next` code before it
     link_t cur = kFromStart;
     for (int b = first - 1; b >= 0; b--) {
-        const link_t nx = code_next[(long)b * g.count + j];
+        const link_t nx = code_next[(long)b * cstride + j * fstride];
         if (nx != 0) {
             cur = nx;
             break;
@@ -794,8 +953,8 @@ __global__ __launch_bounds__(64) void sweep_repair_kernel(SweepArgs p, FibreGeom
 #pragma unroll
             for (int u = 0; u < UB; u++) {
                 const int cc = min(c + u, NC - 1);
-                mm[u] = code_mine[(long)cc * g.count + j];
-                nn[u] = code_next[(long)cc * g.count + j];
+                mm[u] = code_mine[(long)cc * cstride + j * fstride];
+                nn[u] = code_next[(long)cc * cstride + j * fstride];
             }
             const int c0 = c;
 #pragma unroll
@@ -1042,7 +1201,38 @@ void launch_chunk_h(const SweepArgs &args, const FibreGeom &g, hipStream_t strea
             rattr_set = true;
         }
         hipLaunchKernelGGL(rkern, dim3((unsigned)groups), dim3(64), rlds, stream, args, g, C, H, plan.qpw * NW,
-                           g_chunk.code_mine, g_chunk.code_next, g_chunk.failflags, g_chunk.failcount + 2 * fam);
+                           g_chunk.code_mine, g_chunk.code_next, g_chunk.failflags, g_chunk.failcount + 2 * fam, (long)g.count, 1L);
+    }
+    PTV_HIP(hipGetLastError());
+    g_chunk.pol[fam].chunks_done += (long)NC * g.count;
+}
+
+// Chunks along the fibre (kernel 2a): dimension-0 sweeps, unweighted.  Codes are laid out [fibre][chunk] (a wave writes
+// the codes of 64 consecutive chunks of one fibre).
+template <int OP, int H>
+void launch_along(const SweepArgs &args, const FibreGeom &g, hipStream_t stream, int fam) {
+    constexpr int C = kAlongC, ROWS = H + kAlongSeg + tail_rows(H);
+    const int nseg = (g.len + kAlongSeg - 1) / kAlongSeg;
+    const int NC = (g.len + C - 1) / C;
+    const long waves = g.count * nseg;
+    ChunkPlan plan{};
+    plan.ablate = options().ablate;
+    g_chunk.ensure(g.count, NC, stream);
+    plan.trace = options().trace ? g_chunk.trace_buffer((size_t)waves) : nullptr;
+    constexpr size_t lds = sizeof(double) * (size_t)(ROWS + 2) * kAlongWaves;
+    auto kern = sweep_along_kernel<OP, H>;
+    hipLaunchKernelGGL(kern, dim3((unsigned)((waves + kAlongWaves - 1) / kAlongWaves)), dim3(64 * kAlongWaves), lds, stream, args, g,
+                       plan, g_chunk.code_mine, g_chunk.code_next, g_chunk.failflags);
+    if (!plan.ablate) {
+        constexpr size_t rlds = sizeof(double) * 2 * kRepairWindow * 64;
+        auto rkern = sweep_repair_kernel<OP, false>;
+        static thread_local bool rattr_set = false;
+        if (!rattr_set) {
+            PTV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(rkern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rlds));
+            rattr_set = true;
+        }
+        hipLaunchKernelGGL(rkern, dim3((unsigned)((g.count + 63) / 64)), dim3(64), rlds, stream, args, g, C, H, 64, g_chunk.code_mine,
+                           g_chunk.code_next, g_chunk.failflags, g_chunk.failcount + 2 * fam, 1L, (long)NC);
     }
     PTV_HIP(hipGetLastError());
     g_chunk.pol[fam].chunks_done += (long)NC * g.count;
@@ -1057,7 +1247,7 @@ void launch_gchunk(const SweepArgs &args, const FibreGeom &g, int C, int H, hipS
     hipLaunchKernelGGL((sweep_gchunk_kernel<OP, WEIGHTED>), dim3((unsigned)groups, (unsigned)NC), dim3(64), 0, stream, args,
                        g, C, H, g_chunk.code_mine, g_chunk.code_next, g_chunk.failflags);
     hipLaunchKernelGGL((sweep_repair_kernel<OP, WEIGHTED>), dim3((unsigned)groups), dim3(64), 0, stream, args, g, C, H, 1,
-                       g_chunk.code_mine, g_chunk.code_next, g_chunk.failflags, g_chunk.failcount + 2 * fam);
+                       g_chunk.code_mine, g_chunk.code_next, g_chunk.failflags, g_chunk.failcount + 2 * fam, (long)g.count, 1L);
     PTV_HIP(hipGetLastError());
     g_chunk.pol[fam].chunks_done += (long)NC * g.count;
 }
@@ -1088,8 +1278,14 @@ void launch_chunk(const SweepArgs &args, const FibreGeom &g, hipStream_t stream,
     else if (mode == 3)    launch_gchunk<OP, WEIGHTED>(args, g, 64, 256, stream, fam);
     else if (mode == 4)    launch_gchunk<OP, WEIGHTED>(args, g, 256, 1024, stream, fam);
     else if constexpr (!WEIGHTED) {
-        if (mode == 2) launch_chunk_h<OP, false, TRANSPOSED, kWarmLong>(args, g, stream, fam, 0);
-        else           launch_chunk_h<OP, false, TRANSPOSED, kWarm>(args, g, stream, fam, rounds);
+        // dimension 0: chunks along the fibre once a fibre fills most of a wave's 64 chunks (modes 1 and 2 both mean "a
+        // longer zone" there); otherwise, and for the other dimensions, the 64-fibre tile
+        if (TRANSPOSED && options().along && g.len >= options().along_min_len) {
+            if (mode == 0) launch_along<OP, kWarm>(args, g, stream, fam);
+            else           launch_along<OP, kWarmLong>(args, g, stream, fam);
+        }
+        else if (mode == 2) launch_chunk_h<OP, false, TRANSPOSED, kWarmLong>(args, g, stream, fam, 0);
+        else                launch_chunk_h<OP, false, TRANSPOSED, kWarm>(args, g, stream, fam, rounds);
     } else {
         launch_chunk_h<OP, true, TRANSPOSED, kWarm>(args, g, stream, fam, rounds);
     }

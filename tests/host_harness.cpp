@@ -68,10 +68,10 @@ struct Identity {
     static double fuse(double, double x) { return x; }
 };
 
-template <bool WEIGHTED, bool PAST, class F>
+template <bool WEIGHTED, bool PAST, class F, int C = 16>
 int chunk_fibre(const double *y, const double *w, double lam, int len, int H, int T, int NW, int seed, double *x,
                 int *first_bad, int *write_errors) {
-    constexpr int C = 16, LOOK = 8;
+    constexpr int LOOK = 8;
     std::mt19937 rng((unsigned)seed);
     const int Q = (len + NW * C - 1) / (NW * C);
     *first_bad = -1;
@@ -171,6 +171,9 @@ extern "C" {
 int host_chunk_fibre(const double *y, const double *w, double lam, int len, int H, int T, int NW, int past, int seed,
                      double *x, int *first_bad, int *write_errors) {
     const bool refl = seed & 1;   // both rebuild flavours: outputs that depend on the row's own sample, and that do not
+    if (!w && NW == 64)   // the along-fibre kernel's geometry: 64 chunks of 17 samples per wave
+        return refl ? chunk_fibre<false, false, Reflect, 17>(y, w, lam, len, H, T, NW, seed, x, first_bad, write_errors)
+                    : chunk_fibre<false, false, Identity, 17>(y, w, lam, len, H, T, NW, seed, x, first_bad, write_errors);
     if (w) {
         if (refl) return past ? chunk_fibre<true, true, Reflect>(y, w, lam, len, H, T, NW, seed, x, first_bad, write_errors)
                               : chunk_fibre<true, false, Reflect>(y, w, lam, len, H, T, NW, seed, x, first_bad, write_errors);

@@ -61,7 +61,7 @@ def test_chunked_walk_equals_oracle_unweighted(harness, oracle):
         y = families(rng, n)
         lam = float(rng.choice([0.0, 0.02, 0.1, 0.3, 1.0]) * abs(rng.standard_normal()))
         truth = oracle.tv1_linearized(y, lam)
-        for (H, T, NW, past) in ((16, 8, 8, 0), (16, 8, 8, 1), (64, 64, 8, 0), (16, 8, 3, 0)):
+        for (H, T, NW, past) in ((16, 8, 8, 0), (16, 8, 8, 1), (64, 64, 8, 0), (16, 8, 3, 0), (16, 8, 64, 0), (64, 64, 64, 0)):
             x, fb, we = run(harness, y, lam, H=H, T=T, NW=NW, past=past, seed=t)
             covered += check(x, fb, we, truth, H, max(1.0, np.max(np.abs(y))))
             total += n
@@ -74,9 +74,10 @@ def test_chunked_walk_headline_regime_is_fully_proven(harness, oracle):
         n = int(rng.integers(100, 3000))
         y = rng.standard_normal(n)
         truth = oracle.tv1_linearized(y, 0.1)
-        x, fb, we = run(harness, y, 0.1, seed=t)
-        assert fb < 0 and we == 0
-        assert np.max(np.abs(x - truth)) <= 1e-14 * np.max(np.abs(y))
+        for NW in (8, 64):     # 64-fibre tile geometry; along-fibre geometry (64 chunks of 17 samples per wave)
+            x, fb, we = run(harness, y, 0.1, NW=NW, seed=t)
+            assert fb < 0 and we == 0
+            assert np.max(np.abs(x - truth)) <= 1e-14 * np.max(np.abs(y))
 
 
 def test_chunked_walk_equals_oracle_weighted(harness, oracle):

@@ -17,8 +17,8 @@ device.tv1_2d(x, lam, out=y)
 
 
 def report(title, rows=16):
-    buf = np.zeros((8192, 8), dtype=np.uint64)
-    n = lib.proxtv_debug_trace(buf.ctypes.data, 8192)
+    buf = np.zeros((32768, 8), dtype=np.uint64)
+    n = lib.proxtv_debug_trace(buf.ctypes.data, 32768)
     buf = buf[:n]
     hw = buf[:, 0]
     hwid = (hw & np.uint64(0xffffffff)).astype(np.int64)
@@ -38,14 +38,14 @@ def report(title, rows=16):
     print("# mean phase lengths (us), all:          stage %.2f walk %.2f link+rebuild %.2f stream-out %.2f" % tuple(ph.mean(axis=0)))
     if later.any():
         print("# mean phase lengths (us), after round 1: stage %.2f walk %.2f link+rebuild %.2f stream-out %.2f" % tuple(ph[later].mean(axis=0)))
-    print("# mean workgroup latency %.2f us; workgroups per CU slot %.1f" % ((t[:, 4] - t[:, 0]).mean(), n / 512.0))
+    print("# mean workgroup latency %.2f us; %d records (one per workgroup; the along-fibre kernel: one per wave)" % ((t[:, 4] - t[:, 0]).mean(), n))
 
 
 lib.proxtv_set_option(b"trace", 1)
 device.tv1_2d(x, lam, out=y)     # the last launch of a DR solve is the final row sweep (OP_DR_ROW_FINAL: two-operand input, epilogue fetches)
 report("row sweep, DR_ROW_FINAL")
 device.tv1_fibres(x, lam, 0, out=y)
-report("column sweep (transposed tile), OP_PROX")
+report("column sweep (chunks along the fibre, one record per wave), OP_PROX")
 device.tv1_fibres(x, lam, 1, out=y)
 report("row sweep, OP_PROX")
 lib.proxtv_set_option(b"trace", 0)
