@@ -13,7 +13,14 @@ ranks wall time.  Rank 0 prints ONE JSON line.
 Extra objects on that line:
   roofline     -- the dominant sweep kernel: algorithmic HBM bytes per launch / average launch duration, measured
                   with hipEvents on the library's own stream during K further solves right after the timed ones (the
-                  events cost ~0.8 ms per solve, so they stay out of the timed region; DESIGN.md "Measurement").
+                  events cost ~0.8 ms per solve, so they stay out of the timed region; DESIGN.md "Measurement");
+                  `by_kernel` = the same fraction for every sweep flavour (DR_COL, DR_ROW inside the solve; plain OP_PROX
+                  sweeps in both directions measured on their own), `solve_frac` = the whole solve's algorithmic bytes
+                  / ms_per_step / peak; `traffic` = PMC-measured HBM bytes per launch from profiles/, or null when that
+                  file was measured on another build of the kernels (build id = hash of the kernel sources).
+  step_ms      -- min / median / max of the K timed steps.
+  c5           -- BASELINE config #5 per rank: 64 independent 2048x2048 images through proxtv_DR2_TV_batch_dev, solver
+                  time and (N > 1) the RCCL gather to rank 0 timed separately.
   cpu_baseline -- the compiled reference (oracle/_ref, kind "reference") or, if it did not travel, this repo's
                   C restatement (kind "port"), timed on the host cores on a bounded sample (rank 0, N = 1 only).
 """
@@ -70,6 +77,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-c5", action="store_true", help="skip the config-#5 object (64 x 2048^2 per rank, ~13 GiB of HBM)")
     args = ap.parse_args()
 
     import torch
@@ -108,10 +116,14 @@ def main():
         device.tv1_2d(xd, LAM, out=yd)
 
     # ---- the timed region: exactly K solves, nothing but the product path -------------------------------------------
+    # (every solve returns synchronised, so the per-step stamps cost nothing)
+    step_t = []
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
+        ts = time.perf_counter()
         _, info = device.tv1_2d(xd, LAM, out=yd)
+        step_t.append(time.perf_counter() - ts)
     barrier()
     dt = time.perf_counter() - t0
     assert int(info[0]) == ITERS, info
@@ -131,7 +143,50 @@ def main():
             fam_n[f] += lib.proxtv_last_kernel_launches(f)
     barrier()
     dt_events = time.perf_counter() - t1
+    # plain 1-D prox sweeps (OP_PROX: what PD / Yang / batched tv1_1d launch) in both directions, the same way
+    prox_ms = {}
+    for dim, name in ((0, "prox_col"), (1, "prox_row")):
+        tot, cnt = 0.0, 0
+        for _ in range(max(2, args.steps)):
+            device.tv1_fibres(xd, LAM, dim, out=yd)
+            tot += lib.proxtv_last_kernel_ms(dim)
+            cnt += lib.proxtv_last_kernel_launches(dim)
+        prox_ms[name] = tot / max(cnt, 1)
     lib.proxtv_set_option(b"profile", 0)
+
+    # ---- BASELINE config #5: 64 independent 2048^2 images per rank, then the gather --------------------------------------
+    c5 = None
+    if not args.no_c5:
+        B5, S5 = 64, 2048
+        g5 = torch.Generator(device="cuda").manual_seed(1000 + rank)
+        x5 = torch.randn((B5, S5, S5), dtype=torch.float64, device="cuda", generator=g5).permute(2, 1, 0)   # column-major (M, N, B)
+        y5 = device.colmajor_empty((S5, S5, B5))
+        device.tv1_2d_batch(x5, LAM, out=y5)
+        barrier()
+        ts = time.perf_counter()
+        device.tv1_2d_batch(x5, LAM, out=y5)
+        barrier()
+        t_solve = time.perf_counter() - ts
+        t_gather = None
+        if world > 1 and not shared:
+            send = y5.permute(2, 1, 0)                      # (B, N, M) contiguous view of the same bytes
+            bufs = [torch.empty_like(send) for _ in range(world)] if rank == 0 else None
+            barrier()
+            ts = time.perf_counter()
+            dist.gather(send, gather_list=bufs, dst=0)
+            barrier()
+            t_gather = time.perf_counter() - ts
+            del bufs
+        if world > 1:
+            tt = torch.tensor([t_solve], dtype=torch.float64, device="cpu" if shared else "cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            t_solve = float(tt.item())
+        c5 = {"workload": f"{B5} independent {S5}x{S5} f64 images per rank, tv1_2d DR (35 iterations), lambda={LAM}, one batched solve",
+              "images": B5 * world, "solve_ms": t_solve * 1e3, "value": world * B5 * S5 * S5 / t_solve / 1e6, "unit": "Mpixel/s",
+              "gather_ms": None if t_gather is None else t_gather * 1e3,
+              "gather_bytes": None if t_gather is None else (world - 1) * B5 * S5 * S5 * 8,
+              "ranks": world, "backend": (dist.get_backend() if world > 1 else None)}
+        del x5, y5
 
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cpu" if shared else "cuda")
@@ -147,15 +202,27 @@ def main():
         dom = 0 if fam_ms[0] >= fam_ms[1] else 1
         avg_ms = fam_ms[dom] / max(fam_n[dom], 1)
         achieved = per_px[dom] * M * N / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        # HBM bytes per launch from the committed PMC run of this same command (tools/pmc_traffic.py: FETCH_SIZE +
-        # WRITE_SIZE, separate passes, calibrated on an 8-B/lane copy of known size).  bench.py cannot run under the
-        # profiler itself, so the figure is read from profiles/; null if that run has not been made for this build.
+
+        def frac(bytes_per_px, ms):
+            return (bytes_per_px * M * N / (ms * 1e-3) / 1e9) / HBM_PEAK_GBS if ms > 0 else None
+        by_kernel = {
+            "DR_COL": {"bytes_per_px": 16, "avg_launch_ms": fam_ms[0] / max(fam_n[0], 1), "frac": frac(16, fam_ms[0] / max(fam_n[0], 1))},
+            "DR_ROW": {"bytes_per_px": 32, "avg_launch_ms": fam_ms[1] / max(fam_n[1], 1), "frac": frac(32, fam_ms[1] / max(fam_n[1], 1))},
+            "PROX_COL": {"bytes_per_px": 16, "avg_launch_ms": prox_ms["prox_col"], "frac": frac(16, prox_ms["prox_col"])},
+            "PROX_ROW": {"bytes_per_px": 16, "avg_launch_ms": prox_ms["prox_row"], "frac": frac(16, prox_ms["prox_row"])},
+        }
+        solve_bytes = 8 * M * N * (6 * ITERS + 7)          # 1736 B/pixel at 35 iterations
+        # HBM bytes per launch from the PMC run of this same command (tools/pmc_traffic.py: FETCH_SIZE + WRITE_SIZE,
+        # separate passes, calibrated on an 8-B/lane copy of known size).  bench.py cannot run under the profiler
+        # itself, so the figure is read from profiles/ -- and only if it was measured on THIS build of the kernels.
         traffic = None
         try:
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            from proxtv_amd import build as _build
+            with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as f:
                 pmc = json.load(f)
-            label = ["column sweep (DR_COL)", "row sweep (DR_ROW)"][dom]
-            traffic = pmc["kernels"][label]["hbm_total"]
+            if pmc.get("build_id") == _build.build_id():
+                label = ["column sweep (DR_COL)", "row sweep (DR_ROW)"][dom]
+                traffic = pmc["kernels"][label]["hbm_total"]
         except (OSError, KeyError, ValueError):
             pass
         line = {
@@ -173,8 +240,14 @@ def main():
                                      f"({dt_events / args.steps * 1e3:.2f} ms per solve with the events in the stream)",
                          "algorithmic_bytes_per_launch": per_px[dom] * M * N,
                          "family_ms_per_solve": {"col": fam_ms[0] / args.steps, "row": fam_ms[1] / args.steps,
-                                                 "other": fam_ms[2] / args.steps}},
+                                                 "other": fam_ms[2] / args.steps},
+                         "by_kernel": by_kernel,
+                         "solve_frac": (solve_bytes / (ms_per_step * 1e-3) / 1e9) / HBM_PEAK_GBS,
+                         "solve_algorithmic_bytes": solve_bytes},
+            "step_ms": {"min": min(step_t) * 1e3, "median": float(np.median(step_t)) * 1e3, "max": max(step_t) * 1e3},
         }
+        if c5 is not None:
+            line["c5"] = c5
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)

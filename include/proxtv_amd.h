@@ -110,11 +110,17 @@ void freeWorkspaces(Workspace **wa, int p);
 /* =============================== PART 2: MI355X-native extensions ============================== */
 
 /* Library / device state.  proxtv_init returns 0 when a gfx950 device is usable, else non-zero and
-   prints the reason.  device < 0 keeps the current HIP device. */
+   prints the reason.  device < 0 keeps the current HIP device; device >= 0 makes it current (hipSetDevice).
+   Everything the library keeps between calls (stream, scratch pool, chunk-kernel buffers, geometry policy) is
+   per host thread AND per device: a thread may move between GPUs freely (hipSetDevice / proxtv_init), every entry
+   point works on the device that is current when it is called, and pointers must belong to that device.
+   Host threads never share state: concurrent calls from several threads are safe (options below are process-wide:
+   set them before the threads start solving -- a change mid-solve takes effect at that solve's next sweep). */
 int  proxtv_init(int device);
 const char *proxtv_version(void);
 const char *proxtv_last_error(void);
-/* free every cached HBM scratch block held by the calling thread's pool */
+/* free every cached HBM scratch block held by the calling thread's pool on the current device (the pool is capped:
+   PROXTV_POOL_CAP_MB, default 65536) */
 void proxtv_release_scratch(void);
 
 /* Knobs (process-wide; returns the previous value, -1 for an unknown key).  Each also has an environment variable
@@ -131,7 +137,9 @@ int proxtv_set_option(const char *key, int value);
 /* Device-pointer solvers: every double* is an HBM pointer valid on the current device, `stream` is
    a hipStream_t (NULL = the library's per-thread stream), `info` is a HOST double[3] or NULL.
    Work is enqueued AND completed (the call synchronises `stream`) unless `info` is NULL and
-   PD-type stopping is not involved; see DESIGN.md.  Same return conventions as part 1. */
+   PD-type stopping is not involved; see DESIGN.md.  Same return conventions as part 1.
+   Aliasing: an output array may overlap an input (in-place use); the solve then runs into a scratch array that is
+   copied over the caller's at the end -- one extra pass; distinct arrays cost nothing. */
 int proxtv_DR2_TV_dev(size_t M, size_t N, const double *unary, double W1, double W2, double *s,
                       int maxit, double *info, void *stream);
 int proxtv_DR2L1W_TV_dev(size_t M, size_t N, const double *unary, const double *W1, const double *W2,

@@ -4,7 +4,8 @@ The module mirrors the Python surface of proxTV (reference: ``prox_tv/__init__.p
 same function names, argument order, defaults, assertions, dtype / memory-order coercions and return shapes,
 so ``import proxtv_amd as prox_tv`` is a drop-in for
 
-    tv1_1d, tv1w_1d, tv1_2d (methods 'dr', 'pd', 'yang'), tv1w_2d, tvp_2d (p = 1), tvgen.
+    tv1_1d, tv1w_1d, tv1_2d (all seven methods: 'dr', 'pd', 'yang', 'condat', 'chambolle-pock',
+    'chambolle-pock-acc', 'kolmogorov'), tv1w_2d, tvp_2d (p = 1), tvgen.
 
 Every call runs hand-written HIP kernels through the C-ABI of ``libproxtv_amd.so`` (``include/proxtv_amd.h``);
 there is no CPU path.  Without a gfx950 device the functions raise :class:`ProxTVError`.
@@ -13,7 +14,11 @@ New (not in the reference): :func:`tv1_2d_batch` for stacks of independent image
 for arrays that already live in HBM (torch tensors).
 
 Out of scope (raise ``NotImplementedError``): the TV-L2 / TV-Lp solvers (``tv2_1d``, ``tvp_1d``, ``tvp_2d`` with
-p != 1) and the pointwise 2-D baselines ('condat', 'chambolle-pock', 'chambolle-pock-acc', 'kolmogorov').
+p != 1).  ``tv1_1d``'s alternative method names are served by the one exact HIP solver.
+
+Reproducibility: results are exact minimisers whatever kernel geometry the adaptive policy picks, but geometries differ
+in the last ulps (refined-reciprocal division, closed-form piece values); pin one with ``PROXTV_CHUNK_MODE`` (or
+``proxtv_set_option("chunk_mode", m)``) when bit-identical reruns matter.
 """
 import numpy as np
 

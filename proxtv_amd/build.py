@@ -21,6 +21,19 @@ FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-ffp-contract=o
          "-Wall", "-Wno-unused-function"]
 
 
+def build_id():
+    """Short content hash of the kernel sources (csrc/ + the C header): what a measurement under profiles/ is keyed to,
+    so that bench.py never quotes counters of another build (there is no .git on the GPU box)."""
+    import hashlib
+    h = hashlib.sha1()
+    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".hpp")))
+    files.append(os.path.join(HERE, "..", "include", "proxtv_amd.h"))
+    for f in files:
+        with open(f, "rb") as fh:
+            h.update(os.path.basename(f).encode() + b"\0" + fh.read())
+    return h.hexdigest()[:12]
+
+
 def _newer(target, deps):
     if not os.path.exists(target):
         return True

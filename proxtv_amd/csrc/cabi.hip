@@ -5,6 +5,7 @@
 // solver of solvers.hip on the calling thread's stream and copies the result back.
 // Part 2 exposes the same solvers on device pointers.
 #include <exception>
+#include <initializer_list>
 #include <memory>
 #include <vector>
 
@@ -23,6 +24,7 @@ template <class F>
 int guarded(const char *who, double *info, int ok_ret, F &&body) {
     try {
         set_error("");
+        (void)hipGetLastError();   // an error another HIP user of this thread left behind is not ours to report
         ensure_device();
         body();
         return ok_ret;
@@ -67,6 +69,32 @@ void put_info(double *info, const SolveInfo &si) {
 
 hipStream_t pick(void *stream) { return stream ? (hipStream_t)stream : thread_stream(); }
 
+// Device entry points: an output array that overlaps an input.  The chunked sweeps read their operands through windows
+// that reach into rows other workgroups own, and the splitting loops read the input every iteration while the iterate
+// is written, so in-place use would race.  Overlap is therefore detected here and the solve goes to a scratch array
+// that is copied to the caller's at the end (one extra pass); distinct arrays cost nothing.
+struct OutGuard {
+    double *user;
+    size_t count;
+    std::unique_ptr<Scratch> tmp;
+    struct In { const double *p; size_t n; };
+    OutGuard(double *out, size_t n, std::initializer_list<In> inputs) : user(out), count(n) {
+        const char *o0 = reinterpret_cast<const char *>(out), *o1 = o0 + sizeof(double) * n;
+        for (const In &in : inputs) {
+            if (!in.p || !in.n) continue;
+            const char *i0 = reinterpret_cast<const char *>(in.p), *i1 = i0 + sizeof(double) * in.n;
+            if (i0 < o1 && o0 < i1) {
+                tmp.reset(new Scratch(sizeof(double) * (n ? n : 1)));
+                break;
+            }
+        }
+    }
+    double *ptr() const { return tmp ? tmp->d() : user; }
+    void commit(hipStream_t s) {
+        if (tmp && count) PTV_HIP(hipMemcpyAsync(user, tmp->d(), sizeof(double) * count, hipMemcpyDeviceToDevice, s));
+    }
+};
+
 struct SolveScope {
     hipStream_t s;
     explicit SolveScope(hipStream_t st) : s(st) {
@@ -85,6 +113,7 @@ struct SolveScope {
 void prox1d_host(const double *y, const double *w, double lam, double *x, int n, double first_offset) {
     if (n <= 0) return;
     hipStream_t s = thread_stream();
+    SolveScope scope(s);   // per-call counters, profile option, the policy's across-call exploration
     Staged in(y, (size_t)n, s);
     if (first_offset != 0.0) {
         // a start `offset` above the tube centre == the same tube with its first increment lowered by `offset`
@@ -97,6 +126,7 @@ void prox1d_host(const double *y, const double *w, double lam, double *x, int n,
     const int ns[1] = {n};
     tv1_fibres(in.d(), out.d(), ns, 1, 0, lam, wd ? wd->d() : nullptr, s);
     download(x, out.d(), (size_t)n, s);
+    scope.finish();
 }
 
 void check_norms(const double *norms, int npen) {
@@ -336,6 +366,7 @@ int proxtv_init(int device) {
         (void)thread_stream();
         return 0;
     } catch (...) {
+        (void)hipGetLastError();   // (a failed hipSetDevice must not resurface after this thread's next launch)
         printf("proxtv_init: %s\n", last_error());
         fflush(stdout);
         return 1;
@@ -384,7 +415,9 @@ int proxtv_DR2_TV_batch_dev(size_t M, size_t N, size_t B, const double *unary, d
     return guarded("proxtv_DR2_TV_batch_dev", info, 0, [&] {
         hipStream_t st = pick(stream);
         SolveScope scope(st);
-        const SolveInfo si = dr2(M, N, B, unary, W1, W2, nullptr, nullptr, s, maxit, st);
+        OutGuard out(s, M * N * B, {{unary, M * N * B}});
+        const SolveInfo si = dr2(M, N, B, unary, W1, W2, nullptr, nullptr, out.ptr(), maxit, st);
+        out.commit(st);
         PTV_HIP(hipStreamSynchronize(st));
         scope.finish();
         put_info(info, si);
@@ -416,7 +449,9 @@ int proxtv_DR2L1W_TV_dev(size_t M, size_t N, const double *unary, const double *
     return guarded("proxtv_DR2L1W_TV_dev", info, 0, [&] {
         hipStream_t st = pick(stream);
         SolveScope scope(st);
-        const SolveInfo si = dr2(M, N, 1, unary, 0, 0, W1, W2, s, maxit, st);
+        OutGuard out(s, M * N, {{unary, M * N}, {W1, M > 0 ? (M - 1) * N : 0}, {W2, N > 0 ? M * (N - 1) : 0}});
+        const SolveInfo si = dr2(M, N, 1, unary, 0, 0, W1, W2, out.ptr(), maxit, st);
+        out.commit(st);
         PTV_HIP(hipStreamSynchronize(st));
         scope.finish();
         put_info(info, si);
@@ -430,7 +465,9 @@ int proxtv_PD2_TV_dev(const double *y, const double *lambdas, const double *dims
         check_dims(dims, npen, nds);
         hipStream_t st = pick(stream);
         SolveScope scope(st);
-        const SolveInfo si = pd2(y, lambdas, dims, x, ns, nds, npen, maxIters, st);
+        OutGuard out(x, (size_t)total(ns, nds), {{y, (size_t)total(ns, nds)}});
+        const SolveInfo si = pd2(y, lambdas, dims, out.ptr(), ns, nds, npen, maxIters, st);
+        out.commit(st);
         PTV_HIP(hipStreamSynchronize(st));
         scope.finish();
         put_info(info, si);
@@ -444,8 +481,10 @@ static int pd_family_dev(const char *who, bool dr_variant, const double *y, cons
         check_dims(dims, npen, nds);
         hipStream_t st = pick(stream);
         SolveScope scope(st);
-        const SolveInfo si = dr_variant ? pdr(y, lambdas, dims, x, ns, nds, npen, maxIters, st)
-                                        : pd(y, lambdas, dims, x, ns, nds, npen, maxIters, st);
+        OutGuard out(x, (size_t)total(ns, nds), {{y, (size_t)total(ns, nds)}});
+        const SolveInfo si = dr_variant ? pdr(y, lambdas, dims, out.ptr(), ns, nds, npen, maxIters, st)
+                                        : pd(y, lambdas, dims, out.ptr(), ns, nds, npen, maxIters, st);
+        out.commit(st);
         PTV_HIP(hipStreamSynchronize(st));
         scope.finish();
         put_info(info, si);
@@ -471,7 +510,9 @@ int proxtv_Yang_TV_dev(const int *ns, int nds, const double *Y, const double *la
         int order[3] = {0, 1, 2};
         double lams[3] = {lambdas[0], lambdas[1], nds == 3 ? lambdas[2] : 0.0};
         if (nds == 2) { order[0] = 1; order[1] = 0; std::swap(lams[0], lams[1]); }   // (Z1,U1) = rows = dim 2
-        const SolveInfo si = yang(ns, nds, order, lams, Y, X, maxit, st);
+        OutGuard out(X, (size_t)total(ns, nds), {{Y, (size_t)total(ns, nds)}});
+        const SolveInfo si = yang(ns, nds, order, lams, Y, out.ptr(), maxit, st);
+        out.commit(st);
         PTV_HIP(hipStreamSynchronize(st));
         scope.finish();
         put_info(info, si);
@@ -483,7 +524,9 @@ int proxtv_Kolmogorov2_TV_dev(size_t M, size_t N, const double *Y, double lambda
     return guarded("proxtv_Kolmogorov2_TV_dev", info, 1, [&] {
         hipStream_t st = pick(stream);
         SolveScope scope(st);
-        const SolveInfo si = kolmogorov2(M, N, Y, lambda, X, maxit, st);
+        OutGuard out(X, M * N, {{Y, M * N}});
+        const SolveInfo si = kolmogorov2(M, N, Y, lambda, out.ptr(), maxit, st);
+        out.commit(st);
         PTV_HIP(hipStreamSynchronize(st));
         scope.finish();
         put_info(info, si);
@@ -495,7 +538,9 @@ int proxtv_CondatChambollePock2_TV_dev(size_t M, size_t N, const double *Y, doub
     return guarded("proxtv_CondatChambollePock2_TV_dev", info, 1, [&] {
         hipStream_t st = pick(stream);
         SolveScope scope(st);
-        const SolveInfo si = ccp2(M, N, Y, lambda, X, alg, maxit, st);
+        OutGuard out(X, M * N, {{Y, M * N}});
+        const SolveInfo si = ccp2(M, N, Y, lambda, out.ptr(), alg, maxit, st);
+        out.commit(st);
         PTV_HIP(hipStreamSynchronize(st));
         scope.finish();
         put_info(info, si);
@@ -508,7 +553,10 @@ int proxtv_tv1_fibres_dev(const double *in, double *out, const int *ns, int nds,
         if (dim < 0 || dim >= nds) reject("dimension out of range");
         hipStream_t st = pick(stream);
         SolveScope scope(st);
-        tv1_fibres(in, out, ns, nds, dim, lambda, weights, st);
+        const size_t n = (size_t)total(ns, nds);
+        OutGuard guard(out, n, {{in, n}, {weights, weights ? n : 0}});
+        tv1_fibres(in, guard.ptr(), ns, nds, dim, lambda, weights, st);
+        guard.commit(st);
         PTV_HIP(hipStreamSynchronize(st));
         scope.finish();
     });

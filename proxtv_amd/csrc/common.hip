@@ -33,38 +33,54 @@ Options &options() {
 }
 
 // ---- device ------------------------------------------------------------------------------------------------------
-static std::once_flag g_dev_once;
-static bool g_dev_ok = false;
-static char g_dev_why[256] = "";
+// Everything the library keeps between calls -- stream, scratch pool, the chunk kernels' link buffers and geometry
+// policies -- is per host thread AND per HIP device: a thread that moves to another GPU (hipSetDevice, proxtv_init,
+// torch.cuda.device) gets that device's own state, never a stream or a cached block of the previous one.
+static std::once_flag g_dev_once[kMaxDevices];
+static bool g_dev_ok[kMaxDevices] = {};
+static char g_dev_why[kMaxDevices][256] = {};
 
-static void probe_device() {
-    int count = 0;
-    hipError_t e = hipGetDeviceCount(&count);
-    if (e != hipSuccess || count <= 0) {
-        snprintf(g_dev_why, sizeof(g_dev_why), "no HIP device available (%s); libproxtv_amd has no CPU fallback",
-                 e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
-        return;
-    }
+int current_device() {
     int dev = 0;
-    (void)hipGetDevice(&dev);
-    hipDeviceProp_t prop;
-    e = hipGetDeviceProperties(&prop, dev);
+    const hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) {
-        snprintf(g_dev_why, sizeof(g_dev_why), "hipGetDeviceProperties failed: %s", hipGetErrorString(e));
+        set_error("no HIP device available (%s); libproxtv_amd has no CPU fallback", hipGetErrorString(e));
+        throw HipFailure{hipErrorNoDevice};
+    }
+    if (dev < 0 || dev >= kMaxDevices) {
+        set_error("device ordinal %d is outside the %d devices this library keeps state for", dev, kMaxDevices);
+        throw HipFailure{hipErrorInvalidDevice};
+    }
+    return dev;
+}
+
+static void probe_device(int dev) {
+    hipDeviceProp_t prop;
+    const hipError_t e = hipGetDeviceProperties(&prop, dev);
+    if (e != hipSuccess) {
+        snprintf(g_dev_why[dev], sizeof(g_dev_why[dev]), "hipGetDeviceProperties failed: %s", hipGetErrorString(e));
         return;
     }
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
-        snprintf(g_dev_why, sizeof(g_dev_why), "device %d is %s; this library carries gfx950 (MI355X) code objects only",
+        snprintf(g_dev_why[dev], sizeof(g_dev_why[dev]), "device %d is %s; this library carries gfx950 (MI355X) code objects only",
                  dev, prop.gcnArchName);
         return;
     }
-    g_dev_ok = true;
+    g_dev_ok[dev] = true;
 }
 
 void ensure_device() {
-    std::call_once(g_dev_once, probe_device);
-    if (!g_dev_ok) {
-        set_error("%s", g_dev_why);
+    int count = 0;
+    const hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) {
+        set_error("no HIP device available (%s); libproxtv_amd has no CPU fallback",
+                  e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+        throw HipFailure{hipErrorNoDevice};
+    }
+    const int dev = current_device();
+    std::call_once(g_dev_once[dev], probe_device, dev);
+    if (!g_dev_ok[dev]) {
+        set_error("%s", g_dev_why[dev]);
         throw HipFailure{hipErrorNoDevice};
     }
 }
@@ -72,24 +88,47 @@ void ensure_device() {
 struct ThreadState {
     hipStream_t stream = nullptr;
     std::multimap<size_t, void *> free_blocks;
-    ~ThreadState() {
-        // process teardown: the HIP runtime may already be gone; leak rather than crash
+    size_t cached = 0;   // bytes in free_blocks
+};
+struct ThreadStates {
+    ThreadState dev[kMaxDevices];
+    bool alive = true;
+    ~ThreadStates() {
+        // thread exit: hand the cached blocks back (at process teardown the runtime may be gone: errors are ignored);
+        // Scratch objects that outlive this one (other thread_locals) free their block directly from now on
+        alive = false;
+        for (auto &t : dev)
+            for (auto &kv : t.free_blocks) (void)hipFree(kv.second);
     }
 };
-static thread_local ThreadState g_ts;
+static thread_local ThreadStates g_ts;
+
+static size_t pool_cap_bytes() {
+    static const size_t cap = [] {
+        const char *e = getenv("PROXTV_POOL_CAP_MB");
+        return (size_t)(e ? atol(e) : 65536) << 20;   // 64 GiB of 288: a 64 x 2048^2 batch solve keeps ~11 GiB
+    }();
+    return cap;
+}
 
 hipStream_t thread_stream() {
     ensure_device();
-    if (!g_ts.stream) PTV_HIP(hipStreamCreateWithFlags(&g_ts.stream, hipStreamNonBlocking));
-    return g_ts.stream;
+    ThreadState &t = g_ts.dev[current_device()];
+    if (!t.stream) PTV_HIP(hipStreamCreateWithFlags(&t.stream, hipStreamNonBlocking));
+    return t.stream;
 }
 
 // ---- scratch pool --------------------------------------------------------------------------------------------------
-Scratch::Scratch(size_t bytes) : bytes_(bytes ? bytes : 8) {
-    auto it = g_ts.free_blocks.find(bytes_);
-    if (it != g_ts.free_blocks.end()) {
+// Best fit among the cached blocks of this thread and device (a block up to 25 % larger than asked for is taken), a cap
+// on what stays cached (PROXTV_POOL_CAP_MB): workloads with varying shapes do not hoard HBM.
+Scratch::Scratch(size_t bytes) : bytes_(bytes ? bytes : 8), dev_(current_device()) {
+    ThreadState &t = g_ts.dev[dev_];
+    auto it = t.free_blocks.lower_bound(bytes_);
+    if (it != t.free_blocks.end() && it->first <= bytes_ + bytes_ / 4) {
         ptr_ = it->second;
-        g_ts.free_blocks.erase(it);
+        bytes_ = it->first;
+        t.cached -= it->first;
+        t.free_blocks.erase(it);
         return;
     }
     hipError_t e = hipMalloc(&ptr_, bytes_);
@@ -106,12 +145,22 @@ Scratch::Scratch(size_t bytes) : bytes_(bytes ? bytes : 8) {
 }
 
 Scratch::~Scratch() {
-    if (ptr_) g_ts.free_blocks.emplace(bytes_, ptr_);
+    if (!ptr_) return;
+    if (!g_ts.alive || g_ts.dev[dev_].cached + bytes_ > pool_cap_bytes()) {
+        (void)hipFree(ptr_);
+        return;
+    }
+    g_ts.dev[dev_].free_blocks.emplace(bytes_, ptr_);
+    g_ts.dev[dev_].cached += bytes_;
 }
 
 void release_scratch() {
-    for (auto &kv : g_ts.free_blocks) (void)hipFree(kv.second);
-    g_ts.free_blocks.clear();
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return;
+    ThreadState &t = g_ts.dev[dev];
+    for (auto &kv : t.free_blocks) (void)hipFree(kv.second);
+    t.free_blocks.clear();
+    t.cached = 0;
 }
 
 // ---- kernel-family timers --------------------------------------------------------------------------------------------

@@ -52,13 +52,16 @@ struct Options {
 Options &options();
 
 // ---- device / stream -------------------------------------------------------------------------------------------
-// Throws HipFailure (with last_error set) when no usable gfx950 device exists.
+// Throws HipFailure (with last_error set) when the current device is not a usable gfx950.  All library state is kept per
+// host thread and per device (current_device(): the ordinal hipGetDevice reports, below kMaxDevices).
+constexpr int kMaxDevices = 16;
+int current_device();
 void ensure_device();
 hipStream_t thread_stream();
 
 // ---- HBM scratch pool ------------------------------------------------------------------------------------------
-// Per-thread cache of device allocations: solvers ask for a handful of image-sized arrays per call and
-// hipMalloc/hipFree cost ~100 us each, so blocks are kept and reused by exact byte size.
+// Per-thread, per-device cache of device allocations: solvers ask for a handful of image-sized arrays per call and
+// hipMalloc/hipFree cost ~100 us each, so blocks are kept and reused (best fit, capped total: common.hip).
 class Scratch {
   public:
     explicit Scratch(size_t bytes);
@@ -72,6 +75,7 @@ class Scratch {
   private:
     void *ptr_ = nullptr;
     size_t bytes_ = 0;
+    int dev_ = 0;   // device the block lives on (it returns to that device's pool)
 };
 void release_scratch();
 

@@ -1146,7 +1146,8 @@ struct ChunkScratch {
         pl.measured(r, t, f);
     }
 };
-static thread_local ChunkScratch g_chunk;
+static thread_local ChunkScratch g_chunks[kMaxDevices];   // per host thread and per device, like the stream and the pool
+static ChunkScratch &chunk_state() { return g_chunks[current_device()]; }
 
 // Chunk geometry: C = 16 samples per chunk, 8 waves (chunks) per block of 128 samples.  LDS per workgroup = one window
 // of H + 128 + 8 rows x 512 B: ~77 KiB for H = 16 -> two workgroups = 16 waves per CU; ~101 KiB for H = 64 -> one.
@@ -1167,20 +1168,21 @@ void launch_chunk_h(const SweepArgs &args, const FibreGeom &g, hipStream_t strea
     plan.qpw = qpw < plan.Q ? qpw : plan.Q;
     plan.ablate = options().ablate;
     plan.rounds = rounds_wanted;
-    plan.trace = options().trace ? g_chunk.trace_buffer((size_t)groups * (size_t)((plan.Q + plan.qpw - 1) / plan.qpw)) : nullptr;
+    plan.trace = options().trace ? chunk_state().trace_buffer((size_t)groups * (size_t)((plan.Q + plan.qpw - 1) / plan.qpw)) : nullptr;
     const int WQ = (plan.Q + plan.qpw - 1) / plan.qpw;
     constexpr size_t lds = sizeof(double) * PITCH * (size_t)ROWS * (WEIGHTED ? 2 : 1) + sizeof(link_t) * ((NW + 2) * 64 + 32);
     static_assert(WEIGHTED || H > kWarm || 2 * lds <= 160 * 1024, "the short-zone geometry is meant to run two workgroups per CU");
     static_assert(lds <= 160 * 1024, "chunk geometry does not fit the LDS of a CU");
     const int NC = (g.len + C - 1) / C;
-    g_chunk.ensure(g.count, NC, stream);
+    chunk_state().ensure(g.count, NC, stream);
     // the second-chance rounds are a separate instantiation: their live state costs the plain kernel registers it
     // does not have (it sits at the 128-VGPR budget of two workgroups per CU)
     constexpr bool kCanRound = (H <= kWarm) && C == 16;
     const bool rounds = kCanRound && plan.rounds > 0;
     auto kern = sweep_chunk_kernel<OP, WEIGHTED, TRANSPOSED, C, NW, H, false>;
     auto kern_r = sweep_chunk_kernel<OP, WEIGHTED, TRANSPOSED, C, NW, H, kCanRound>;
-    static thread_local bool attr_set = false;
+    static thread_local bool attr_done[kMaxDevices] = {};   // function attributes are per device
+    bool &attr_set = attr_done[current_device()];
     if (!attr_set) {
         PTV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     160 * 1024));
@@ -1189,22 +1191,23 @@ void launch_chunk_h(const SweepArgs &args, const FibreGeom &g, hipStream_t strea
         attr_set = true;
     }
     const dim3 grid((unsigned)groups, (unsigned)WQ);
-    hipLaunchKernelGGL(rounds ? kern_r : kern, grid, dim3(64 * NW), lds, stream, args, g, plan, g_chunk.code_mine,
-                       g_chunk.code_next, g_chunk.failflags);
+    hipLaunchKernelGGL(rounds ? kern_r : kern, grid, dim3(64 * NW), lds, stream, args, g, plan, chunk_state().code_mine,
+                       chunk_state().code_next, chunk_state().failflags);
     if (!plan.ablate) {
         constexpr size_t rlds = sizeof(double) * (2 + (WEIGHTED ? 1 : 0)) * kRepairWindow * 64;
         auto rkern = sweep_repair_kernel<OP, WEIGHTED>;
-        static thread_local bool rattr_set = false;
+        static thread_local bool rattr_done[kMaxDevices] = {};
+        bool &rattr_set = rattr_done[current_device()];
         if (!rattr_set) {
             PTV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(rkern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)rlds));
             rattr_set = true;
         }
         hipLaunchKernelGGL(rkern, dim3((unsigned)groups), dim3(64), rlds, stream, args, g, C, H, plan.qpw * NW,
-                           g_chunk.code_mine, g_chunk.code_next, g_chunk.failflags, g_chunk.failcount + 2 * fam, (long)g.count, 1L);
+                           chunk_state().code_mine, chunk_state().code_next, chunk_state().failflags, chunk_state().failcount + 2 * fam, (long)g.count, 1L);
     }
     PTV_HIP(hipGetLastError());
-    g_chunk.pol[fam].chunks_done += (long)NC * g.count;
+    chunk_state().pol[fam].chunks_done += (long)NC * g.count;
 }
 
 // Chunks along the fibre (kernel 2a): dimension-0 sweeps, unweighted.  Codes are laid out [fibre][chunk] (a wave writes
@@ -1217,25 +1220,26 @@ void launch_along(const SweepArgs &args, const FibreGeom &g, hipStream_t stream,
     const long waves = g.count * nseg;
     ChunkPlan plan{};
     plan.ablate = options().ablate;
-    g_chunk.ensure(g.count, NC, stream);
-    plan.trace = options().trace ? g_chunk.trace_buffer((size_t)waves) : nullptr;
+    chunk_state().ensure(g.count, NC, stream);
+    plan.trace = options().trace ? chunk_state().trace_buffer((size_t)waves) : nullptr;
     constexpr size_t lds = sizeof(double) * (size_t)(ROWS + 2) * kAlongWaves;
     auto kern = sweep_along_kernel<OP, H>;
     hipLaunchKernelGGL(kern, dim3((unsigned)((waves + kAlongWaves - 1) / kAlongWaves)), dim3(64 * kAlongWaves), lds, stream, args, g,
-                       plan, g_chunk.code_mine, g_chunk.code_next, g_chunk.failflags);
+                       plan, chunk_state().code_mine, chunk_state().code_next, chunk_state().failflags);
     if (!plan.ablate) {
         constexpr size_t rlds = sizeof(double) * 2 * kRepairWindow * 64;
         auto rkern = sweep_repair_kernel<OP, false>;
-        static thread_local bool rattr_set = false;
+        static thread_local bool rattr_done[kMaxDevices] = {};
+        bool &rattr_set = rattr_done[current_device()];
         if (!rattr_set) {
             PTV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(rkern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rlds));
             rattr_set = true;
         }
-        hipLaunchKernelGGL(rkern, dim3((unsigned)((g.count + 63) / 64)), dim3(64), rlds, stream, args, g, C, H, 64, g_chunk.code_mine,
-                           g_chunk.code_next, g_chunk.failflags, g_chunk.failcount + 2 * fam, 1L, (long)NC);
+        hipLaunchKernelGGL(rkern, dim3((unsigned)((g.count + 63) / 64)), dim3(64), rlds, stream, args, g, C, H, 64, chunk_state().code_mine,
+                           chunk_state().code_next, chunk_state().failflags, chunk_state().failcount + 2 * fam, 1L, (long)NC);
     }
     PTV_HIP(hipGetLastError());
-    g_chunk.pol[fam].chunks_done += (long)NC * g.count;
+    chunk_state().pol[fam].chunks_done += (long)NC * g.count;
 }
 
 // Global-memory chunks (kernel 2b): chunk C and zone H are run-time values; every link is checked by the repair kernel.
@@ -1243,18 +1247,18 @@ template <int OP, bool WEIGHTED>
 void launch_gchunk(const SweepArgs &args, const FibreGeom &g, int C, int H, hipStream_t stream, int fam) {
     const long groups = (g.count + 63) / 64;
     const int NC = (g.len + C - 1) / C;
-    g_chunk.ensure(g.count, NC, stream);
+    chunk_state().ensure(g.count, NC, stream);
     hipLaunchKernelGGL((sweep_gchunk_kernel<OP, WEIGHTED>), dim3((unsigned)groups, (unsigned)NC), dim3(64), 0, stream, args,
-                       g, C, H, g_chunk.code_mine, g_chunk.code_next, g_chunk.failflags);
+                       g, C, H, chunk_state().code_mine, chunk_state().code_next, chunk_state().failflags);
     hipLaunchKernelGGL((sweep_repair_kernel<OP, WEIGHTED>), dim3((unsigned)groups), dim3(64), 0, stream, args, g, C, H, 1,
-                       g_chunk.code_mine, g_chunk.code_next, g_chunk.failflags, g_chunk.failcount + 2 * fam, (long)g.count, 1L);
+                       chunk_state().code_mine, chunk_state().code_next, chunk_state().failflags, chunk_state().failcount + 2 * fam, (long)g.count, 1L);
     PTV_HIP(hipGetLastError());
-    g_chunk.pol[fam].chunks_done += (long)NC * g.count;
+    chunk_state().pol[fam].chunks_done += (long)NC * g.count;
 }
 
 template <int OP, bool WEIGHTED, bool TRANSPOSED>
 void launch_chunk(const SweepArgs &args, const FibreGeom &g, hipStream_t stream, int fam) {
-    ChunkScratch &st = g_chunk;
+    ChunkScratch &st = chunk_state();
     ChunkScratch::Policy &pl = st.pol[fam];
     const bool pinned = options().chunk_mode >= 0;
     if (pl.workload(g.len, g.count, WEIGHTED) && pl.meas) {   // a new workload: the measurement in flight is of the old one
@@ -1312,7 +1316,7 @@ void launch_op_w(const SweepArgs &args, const FibreGeom &g, hipStream_t stream, 
 
 // Called at the start of every solve on this thread's stream.
 void chunk_stats_reset(hipStream_t s) {
-    ChunkScratch &st = g_chunk;
+    ChunkScratch &st = chunk_state();
     const bool adaptive = options().chunk_mode < 0;
     if (st.h_counts) st.poll(true);
     for (int f = 0; f < FAM_COUNT; f++) {
@@ -1330,9 +1334,9 @@ void chunk_stats_reset(hipStream_t s) {
 }
 
 long chunk_stats_fixups(hipStream_t s) {
-    if (!g_chunk.failcount) return 0;
+    if (!chunk_state().failcount) return 0;
     int h[ChunkScratch::kCounters] = {};
-    PTV_HIP(hipMemcpyAsync(h, g_chunk.failcount, sizeof(h), hipMemcpyDeviceToHost, s));
+    PTV_HIP(hipMemcpyAsync(h, chunk_state().failcount, sizeof(h), hipMemcpyDeviceToHost, s));
     PTV_HIP(hipStreamSynchronize(s));
     long total = 0;
     for (int f = 0; f < FAM_COUNT; f++) total += h[2 * f];
@@ -1341,16 +1345,16 @@ long chunk_stats_fixups(hipStream_t s) {
 
 // option "trace": copy the phase timestamps of the last chunk-kernel launch of this thread (8 words per workgroup) to the host
 long chunk_trace_fetch(unsigned long long *dst, long max_wgs, hipStream_t s) {
-    if (!g_chunk.trace) return 0;
-    const long n = (long)g_chunk.trace_wgs < max_wgs ? (long)g_chunk.trace_wgs : max_wgs;
-    PTV_HIP(hipMemcpyAsync(dst, g_chunk.trace->as<unsigned long long>(), (size_t)n * 64, hipMemcpyDeviceToHost, s));
+    if (!chunk_state().trace) return 0;
+    const long n = (long)chunk_state().trace_wgs < max_wgs ? (long)chunk_state().trace_wgs : max_wgs;
+    PTV_HIP(hipMemcpyAsync(dst, chunk_state().trace->as<unsigned long long>(), (size_t)n * 64, hipMemcpyDeviceToHost, s));
     PTV_HIP(hipStreamSynchronize(s));
     return n;
 }
 
 int chunk_stats_mode() {
     int m = 0;
-    for (int f = 0; f < FAM_COUNT; f++) m = g_chunk.pol[f].mode > m ? g_chunk.pol[f].mode : m;
+    for (int f = 0; f < FAM_COUNT; f++) m = chunk_state().pol[f].mode > m ? chunk_state().pol[f].mode : m;
     return m;
 }
 

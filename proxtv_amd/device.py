@@ -30,16 +30,32 @@ def _is_colmajor(t):
     return t.permute(*reversed(range(t.dim()))).is_contiguous()
 
 
-def _check(t, name):
+def _check(t, name, like=None, shape=None):
     if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float64 and _is_colmajor(t)):
         raise ValueError(f"{name}: expected a float64 CUDA tensor in column-major storage (see to_colmajor)")
+    if like is not None and t.device != like.device:
+        raise ValueError(f"{name}: lives on {t.device}, the input on {like.device}")
+    if shape is not None and tuple(t.shape) != tuple(shape):
+        raise ValueError(f"{name}: shape {tuple(t.shape)}, expected {tuple(shape)}")
 
 
-def _stream():
-    """hipStream_t handle for the C-ABI.  torch's legacy default stream has handle 0, which the library reads as "use
-    my own per-thread (non-blocking) stream"; that stream does not order against the null stream, so drain torch's
-    producers first.  Every *_dev entry point synchronises before returning, so consumers need no extra fence."""
-    cur = torch.cuda.current_stream()
+def _out(out, x, name="out"):
+    """The output tensor: a fresh column-major one on x's device, or the caller's (checked: a tensor of another
+    dtype / layout / shape / device would be filled with the wrong bytes or fault).  It may alias x: the library
+    detects the overlap and solves through a scratch array."""
+    if out is None:
+        return colmajor_empty(x.shape, device=x.device)
+    _check(out, name, like=x, shape=x.shape)
+    return out
+
+
+def _stream(dev):
+    """hipStream_t handle for the C-ABI: torch's current stream ON THE TENSOR'S DEVICE (callers run under
+    ``torch.cuda.device(x.device)``: the library keeps its state per device and uses the current one).  torch's legacy
+    default stream has handle 0, which the library reads as "use my own per-thread (non-blocking) stream"; that stream
+    does not order against the null stream, so drain torch's producers first.  Every *_dev entry point synchronises
+    before returning, so consumers need no extra fence."""
+    cur = torch.cuda.current_stream(dev)
     if cur.cuda_stream == 0:
         cur.synchronize()
     return cur.cuda_stream
@@ -48,12 +64,16 @@ def _stream():
 def tv1_2d(x, w, max_iters=0, method="dr", out=None, w_row=None):
     """tv1_2d on an HBM-resident (M, N) image.  Returns (y, info)."""
     _check(x, "x")
+    with torch.cuda.device(x.device):
+        return _tv1_2d(x, w, max_iters, method, _out(out, x), w_row)
+
+
+def _tv1_2d(x, w, max_iters, method, y, w_row):
     lib = _lib.require_device()
-    y = colmajor_empty(x.shape, device=x.device) if out is None else out
-    _check(y, "out")
     info = np.zeros(_N_INFO)
     M, N = x.shape
     w_row = w if w_row is None else w_row
+    _stream = lambda: globals()["_stream"](x.device)   # noqa: E731
     if method == "dr":
         lib.proxtv_DR2_TV_dev(M, N, x.data_ptr(), float(w), float(w_row), y.data_ptr(), int(max_iters),
                               info.ctypes.data, _stream())
@@ -82,14 +102,16 @@ def tv1_2d(x, w, max_iters=0, method="dr", out=None, w_row=None):
 
 def tv1w_2d(x, w_col, w_row, max_iters=0, out=None):
     """Weighted DR on HBM-resident arrays: w_col (M-1, N), w_row (M, N-1), all column-major."""
-    for t, nm in ((x, "x"), (w_col, "w_col"), (w_row, "w_row")):
-        _check(t, nm)
-    lib = _lib.require_device()
-    y = colmajor_empty(x.shape, device=x.device) if out is None else out
-    info = np.zeros(_N_INFO)
+    _check(x, "x")
     M, N = x.shape
-    lib.proxtv_DR2L1W_TV_dev(M, N, x.data_ptr(), w_col.data_ptr(), w_row.data_ptr(), y.data_ptr(), int(max_iters),
-                             info.ctypes.data, _stream())
+    _check(w_col, "w_col", like=x, shape=(M - 1, N))
+    _check(w_row, "w_row", like=x, shape=(M, N - 1))
+    y = _out(out, x)
+    info = np.zeros(_N_INFO)
+    with torch.cuda.device(x.device):
+        lib = _lib.require_device()
+        lib.proxtv_DR2L1W_TV_dev(M, N, x.data_ptr(), w_col.data_ptr(), w_row.data_ptr(), y.data_ptr(), int(max_iters),
+                                 info.ctypes.data, _stream(x.device))
     _lib.check("device.tv1w_2d")
     return y, info
 
@@ -97,12 +119,13 @@ def tv1w_2d(x, w_col, w_row, max_iters=0, out=None):
 def tv1_2d_batch(xs, w, max_iters=0, out=None):
     """DR on a stack of B images held as a column-major (M, N, B) tensor (image b = xs[:, :, b])."""
     _check(xs, "xs")
-    lib = _lib.require_device()
-    y = colmajor_empty(xs.shape, device=xs.device) if out is None else out
+    y = _out(out, xs)
     info = np.zeros(_N_INFO)
     M, N, B = xs.shape
-    lib.proxtv_DR2_TV_batch_dev(M, N, B, xs.data_ptr(), float(w), float(w), y.data_ptr(), int(max_iters),
-                                info.ctypes.data, _stream())
+    with torch.cuda.device(xs.device):
+        lib = _lib.require_device()
+        lib.proxtv_DR2_TV_batch_dev(M, N, B, xs.data_ptr(), float(w), float(w), y.data_ptr(), int(max_iters),
+                                    info.ctypes.data, _stream(xs.device))
     _lib.check("device.tv1_2d_batch")
     return y, info
 
@@ -111,13 +134,18 @@ def tvgen(x, ws, ds, max_iters=0, method=None, out=None):
     """N-D TV-L1 on an HBM-resident column-major array.  method: None = reference dispatch (2 terms -> 'pd2',
     otherwise 'pd'); 'pdr' = parallel Douglas-Rachford; 'yang' = Yang ADMM (2-D / 3-D, one lambda per dim)."""
     _check(x, "x")
+    with torch.cuda.device(x.device):
+        return _tvgen(x, ws, ds, max_iters, method, _out(out, x))
+
+
+def _tvgen(x, ws, ds, max_iters, method, y):
     lib = _lib.require_device()
-    y = colmajor_empty(x.shape, device=x.device) if out is None else out
     info = np.zeros(_N_INFO)
     ns = np.array(x.shape, dtype=np.int32)
     lam = np.array(ws, dtype=np.float64)
     dims = np.array(ds, dtype=np.float64)
     npen = lam.size
+    _stream = lambda: globals()["_stream"](x.device)   # noqa: E731
     if method is None:
         method = "pd2" if npen == 2 else "pd"
     if method == "pd2":
@@ -140,13 +168,19 @@ def tvgen(x, ws, ds, max_iters=0, method=None, out=None):
 def tv1_fibres(x, w, dim, weights=None, out=None):
     """Batched exact 1-D TV-L1 prox of every fibre of `x` along 0-based `dim` (the per-sweep kernel)."""
     _check(x, "x")
-    lib = _lib.require_device()
-    y = colmajor_empty(x.shape, device=x.device) if out is None else out
+    y = _out(out, x)
     ns = np.array(x.shape, dtype=np.int32)
+    if not 0 <= int(dim) < x.dim():
+        raise ValueError(f"dim {dim} out of range for a {x.dim()}-D array")
     wp = 0
     if weights is not None:
-        _check(weights, "weights")
+        wshape = list(x.shape)
+        wshape[int(dim)] -= 1              # one penalty per edge along the fibre
+        _check(weights, "weights", like=x, shape=wshape)
         wp = weights.data_ptr()
-    lib.proxtv_tv1_fibres_dev(x.data_ptr(), y.data_ptr(), ns.ctypes.data, x.dim(), int(dim), float(w), wp, _stream())
+    with torch.cuda.device(x.device):
+        lib = _lib.require_device()
+        lib.proxtv_tv1_fibres_dev(x.data_ptr(), y.data_ptr(), ns.ctypes.data, x.dim(), int(dim), float(w), wp,
+                                  _stream(x.device))
     _lib.check("device.tv1_fibres")
     return y

@@ -23,6 +23,22 @@ def shard_sizes(n_items, world):
     return [shard_bounds(n_items, world, r)[1] - shard_bounds(n_items, world, r)[0] for r in range(world)]
 
 
+def device_dr_solver(lam, max_iters=0):
+    """The single-GPU solver for `solve_sharded`: 2-D TV-L1 Douglas-Rachford on a stack of images held as a contiguous
+    (B, N, M) CUDA float64 tensor -- image b stored column-major (M, N), which is what the library wants: the stack is
+    the column-major (M, N, B) array of `proxtv_DR2_TV_batch_dev` seen from the other end.  All images of the shard
+    advance together, one launch per sweep."""
+    from . import device
+
+    def solve(images):
+        if images.shape[0] == 0:
+            return images.clone()
+        x = images.contiguous().permute(2, 1, 0)          # (M, N, B), dimension 0 fastest
+        y, _ = device.tv1_2d_batch(x, lam, max_iters=max_iters)
+        return y.permute(2, 1, 0)                          # back to (B, N, M), contiguous
+    return solve
+
+
 def solve_sharded(get_images, n_items, solve, gather_to=0, group=None):
     """Solve a batch of `n_items` independent images across the ranks of `group`.
 

@@ -4,7 +4,7 @@
 Run on the GPU box (one --pmc pass per counter, no trace domains besides --kernel-trace):
 
     python tools/pmc_traffic.py collect gpurun_out/pmc      # runs rocprofv3 four times
-    python tools/pmc_traffic.py report  gpurun_out/pmc > profiles/r01_pmc_traffic.json
+    python tools/pmc_traffic.py report  gpurun_out/pmc > profiles/r02_pmc_traffic.json
 
 Calibration (MI355X_MICROARCH.md, "HBM"): FETCH_SIZE / WRITE_SIZE come from the L2's fabric request counters and, on
 gfx950, FETCH_SIZE under-reports wide coalesced reads; other widths are uncalibrated.  The sweep kernels move 8 bytes
@@ -47,7 +47,7 @@ def collect(outdir):
         run(env_cmd + ["--pmc", counter, "-d", os.path.join(outdir, f"calib_{counter}"), "-o", "c", "--",
                        sys.executable, me, "calib"])
         run(env_cmd + ["--pmc", counter, "-d", os.path.join(outdir, f"bench_{counter}"), "-o", "b", "--",
-                       sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1", "--no-cpu-baseline"])
+                       sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-c5"])
 
 
 def averages(db, counter):
@@ -59,7 +59,10 @@ def averages(db, counter):
 
 def report(outdir):
     M = N = 4096
+    sys.path.insert(0, ROOT)
+    from proxtv_amd import build as _build
     out = {"source": "rocprofv3 --kernel-trace --pmc <counter> (one pass per counter), python bench.py --steps 1 --warmup 1",
+           "build_id": _build.build_id(),   # hash of the kernel sources: bench.py quotes these numbers for this build only
            "unit": "bytes per launch", "calibration": {}, "kernels": {}}
     factor = {}
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -70,7 +73,8 @@ def report(outdir):
         factor[counter] = true_bytes / reported
         out["calibration"][counter] = {"kernel": "calib_copy_kernel (8 B/lane, 1 GiB)", "true_bytes": true_bytes,
                                        "reported_bytes": reported, "factor": factor[counter], "dispatches": n}
-    names = {"row sweep (DR_ROW)": "sweep_chunk_kernel<3,", "column sweep (DR_COL)": "sweep_chunk_kernel<1,"}
+    # (DR_COL: the along-fibre kernel of dimension-0 sweeps, or the transposed tile when that is switched off)
+    names = {"row sweep (DR_ROW)": "sweep_chunk_kernel<3,", "column sweep (DR_COL)": "sweep_along_kernel<1,"}
     algo = {"row sweep (DR_ROW)": {"read": 24 * M * N, "write": 8 * M * N},
             "column sweep (DR_COL)": {"read": 8 * M * N, "write": 8 * M * N}}
     per = {k: {} for k in names}
