@@ -52,8 +52,16 @@ typedef struct Workspace Workspace;
 
 /* =============================== PART 1: drop-in entry points ================================== */
 
-/* replaces src/TVgenopt.cpp:30 `TV` -- p == 1 only; p < 1 or p != 1 -> RC_ERROR, returns 0 */
+/* replaces src/TVgenopt.cpp:30 `TV` -- p == 1 (TV-L1, the hot path) and p == 2 (TV-L2); p < 1 or any other p ->
+   RC_ERROR, returns 0 */
 int TV(double *y, double lambda, double *x, double *info, int n, double p, Workspace *ws);
+/* replace src/TVL2opt.cpp:35, :190, :446 -- the TV-L2 prox  min 1/2 ||x-y||^2 + lambda ||Dx||_2.  The three reference
+   entry points are three iteration schemes for the same minimiser (which they reach to a duality gap of 1e-5, the
+   hybrid one warm-started from its workspace); all are served by one exact device solve that depends on (y, lambda)
+   only (tv2.hip).  info: iterations 0, gap 0, RC_OK. */
+int more_TV2(double *y, double lambda, double *x, double *info, int n);
+int morePG_TV2(double *y, double lambda, double *x, double *info, int n, Workspace *ws);
+int PG_TV2(double *y, double lambda, double *x, double *info, int n);
 
 /* replaces src/TVL1opt.cpp:359 */
 int linearizedTautString_TV1(double *y, double lambda, double *x, int n);
@@ -70,13 +78,13 @@ int tautString_TV1_Weighted(double *y, double *lambda, double *x, int n);
 /* replaces src/condat_fast_tv.cpp:78 -- no-op when width <= 0 or lambda < 0; in-place allowed */
 void TV1D_denoise(double *input, double *output, const int width, const double lambda);
 
-/* replaces src/TV2Dopt.cpp:352 -- returns 0 on success (sic) */
+/* replaces src/TV2Dopt.cpp:352 -- returns 0 on success (sic); norm1 / norm2 in {1, 2} (2: TV-L2 fibres, exact solve) */
 int DR2_TV(size_t M, size_t N, double *unary, double W1, double W2, double norm1, double norm2,
            double *s, int nThreads, int maxit, double *info);
 /* replaces src/TV2DWopt.cpp:46 -- W1 is (M-1)xN, W2 is Mx(N-1), column-major; returns 0 on success (sic) */
 int DR2L1W_TV(size_t M, size_t N, double *unary, double *W1, double *W2, double *s, int nThreads,
               int maxit, double *info);
-/* replaces src/TV2Dopt.cpp:59 -- npen in {1,2}; dims are 1-based doubles */
+/* replaces src/TV2Dopt.cpp:59 -- npen in {1,2}; dims are 1-based doubles; norms in {1, 2} (here and below) */
 int PD2_TV(double *y, double *lambdas, double *norms, double *dims, double *x, double *info, int *ns,
            int nds, int npen, int ncores, int maxIters);
 /* replaces src/TVNDopt.cpp:48 -- multiplies lambdas[] by npen in caller memory, like the reference */
@@ -178,6 +186,16 @@ int proxtv_DR2_TV_batch_dev(size_t M, size_t N, size_t B, const double *unary, d
 /* Same on HOST pointers (stages through HBM like part 1). */
 int proxtv_DR2_TV_batch(size_t M, size_t N, size_t B, const double *unary, double W1, double W2, double *s,
                         int maxit, double *info);
+
+/* The same solvers with a TV-L2 penalty (p = 2: lambda ||Dx||_2 per fibre, exact trust-region solve, tv2.hip) allowed
+   per dimension / per term; norms in {1, 2}.  proxtv_PD_TVp_dev: which = 0 PD2_TV, 1 PD_TV, 2 PDR_TV (lambdas already
+   scaled by npen for 1 and 2, like proxtv_PD_TV_dev). */
+int proxtv_tvp_fibres_dev(const double *in, double *out, const int *ns, int nds, int dim, double lambda, double p,
+                          void *stream);
+int proxtv_DR2_TVp_dev(size_t M, size_t N, const double *unary, double W1, double W2, double norm1, double norm2,
+                       double *s, int maxit, double *info, void *stream);
+int proxtv_PD_TVp_dev(int which, const double *y, const double *lambdas_scaled, const double *norms, const double *dims,
+                      double *x, double *info, const int *ns, int nds, int npen, int maxIters, void *stream);
 
 /* Timing hook for bench.py: average device time in milliseconds of the `which`-th kernel family
    over the last solve (0 = column sweep, 1 = row sweep, 2 = everything else), measured with

@@ -126,17 +126,33 @@ class CpuLib:
             raise ValueError(method)
         return out
 
+    def tv(self, x, lam, p):
+        """TV() dispatcher: p = 1 (hybrid taut string) or p = 2.  For p = 2 the two libraries differ BY DESIGN: the
+        oracle solves the TV-L2 prox to convergence (orc_TV2_exact), the reference's morePG_TV2 stops at a duality gap
+        of 1e-5 (the reference has 7 arguments: a NULL workspace -- no warm start -- is passed)."""
+        x = np.ascontiguousarray(x, dtype=np.float64).ravel()
+        out, info = np.zeros(x.size), np.zeros(3)
+        f = self._lib.orc_TV if self.kind == "port" else self._lib.TV
+        f.restype = C.c_int
+        if self.kind == "port":
+            f.argtypes = [_dp, C.c_double, _dp, _dp, C.c_int, C.c_double]
+            f(x.ctypes.data, lam, out.ctypes.data, info.ctypes.data, x.size, float(p))
+        else:
+            f.argtypes = [_dp, C.c_double, _dp, _dp, C.c_int, C.c_double, _dp]
+            f(x.ctypes.data, lam, out.ctypes.data, info.ctypes.data, x.size, float(p), None)
+        return out, info
+
     def tv1_weighted(self, x, w):
         w = np.ascontiguousarray(w, dtype=np.float64).ravel()
         return self._run1d(lambda a, o: self._fn["tautString_TV1_Weighted"](a.ctypes.data, w.ctypes.data, o.ctypes.data, a.size), x)
 
     # ---- 2-D / N-D (inputs any layout; converted to column-major; outputs column-major) -----------------------
-    def dr2(self, X, w1, w2=None, max_iters=0, n_threads=1):
+    def dr2(self, X, w1, w2=None, max_iters=0, n_threads=1, norm1=1.0, norm2=1.0):
         X = np.asfortranarray(X, dtype=np.float64)
         out = np.zeros(X.shape, order="F")
         info = np.zeros(3)
         w2 = w1 if w2 is None else w2
-        rc = self._fn["DR2_TV"](X.shape[0], X.shape[1], X.ctypes.data, w1, w2, 1.0, 1.0, out.ctypes.data,
+        rc = self._fn["DR2_TV"](X.shape[0], X.shape[1], X.ctypes.data, w1, w2, float(norm1), float(norm2), out.ctypes.data,
                                 n_threads, max_iters, info.ctypes.data)
         return out, info, rc
 

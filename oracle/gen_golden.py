@@ -295,17 +295,55 @@ def gen_large(ref, threads):
     np.savez_compressed(os.path.join(GOLD, "golden_large.npz"), **out)
 
 
+def gen_p2(ref):
+    """TV-L2 (p = 2) fibres: what the compiled reference returns -- single-threaded (its fibres warm-start each other per
+    OpenMP thread, so its output depends on the thread count) and to its own accuracy (duality gap 1e-5).  The exact
+    solvers of this repo are checked against these within that accuracy, not to 1e-6."""
+    rng = np.random.default_rng(20260927)
+    out, names1, names2 = {}, [], []
+    for n in (1, 2, 3, 10, 64, 100, 257, 1000, 4096):
+        for lam in (0.05, 1.0, 7.0, 300.0):
+            name = f"n{n}_lam{lam}"
+            names1.append(name)
+            x = rng.standard_normal(n) * (3.0 if n % 2 else 1.0)
+            out[f"{name}/x"] = x
+            out[f"{name}/lam"] = np.float64(lam)
+            out[f"{name}/tv2"], out[f"{name}/tv2_info"] = ref.tv(x, lam, 2)
+    for shape, lam in (((33, 47), 0.4), ((96, 64), 1.5), ((128, 200), 0.2)):
+        name = f"img{shape[0]}x{shape[1]}"
+        names2.append(name)
+        X = rng.standard_normal(shape)
+        out[f"{name}/X"] = X
+        out[f"{name}/lam"] = np.float64(lam)
+        for n1, n2 in ((2, 2), (1, 2), (2, 1)):
+            out[f"{name}/dr2_{n1}{n2}"] = ref.dr2(X, lam, 0.7 * lam, n_threads=1, norm1=n1, norm2=n2)[0]
+            y, info, rc, _ = ref.pd2(X, [lam, 0.7 * lam], [1, 2], norms=[n1, n2], n_threads=1)
+            out[f"{name}/pd2_{n1}{n2}"], out[f"{name}/pd2_{n1}{n2}_info"] = y, info
+    V = rng.standard_normal((24, 30, 12))
+    out["vol/X"] = V
+    y, info, rc, _ = ref.pd(V, [0.3, 0.2, 0.4], [1, 2, 3], norms=[2, 1, 2], n_threads=1)
+    out["vol/pd_212"], out["vol/pd_212_info"] = y, info
+    out["names1"] = np.array(names1)
+    out["names2"] = np.array(names2)
+    np.savez_compressed(os.path.join(GOLD, "golden_p2.npz"), **out)
+    print("golden_p2.npz:", len(names1), "1-D cases,", len(names2), "images, 1 volume")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--large", action="store_true")
     ap.add_argument("--only-large", action="store_true")
     ap.add_argument("--only-primal-dual", action="store_true", help="regenerate golden_2d_primal_dual.npz only")
+    ap.add_argument("--only-p2", action="store_true", help="regenerate golden_p2.npz only")
     ap.add_argument("--threads", type=int, default=os.cpu_count() or 1)
     args = ap.parse_args()
     if not cpu.have_reference():
         cpu.build_reference(quiet=False)
     ref = cpu.reference()
     os.makedirs(GOLD, exist_ok=True)
+    if args.only_p2:
+        gen_p2(ref)
+        return
     if args.only_primal_dual:
         gen_1d_other_methods(ref)
         gen_2d_primal_dual(ref)
@@ -316,6 +354,7 @@ def main():
         gen_1d_other_methods(ref)
         gen_2d_primal_dual(ref)
         gen_nd(ref)
+        gen_p2(ref)
     if args.large or args.only_large:
         gen_large(ref, args.threads)
 

@@ -59,7 +59,10 @@ int  orc_tautString_TV1_Weighted(const double *y, const double *lambda, double *
 void orc_TV1D_denoise(const double *input, double *output, int width, double lambda);
 /* src/johnsonRyanTV.cpp:9-116 -- Johnson's dynamic programme (tv1_1d method 'dp'), an independent exact algorithm */
 void orc_dp(int n, const double *y, double lam, double *beta);
-/* src/TVgenopt.cpp:30-57 (p==1 arm only; other p -> RC_ERROR, the oracle does not cover them) */
+/* src/TVL2opt.cpp:190-445 (morePG_TV2), solved to convergence from mu = 0 for every fibre: no projected-gradient
+   prelude, no 1e-5 gap stop, no warm start across fibres (see tv1d_oracle.c) */
+int  orc_TV2_exact(const double *y, double lambda, double *x, double *info, int n);
+/* src/TVgenopt.cpp:30-57: p == 1 (bit-identical) and p == 2 (exact TV-L2 prox); other p -> RC_ERROR */
 int  orc_TV(const double *y, double lambda, double *x, double *info, int n, double p);
 
 /* ---- combiners (oracle/tvnd_oracle.c) ---- */

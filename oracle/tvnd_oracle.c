@@ -4,8 +4,11 @@
  * Plain-C restatement of the reference's 2-D / N-D anisotropic TV-L1
  * splitting loops (Douglas-Rachford, proximal Dykstra, parallel proximal
  * Dykstra, parallel Douglas-Rachford, Yang ADMM).  Arrays are column-major
- * (dimension 0 fastest), exactly like the reference.  Only the p == 1 norm is
- * covered (the hot path); any other norm returns RC_ERROR.
+ * (dimension 0 fastest), exactly like the reference.  Norms p == 1 (the hot
+ * path, bit-identical to the reference) and p == 2 (fibres go through the EXACT
+ * TV-L2 prox orc_TV2_exact, see tv1d_oracle.c: the reference's own p == 2 solver
+ * stops at a duality gap of 1e-5 and warm-starts across fibres) are covered;
+ * any other norm returns RC_ERROR.
  * See tv_oracle.h for the parity status.
  */
 #include "tv_oracle.h"
@@ -60,8 +63,8 @@ static inline long fibre_start(const fibres_t *f, long j)
 
 /* out_fibre = prox_lambda( a[.] + sb * b[.] ) along dimension d, for every fibre.
    b may be NULL.  solver: 0 = hybrid taut string via TV() ; 1 = Condat. */
-static void sweep_prox(const double *a, const double *b, double sb, double *out,
-                       const int *ns, int nds, int d, double lambda, int solver)
+static void sweep_prox_p(const double *a, const double *b, double sb, double *out,
+                         const int *ns, int nds, int d, double lambda, int solver, double pnorm)
 {
     const fibres_t f = fibres_along(ns, nds, d);
     #pragma omp parallel
@@ -75,13 +78,19 @@ static void sweep_prox(const double *a, const double *b, double sb, double *out,
                 const long idx = base + k * f.inc;
                 in[k] = b ? a[idx] + sb * b[idx] : a[idx];
             }
-            if (solver == 1) orc_TV1D_denoise(in, res, (int)f.len, lambda);
-            else             orc_TV(in, lambda, res, NULL, (int)f.len, 1);
+            if (solver == 1 && pnorm == 1) orc_TV1D_denoise(in, res, (int)f.len, lambda);
+            else                           orc_TV(in, lambda, res, NULL, (int)f.len, pnorm);
             for (long k = 0; k < f.len; k++) out[base + k * f.inc] = res[k];
         }
         free(in);
         free(res);
     }
+}
+
+static void sweep_prox(const double *a, const double *b, double sb, double *out,
+                       const int *ns, int nds, int d, double lambda, int solver)
+{
+    sweep_prox_p(a, b, sb, out, ns, nds, d, lambda, solver, 1);
 }
 
 /* ------------------------------------------------------------------------- */
@@ -90,7 +99,7 @@ static void sweep_prox(const double *a, const double *b, double sb, double *out,
 /* ------------------------------------------------------------------------- */
 
 /* projection onto B_cols: out = in - colprox(in)   (:459-481, :539-547) */
-static void dr_cols(size_t M, size_t N, const double *in, double *out, double W, const double *Wmat)
+static void dr_cols(size_t M, size_t N, const double *in, double *out, double W, const double *Wmat, double pnorm)
 {
     #pragma omp parallel
     {
@@ -99,7 +108,7 @@ static void dr_cols(size_t M, size_t N, const double *in, double *out, double W,
         for (long j = 0; j < (long)N; j++) {
             const double *col = in + M * (size_t)j;
             if (Wmat) orc_tautString_TV1_Weighted(col, Wmat + (M - 1) * (size_t)j, res, (int)M);
-            else      orc_TV(col, W, res, NULL, (int)M, 1);
+            else      orc_TV(col, W, res, NULL, (int)M, pnorm);
             for (size_t i = 0; i < M; i++) out[M * (size_t)j + i] = col[i] - res[i];
         }
         free(res);
@@ -109,7 +118,7 @@ static void dr_cols(size_t M, size_t N, const double *in, double *out, double W,
 /* projection onto B_{-rows*}: (:498-523).  sign = +1: out = ref - (v - rowprox(v)), v = ref - in
    (unweighted) ; sign = -1: out = (v - rowprox(v)) - ref  (weighted, src/TV2DWopt.cpp:191-221) */
 static void dr_rows(size_t M, size_t N, const double *in, double *out, const double *ref,
-                    double W, const double *Wmat, int sign)
+                    double W, const double *Wmat, int sign, double pnorm)
 {
     #pragma omp parallel
     {
@@ -123,7 +132,7 @@ static void dr_rows(size_t M, size_t N, const double *in, double *out, const dou
                 for (size_t i = 0; i + 1 < N; i++) wl[i] = Wmat[(size_t)j + M * i];
                 orc_tautString_TV1_Weighted(v, wl, res, (int)N);
             } else {
-                orc_TV(v, W, res, NULL, (int)N, 1);
+                orc_TV(v, W, res, NULL, (int)N, pnorm);
             }
             for (size_t i = 0; i < N; i++) {
                 const double diff = v[i] - res[i];
@@ -136,7 +145,8 @@ static void dr_rows(size_t M, size_t N, const double *in, double *out, const dou
 }
 
 static int dr_generic(const char *who, size_t M, size_t N, const double *unary, double W1, double W2,
-                      const double *W1m, const double *W2m, double *s, int nThreads, int maxit, double *info)
+                      const double *W1m, const double *W2m, double *s, int nThreads, int maxit, double *info,
+                      double norm1, double norm2)
 {
     const size_t n = M * N;
     const int weighted = (W1m != NULL);
@@ -155,16 +165,16 @@ static int dr_generic(const char *who, size_t M, size_t N, const double *unary, 
     int iter = 0;
     while (iter < maxit) {
         iter++;
-        dr_cols(M, N, t, s, W1, W1m);                                  /* :408 */
+        dr_cols(M, N, t, s, W1, W1m, norm1);                                  /* :408 */
         for (size_t i = 0; i < n; i++) s[i] = 2 * s[i] - t[i];         /* :411 */
-        dr_rows(M, N, s, tb, unary, W2, W2m, weighted ? -1 : +1);      /* :417 */
+        dr_rows(M, N, s, tb, unary, W2, W2m, weighted ? -1 : +1, norm2);      /* :417 */
         if (weighted) for (size_t i = 0; i < n; i++) tb[i] = -2 * tb[i] - s[i];   /* TV2DWopt.cpp:117 */
         else          for (size_t i = 0; i < n; i++) tb[i] = 2 * tb[i] - s[i];    /* :419 */
         for (size_t i = 0; i < n; i++) t[i] = 0.5 * (t[i] + tb[i]);    /* :422 */
     }
     /* recovery projection (:427-430 ; TV2DWopt.cpp:124-126) */
-    dr_cols(M, N, t, s, W1, W1m);
-    dr_rows(M, N, s, tb, unary, W2, W2m, weighted ? -1 : +1);
+    dr_cols(M, N, t, s, W1, W1m, norm1);
+    dr_rows(M, N, s, tb, unary, W2, W2m, weighted ? -1 : +1, norm2);
     if (weighted) for (size_t i = 0; i < n; i++) s[i] = -s[i] - tb[i];
     else          for (size_t i = 0; i < n; i++) s[i] = tb[i] - s[i];
 
@@ -176,14 +186,15 @@ static int dr_generic(const char *who, size_t M, size_t N, const double *unary, 
 int orc_DR2_TV(size_t M, size_t N, const double *unary, double W1, double W2, double norm1, double norm2,
                double *s, int nThreads, int maxit, double *info)
 {
-    if (norm1 != 1 || norm2 != 1) return fail("DR2_TV(oracle)", "only p == 1 is covered", info);
-    return dr_generic("DR2_TV", M, N, unary, W1, W2, NULL, NULL, s, nThreads, maxit, info);
+    if ((norm1 != 1 && norm1 != 2) || (norm2 != 1 && norm2 != 2))
+        return fail("DR2_TV(oracle)", "only p == 1 and p == 2 are covered", info);
+    return dr_generic("DR2_TV", M, N, unary, W1, W2, NULL, NULL, s, nThreads, maxit, info, norm1, norm2);
 }
 
 int orc_DR2L1W_TV(size_t M, size_t N, const double *unary, const double *W1, const double *W2,
                   double *s, int nThreads, int maxit, double *info)
 {
-    return dr_generic("DR2L1W_TV", M, N, unary, 0, 0, W1, W2, s, nThreads, maxit, info);
+    return dr_generic("DR2L1W_TV", M, N, unary, 0, 0, W1, W2, s, nThreads, maxit, info, 1, 1);
 }
 
 /* ------------------------------------------------------------------------- */
@@ -211,7 +222,7 @@ int orc_PD2_TV(const double *y, const double *lambdas, const double *norms, cons
     if (maxIters <= 0) maxIters = ORC_MAX_ITERS_PD;
     if (npen > 2) return fail("PD2_TV", "this algorithm can not work with more than 2 penalties", info);
     for (int i = 0; i < npen; i++)
-        if (norms[i] != 1) return fail("PD2_TV(oracle)", "only p == 1 is covered", info);
+        if (norms[i] != 1 && norms[i] != 2) return fail("PD2_TV(oracle)", "only p == 1 and p == 2 are covered", info);
 
     const long n = total_size(ns, nds);
     double *p = (double *)calloc((size_t)n, sizeof(double));
@@ -226,11 +237,11 @@ int orc_PD2_TV(const double *y, const double *lambdas, const double *norms, cons
     while (stop > ORC_STOP_PD && (npen > 1 || !iters) && iters < maxIters) {   /* :157 */
         memcpy(xl, x, sizeof(double) * (size_t)n);
         /* z = prox_{d0}(x + p) ; p += x - z   (:169-213) */
-        sweep_prox(x, p, 1.0, z, ns, nds, (int)(dims[0] - 1), lambdas[0], 0);
+        sweep_prox_p(x, p, 1.0, z, ns, nds, (int)(dims[0] - 1), lambdas[0], 0, norms[0]);
         for (long i = 0; i < n; i++) p[i] += x[i] - z[i];
         if (npen >= 2) {
             /* x = prox_{d1}(z + q) ; q += z - x   (:216-263) */
-            sweep_prox(z, q, 1.0, x, ns, nds, (int)(dims[1] - 1), lambdas[1], 0);
+            sweep_prox_p(z, q, 1.0, x, ns, nds, (int)(dims[1] - 1), lambdas[1], 0, norms[1]);
             for (long i = 0; i < n; i++) q[i] += z[i] - x[i];
         } else {
             memcpy(x, z, sizeof(double) * (size_t)n);                  /* :265-270 */
@@ -274,7 +285,7 @@ int orc_PD_TV(const double *y, double *lambdas, const double *norms, const doubl
     set_threads(ncores);
     if (maxIters <= 0) maxIters = ORC_MAX_ITERS_PD;
     for (int i = 0; i < npen; i++)
-        if (norms[i] != 1) return fail("PD_TV(oracle)", "only p == 1 is covered", info);
+        if (norms[i] != 1 && norms[i] != 2) return fail("PD_TV(oracle)", "only p == 1 and p == 2 are covered", info);
     const long n = total_size(ns, nds);
 
     for (int i = 0; i < npen; i++) lambdas[i] *= npen;                 /* :100-101, caller memory */
@@ -293,7 +304,7 @@ int orc_PD_TV(const double *y, double *lambdas, const double *norms, const doubl
     while (stop > ORC_STOP_PD && iters < maxIters) {                   /* :151 */
         for (long k = 0; k < n; k++) { xl[k] = x[k]; x[k] = 0; }
         for (int i = 0; i < npen; i++)                                 /* :164-209 */
-            sweep_prox(z[i], NULL, 0, p[i], ns, nds, (int)(dims[i] - 1), lambdas[i], 0);
+            sweep_prox_p(z[i], NULL, 0, p[i], ns, nds, (int)(dims[i] - 1), lambdas[i], 0, norms[i]);
         for (long k = 0; k < n; k++)                                   /* :212-214 */
             for (int i = 0; i < npen; i++) x[k] += p[i][k] / npen;
         for (long k = 0; k < n; k++)                                   /* :217-220 */
@@ -320,7 +331,7 @@ int orc_PDR_TV(const double *y, double *lambdas, const double *norms, const doub
     set_threads(ncores);
     if (maxIters <= 0) maxIters = ORC_MAX_ITERS_DR;
     for (int i = 0; i < npen; i++)
-        if (norms[i] != 1) return fail("PDR_TV(oracle)", "only p == 1 is covered", info);
+        if (norms[i] != 1 && norms[i] != 2) return fail("PDR_TV(oracle)", "only p == 1 and p == 2 are covered", info);
     const long n = total_size(ns, nds);
 
     for (int i = 0; i < npen; i++) lambdas[i] *= npen;                 /* :334-335, caller memory */
@@ -340,7 +351,7 @@ int orc_PDR_TV(const double *y, double *lambdas, const double *norms, const doub
     while (iters < maxIters) {                                         /* :390 */
         for (long k = 0; k < n; k++) { xl[k] = x[k]; x[k] = 0; q[k] = 0; }
         for (int i = 0; i < npen; i++)                                 /* :405-458, Condat inner solver :438-439 */
-            sweep_prox(z[i], NULL, 0, p[i], ns, nds, (int)(dims[i] - 1), lambdas[i], 1);
+            sweep_prox_p(z[i], NULL, 0, p[i], ns, nds, (int)(dims[i] - 1), lambdas[i], 1, norms[i]);
         for (long k = 0; k < n; k++)                                   /* :465-470 */
             for (int i = 0; i < npen; i++) { q[k] += p[i][k] / npen; x[k] += z[i][k] / npen; }
         for (long k = 0; k < n; k++)                                   /* :474-477 */

@@ -13,8 +13,12 @@ there is no CPU path.  Without a gfx950 device the functions raise :class:`ProxT
 New (not in the reference): :func:`tv1_2d_batch` for stacks of independent images, and :mod:`proxtv_amd.device`
 for arrays that already live in HBM (torch tensors).
 
-Out of scope (raise ``NotImplementedError``): the TV-L2 / TV-Lp solvers (``tv2_1d``, ``tvp_1d``, ``tvp_2d`` with
-p != 1).  ``tv1_1d``'s alternative method names are served by the one exact HIP solver.
+TV-L2 (p = 2) is covered as well: ``tv2_1d``, ``tvp_1d(p=2)``, ``tvp_2d`` and ``tvgen`` with p in {1, 2} -- the fibre prox
+is solved EXACTLY on the device (trust-region / More-Sorensen on the tridiagonal dual), which the reference's own p = 2
+solver is not (it stops at a duality gap of 1e-5 and warm-starts fibres from each other: its results depend on the
+thread count); results agree with the reference within the reference's own guarantee, see DESIGN.md.
+Out of scope (raise ``NotImplementedError``): general p (``tvp_1d`` / ``tvp_2d`` / ``tvgen`` with p not in {1, 2}).
+``tv1_1d``'s alternative method names are served by the one exact HIP solver.
 
 Reproducibility: results are exact minimisers whatever kernel geometry the adaptive policy picks, but geometries differ
 in the last ulps (refined-reciprocal division, closed-form piece values); pin one with ``PROXTV_CHUNK_MODE`` (or
@@ -113,13 +117,43 @@ def tv1w_1d(x, w, method="tautstring", sigma=0.05):
 
 
 def tv2_1d(x, w, method="mspg"):
-    """TV-L2 (reference: prox_tv/__init__.py:257-296) is outside the TV-L1 hot path."""
-    raise NotImplementedError("proxtv_amd implements the TV-L1 solver path only (tv2_1d is out of scope)")
+    r"""1D proximal operator for :math:`\ell_2`: min_y 1/2 ||x-y||^2 + w ||Dy||_2 (reference: prox_tv/__init__.py:257-310).
+    The three method names ('ms', 'pg', 'mspg') call the reference's three C entry points; all are served by the
+    one exact device solver."""
+    assert w >= 0
+    assert method in ("ms", "pg", "mspg")
+    w = force_float_scalar(w)
+    x = _contig(force_float_matrix(x))
+    info = np.zeros(_N_INFO)
+    y = np.zeros(np.size(x), order="F")
+    lib = _lib.require_device()
+    n = int(np.size(x))
+    if method == "ms":
+        lib.more_TV2(_ptr(x), w, _ptr(y), _ptr(info), n)
+    elif method == "pg":
+        lib.PG_TV2(_ptr(x), w, _ptr(y), _ptr(info), n)
+    else:
+        lib.morePG_TV2(_ptr(x), w, _ptr(y), _ptr(info), n, None)
+    _lib.check("tv2_1d")
+    return y
 
 
 def tvp_1d(x, w, p, method="gpfw", max_iters=0):
-    """TV-Lp (reference: prox_tv/__init__.py:311-352) is outside the TV-L1 hot path."""
-    raise NotImplementedError("proxtv_amd implements the TV-L1 solver path only (tvp_1d is out of scope)")
+    """1D proximal operator for the l_p norm (reference: prox_tv/__init__.py:311-352): p = 1 and p = 2 are implemented
+    (the exact TV-L1 / TV-L2 device solvers, whatever `method`); general p is out of scope."""
+    assert method in ("gp", "fw", "gpfw")
+    assert w >= 0
+    assert p >= 1
+    if p not in (1, 2):
+        raise NotImplementedError("proxtv_amd implements p = 1 and p = 2 only (general-p TV is out of scope)")
+    w = force_float_scalar(w)
+    x = _contig(force_float_matrix(x))
+    info = np.zeros(_N_INFO)
+    y = np.zeros(np.size(x), order="F")
+    lib = _lib.require_device()
+    lib.TV(_ptr(x), w, _ptr(y), _ptr(info), int(np.size(x)), float(p), None)
+    _lib.check("tvp_1d")
+    return y
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -180,21 +214,22 @@ def tv1w_2d(x, w_col, w_row, max_iters=0, n_threads=1):
 
 
 def tvp_2d(x, w_col, w_row, p_col, p_row, n_threads=1, max_iters=0):
-    r"""2D proximal operator for :math:`\ell_p` norms (reference: prox_tv/__init__.py:484-530); only
-    p_col == p_row == 1 is implemented (DR2_TV with separate column / row penalties)."""
+    r"""2D proximal operator for :math:`\ell_p` norms (reference: prox_tv/__init__.py:484-530): DR2_TV with separate
+    column / row penalties and norms; p in {1, 2} is implemented."""
     assert w_col >= 0
     assert w_row >= 0
     assert p_col >= 1
     assert p_row >= 1
-    if p_col != 1 or p_row != 1:
-        raise NotImplementedError("proxtv_amd implements the TV-L1 solver path only (tvp_2d needs p_col = p_row = 1)")
+    if p_col not in (1, 2) or p_row not in (1, 2):
+        raise NotImplementedError("proxtv_amd implements p = 1 and p = 2 only (general-p TV is out of scope)")
     info = np.zeros(_N_INFO)
     x = np.asfortranarray(x, dtype="float64")
     w_col = force_float_scalar(w_col)
     w_row = force_float_scalar(w_row)
     y = np.zeros(np.shape(x), order="F")
     lib = _lib.require_device()
-    lib.DR2_TV(x.shape[0], x.shape[1], _ptr(x), w_col, w_row, 1.0, 1.0, _ptr(y), int(n_threads), int(max_iters), _ptr(info))
+    lib.DR2_TV(x.shape[0], x.shape[1], _ptr(x), w_col, w_row, float(p_col), float(p_row), _ptr(y), int(n_threads),
+               int(max_iters), _ptr(info))
     _lib.check("tvp_2d")
     return y
 
@@ -220,8 +255,10 @@ def tvgen(x, ws, ds, ps, n_threads=1, max_iters=0):
     ws = force_float_matrix(ws)
     ps = force_float_matrix(ps)
     y = np.zeros(np.shape(x), order="F")
-    if np.any(ps != 1):
-        raise NotImplementedError("proxtv_amd implements the TV-L1 solver path only (tvgen needs every p = 1)")
+    if np.any((ps != 1) & (ps != 2)):
+        raise NotImplementedError("proxtv_amd implements p = 1 and p = 2 only (general-p TV is out of scope)")
+    if not (ps.flags.c_contiguous or ps.flags.f_contiguous):
+        ps = np.ascontiguousarray(ps)
     dims = np.array(ds, dtype=np.float64)            # cffi turns the `ds` sequence into a temporary double[]
     ns = np.array(x.shape, dtype=np.int32)           # ... and x.shape into a temporary int[]
     if not (ws.flags.c_contiguous or ws.flags.f_contiguous):

@@ -34,6 +34,9 @@ SIGNATURES = {
     "Yang3_TV": (C.c_int, [C.c_size_t, C.c_size_t, C.c_size_t, _dp, C.c_double, _dp, C.c_int, _dp]),
     "Kolmogorov2_TV": (C.c_int, [C.c_size_t, C.c_size_t, _dp, C.c_double, _dp, C.c_int, _dp]),
     "CondatChambollePock2_TV": (C.c_int, [C.c_size_t, C.c_size_t, _dp, C.c_double, _dp, C.c_short, C.c_int, _dp]),
+    "more_TV2": (C.c_int, [_dp, C.c_double, _dp, _dp, C.c_int]),
+    "morePG_TV2": (C.c_int, [_dp, C.c_double, _dp, _dp, C.c_int, C.c_void_p]),
+    "PG_TV2": (C.c_int, [_dp, C.c_double, _dp, _dp, C.c_int]),
     "newWorkspace": (C.c_void_p, [C.c_int]),
     "resetWorkspace": (None, [C.c_void_p]),
     "freeWorkspace": (None, [C.c_void_p]),
@@ -58,6 +61,10 @@ SIGNATURES = {
     "proxtv_DR2_TV_batch_dev": (C.c_int, [C.c_size_t, C.c_size_t, C.c_size_t, _dp, C.c_double, C.c_double, _dp,
                                           C.c_int, _dp, C.c_void_p]),
     "proxtv_DR2_TV_batch": (C.c_int, [C.c_size_t, C.c_size_t, C.c_size_t, _dp, C.c_double, C.c_double, _dp, C.c_int, _dp]),
+    "proxtv_tvp_fibres_dev": (C.c_int, [_dp, _dp, _ip, C.c_int, C.c_int, C.c_double, C.c_double, C.c_void_p]),
+    "proxtv_DR2_TVp_dev": (C.c_int, [C.c_size_t, C.c_size_t, _dp, C.c_double, C.c_double, C.c_double, C.c_double, _dp, C.c_int,
+                                     _dp, C.c_void_p]),
+    "proxtv_PD_TVp_dev": (C.c_int, [C.c_int, _dp, _dp, _dp, _dp, _dp, _dp, _ip, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "proxtv_last_fixups": (C.c_long, []),
     "proxtv_chunk_mode": (C.c_int, []),
     "proxtv_debug_trace": (C.c_long, [C.c_void_p, C.c_long]),

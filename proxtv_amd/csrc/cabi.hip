@@ -110,7 +110,7 @@ struct SolveScope {
 };
 
 // exact 1-D prox of one host signal (all unweighted 1-D entry points land here)
-void prox1d_host(const double *y, const double *w, double lam, double *x, int n, double first_offset) {
+void prox1d_host(const double *y, const double *w, double lam, double *x, int n, double first_offset, double norm = 1) {
     if (n <= 0) return;
     hipStream_t s = thread_stream();
     SolveScope scope(s);   // per-call counters, profile option, the policy's across-call exploration
@@ -124,14 +124,19 @@ void prox1d_host(const double *y, const double *w, double lam, double *x, int n,
     std::unique_ptr<Staged> wd;
     if (w && n > 1) wd.reset(new Staged(w, (size_t)n - 1, s));
     const int ns[1] = {n};
-    tv1_fibres(in.d(), out.d(), ns, 1, 0, lam, wd ? wd->d() : nullptr, s);
+    if (norm == 2) prox_fibres(in.d(), out.d(), ns, 1, 0, lam, 2, s);
+    else           tv1_fibres(in.d(), out.d(), ns, 1, 0, lam, wd ? wd->d() : nullptr, s);
     download(x, out.d(), (size_t)n, s);
     scope.finish();
 }
 
-void check_norms(const double *norms, int npen) {
-    for (int i = 0; i < npen; i++)
-        if (norms[i] != 1) reject("only the p = 1 norm (TV-L1) is implemented on the HIP path");
+bool check_norms(const double *norms, int npen) {   // returns whether any term is TV-L2
+    bool l2 = false;
+    for (int i = 0; i < npen; i++) {
+        if (norms[i] != 1 && norms[i] != 2) reject("only the p = 1 (TV-L1) and p = 2 (TV-L2) norms are implemented on the HIP path");
+        l2 = l2 || norms[i] == 2;
+    }
+    return l2;
 }
 
 long total(const int *ns, int nds) {
@@ -160,11 +165,25 @@ int TV(double *y, double lambda, double *x, double *info, int n, double p, Works
         return 0;
     }
     return guarded("TVopt", info, 1, [&] {
-        if (p != 1) reject("only the p = 1 norm (TV-L1) is implemented on the HIP path");
-        prox1d_host(y, nullptr, lambda, x, n, 0.0);
+        if (p != 1 && p != 2) reject("only the p = 1 (TV-L1) and p = 2 (TV-L2) norms are implemented on the HIP path");
+        prox1d_host(y, nullptr, lambda, x, n, 0.0, p);
         if (info) { info[INFO_RC] = RC_OK; info[INFO_ITERS] = 0; info[INFO_GAP] = 0; }
     });
 }
+
+// TV-L2 (src/TVL2opt.cpp: more_TV2 :35, morePG_TV2 :190, PG_TV2 :446 -- three iteration schemes for the same prox; all are
+// served by the exact trust-region solve of tv2.hip, which reports its mu-search as iterations and 0 as the gap)
+static int tv2_host(const char *who, double *y, double lambda, double *x, double *info, int n) {
+    return guarded(who, info, 1, [&] {
+        prox1d_host(y, nullptr, lambda, x, n, 0.0, 2);
+        if (info) { info[INFO_RC] = RC_OK; info[INFO_ITERS] = 0; info[INFO_GAP] = 0; }
+    });
+}
+int more_TV2(double *y, double lambda, double *x, double *info, int n) { return tv2_host("more_TV2", y, lambda, x, info, n); }
+int morePG_TV2(double *y, double lambda, double *x, double *info, int n, Workspace *) {
+    return tv2_host("more_TV2", y, lambda, x, info, n);
+}
+int PG_TV2(double *y, double lambda, double *x, double *info, int n) { return tv2_host("PG_TV2", y, lambda, x, info, n); }
 
 int linearizedTautString_TV1(double *y, double lambda, double *x, int n) {
     return guarded("linearizedTautString_TV1", nullptr, 1, [&] { prox1d_host(y, nullptr, lambda, x, n, 0.0); });
@@ -204,12 +223,14 @@ int DR2_TV(size_t M, size_t N, double *unary, double W1, double W2, double norm1
            int maxit, double *info) {
     // returns 0 on success like the reference (src/TV2Dopt.cpp:440); failures also return 0 with info[RC]=RC_ERROR
     return guarded("DR2_TV", info, 0, [&] {
-        if (norm1 != 1 || norm2 != 1) reject("only the p = 1 norm (TV-L1) is implemented on the HIP path");
+        const double nrm[2] = {norm1, norm2};
+        const bool l2 = check_norms(nrm, 2);
         hipStream_t st = thread_stream();
         SolveScope scope(st);
         Staged u(unary, M * N, st);
         Scratch out(sizeof(double) * M * N);
-        const SolveInfo si = dr2(M, N, 1, u.d(), W1, W2, nullptr, nullptr, out.d(), maxit, st);
+        const SolveInfo si = l2 ? dr2_norms(M, N, u.d(), W1, W2, norm1, norm2, out.d(), maxit, st)
+                                : dr2(M, N, 1, u.d(), W1, W2, nullptr, nullptr, out.d(), maxit, st);
         download(s, out.d(), M * N, st);
         scope.finish();
         put_info(info, si);
@@ -242,7 +263,7 @@ int PD2_TV(double *y, double *lambdas, double *norms, double *dims, double *x, d
         const size_t n = (size_t)total(ns, nds);
         Staged in(y, n, st);
         Scratch out(sizeof(double) * n);
-        const SolveInfo si = pd2(in.d(), lambdas, dims, out.d(), ns, nds, npen, maxIters, st);
+        const SolveInfo si = pd2(in.d(), lambdas, dims, out.d(), ns, nds, npen, maxIters, st, norms);
         download(x, out.d(), n, st);
         scope.finish();
         put_info(info, si);
@@ -261,8 +282,8 @@ static int pd_family_host(const char *who, bool dr_variant, double *y, double *l
         const size_t n = (size_t)total(ns, nds);
         Staged in(y, n, st);
         Scratch out(sizeof(double) * n);
-        const SolveInfo si = dr_variant ? pdr(in.d(), lambdas, dims, out.d(), ns, nds, npen, maxIters, st)
-                                        : pd(in.d(), lambdas, dims, out.d(), ns, nds, npen, maxIters, st);
+        const SolveInfo si = dr_variant ? pdr(in.d(), lambdas, dims, out.d(), ns, nds, npen, maxIters, st, norms)
+                                        : pd(in.d(), lambdas, dims, out.d(), ns, nds, npen, maxIters, st, norms);
         download(x, out.d(), n, st);
         scope.finish();
         put_info(info, si);
@@ -559,6 +580,59 @@ int proxtv_tv1_fibres_dev(const double *in, double *out, const int *ns, int nds,
         guard.commit(st);
         PTV_HIP(hipStreamSynchronize(st));
         scope.finish();
+    });
+}
+
+int proxtv_tvp_fibres_dev(const double *in, double *out, const int *ns, int nds, int dim, double lambda, double p,
+                          void *stream) {
+    return guarded("proxtv_tvp_fibres_dev", nullptr, 1, [&] {
+        if (dim < 0 || dim >= nds) reject("dimension out of range");
+        if (p != 1 && p != 2) reject("only the p = 1 (TV-L1) and p = 2 (TV-L2) norms are implemented on the HIP path");
+        hipStream_t st = pick(stream);
+        SolveScope scope(st);
+        const size_t n = (size_t)total(ns, nds);
+        OutGuard guard(out, n, {{in, n}});
+        prox_fibres(in, guard.ptr(), ns, nds, dim, lambda, p, st);
+        guard.commit(st);
+        PTV_HIP(hipStreamSynchronize(st));
+        scope.finish();
+    });
+}
+
+int proxtv_DR2_TVp_dev(size_t M, size_t N, const double *unary, double W1, double W2, double norm1, double norm2, double *s,
+                       int maxit, double *info, void *stream) {
+    return guarded("proxtv_DR2_TVp_dev", info, 0, [&] {
+        const double nrm[2] = {norm1, norm2};
+        const bool l2 = check_norms(nrm, 2);
+        hipStream_t st = pick(stream);
+        SolveScope scope(st);
+        OutGuard out(s, M * N, {{unary, M * N}});
+        const SolveInfo si = l2 ? dr2_norms(M, N, unary, W1, W2, norm1, norm2, out.ptr(), maxit, st)
+                                : dr2(M, N, 1, unary, W1, W2, nullptr, nullptr, out.ptr(), maxit, st);
+        out.commit(st);
+        PTV_HIP(hipStreamSynchronize(st));
+        scope.finish();
+        put_info(info, si);
+    });
+}
+
+int proxtv_PD_TVp_dev(int which, const double *y, const double *lambdas_scaled, const double *norms, const double *dims,
+                      double *x, double *info, const int *ns, int nds, int npen, int maxIters, void *stream) {
+    return guarded("proxtv_PD_TVp_dev", info, 1, [&] {
+        if (npen < 1) reject("at least one penalty term is required");
+        if (which == 0 && npen > 2) reject("PD2 works with 1 or 2 penalties");
+        check_norms(norms, npen);
+        check_dims(dims, npen, nds);
+        hipStream_t st = pick(stream);
+        SolveScope scope(st);
+        OutGuard out(x, (size_t)total(ns, nds), {{y, (size_t)total(ns, nds)}});
+        const SolveInfo si = which == 0 ? pd2(y, lambdas_scaled, dims, out.ptr(), ns, nds, npen, maxIters, st, norms)
+                           : which == 1 ? pd(y, lambdas_scaled, dims, out.ptr(), ns, nds, npen, maxIters, st, norms)
+                                        : pdr(y, lambdas_scaled, dims, out.ptr(), ns, nds, npen, maxIters, st, norms);
+        out.commit(st);
+        PTV_HIP(hipStreamSynchronize(st));
+        scope.finish();
+        put_info(info, si);
     });
 }
 

@@ -249,6 +249,26 @@ void calib_copy(const double *src, double *dst, long n, hipStream_t s) {
     PTV_HIP(hipGetLastError());
 }
 
+__global__ void lincomb_kernel(double *out, const double *a, double ca, const double *b, double cb, const double *c, double cc,
+                               const double *d, double cd, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        double v = ca * a[i];
+        if (b) v += cb * b[i];
+        if (c) v += cc * c[i];
+        if (d) v += cd * d[i];
+        out[i] = v;
+    }
+}
+
+void lincomb(double *out, const double *a, double ca, const double *b, double cb, const double *c, double cc,
+             const double *d, double cd, long n, hipStream_t s) {
+    if (n <= 0) return;
+    const long blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(lincomb_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, s, out, a, ca, b, cb, c, cc, d,
+                       cd, n);
+    PTV_HIP(hipGetLastError());
+}
+
 void scale_to(const double *y, double *x, double divisor, long n, hipStream_t s) {
     hipLaunchKernelGGL(scale_kernel, dim3(grid_for(n, 4096)), dim3(kThreads), 0, s, y, x, divisor, n);
     PTV_HIP(hipGetLastError());

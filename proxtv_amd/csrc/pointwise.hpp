@@ -28,6 +28,10 @@ void pdr_combine(const PtrPack &p, const PtrPack &z, const double *x, double *xo
                  double *out, hipStream_t s);
 // x = y / P                                                 (PDR initialisation, src/TVNDopt.cpp:362-367)
 void scale_to(const double *y, double *x, double divisor, long n, hipStream_t s);
+// out = ca a + cb b + cc c + cd d   (null pointers are skipped; out may alias any operand).  The unfused splitting loops
+// of the mixed-norm solvers are made of these.
+void lincomb(double *out, const double *a, double ca, const double *b, double cb, const double *c, double cc,
+             const double *d, double cd, long n, hipStream_t s);
 // dst = src, 8 bytes per lane (counter calibration only)
 void calib_copy(const double *src, double *dst, long n, hipStream_t s);
 // Yang X update (src/TV2Dopt.cpp:832-833 ; src/TVNDopt.cpp:729-730): X = (Y + sum U_k + rho sum Z_k) / (1 + D rho)

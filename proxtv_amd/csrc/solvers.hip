@@ -14,6 +14,7 @@
 
 #include "pointwise.hpp"
 #include "sweep.hpp"
+#include "tv2.hpp"
 
 namespace ptv {
 
@@ -45,6 +46,11 @@ void tv1_fibres(const double *in, double *out, const int *ns, int nds, int dim, 
     a.lam = lam;
     a.w = weights;
     launch_sweep(OP_PROX, weights != nullptr, a, fibres_along(ns, nds, dim), s, fam_of_dim(dim), in != out);
+}
+
+void prox_fibres(const double *in, double *out, const int *ns, int nds, int dim, double lam, double norm, hipStream_t s) {
+    if (norm == 2) tv2_fibres(in, out, ns, nds, dim, lam, s);
+    else           tv1_fibres(in, out, ns, nds, dim, lam, nullptr, s);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -98,12 +104,47 @@ SolveInfo dr2(size_t M, size_t N, size_t B, const double *unary, double W1, doub
     return info;
 }
 
+// The same recurrence with the fibre prox of either norm as a separate step (src/TV2Dopt.cpp:539-547 applies
+// TV(..., norm) per fibre): s = t - prox_c(t) ; s' = 2 s - t ; v = U - s' ; tb = U - (v - prox_r(v)) ; t <- 1/2 (t + 2 tb - s').
+SolveInfo dr2_norms(size_t M, size_t N, const double *unary, double W1, double W2, double norm1, double norm2, double *out,
+                    int maxit, hipStream_t s) {
+    SolveInfo info;
+    const long n = (long)(M * N);
+    if (maxit <= 0) maxit = MAX_ITERS_DR;
+    info.iters = maxit;
+    if (n == 0) return info;
+    const int ns[2] = {(int)M, (int)N};
+    const size_t bytes = sizeof(double) * (size_t)n;
+    Scratch t(bytes), x(bytes), sp(bytes), v(bytes);
+    Scratch partials(sizeof(double) * kReduceBlocks), sums(sizeof(double));
+    sum_to(unary, n, 1, partials.d(), sums.d(), s);
+    dr_fill(t.d(), n, 1, sums.d(), 1.0, s);
+    auto cols = [&](const double *tin, double *sout, double c_s, double c_t) {   // sout = c_s (t - prox_c(t)) + c_t t
+        prox_fibres(tin, x.d(), ns, 2, 0, W1, norm1, s);
+        lincomb(sout, tin, c_s + c_t, x.d(), -c_s, nullptr, 0, nullptr, 0, n, s);
+    };
+    for (int it = 0; it < maxit; it++) {
+        cols(t.d(), sp.d(), 2.0, -1.0);                                                  // s' = 2 (t - x) - t
+        lincomb(v.d(), unary, 1.0, sp.d(), -1.0, nullptr, 0, nullptr, 0, n, s);          // v = U - s'
+        prox_fibres(v.d(), x.d(), ns, 2, 1, W2, norm2, s);
+        // tb = U - (v - x) ; t = 1/2 (t + 2 tb - s') = 1/2 t + U - v + x - 1/2 s' = 1/2 t + x + 1/2 s'   (U - v = s')
+        lincomb(t.d(), t.d(), 0.5, x.d(), 1.0, sp.d(), 0.5, nullptr, 0, n, s);
+    }
+    cols(t.d(), sp.d(), 1.0, 0.0);                                                       // s = t - prox_c(t)
+    lincomb(v.d(), unary, 1.0, sp.d(), -1.0, nullptr, 0, nullptr, 0, n, s);
+    prox_fibres(v.d(), x.d(), ns, 2, 1, W2, norm2, s);
+    // out = [U - (v - x)] - s = (U - v) + x - s = x        (U - v = s)
+    PTV_HIP(hipMemcpyAsync(out, x.d(), bytes, hipMemcpyDeviceToDevice, s));
+    return info;
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // Proximal Dykstra with one or two terms, reference: src/TV2Dopt.cpp:59-302.
 //   x = y, p = q = 0 ; repeat: z = prox_d0(x + p), p += x - z ; x' = prox_d1(z + q), q += z - x' ; stop = mean|x' - x|
 SolveInfo pd2(const double *y, const double *lambdas, const double *dims, double *x, const int *ns, int nds, int npen,
-              int maxIters, hipStream_t s) {
+              int maxIters, hipStream_t s, const double *norms) {
     SolveInfo info;
+    const bool l2a = norms && norms[0] == 2, l2b = norms && npen >= 2 && norms[1] == 2;
     info.gap_set = true;
     if (maxIters <= 0) maxIters = MAX_ITERS_PD;
     const long n = total(ns, nds);
@@ -124,15 +165,27 @@ SolveInfo pd2(const double *y, const double *lambdas, const double *dims, double
     double stop = DBL_MAX;
     int iters = 0;
     while (stop > STOP_PD && (npen > 1 || !iters) && iters < maxIters) {   // :157
-        SweepArgs a;
-        a.a = xc; a.b = pi; a.o0 = z.d(); a.o1 = po; a.lam = lambdas[0];
-        launch_sweep(OP_PD2_A, false, a, g0, s, fam_of_dim(d0), true);
+        if (l2a) {   // z = prox2(x + p) ; p += x - z     (unfused: the TV-L2 prox is its own kernel)
+            lincomb(po, xc, 1.0, pi, 1.0, nullptr, 0, nullptr, 0, n, s);
+            tv2_fibres(po, z.d(), ns, nds, d0, lambdas[0], s);
+            lincomb(po, pi, 1.0, xc, 1.0, z.d(), -1.0, nullptr, 0, n, s);
+        } else {
+            SweepArgs a;
+            a.a = xc; a.b = pi; a.o0 = z.d(); a.o1 = po; a.lam = lambdas[0];
+            launch_sweep(OP_PD2_A, false, a, g0, s, fam_of_dim(d0), true);
+        }
         std::swap(pi, po);
         const double *xnew;
         if (npen >= 2) {
-            SweepArgs b;
-            b.a = z.d(); b.b = qi; b.o0 = xn; b.o1 = qo; b.lam = lambdas[1];
-            launch_sweep(OP_PD2_B, false, b, g1, s, fam_of_dim(d1), true);
+            if (l2b) {
+                lincomb(qo, z.d(), 1.0, qi, 1.0, nullptr, 0, nullptr, 0, n, s);
+                tv2_fibres(qo, xn, ns, nds, d1, lambdas[1], s);
+                lincomb(qo, qi, 1.0, z.d(), 1.0, xn, -1.0, nullptr, 0, n, s);
+            } else {
+                SweepArgs b;
+                b.a = z.d(); b.b = qi; b.o0 = xn; b.o1 = qo; b.lam = lambdas[1];
+                launch_sweep(OP_PD2_B, false, b, g1, s, fam_of_dim(d1), true);
+            }
             std::swap(qi, qo);
             xnew = xn;
         } else {
@@ -170,7 +223,7 @@ struct Family {
 };
 
 SolveInfo pd_like(bool dr_variant, const double *y, const double *lambdas, const double *dims, double *x, const int *ns,
-                  int nds, int npen, int maxIters, hipStream_t s) {
+                  int nds, int npen, int maxIters, hipStream_t s, const double *norms) {
     SolveInfo info;
     info.gap_set = true;
     if (npen > kMaxTerms) {
@@ -192,6 +245,10 @@ SolveInfo pd_like(bool dr_variant, const double *y, const double *lambdas, const
     while ((dr_variant || stop > STOP_PD) && iters < maxIters) {
         for (int i = 0; i < npen; i++) {
             const int d = (int)(dims[i] - 1);
+            if (norms && norms[i] == 2) {
+                tv2_fibres(z.pack.v[i], p.pack.v[i], ns, nds, d, lambdas[i], s);
+                continue;
+            }
             SweepArgs a;
             a.a = z.pack.v[i]; a.o0 = p.pack.v[i]; a.lam = lambdas[i];
             launch_sweep(OP_PROX, false, a, fibres_along(ns, nds, d), s, fam_of_dim(d), true);
@@ -213,13 +270,13 @@ SolveInfo pd_like(bool dr_variant, const double *y, const double *lambdas, const
 }  // namespace
 
 SolveInfo pd(const double *y, const double *lambdas, const double *dims, double *x, const int *ns, int nds, int npen,
-             int maxIters, hipStream_t s) {
-    return pd_like(false, y, lambdas, dims, x, ns, nds, npen, maxIters, s);
+             int maxIters, hipStream_t s, const double *norms) {
+    return pd_like(false, y, lambdas, dims, x, ns, nds, npen, maxIters, s, norms);
 }
 
 SolveInfo pdr(const double *y, const double *lambdas, const double *dims, double *x, const int *ns, int nds, int npen,
-              int maxIters, hipStream_t s) {
-    return pd_like(true, y, lambdas, dims, x, ns, nds, npen, maxIters, s);
+              int maxIters, hipStream_t s, const double *norms) {
+    return pd_like(true, y, lambdas, dims, x, ns, nds, npen, maxIters, s, norms);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

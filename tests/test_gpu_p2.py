@@ -1,0 +1,90 @@
+"""TV-L2 (p = 2) on the HIP path: the exact device fibre solver and the mixed-norm splitting
+loops against the oracle (tight: both are exact), optimality conditions on the device output, and the compiled
+reference's golden outputs within the reference's own accuracy (see tests/test_oracle_p2.py for that bar)."""
+import numpy as np
+import pytest
+
+from conftest import assert_close, load_golden
+from test_oracle_p2 import REF_FIBRE_BOUND, kkt_gap, objective
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gp2():
+    return load_golden("golden_p2.npz")
+
+
+def test_tv2_1d_vs_oracle_and_optimality(ptv, oracle):
+    rng = np.random.default_rng(11)
+    for t in range(60):
+        n = int(rng.choice([1, 2, 3, 7, 64, 65, 300, 1000, 5000]))
+        y = rng.standard_normal(n) * float(rng.choice([0.01, 1.0, 20.0]))
+        lam = float(abs(rng.standard_normal()) * rng.choice([0.0, 0.05, 1.0, 40.0, 1e5]))
+        got = ptv.tv2_1d(y, lam, method=str(rng.choice(["ms", "pg", "mspg"])))
+        want, _ = oracle.tv(y, lam, 2)
+        assert np.max(np.abs(got - want)) <= 1e-9 * max(1.0, np.max(np.abs(y))), (n, lam)
+        if n >= 2 and lam > 0:
+            gap, infeas = kkt_gap(got, y, lam)
+            assert gap <= 1e-10 * max(1.0, objective(y * 0 + y.mean(), y, lam)) and infeas <= 1e-11 * max(lam, 1.0)
+    np.testing.assert_allclose(ptv.tvp_1d(y, lam, 2), ptv.tv2_1d(y, lam), rtol=0, atol=1e-12 * max(1.0, np.max(np.abs(y))))
+    with pytest.raises(NotImplementedError):
+        ptv.tvp_1d(y, lam, 1.5)
+
+
+def test_tv_symbol_p2_info(clib, oracle):
+    y = np.random.default_rng(12).standard_normal(400)
+    x, info = np.zeros(400), np.array([-7.0, -7.0, -7.0])
+    assert clib.TV(y.ctypes.data, 2.5, x.ctypes.data, info.ctypes.data, 400, 2.0, None) == 1
+    assert info[2] == 0
+    assert_close(x, oracle.tv(y, 2.5, 2)[0], tol=1e-10)
+    assert clib.TV(y.ctypes.data, 2.5, x.ctypes.data, info.ctypes.data, 400, 3.0, None) == 0 and info[2] == 3   # general p: RC_ERROR
+
+
+def test_batched_fibres_both_directions(oracle):
+    import torch
+    from proxtv_amd import _lib, device
+    lib = _lib.require_device()
+    rng = np.random.default_rng(13)
+    X = rng.standard_normal((150, 70, 5))
+    xd = device.to_colmajor(torch.from_numpy(X).cuda())
+    for dim in (0, 1, 2):
+        out = device.colmajor_empty(X.shape)
+        ns = np.array(X.shape, dtype=np.int32)
+        lib.proxtv_tvp_fibres_dev(xd.data_ptr(), out.data_ptr(), ns.ctypes.data, 3, dim, 0.8, 2.0, None)
+        _lib.check("tvp_fibres")
+        got = out.cpu().numpy()
+        want = np.apply_along_axis(lambda f: oracle.tv(f, 0.8, 2)[0], dim, X)
+        assert np.max(np.abs(got - want)) <= 1e-10
+
+
+def test_mixed_norm_loops_vs_oracle(ptv, oracle):
+    rng = np.random.default_rng(14)
+    X = rng.standard_normal((90, 120))
+    for n1, n2 in ((2, 2), (1, 2), (2, 1)):
+        assert_close(ptv.tvp_2d(X, 0.6, 0.4, n1, n2), oracle.dr2(X, 0.6, 0.4, norm1=n1, norm2=n2)[0], tol=1e-9, what=f"dr2 {n1}{n2}")
+        assert_close(ptv.tvp_2d(X, 0.6, 0.4, n1, n2, max_iters=5), oracle.dr2(X, 0.6, 0.4, max_iters=5, norm1=n1, norm2=n2)[0],
+                     tol=1e-9, what=f"dr2 {n1}{n2} 5 its")
+        want, info, rc, _ = oracle.pd2(X, [0.6, 0.4], [1, 2], norms=[n1, n2])
+        assert_close(ptv.tvgen(X, [0.6, 0.4], [1, 2], [n1, n2]), want, tol=1e-9, what=f"pd2 {n1}{n2}")
+    V = rng.standard_normal((20, 26, 14))
+    want, info, rc, _ = oracle.pd(V, [0.3, 0.2, 0.4], [1, 2, 3], norms=[2, 1, 2])
+    assert_close(ptv.tvgen(V, [0.3, 0.2, 0.4], [1, 2, 3], [2, 1, 2]), want, tol=1e-9, what="pd 212")
+    with pytest.raises(NotImplementedError):
+        ptv.tvgen(V, [0.3, 0.2, 0.4], [1, 2, 3], [2, 1, 1.5])
+
+
+def test_vs_reference_goldens_within_reference_accuracy(ptv, gp2):
+    for name in gp2["names1"]:
+        x, lam = gp2[f"{name}/x"], float(gp2[f"{name}/lam"])
+        got = ptv.tv2_1d(x, lam)
+        if x.size == 1:
+            np.testing.assert_array_equal(got, x)     # (the reference fails on n = 1: malloc(0))
+            continue
+        assert np.sqrt(np.sum((got - gp2[f"{name}/tv2"]) ** 2)) <= REF_FIBRE_BOUND, name
+    for name in gp2["names2"]:
+        X, lam = gp2[f"{name}/X"], float(gp2[f"{name}/lam"])
+        for n1, n2 in ((2, 2), (1, 2), (2, 1)):
+            assert np.max(np.abs(ptv.tvp_2d(X, lam, 0.7 * lam, n1, n2) - gp2[f"{name}/dr2_{n1}{n2}"])) <= 4 * REF_FIBRE_BOUND
+            assert np.max(np.abs(ptv.tvgen(X, [lam, 0.7 * lam], [1, 2], [n1, n2]) - gp2[f"{name}/pd2_{n1}{n2}"])) <= 4 * REF_FIBRE_BOUND
+    assert np.max(np.abs(ptv.tvgen(gp2["vol/X"], [0.3, 0.2, 0.4], [1, 2, 3], [2, 1, 2]) - gp2["vol/pd_212"])) <= 4 * REF_FIBRE_BOUND
