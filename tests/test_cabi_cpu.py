@@ -108,8 +108,9 @@ def test_python_surface_argument_checks():
     with pytest.raises(AssertionError):
         ptv.tvp_2d(x, 1, 1, 0.5, 1)
     # out-of-scope solvers say so instead of silently doing something else
-    for call in (lambda: ptv.tv2_1d(np.zeros(5), 1.0), lambda: ptv.tvp_1d(np.zeros(5), 1.0, 1.5),
-                 lambda: ptv.tvp_2d(x, 1, 1, 2, 2), lambda: ptv.tvgen(x, [1, 1], [1, 2], [1, 2])):
+    # (general p; p = 1 and p = 2 are implemented)
+    for call in (lambda: ptv.tvp_1d(np.zeros(5), 1.0, 1.5), lambda: ptv.tvp_2d(x, 1, 1, 2, 1.5),
+                 lambda: ptv.tvgen(x, [1, 1], [1, 2], [1, 3])):
         with pytest.raises(NotImplementedError):
             call()
 
