@@ -212,7 +212,9 @@ struct NoFar {
 // before it are read-only); `block_last`: this is the last chunk of its block (or of the fibre); `link_ok`: the lane's
 // walk is known to continue its predecessor's (or began at the fibre start / at a bend known a priori).
 // Rows are replaced by F::fuse(y, v): the prox value itself, or directly the sweep's output when it depends on (y, x) only.
-template <class F, bool WEIGHTED, int C, class Win>
+// UNROLL: how many rows of the two passes are in flight together (1 where registers are scarce: the 64-fibre tile at two
+// workgroups per CU; more where the LDS latency of a row would otherwise be paid row by row).
+template <class F, bool WEIGHTED, int C, int UNROLL = 1, class Win>
 __device__ __forceinline__ void rebuild_owned(Win &win, const ChunkRec &rec, int cs, int ce, int len, int start, bool link_ok,
                                               int wlo, bool block_last, double lam) {
     // An unproven lane keeps to its own rows -- but if its own walk bent exactly at the chunk start, the piece that
@@ -272,7 +274,7 @@ __device__ __forceinline__ void rebuild_owned(Win &win, const ChunkRec &rec, int
     if (!F::USES_Y) {
         // The output does not depend on the row's own sample: the value of a piece is parked in the row where the piece
         // ends (forward pass), then every other row takes the value of the next piece end after it (backward pass).
-#pragma unroll 1
+#pragma unroll UNROLL
         for (int u = 0; u < C; u++) {
             const bool in = cs + u < ce;
             const double v = step(u, in ? win.y(cs + u) : 0.0, s, cnt, hprev, true);
@@ -280,7 +282,7 @@ __device__ __forceinline__ void rebuild_owned(Win &win, const ChunkRec &rec, int
         }
         have = tail_value(s, cnt, hprev, cur);
         if (have) cur = F::fuse(0.0, cur);
-#pragma unroll 1
+#pragma unroll UNROLL
         for (int u = C - 1; u >= 0; u--) {
             const bool e = (rec.ends >> u) & 1u;
             const bool in = cs + u < ce;
@@ -294,7 +296,7 @@ __device__ __forceinline__ void rebuild_owned(Win &win, const ChunkRec &rec, int
         // first (it is in a register), the earlier ones -- none for a one-sample piece -- in a short loop.  No second pass,
         // nothing waits in registers (sixteen parked values spill at the 128-VGPR budget of two workgroups per CU).
         int first = a0 > wlo ? a0 : wlo;
-#pragma unroll 1
+#pragma unroll UNROLL
         for (int u = 0; u < C; u++) {
             const bool in = cs + u < ce;
             const double yu = in ? win.y(cs + u) : 0.0;

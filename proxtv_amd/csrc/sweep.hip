@@ -546,26 +546,27 @@ __global__ __launch_bounds__(64 * NW, ((WEIGHTED || H > 16) ? NW / 4 : NW / 2)) 
 // of a read hit 32 different bank pairs -- the floor for 8-byte accesses -- without any padding (with 16 they would
 // hit two).
 constexpr int kAlongC = 17;
-constexpr int kAlongSeg = 64 * kAlongC;
 constexpr int kAlongWaves = 4;
 
-template <int OP, int H>
+// G lanes share one segment of G chunks: 64 for long fibres; 32 or 16 pack two or four shorter fibres into a wave.
+template <int OP, int H, int G>
 __global__ __launch_bounds__(64 * kAlongWaves) void sweep_along_kernel(SweepArgs p, FibreGeom g, ChunkPlan plan, link_t *code_mine,
                                                                         link_t *code_next, int *failflags) {
-    constexpr int C = kAlongC, SEG = kAlongSeg, T = tail_rows(H), ROWS = H + SEG + T;
-    constexpr int NU = (ROWS + 63) / 64;     // staged elements per lane
-    constexpr int NO = SEG / 64;             // output elements per lane
-    constexpr int UL = 8;                    // epilogue operand fetches in flight per lane
+    constexpr int C = kAlongC, SEG = G * C, T = tail_rows(H), ROWS = H + SEG + T, NG = 64 / G;
+    constexpr int NU = (ROWS + G - 1) / G;   // staged elements per lane
+    constexpr int UL = 9;                    // epilogue operand fetches in flight per lane (C = 17 rows per lane: 9 + 8)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (p.gate && *p.gate == 0) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    double *Yp = reinterpret_cast<double *>(smem) + (size_t)wave * (ROWS + 2);
+    const int gi = lane / G, gl = lane % G;
+    double *Yp = reinterpret_cast<double *>(smem) + (size_t)(wave * NG + gi) * (ROWS + 2);
     const int len = g.len;
     const int nseg = (len + SEG - 1) / SEG, NC = (len + C - 1) / C;
-    const long wid = (long)blockIdx.x * kAlongWaves + wave;   // one wave = one segment of one fibre
-    const long j = wid / nseg;
-    const int sg = (int)(wid % nseg);
-    if (j >= g.count) return;                // (wave-uniform; nothing in this kernel synchronises across waves)
+    const long wid = (long)blockIdx.x * kAlongWaves + wave;
+    const long unit = wid * NG + gi;         // one group of G lanes = one segment of one fibre
+    const long j = unit / nseg;
+    const int sg = (int)(unit % nseg);
+    const bool live = j < g.count;           // (nothing in this kernel synchronises across waves; a group past the end idles)
     if (plan.trace && lane == 0) {
         unsigned hwid, xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
@@ -573,22 +574,22 @@ __global__ __launch_bounds__(64 * kAlongWaves) void sweep_along_kernel(SweepArgs
         plan.trace[8 * (size_t)wid] = ((unsigned long long)xcc << 32) | hwid;
         plan.trace[8 * (size_t)wid + 1] = wall_clock64();
     }
-    const long fbase = j * len;
-    const int seg_s = sg * SEG, seg_e = min(len, seg_s + SEG);
+    const long fbase = live ? j * len : 0;
+    const int seg_s = sg * SEG, seg_e = live ? min(len, seg_s + SEG) : seg_s;
     const int lo = seg_s - H, hi = min(len, seg_s + SEG + T);
 
     // ---- stage: the segment as it lies in memory ---------------------------------------------------------------------------
-    if (!(plan.ablate & 4)) {
+    if (live && !(plan.ablate & 4)) {
         double s0[NU], s1[NU];
 #pragma unroll
         for (int u = 0; u < NU; u++) {
-            const int r = lo + 64 * u + lane;
+            const int r = lo + G * u + gl;
             s0[u] = s1[u] = 0.0;
             if (r >= 0 && r < hi) Op<OP>::fetch_in(p, fbase + r, s0[u], s1[u]);
         }
 #pragma unroll
         for (int u = 0; u < NU; u++) {
-            const int r = lo + 64 * u + lane;
+            const int r = lo + G * u + gl;
             if (r >= 0 && r < hi) Yp[r - lo] = Op<OP>::y_of(p, s0[u], s1[u]);
         }
     }
@@ -597,7 +598,7 @@ __global__ __launch_bounds__(64 * kAlongWaves) void sweep_along_kernel(SweepArgs
     if (plan.trace && lane == 0) plan.trace[8 * (size_t)wid + 2] = wall_clock64();
 
     // ---- speculative walk of this lane's chunk ---------------------------------------------------------------------------------
-    const int cs = seg_s + lane * C;
+    const int cs = seg_s + gl * C;
     const int ce = min(cs + C, len);
     const bool has_chunk = cs < seg_e;
     const int start = max(0, cs - H);
@@ -621,16 +622,16 @@ __global__ __launch_bounds__(64 * kAlongWaves) void sweep_along_kernel(SweepArgs
     }
     if (plan.trace && lane == 0) plan.trace[8 * (size_t)wid + 3] = wall_clock64();
 
-    // ---- links: the predecessor is the lane before (lane 0's is in another wave: left to the repair kernel) ---------------------
+    // ---- links: the predecessor is the lane before (a group's first lane: in another group or wave, left to the repair kernel) ----
     const link_t prev_next = (link_t)__shfl_up((int)rec.next, 1);
-    const bool linked = has_chunk && !(start == 0 || certain) && lane > 0;
+    const bool linked = has_chunk && !(start == 0 || certain) && gl > 0;
     const bool bad = has_chunk && (rec.failed || (linked && (rec.mine == 0 || rec.mine != prev_next)));
     if (has_chunk) {
         if (rec.failed) {
             rec.mine = kLinkBad;
             rec.next = 0;
         }
-        const int chunk = sg * 64 + lane;
+        const int chunk = sg * G + gl;
         if (bad) flag_chunk(failflags, j, chunk, NC);
         code_mine[j * NC + chunk] = (certain && rec.mine != kLinkBad) ? (rec.mine | kLinkCertain) : rec.mine;
         code_next[j * NC + chunk] = rec.next;
@@ -638,29 +639,31 @@ __global__ __launch_bounds__(64 * kAlongWaves) void sweep_along_kernel(SweepArgs
     // a lane's writes stop at the nearest unproven chunk before it (see GUARD in sweep_chunk_kernel; needed for H > C)
     int wlo = seg_s;
     if (H > C) {
-        const unsigned long long below = __ballot(bad) & ((1ull << lane) - 1ull);
+        const unsigned long long all = __ballot(bad);
+        const unsigned long long grp = (G == 64) ? all : ((all >> (gi * G)) & ((1ull << (G & 63)) - 1ull));
+        const unsigned long long below = grp & ((1ull << gl) - 1ull);
         if (below) wlo = seg_s + (63 - __clzll((long long)below)) * C;
     }
     if (has_chunk && !(plan.ablate & 1))
-        rebuild_owned<Op<OP>, false, C>(win, rec, cs, ce, len, start, !bad, wlo, lane == 63 || ce == len, p.lam);
+        rebuild_owned<Op<OP>, false, C, 4>(win, rec, cs, ce, len, start, !bad, wlo, gl == G - 1 || ce == len, p.lam);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     if (plan.trace && lane == 0) plan.trace[8 * (size_t)wid + 4] = wall_clock64();
 
-    // ---- stream the segment out ---------------------------------------------------------------------------------------------------
-    if (!(plan.ablate & 2)) {
+    // ---- stream the segment out: rows seg_s + G t + gl, t < C ----------------------------------------------------------------------
+    if (live && !(plan.ablate & 2)) {
 #pragma unroll
-        for (int t0 = 0; t0 < NO; t0 += UL) {
+        for (int t0 = 0; t0 < C; t0 += UL) {
             Ext ex[UL];
 #pragma unroll
             for (int u = 0; u < UL; u++) {
-                const int k = seg_s + 64 * (t0 + u) + lane;
-                ex[u] = (t0 + u < NO && k < seg_e && !Op<OP>::FUSED) ? Op<OP>::fetch(p, fbase + k) : Ext{0, 0};
+                const int k = seg_s + G * (t0 + u) + gl;
+                ex[u] = (t0 + u < C && k < seg_e && !Op<OP>::FUSED) ? Op<OP>::fetch(p, fbase + k) : Ext{0, 0};
             }
 #pragma unroll
             for (int u = 0; u < UL; u++) {
-                const int k = seg_s + 64 * (t0 + u) + lane;
-                if (t0 + u < NO && k < seg_e) {
+                const int k = seg_s + G * (t0 + u) + gl;
+                if (t0 + u < C && k < seg_e) {
                     const double v = Yp[k - lo];
                     if (Op<OP>::FUSED) Op<OP>::store_fused(p, fbase + k, v);
                     else               Op<OP>::finish(p, fbase + k, ex[u], v);
@@ -669,6 +672,132 @@ __global__ __launch_bounds__(64 * kAlongWaves) void sweep_along_kernel(SweepArgs
         }
     }
     if (plan.trace && lane == 0) plan.trace[8 * (size_t)wid + 5] = wall_clock64();
+}
+
+// ---- kernel 1b: short fibres, whole in LDS ---------------------------------------------------------------------------------
+// Fibres shorter than a few chunks (the 64-sample dimension of a 512 x 512 x 64 volume) have no room for speculation and
+// do not need it: a wave takes 64 adjacent fibres WHOLE into LDS (all loads in flight together, where the sequential
+// kernel pays a dependent global access per sample), every lane walks its own fibre from LDS with the assembly walk,
+// 32 samples of outputs at a time (the walk records piece ends in 32-bit masks): the walk of the next 32 restarts at
+// the last bend at or before its first sample -- the state after a bend is a function of the bend -- so nothing is
+// carried but that bend.  Exact, no links, no repair; outputs may alias inputs (a wave reads all it needs before it
+// writes).  Unweighted sweeps.
+constexpr int kWholeC = 32;
+constexpr int kWholeMax = 96;   // longest fibre this kernel takes (LDS: 512 B per sample per wave)
+
+template <int OP, bool TRANSPOSED>
+__global__ __launch_bounds__(64) void sweep_whole_kernel(SweepArgs p, FibreGeom g) {
+    constexpr int PITCH = TRANSPOSED ? 65 : 64, C = kWholeC, NB = Op<OP>::NIN > 1 ? 16 : 32;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double *Yp = reinterpret_cast<double *>(smem);
+    if (p.gate && *p.gate == 0) return;
+    const int lane = threadIdx.x;
+    const int len = g.len;
+    const long j0 = (long)blockIdx.x * 64;
+    const long j = j0 + lane;
+    const bool active = j < g.count;
+    long base = 0;
+    if (active) {
+        const long blk = j / g.inc, off = j % g.inc;
+        base = blk * g.inc * len + off;
+    }
+    // ---- stage ---------------------------------------------------------------------------------------------------------------
+    if (!TRANSPOSED) {
+        for (int k0 = 0; k0 < len; k0 += NB) {
+            double s0[NB], s1[NB];
+#pragma unroll
+            for (int v = 0; v < NB; v++) {
+                s0[v] = s1[v] = 0.0;
+                if (active && k0 + v < len) Op<OP>::fetch_in(p, base + (long)(k0 + v) * g.inc, s0[v], s1[v]);
+            }
+#pragma unroll
+            for (int v = 0; v < NB; v++)
+                if (active && k0 + v < len) Yp[(k0 + v) * PITCH + lane] = Op<OP>::y_of(p, s0[v], s1[v]);
+        }
+    } else {
+        // 64 contiguous fibres = 64 * len contiguous samples: lanes run along memory, the tile is transposed into LDS
+        const long nfib = min((long)64, g.count - j0);
+        const long total = nfib * len;
+        for (long e0 = 0; e0 < total; e0 += 64 * NB) {
+            double s0[NB], s1[NB];
+#pragma unroll
+            for (int v = 0; v < NB; v++) {
+                const long e = e0 + 64 * v + lane;
+                s0[v] = s1[v] = 0.0;
+                if (e < total) Op<OP>::fetch_in(p, j0 * len + e, s0[v], s1[v]);
+            }
+#pragma unroll
+            for (int v = 0; v < NB; v++) {
+                const long e = e0 + 64 * v + lane;
+                if (e < total) Yp[(int)(e % len) * PITCH + (int)(e / len)] = Op<OP>::y_of(p, s0[v], s1[v]);
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- walk and rebuild, 32 samples of outputs at a time ---------------------------------------------------------------------
+    if (active) {
+        const LdsWin<false, PITCH> win{(lds_double *)Yp + lane, (lds_double *)Yp + lane, 0};
+        const FarFibre<OP> far{p, base, g.inc, 0};
+        link_t carry = 0;   // last bend at or before the first sample of the coming 32
+        for (int cs = 0; cs < len; cs += C) {
+            const int ce = min(cs + C, len);
+            ChunkRec rec;
+            Walker w;
+            int start = 0;
+            if (carry != 0) {
+                start = (int)(carry >> 1);
+                walker_restart_with<false>(w, start, (int)(carry & 1u), len, p.lam, win.y(start), 0.0, 0.0);
+                rec.mine = rec.next = rec.last = carry;
+            } else {
+                walker_start<false>(w, win, 0, p.lam);
+            }
+            walk_chunk<OP, false, PITCH, false>(w, rec, win, far, len, cs, ce, len, p.lam);
+            rebuild_owned<Op<OP>, false, C, 8>(win, rec, cs, ce, len, start, true, 0, ce == len, p.lam);
+            carry = rec.next;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- stream out ------------------------------------------------------------------------------------------------------------------
+    if (!TRANSPOSED) {
+        for (int k0 = 0; k0 < len; k0 += NB) {
+            Ext ex[NB];
+#pragma unroll
+            for (int v = 0; v < NB; v++)
+                ex[v] = (active && k0 + v < len && !Op<OP>::FUSED) ? Op<OP>::fetch(p, base + (long)(k0 + v) * g.inc) : Ext{0, 0};
+#pragma unroll
+            for (int v = 0; v < NB; v++) {
+                if (active && k0 + v < len) {
+                    const double x = Yp[(k0 + v) * PITCH + lane];
+                    if (Op<OP>::FUSED) Op<OP>::store_fused(p, base + (long)(k0 + v) * g.inc, x);
+                    else               Op<OP>::finish(p, base + (long)(k0 + v) * g.inc, ex[v], x);
+                }
+            }
+        }
+    } else {
+        const long nfib = min((long)64, g.count - j0);
+        const long total = nfib * len;
+        for (long e0 = 0; e0 < total; e0 += 64 * NB) {
+            Ext ex[NB];
+#pragma unroll
+            for (int v = 0; v < NB; v++) {
+                const long e = e0 + 64 * v + lane;
+                ex[v] = (e < total && !Op<OP>::FUSED) ? Op<OP>::fetch(p, j0 * len + e) : Ext{0, 0};
+            }
+#pragma unroll
+            for (int v = 0; v < NB; v++) {
+                const long e = e0 + 64 * v + lane;
+                if (e < total) {
+                    const double x = Yp[(int)(e % len) * PITCH + (int)(e / len)];
+                    if (Op<OP>::FUSED) Op<OP>::store_fused(p, j0 * len + e, x);
+                    else               Op<OP>::finish(p, j0 * len + e, ex[v], x);
+                }
+            }
+        }
+    }
 }
 
 // ---- kernel 2b: speculative chunks straight from global memory (long pieces) ---------------------------------------------------
@@ -1212,18 +1341,19 @@ void launch_chunk_h(const SweepArgs &args, const FibreGeom &g, hipStream_t strea
 
 // Chunks along the fibre (kernel 2a): dimension-0 sweeps, unweighted.  Codes are laid out [fibre][chunk] (a wave writes
 // the codes of 64 consecutive chunks of one fibre).
-template <int OP, int H>
-void launch_along(const SweepArgs &args, const FibreGeom &g, hipStream_t stream, int fam) {
-    constexpr int C = kAlongC, ROWS = H + kAlongSeg + tail_rows(H);
-    const int nseg = (g.len + kAlongSeg - 1) / kAlongSeg;
+template <int OP, int H, int G>
+void launch_along_g(const SweepArgs &args, const FibreGeom &g, hipStream_t stream, int fam) {
+    constexpr int C = kAlongC, SEG = G * C, ROWS = H + SEG + tail_rows(H), NG = 64 / G;
+    const int nseg = (g.len + SEG - 1) / SEG;
     const int NC = (g.len + C - 1) / C;
-    const long waves = g.count * nseg;
+    const long units = g.count * nseg;
+    const long waves = (units + NG - 1) / NG;
     ChunkPlan plan{};
     plan.ablate = options().ablate;
     chunk_state().ensure(g.count, NC, stream);
     plan.trace = options().trace ? chunk_state().trace_buffer((size_t)waves) : nullptr;
-    constexpr size_t lds = sizeof(double) * (size_t)(ROWS + 2) * kAlongWaves;
-    auto kern = sweep_along_kernel<OP, H>;
+    constexpr size_t lds = sizeof(double) * (size_t)(ROWS + 2) * NG * kAlongWaves;
+    auto kern = sweep_along_kernel<OP, H, G>;
     hipLaunchKernelGGL(kern, dim3((unsigned)((waves + kAlongWaves - 1) / kAlongWaves)), dim3(64 * kAlongWaves), lds, stream, args, g,
                        plan, chunk_state().code_mine, chunk_state().code_next, chunk_state().failflags);
     if (!plan.ablate) {
@@ -1235,11 +1365,21 @@ void launch_along(const SweepArgs &args, const FibreGeom &g, hipStream_t stream,
             PTV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(rkern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rlds));
             rattr_set = true;
         }
-        hipLaunchKernelGGL(rkern, dim3((unsigned)((g.count + 63) / 64)), dim3(64), rlds, stream, args, g, C, H, 64, chunk_state().code_mine,
+        hipLaunchKernelGGL(rkern, dim3((unsigned)((g.count + 63) / 64)), dim3(64), rlds, stream, args, g, C, H, G, chunk_state().code_mine,
                            chunk_state().code_next, chunk_state().failflags, chunk_state().failcount + 2 * fam, 1L, (long)NC);
     }
     PTV_HIP(hipGetLastError());
     chunk_state().pol[fam].chunks_done += (long)NC * g.count;
+}
+
+// Chunks along the fibre (kernel 2a): dimension-0 sweeps, unweighted.  Codes are laid out [fibre][chunk] (a group writes
+// the codes of consecutive chunks of one fibre).  Lanes per segment: a whole wave for long fibres; half or a quarter of
+// one when the fibre fits 32 or 16 chunks.
+template <int OP, int H>
+void launch_along(const SweepArgs &args, const FibreGeom &g, hipStream_t stream, int fam) {
+    if (g.len <= 16 * kAlongC)      launch_along_g<OP, H, 16>(args, g, stream, fam);
+    else if (g.len <= 32 * kAlongC) launch_along_g<OP, H, 32>(args, g, stream, fam);
+    else                            launch_along_g<OP, H, 64>(args, g, stream, fam);
 }
 
 // Global-memory chunks (kernel 2b): chunk C and zone H are run-time values; every link is checked by the repair kernel.
@@ -1307,7 +1447,18 @@ template <int OP, bool WEIGHTED>
 void launch_op_w(const SweepArgs &args, const FibreGeom &g, hipStream_t stream, bool allow_chunked, int fam) {
     // chunking pays once a fibre spans several blocks; short fibres stay sequential
     const bool chunked = allow_chunked && options().chunk > 0 && g.len >= options().chunk_min_len;
-    if (!chunked) launch_seq<OP, WEIGHTED>(args, g, stream, false);
+    if (!chunked && !WEIGHTED && options().whole && g.len >= 2 && g.len <= kWholeMax && args.lam >= 0.0) {   // (negative
+        // penalties -- tvgen lets them through -- keep the sequential kernel, whose reads past the fibre mirror the reference's)
+        // short fibres: whole in LDS (kernel 1b)
+        const unsigned blocks = (unsigned)((g.count + 63) / 64);
+        if (g.inc == 1) {
+            hipLaunchKernelGGL((sweep_whole_kernel<OP, true>), dim3(blocks), dim3(64), sizeof(double) * 65 * (size_t)g.len, stream, args, g);
+        } else {
+            hipLaunchKernelGGL((sweep_whole_kernel<OP, false>), dim3(blocks), dim3(64), sizeof(double) * 64 * (size_t)g.len, stream, args, g);
+        }
+        PTV_HIP(hipGetLastError());
+    }
+    else if (!chunked) launch_seq<OP, WEIGHTED>(args, g, stream, false);
     else if (g.inc == 1) launch_chunk<OP, WEIGHTED, true>(args, g, stream, fam);
     else launch_chunk<OP, WEIGHTED, false>(args, g, stream, fam);
 }

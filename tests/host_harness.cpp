@@ -171,7 +171,7 @@ extern "C" {
 int host_chunk_fibre(const double *y, const double *w, double lam, int len, int H, int T, int NW, int past, int seed,
                      double *x, int *first_bad, int *write_errors) {
     const bool refl = seed & 1;   // both rebuild flavours: outputs that depend on the row's own sample, and that do not
-    if (!w && NW == 64)   // the along-fibre kernel's geometry: 64 chunks of 17 samples per wave
+    if (!w && (NW == 64 || NW == 32 || NW == 16))   // the along-fibre kernel's geometries: 64 / 32 / 16 chunks of 17 samples per segment
         return refl ? chunk_fibre<false, false, Reflect, 17>(y, w, lam, len, H, T, NW, seed, x, first_bad, write_errors)
                     : chunk_fibre<false, false, Identity, 17>(y, w, lam, len, H, T, NW, seed, x, first_bad, write_errors);
     if (w) {
@@ -184,6 +184,46 @@ int host_chunk_fibre(const double *y, const double *w, double lam, int len, int 
                           : chunk_fibre<false, false, Reflect>(y, w, lam, len, H, T, NW, seed, x, first_bad, write_errors);
     return past ? chunk_fibre<false, true, Identity>(y, w, lam, len, H, T, NW, seed, x, first_bad, write_errors)
                 : chunk_fibre<false, false, Identity>(y, w, lam, len, H, T, NW, seed, x, first_bad, write_errors);
+}
+
+// One short fibre the way sweep_whole_kernel does it (whole fibre in the window, 32 samples of outputs at a time, each
+// 32 restarting at the last bend at or before its first sample).
+int host_whole_fibre(const double *y, double lam, int len, int reflect, double *x) {
+    constexpr int C = 32;
+    HostWin win;
+    win.lo = 0;
+    win.hi = len;
+    win.yy.assign(y, y + len);
+    win.yy.push_back(1e300);
+    win.yy.push_back(1e300);
+    win.writes.assign(win.yy.size(), 0);
+    HostFar far{y, nullptr};
+    unsigned carry = 0;
+    for (int cs = 0; cs < len; cs += C) {
+        const int ce = std::min(cs + C, len);
+        ChunkRec rec;
+        Walker wk;
+        int start = 0;
+        if (carry != 0) {
+            start = (int)(carry >> 1);
+            walker_restart_with<false>(wk, start, (int)(carry & 1u), len, lam, win.y(start), 0.0, 0.0);
+            rec.mine = rec.next = rec.last = carry;
+        } else {
+            walker_start<false>(wk, win, 0, lam);
+        }
+        walk_interior<false>(wk, rec, win, std::min(len - 1, win.hi), cs, ce, lam);
+        TailSource<false, false, 48, HostWin, HostFar> tail{win, far, rec, cs, ce, win.hi, len};
+        walker_run<false>(wk, tail, len, lam);
+        if (reflect) rebuild_owned<Reflect, false, C>(win, rec, cs, ce, len, start, true, 0, ce == len, lam);
+        else         rebuild_owned<Identity, false, C>(win, rec, cs, ce, len, start, true, 0, ce == len, lam);
+        carry = rec.next;
+    }
+    int bad = 0;
+    for (int k = 0; k < len; k++) {
+        x[k] = reflect ? 0.5 * (y[k] - win.y(k)) : win.y(k);
+        if (win.writes[(size_t)k] != 1) bad++;
+    }
+    return bad;
 }
 
 // full sequential walk, what sweep_seq_kernel does per lane

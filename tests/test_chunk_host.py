@@ -18,6 +18,7 @@ def harness():
     subprocess.run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-o", out,
                     os.path.join(HERE, "host_harness.cpp")], check=True)
     lib = C.CDLL(out)
+    lib.host_whole_fibre.argtypes = [C.c_void_p, C.c_double, C.c_int, C.c_int, C.c_void_p]
     lib.host_chunk_fibre.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                      C.c_void_p, C.c_void_p, C.c_void_p]
     return lib
@@ -61,7 +62,7 @@ def test_chunked_walk_equals_oracle_unweighted(harness, oracle):
         y = families(rng, n)
         lam = float(rng.choice([0.0, 0.02, 0.1, 0.3, 1.0]) * abs(rng.standard_normal()))
         truth = oracle.tv1_linearized(y, lam)
-        for (H, T, NW, past) in ((16, 8, 8, 0), (16, 8, 8, 1), (64, 64, 8, 0), (16, 8, 3, 0), (16, 8, 64, 0), (64, 64, 64, 0)):
+        for (H, T, NW, past) in ((16, 8, 8, 0), (16, 8, 8, 1), (64, 64, 8, 0), (16, 8, 3, 0), (16, 8, 64, 0), (64, 64, 64, 0), (16, 8, 32, 0), (64, 64, 16, 0)):
             x, fb, we = run(harness, y, lam, H=H, T=T, NW=NW, past=past, seed=t)
             covered += check(x, fb, we, truth, H, max(1.0, np.max(np.abs(y))))
             total += n
@@ -74,7 +75,7 @@ def test_chunked_walk_headline_regime_is_fully_proven(harness, oracle):
         n = int(rng.integers(100, 3000))
         y = rng.standard_normal(n)
         truth = oracle.tv1_linearized(y, 0.1)
-        for NW in (8, 64):     # 64-fibre tile geometry; along-fibre geometry (64 chunks of 17 samples per wave)
+        for NW in (8, 64, 32, 16):     # 64-fibre tile geometry; along-fibre geometries (64 / 32 / 16 chunks of 17 samples)
             x, fb, we = run(harness, y, 0.1, NW=NW, seed=t)
             assert fb < 0 and we == 0
             assert np.max(np.abs(x - truth)) <= 1e-14 * np.max(np.abs(y))
@@ -93,3 +94,17 @@ def test_chunked_walk_equals_oracle_weighted(harness, oracle):
             covered += check(x, fb, we, truth, 16, max(1.0, np.max(np.abs(y))))
             total += n
     assert covered > 0.6 * total
+
+
+def test_short_fibres_whole_in_window(harness, oracle):
+    """sweep_whole_kernel's per-lane loop: outputs 32 samples at a time, every 32 restarting at the last bend at or
+    before its first sample; every row written exactly once."""
+    rng = np.random.default_rng(3)
+    for t in range(3000):
+        n = int(rng.integers(2, 97))
+        y = np.ascontiguousarray(families(rng, n))
+        lam = float(rng.choice([0.0, 0.02, 0.1, 0.5, 2.0, 50.0]) * abs(rng.standard_normal()))
+        x = np.full(n, np.nan)
+        bad = harness.host_whole_fibre(y.ctypes.data, lam, n, t & 1, x.ctypes.data)
+        assert bad == 0, (t, n, lam, bad)
+        assert np.max(np.abs(x - oracle.tv1_linearized(y, lam))) <= 1e-13 * max(1.0, np.max(np.abs(y))), (t, n, lam)

@@ -135,7 +135,10 @@ def test_tv_dispatcher_symbol(clib, oracle):
     info[:] = -1
     assert clib.TV(x.ctypes.data, 0.3, out.ctypes.data, info.ctypes.data, x.size, 0.5, None) == 0 and info[2] == 3
     info[:] = -1
-    assert clib.TV(x.ctypes.data, 0.3, out.ctypes.data, info.ctypes.data, x.size, 2.0, None) == 0 and info[2] == 3
+    assert clib.TV(x.ctypes.data, 0.3, out.ctypes.data, info.ctypes.data, x.size, 3.0, None) == 0 and info[2] == 3   # general p
+    info[:] = -1
+    assert clib.TV(x.ctypes.data, 0.3, out.ctypes.data, info.ctypes.data, x.size, 2.0, None) == 1 and info[2] == 0   # TV-L2
+    assert_close(out, oracle.tv(x, 0.3, 2)[0], tol=1e-10)
 
 
 def test_condat_inplace_and_noop(clib, oracle):
