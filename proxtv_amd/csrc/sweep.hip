@@ -211,9 +211,10 @@ __device__ __forceinline__ void walk_chunk(Walker &w, ChunkRec &rec, const LdsWi
                                            int hi, int cs, int ce, int len, double lam) {
 #ifndef PTV_NO_ASM_WALK
     if constexpr (!WEIGHTED) walk_interior_asm<PITCH>(w, rec, win, min(len - 1, hi), cs, ce, lam);
-    else
+    else                     walk_interior_asm_w<PITCH>(w, rec, win, min(len - 1, hi), cs, ce);
+#else
+    walk_interior<WEIGHTED>(w, rec, win, min(len - 1, hi), cs, ce, lam);
 #endif
-        walk_interior<WEIGHTED>(w, rec, win, min(len - 1, hi), cs, ce, lam);
     TailSource<WEIGHTED, PAST, kOverflow, LdsWin<WEIGHTED, PITCH>, FarFibre<OP>> tail{win, far, rec, cs, ce, hi, len};
     walker_run<WEIGHTED>(w, tail, len, lam);
     if (rec.failed) rec.next = 0;   // ran off the window: nothing this lane recorded may be trusted
@@ -549,7 +550,7 @@ constexpr int kAlongC = 17;
 constexpr int kAlongWaves = 4;
 
 // G lanes share one segment of G chunks: 64 for long fibres; 32 or 16 pack two or four shorter fibres into a wave.
-template <int OP, int H, int G>
+template <int OP, bool WEIGHTED, int H, int G>
 __global__ __launch_bounds__(64 * kAlongWaves) void sweep_along_kernel(SweepArgs p, FibreGeom g, ChunkPlan plan, link_t *code_mine,
                                                                         link_t *code_next, int *failflags) {
     constexpr int C = kAlongC, SEG = G * C, T = tail_rows(H), ROWS = H + SEG + T, NG = 64 / G;
@@ -559,7 +560,8 @@ __global__ __launch_bounds__(64 * kAlongWaves) void sweep_along_kernel(SweepArgs
     if (p.gate && *p.gate == 0) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int gi = lane / G, gl = lane % G;
-    double *Yp = reinterpret_cast<double *>(smem) + (size_t)(wave * NG + gi) * (ROWS + 2);
+    double *Yp = reinterpret_cast<double *>(smem) + (size_t)(wave * NG + gi) * (ROWS + 2) * (WEIGHTED ? 2 : 1);
+    double *Wp = Yp + (WEIGHTED ? ROWS + 2 : 0);   // per-edge penalties, same rows (weighted sweeps)
     const int len = g.len;
     const int nseg = (len + SEG - 1) / SEG, NC = (len + C - 1) / C;
     const long wid = (long)blockIdx.x * kAlongWaves + wave;
@@ -574,23 +576,27 @@ __global__ __launch_bounds__(64 * kAlongWaves) void sweep_along_kernel(SweepArgs
         plan.trace[8 * (size_t)wid] = ((unsigned long long)xcc << 32) | hwid;
         plan.trace[8 * (size_t)wid + 1] = wall_clock64();
     }
-    const long fbase = live ? j * len : 0;
+    const long fbase = live ? j * len : 0, wbase = live ? j * (len - 1) : 0;
     const int seg_s = sg * SEG, seg_e = live ? min(len, seg_s + SEG) : seg_s;
     const int lo = seg_s - H, hi = min(len, seg_s + SEG + T);
 
     // ---- stage: the segment as it lies in memory ---------------------------------------------------------------------------
     if (live && !(plan.ablate & 4)) {
-        double s0[NU], s1[NU];
+        double s0[NU], s1[NU], sw[WEIGHTED ? NU : 1];
 #pragma unroll
         for (int u = 0; u < NU; u++) {
             const int r = lo + G * u + gl;
             s0[u] = s1[u] = 0.0;
             if (r >= 0 && r < hi) Op<OP>::fetch_in(p, fbase + r, s0[u], s1[u]);
+            if (WEIGHTED) sw[WEIGHTED ? u : 0] = (r >= 0 && r < hi && r < len - 1) ? p.w[wbase + r] : 0.0;
         }
 #pragma unroll
         for (int u = 0; u < NU; u++) {
             const int r = lo + G * u + gl;
-            if (r >= 0 && r < hi) Yp[r - lo] = Op<OP>::y_of(p, s0[u], s1[u]);
+            if (r >= 0 && r < hi) {
+                Yp[r - lo] = Op<OP>::y_of(p, s0[u], s1[u]);
+                if (WEIGHTED) Wp[r - lo] = sw[WEIGHTED ? u : 0];
+            }
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -602,23 +608,24 @@ __global__ __launch_bounds__(64 * kAlongWaves) void sweep_along_kernel(SweepArgs
     const int ce = min(cs + C, len);
     const bool has_chunk = cs < seg_e;
     const int start = max(0, cs - H);
-    const LdsWin<false, 1> win{(lds_double *)Yp, (lds_double *)Yp, lo};
-    const FarFibre<OP> far{p, fbase, 1, 0};
+    const LdsWin<WEIGHTED, 1> win{(lds_double *)Yp, (lds_double *)Wp, lo};
+    const FarFibre<OP> far{p, fbase, 1, wbase};
     ChunkRec rec;
     bool certain = false;
     if (has_chunk && !(plan.ablate & 1)) {
         Walker w;
         constexpr int kLook = 8;
         int cat = -1, ctype = 0;
-        if (start > 0 && H <= kWarm && p.lam > 0.0) cat = certain_bend_before<false, kLook>(win, cs, len, p.lam, ctype);
+        if (start > 0 && H <= kWarm && (WEIGHTED || p.lam > 0.0)) cat = certain_bend_before<WEIGHTED, kLook>(win, cs, len, p.lam, ctype);
         if (cat >= 0) {
             certain = true;
-            walker_restart_with<false>(w, cat, ctype, len, p.lam, win.y(cat), 0.0, 0.0);
+            walker_restart_with<WEIGHTED>(w, cat, ctype, len, p.lam, win.y(cat), WEIGHTED ? win.r(cat - 1) : 0.0,
+                                          (WEIGHTED && cat < len - 1) ? win.r(cat) : 0.0);
             rec.mine = rec.next = rec.last = ((link_t)cat << 1) | (link_t)ctype;
         } else {
-            walker_start<false>(w, win, start, p.lam);
+            walker_start<WEIGHTED>(w, win, start, p.lam);
         }
-        walk_chunk<OP, false, 1, false>(w, rec, win, far, hi, cs, ce, len, p.lam);
+        walk_chunk<OP, WEIGHTED, 1, false>(w, rec, win, far, hi, cs, ce, len, p.lam);
     }
     if (plan.trace && lane == 0) plan.trace[8 * (size_t)wid + 3] = wall_clock64();
 
@@ -645,7 +652,7 @@ __global__ __launch_bounds__(64 * kAlongWaves) void sweep_along_kernel(SweepArgs
         if (below) wlo = seg_s + (63 - __clzll((long long)below)) * C;
     }
     if (has_chunk && !(plan.ablate & 1))
-        rebuild_owned<Op<OP>, false, C, 4>(win, rec, cs, ce, len, start, !bad, wlo, gl == G - 1 || ce == len, p.lam);
+        rebuild_owned<Op<OP>, WEIGHTED, C, 4>(win, rec, cs, ce, len, start, !bad, wlo, gl == G - 1 || ce == len, p.lam);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     if (plan.trace && lane == 0) plan.trace[8 * (size_t)wid + 4] = wall_clock64();
@@ -1341,7 +1348,7 @@ void launch_chunk_h(const SweepArgs &args, const FibreGeom &g, hipStream_t strea
 
 // Chunks along the fibre (kernel 2a): dimension-0 sweeps, unweighted.  Codes are laid out [fibre][chunk] (a wave writes
 // the codes of 64 consecutive chunks of one fibre).
-template <int OP, int H, int G>
+template <int OP, bool WEIGHTED, int H, int G>
 void launch_along_g(const SweepArgs &args, const FibreGeom &g, hipStream_t stream, int fam) {
     constexpr int C = kAlongC, SEG = G * C, ROWS = H + SEG + tail_rows(H), NG = 64 / G;
     const int nseg = (g.len + SEG - 1) / SEG;
@@ -1352,13 +1359,22 @@ void launch_along_g(const SweepArgs &args, const FibreGeom &g, hipStream_t strea
     plan.ablate = options().ablate;
     chunk_state().ensure(g.count, NC, stream);
     plan.trace = options().trace ? chunk_state().trace_buffer((size_t)waves) : nullptr;
-    constexpr size_t lds = sizeof(double) * (size_t)(ROWS + 2) * NG * kAlongWaves;
-    auto kern = sweep_along_kernel<OP, H, G>;
+    constexpr size_t lds = sizeof(double) * (size_t)(ROWS + 2) * NG * kAlongWaves * (WEIGHTED ? 2 : 1);
+    static_assert(lds <= 160 * 1024, "along-fibre geometry does not fit the LDS of a CU");
+    auto kern = sweep_along_kernel<OP, WEIGHTED, H, G>;
+    if (lds > 64 * 1024) {   // above the default dynamic-LDS limit
+        static thread_local bool attr_done[kMaxDevices] = {};
+        bool &attr_set = attr_done[current_device()];
+        if (!attr_set) {
+            PTV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr_set = true;
+        }
+    }
     hipLaunchKernelGGL(kern, dim3((unsigned)((waves + kAlongWaves - 1) / kAlongWaves)), dim3(64 * kAlongWaves), lds, stream, args, g,
                        plan, chunk_state().code_mine, chunk_state().code_next, chunk_state().failflags);
     if (!plan.ablate) {
-        constexpr size_t rlds = sizeof(double) * 2 * kRepairWindow * 64;
-        auto rkern = sweep_repair_kernel<OP, false>;
+        constexpr size_t rlds = sizeof(double) * (2 + (WEIGHTED ? 1 : 0)) * kRepairWindow * 64;
+        auto rkern = sweep_repair_kernel<OP, WEIGHTED>;
         static thread_local bool rattr_done[kMaxDevices] = {};
         bool &rattr_set = rattr_done[current_device()];
         if (!rattr_set) {
@@ -1375,11 +1391,11 @@ void launch_along_g(const SweepArgs &args, const FibreGeom &g, hipStream_t strea
 // Chunks along the fibre (kernel 2a): dimension-0 sweeps, unweighted.  Codes are laid out [fibre][chunk] (a group writes
 // the codes of consecutive chunks of one fibre).  Lanes per segment: a whole wave for long fibres; half or a quarter of
 // one when the fibre fits 32 or 16 chunks.
-template <int OP, int H>
+template <int OP, bool WEIGHTED, int H>
 void launch_along(const SweepArgs &args, const FibreGeom &g, hipStream_t stream, int fam) {
-    if (g.len <= 16 * kAlongC)      launch_along_g<OP, H, 16>(args, g, stream, fam);
-    else if (g.len <= 32 * kAlongC) launch_along_g<OP, H, 32>(args, g, stream, fam);
-    else                            launch_along_g<OP, H, 64>(args, g, stream, fam);
+    if (g.len <= 16 * kAlongC)      launch_along_g<OP, WEIGHTED, H, 16>(args, g, stream, fam);
+    else if (g.len <= 32 * kAlongC) launch_along_g<OP, WEIGHTED, H, 32>(args, g, stream, fam);
+    else                            launch_along_g<OP, WEIGHTED, H, 64>(args, g, stream, fam);
 }
 
 // Global-memory chunks (kernel 2b): chunk C and zone H are run-time values; every link is checked by the repair kernel.
@@ -1421,15 +1437,15 @@ void launch_chunk(const SweepArgs &args, const FibreGeom &g, hipStream_t stream,
     if (mode >= kModeSeq)  launch_seq<OP, WEIGHTED>(args, g, stream, true);
     else if (mode == 3)    launch_gchunk<OP, WEIGHTED>(args, g, 64, 256, stream, fam);
     else if (mode == 4)    launch_gchunk<OP, WEIGHTED>(args, g, 256, 1024, stream, fam);
+    // dimension 0: chunks along the fibre once a fibre fills most of a lane group (modes 1 and 2 both mean "a longer
+    // zone" there); otherwise, and for the other dimensions, the 64-fibre tile
+    else if (TRANSPOSED && options().along && g.len >= options().along_min_len) {
+        if (mode == 0) launch_along<OP, WEIGHTED, kWarm>(args, g, stream, fam);
+        else           launch_along<OP, WEIGHTED, kWarmLong>(args, g, stream, fam);
+    }
     else if constexpr (!WEIGHTED) {
-        // dimension 0: chunks along the fibre once a fibre fills most of a wave's 64 chunks (modes 1 and 2 both mean "a
-        // longer zone" there); otherwise, and for the other dimensions, the 64-fibre tile
-        if (TRANSPOSED && options().along && g.len >= options().along_min_len) {
-            if (mode == 0) launch_along<OP, kWarm>(args, g, stream, fam);
-            else           launch_along<OP, kWarmLong>(args, g, stream, fam);
-        }
-        else if (mode == 2) launch_chunk_h<OP, false, TRANSPOSED, kWarmLong>(args, g, stream, fam, 0);
-        else                launch_chunk_h<OP, false, TRANSPOSED, kWarm>(args, g, stream, fam, rounds);
+        if (mode == 2) launch_chunk_h<OP, false, TRANSPOSED, kWarmLong>(args, g, stream, fam, 0);
+        else           launch_chunk_h<OP, false, TRANSPOSED, kWarm>(args, g, stream, fam, rounds);
     } else {
         launch_chunk_h<OP, true, TRANSPOSED, kWarm>(args, g, stream, fam, rounds);
     }
@@ -1447,8 +1463,10 @@ template <int OP, bool WEIGHTED>
 void launch_op_w(const SweepArgs &args, const FibreGeom &g, hipStream_t stream, bool allow_chunked, int fam) {
     // chunking pays once a fibre spans several blocks; short fibres stay sequential
     const bool chunked = allow_chunked && options().chunk > 0 && g.len >= options().chunk_min_len;
-    if (!chunked && !WEIGHTED && options().whole && g.len >= 2 && g.len <= kWholeMax && args.lam >= 0.0) {   // (negative
-        // penalties -- tvgen lets them through -- keep the sequential kernel, whose reads past the fibre mirror the reference's)
+    if (!chunked && !WEIGHTED && options().whole && g.len >= 16 && g.len <= kWholeMax && args.lam >= 0.0) {   // (negative
+        // penalties -- tvgen lets them through -- keep the sequential kernel, whose reads past the fibre mirror the reference's;
+        // so do fibres of a handful of samples: that kernel divides like the CPU, bit for bit, and loops that end at a
+        // bitwise fixed point -- Kolmogorov2_TV -- count their iterations on the last bit)
         // short fibres: whole in LDS (kernel 1b)
         const unsigned blocks = (unsigned)((g.count + 63) / 64);
         if (g.inc == 1) {

@@ -58,7 +58,9 @@ def test_golden_pd2(ptv, clib, g2d):
         want = g2d[f"{name}/pd2_info"]
         assert rc == int(g2d[f"{name}/pd2_rc"]) == 1
         assert info[0] == want[0] and info[2] == want[2], (name, info, want)
-        assert abs(info[1] - want[1]) <= 1e-9 * max(abs(want[1]), 1e-30) + 1e-18
+        # (+1e-15: at a bitwise fixed point of the reference two sweeps of ours may run different kernel geometries
+        # -- the policy explores -- which differ in the last ulp of a few pixels)
+        assert abs(info[1] - want[1]) <= 1e-9 * max(abs(want[1]), 1e-30) + 1e-15
         # single penalty along rows / 1-penalty tvgen (-> PD_TV)
         lam1, dim1 = np.array([lam]), np.array([2.0])
         info[:] = 0
@@ -260,7 +262,7 @@ def test_input_coercions(ptv, oracle):
 def test_unsupported_norms_fail_loudly(clib):
     X = np.asfortranarray(np.random.default_rng(25).standard_normal((8, 8)))
     out, info = np.zeros((8, 8), order="F"), np.zeros(3)
-    rc = clib.DR2_TV(8, 8, X.ctypes.data, 0.1, 0.1, 2.0, 1.0, out.ctypes.data, 1, 0, info.ctypes.data)
+    rc = clib.DR2_TV(8, 8, X.ctypes.data, 0.1, 0.1, 3.0, 1.0, out.ctypes.data, 1, 0, info.ctypes.data)   # general p
     assert rc == 0 and info[2] == 3    # RC_ERROR
     lams, norms, dims, ns = np.array([.1, .1, .1]), np.ones(3), np.array([1., 2., 1.]), np.array([8, 8], dtype=np.int32)
     rc = clib.PD2_TV(X.ctypes.data, lams.ctypes.data, norms.ctypes.data, dims.ctypes.data, out.ctypes.data,
