@@ -90,6 +90,7 @@ struct NotFused {
 
 // o0 = prox(a)                                  (PD_TV :164-209, PDR_TV :405-458, batched tv1_1d)
 template <> struct Op<OP_PROX> : InA {
+    static constexpr unsigned IN_MASK = 1, OUT_MASK = 1;   // arrays the op reads (bit 0 a, 1 b, 2 c) / writes (bit 0 o0, 1 o1)
     static constexpr bool FUSED = true;
     static constexpr bool USES_Y = false;
     __device__ static __forceinline__ double fuse(double, double x) { return x; }
@@ -100,6 +101,7 @@ template <> struct Op<OP_PROX> : InA {
 
 // DR, columns (a = t): s = t - prox(t) ; s' = 2 s - t          (src/TV2Dopt.cpp:408-411, 539-547)
 template <> struct Op<OP_DR_COL> : InA {
+    static constexpr unsigned IN_MASK = 1, OUT_MASK = 1;
     static constexpr bool FUSED = true;
     static constexpr bool USES_Y = true;
     __device__ static __forceinline__ double fuse(double y, double x) {
@@ -114,6 +116,7 @@ template <> struct Op<OP_DR_COL> : InA {
 };
 // final projection: s = t - prox(t)                              (src/TV2Dopt.cpp:427)
 template <> struct Op<OP_DR_COL_FINAL> : InA {
+    static constexpr unsigned IN_MASK = 1, OUT_MASK = 1;
     static constexpr bool FUSED = true;
     static constexpr bool USES_Y = true;
     __device__ static __forceinline__ double fuse(double y, double x) { return y - x; }
@@ -128,6 +131,7 @@ template <> struct Op<OP_DR_COL_FINAL> : InA {
 // Both are t = 0.5 (t + (s' + 2 prox(v))) once U - v is replaced by s' (it IS s' up to the rounding of v): evaluated
 // in that form, which needs s' and t but not U at the epilogue -- a few ulps of |U| away from the reference's order.
 template <> struct Op<OP_DR_ROW> : InBminusA, NotFused {
+    static constexpr unsigned IN_MASK = 7, OUT_MASK = 1;
     // s' is staged for the walk (y = U - s') and needed again here.  Keeping it (4 array passes instead of 5) costs the
     // kernel 32 VGPRs it does not have at two workgroups per CU -- measured 4 % slower than fetching it again, and
     // the second read is served by the memory-side cache; the switch stays for builds with a roomier register budget.
@@ -137,7 +141,11 @@ template <> struct Op<OP_DR_ROW> : InBminusA, NotFused {
     static constexpr bool KEEP = false;
 #endif
     __device__ static __forceinline__ Ext fetch_rest(const SweepArgs &p, long idx, double sp) { return Ext{sp, p.c[idx]}; }
+#ifdef PTV_EXP_NOREFETCH   // experiment only (wrong results): what would the sweep cost without the second read of s'?
+    __device__ static __forceinline__ Ext fetch(const SweepArgs &p, long idx) { return Ext{0.0, p.c[idx]}; }
+#else
     __device__ static __forceinline__ Ext fetch(const SweepArgs &p, long idx) { return Ext{p.a[idx], p.c[idx]}; }
+#endif
     __device__ static __forceinline__ void finish(const SweepArgs &p, long idx, const Ext &e, double x) {
         const double tb = e.e0 + 2 * x;
         p.o0[idx] = 0.5 * (e.e1 + tb);
@@ -145,6 +153,7 @@ template <> struct Op<OP_DR_ROW> : InBminusA, NotFused {
 };
 // recovery (a = s, b = unary): out = (U - (v - prox(v))) - s                         (src/TV2Dopt.cpp:429-430)
 template <> struct Op<OP_DR_ROW_FINAL> : InBminusA, NotFused {
+    static constexpr unsigned IN_MASK = 3, OUT_MASK = 1;
     __device__ static __forceinline__ Ext fetch(const SweepArgs &p, long idx) { return Ext{p.b[idx], p.a[idx]}; }
     __device__ static __forceinline__ void finish(const SweepArgs &p, long idx, const Ext &e, double x) {
         const double y = e.e0 - e.e1;
@@ -154,6 +163,7 @@ template <> struct Op<OP_DR_ROW_FINAL> : InBminusA, NotFused {
 };
 // weighted recovery: tbw = (v - prox(v)) - U ; out = -s - tbw                          (src/TV2DWopt.cpp:124-126, 218)
 template <> struct Op<OP_DRW_ROW_FINAL> : InBminusA, NotFused {
+    static constexpr unsigned IN_MASK = 3, OUT_MASK = 1;
     __device__ static __forceinline__ Ext fetch(const SweepArgs &p, long idx) { return Ext{p.b[idx], p.a[idx]}; }
     __device__ static __forceinline__ void finish(const SweepArgs &p, long idx, const Ext &e, double x) {
         const double y = e.e0 - e.e1;
@@ -164,6 +174,7 @@ template <> struct Op<OP_DRW_ROW_FINAL> : InBminusA, NotFused {
 
 // Dykstra term 1 (a = x, b = p_in, o0 = z, o1 = p_out): z = prox(x + p) ; p += x - z   (src/TV2Dopt.cpp:187-213)
 template <> struct Op<OP_PD2_A> : InAplusB, NotFused {
+    static constexpr unsigned IN_MASK = 3, OUT_MASK = 3;
     __device__ static __forceinline__ Ext fetch(const SweepArgs &p, long idx) { return Ext{p.a[idx], p.b[idx]}; }
     __device__ static __forceinline__ void finish(const SweepArgs &p, long idx, const Ext &e, double x) {
         p.o0[idx] = x;
@@ -172,6 +183,7 @@ template <> struct Op<OP_PD2_A> : InAplusB, NotFused {
 };
 // Dykstra term 2 (a = z, b = q_in, o0 = x, o1 = q_out): x = prox(z + q) ; q += z - x    (src/TV2Dopt.cpp:234-263)
 template <> struct Op<OP_PD2_B> : InAplusB, NotFused {
+    static constexpr unsigned IN_MASK = 3, OUT_MASK = 3;
     __device__ static __forceinline__ Ext fetch(const SweepArgs &p, long idx) { return Ext{p.a[idx], p.b[idx]}; }
     __device__ static __forceinline__ void finish(const SweepArgs &p, long idx, const Ext &e, double x) {
         p.o0[idx] = x;
@@ -182,6 +194,7 @@ template <> struct Op<OP_PD2_B> : InAplusB, NotFused {
 // Yang ADMM (a = X, b = U_in, o0 = Z, o1 = U_out, s0 = rho):
 //   Z = prox_{lambda/rho}(-1/rho U + X) ; U += rho (Z - X)          (src/TV2Dopt.cpp:836-862 ; src/TVNDopt.cpp:733-788)
 template <> struct Op<OP_YANG> : NotFused, NoKeep {
+    static constexpr unsigned IN_MASK = 3, OUT_MASK = 3;
     static constexpr int NIN = 2;
     __device__ static __forceinline__ void fetch_in(const SweepArgs &p, long idx, double &i0, double &i1) { i0 = p.a[idx]; i1 = p.b[idx]; }
     __device__ static __forceinline__ double y_of(const SweepArgs &p, double i0, double i1) { return -1. / p.s0 * i1 + i0; }

@@ -34,6 +34,10 @@
 
 #include "chunkcore.hpp"
 #include "walk_asm.hpp"
+
+#ifndef PTV_TILE_UNROLL
+#define PTV_TILE_UNROLL 1   // rows of the rebuild passes in flight together in the 64-fibre tile kernel (registers are scarce there)
+#endif
 #include "policy.hpp"
 #include "walker.hpp"
 
@@ -472,7 +476,7 @@ __global__ __launch_bounds__(64 * NW, ((WEIGHTED || H > 16) ? NW / 4 : NW / 2)) 
                 }
         }
         if (has_chunk && !(plan.ablate & 1))
-            rebuild_owned<Op<OP>, WEIGHTED, C>(win, rec, cs, ce, len, start, !bad, wlo, wave == NW - 1 || ce == len, p.lam);
+            rebuild_owned<Op<OP>, WEIGHTED, C, PTV_TILE_UNROLL>(win, rec, cs, ce, len, start, !bad, wlo, wave == NW - 1 || ce == len, p.lam);
         __syncthreads();
         if (kb == 0) trace_mark(plan, 4);
 
@@ -1412,6 +1416,53 @@ void launch_gchunk(const SweepArgs &args, const FibreGeom &g, int C, int H, hipS
     chunk_state().pol[fam].chunks_done += (long)NC * g.count;
 }
 
+// ---- strided sweeps through the along-fibre kernel: transpose, sweep, transpose back ---------------------------------------
+// When the walks of a strided sweep need long zones (pieces of ~10 samples and more: the row family's modes 1 and 2) the
+// 64-fibre tile pays for them in LDS -- one workgroup per CU, every zone staged again -- while the along-fibre kernel
+// gets them for free: a lane's zone is its neighbours' chunks.  So the operands are transposed (fibres become
+// contiguous; a tiled copy at HBM speed), the sweep runs as a dimension-0 sweep, and the outputs are transposed back.
+// Fibre numbering is unchanged: fibre j = slab * inc + off sits at j * len after the transposition of every
+// (inc x len) slab.
+__global__ __launch_bounds__(256) void slab_transpose_kernel(const double *in, double *out, long rows, long cols) {
+    __shared__ double tile[32][33];
+    const long slab = (long)blockIdx.z * rows * cols;
+    const long r0 = (long)blockIdx.x * 32, c0 = (long)blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int k = ty; k < 32; k += 8) {
+        const long r = r0 + tx, c = c0 + k;
+        if (r < rows && c < cols) tile[k][tx] = in[slab + r + rows * c];
+    }
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8) {
+        const long c = c0 + tx, r = r0 + k;
+        if (r < rows && c < cols) out[slab + c + cols * r] = tile[tx][k];
+    }
+}
+
+static void slab_transpose(const double *in, double *out, long rows, long cols, long slabs, hipStream_t s) {
+    if (rows <= 0 || cols <= 0 || slabs <= 0) return;
+    const dim3 grid((unsigned)((rows + 31) / 32), (unsigned)((cols + 31) / 32), (unsigned)slabs);
+    hipLaunchKernelGGL(slab_transpose_kernel, grid, dim3(256), 0, s, in, out, rows, cols);
+    PTV_HIP(hipGetLastError());
+}
+
+template <int OP, int H>
+void launch_row_along(const SweepArgs &args, const FibreGeom &g, hipStream_t stream, int fam) {
+    const long slabs = g.count / g.inc;
+    const size_t bytes = sizeof(double) * (size_t)g.count * (size_t)g.len;
+    std::unique_ptr<Scratch> ta, tb, tc, to0, to1;
+    SweepArgs t = args;
+    if (Op<OP>::IN_MASK & 1u) { ta.reset(new Scratch(bytes)); slab_transpose(args.a, ta->d(), g.inc, g.len, slabs, stream); t.a = ta->d(); }
+    if (Op<OP>::IN_MASK & 2u) { tb.reset(new Scratch(bytes)); slab_transpose(args.b, tb->d(), g.inc, g.len, slabs, stream); t.b = tb->d(); }
+    if (Op<OP>::IN_MASK & 4u) { tc.reset(new Scratch(bytes)); slab_transpose(args.c, tc->d(), g.inc, g.len, slabs, stream); t.c = tc->d(); }
+    if (Op<OP>::OUT_MASK & 1u) { to0.reset(new Scratch(bytes)); t.o0 = to0->d(); }
+    if (Op<OP>::OUT_MASK & 2u) { to1.reset(new Scratch(bytes)); t.o1 = to1->d(); }
+    const FibreGeom gt{1, g.len, g.count};
+    launch_along<OP, false, H>(t, gt, stream, fam);
+    if (Op<OP>::OUT_MASK & 1u) slab_transpose(to0->d(), args.o0, g.len, g.inc, slabs, stream);
+    if (Op<OP>::OUT_MASK & 2u) slab_transpose(to1->d(), args.o1, g.len, g.inc, slabs, stream);
+}
+
 template <int OP, bool WEIGHTED, bool TRANSPOSED>
 void launch_chunk(const SweepArgs &args, const FibreGeom &g, hipStream_t stream, int fam) {
     ChunkScratch &st = chunk_state();
@@ -1434,14 +1485,20 @@ void launch_chunk(const SweepArgs &args, const FibreGeom &g, hipStream_t stream,
         if (measure) PTV_HIP(hipEventRecord(pl.t0, stream));
     }
     const int rounds = (mode == 1) ? (options().rounds > 0 ? options().rounds : kRounds) : 0;
+    // Geometry ladder.  Dimension 0 (chunks along the fibre once a fibre fills most of a lane group): 0 = 16-sample zones,
+    // 1 / 2 = 64-sample zones, 3 / 4 = chunks from global memory (zones 256 / 1024), 5 = one sequential walk per fibre.
+    // Strided sweeps: 0 / 1 = the 64-fibre tile (1: robust instantiation), 2 = transposed copies + the along-fibre kernel
+    // with 64-sample zones (or the tile with 64-sample zones), 3 / 4 / 5 as above.
+    const bool along_ok = options().along && g.len >= options().along_min_len;
     if (mode >= kModeSeq)  launch_seq<OP, WEIGHTED>(args, g, stream, true);
     else if (mode == 3)    launch_gchunk<OP, WEIGHTED>(args, g, 64, 256, stream, fam);
     else if (mode == 4)    launch_gchunk<OP, WEIGHTED>(args, g, 256, 1024, stream, fam);
-    // dimension 0: chunks along the fibre once a fibre fills most of a lane group (modes 1 and 2 both mean "a longer
-    // zone" there); otherwise, and for the other dimensions, the 64-fibre tile
-    else if (TRANSPOSED && options().along && g.len >= options().along_min_len) {
+    else if (TRANSPOSED && along_ok) {
         if (mode == 0) launch_along<OP, WEIGHTED, kWarm>(args, g, stream, fam);
         else           launch_along<OP, WEIGHTED, kWarmLong>(args, g, stream, fam);
+    }
+    else if (!TRANSPOSED && !WEIGHTED && along_ok && options().row_along && mode == 2) {
+        if constexpr (!WEIGHTED) launch_row_along<OP, kWarmLong>(args, g, stream, fam);
     }
     else if constexpr (!WEIGHTED) {
         if (mode == 2) launch_chunk_h<OP, false, TRANSPOSED, kWarmLong>(args, g, stream, fam, 0);

@@ -108,3 +108,4 @@ def test_short_fibres_whole_in_window(harness, oracle):
         bad = harness.host_whole_fibre(y.ctypes.data, lam, n, t & 1, x.ctypes.data)
         assert bad == 0, (t, n, lam, bad)
         assert np.max(np.abs(x - oracle.tv1_linearized(y, lam))) <= 1e-13 * max(1.0, np.max(np.abs(y))), (t, n, lam)
+
