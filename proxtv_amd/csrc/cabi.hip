@@ -172,7 +172,7 @@ int TV(double *y, double lambda, double *x, double *info, int n, double p, Works
 }
 
 // TV-L2 (src/TVL2opt.cpp: more_TV2 :35, morePG_TV2 :190, PG_TV2 :446 -- three iteration schemes for the same prox; all are
-// served by the exact trust-region solve of tv2.hip, which reports its mu-search as iterations and 0 as the gap)
+// served by the exact trust-region solve of tv2.hip; info reports 0 iterations and a gap of 0)
 static int tv2_host(const char *who, double *y, double lambda, double *x, double *info, int n) {
     return guarded(who, info, 1, [&] {
         prox1d_host(y, nullptr, lambda, x, n, 0.0, 2);
@@ -181,7 +181,7 @@ static int tv2_host(const char *who, double *y, double lambda, double *x, double
 }
 int more_TV2(double *y, double lambda, double *x, double *info, int n) { return tv2_host("more_TV2", y, lambda, x, info, n); }
 int morePG_TV2(double *y, double lambda, double *x, double *info, int n, Workspace *) {
-    return tv2_host("more_TV2", y, lambda, x, info, n);
+    return tv2_host("morePG_TV2", y, lambda, x, info, n);
 }
 int PG_TV2(double *y, double lambda, double *x, double *info, int n) { return tv2_host("PG_TV2", y, lambda, x, info, n); }
 
