@@ -1,0 +1,273 @@
+// pincore.hpp -- the taut string of ONE fibre found by all lanes of a group at once: "pin the worst violator".
+//
+// Why.  The speculative-chunk kernels (chunkcore.hpp) are fast while a walk that starts a few samples early meets the
+// true walk before its chunk begins, i.e. while pieces are short.  When pieces are tens to thousands of samples long
+// (lambda >~ the noise level, block images, the later iterates of a DR solve) they degrade to one sequential lane per
+// fibre, and the linearized walk itself re-walks long pieces again and again (the reference answers that with the
+// convex-hull taut string behind its hybrid switch: src/TVL1opt_tautstring.cpp:256-340,
+// src/TVL1opt_hybridtautstring.cpp:31-35,73).  This is the device counterpart: exact for any input, its cost is
+// (number of levels) x n with ~12-16 levels for anything from white noise to a single flat piece, and every level is
+// data-parallel over the samples of the fibre.
+//
+// The problem as a string.  With S_j = sum_{i<j} y_i (knots j = 0..n), the prox of y is the slope sequence of the
+// shortest path s through the tube S_j - r_j <= s_j <= S_j + r_j (r = lambda at interior knots, 0 at both ends):
+// x_i = s_{i+1} - s_i (the classic taut-string reading of src/TVL1opt_tautstring.cpp:262-280).
+//
+// The rule.  Let A = (ja, ha), B = (jb, hb) be two points known to lie on the string and c the chord between them.
+// If the chord stays inside the tube, it IS the string between A and B.  Otherwise let ku maximise c_j - (S_j + r_j)
+// (how far the chord pokes through the upper wall) and kl maximise (S_j - r_j) - c_j: when positive, BOTH walls' worst
+// knots lie on the string, at their wall's height.  Proof for the upper wall: let P be the string between A and B and
+// g = c - P; g(ja) = g(jb) = 0.  If P passed strictly below the wall at ku then max g > c_ku - (S_ku + r_ku) = the
+// largest upper violation; at a maximum of g the string is convex (its slope grows), and a taut string grows its slope
+// only where it touches the UPPER wall -- so that maximiser k is an upper contact, P_k = S_k + r_k, and its violation
+// c_k - P_k = g(k) exceeds the maximum.  Contradiction; the lower wall is symmetric.  So every level pins, in every
+// unfinished segment, the worst knot of each wall, and segments whose chord fits are final; the fibre ends are pinned
+// from the start.  Levels are independent of the order in which segments are looked at: the result is a function of
+// the input only (the maxima are reduced with atomic max on the bit pattern and ties go to the smallest knot).
+//
+// Work split (concept).  A group of G lanes owns one fibre; lane t owns the interior knots [1 + tP, 1 + (t+1)P) and
+// keeps their pins in two bit masks in registers, plus the nearest pin on either side of its range (la, rb) with the
+// string's height there.  A segment that lies inside one lane's range is resolved by that lane alone.  A segment that
+// spans lanes is reduced through a slot in shared memory keyed by the lane that holds its left pin -- unique, because
+// only one segment can leave a lane's range to the right -- in three steps separated by group barriers:
+//     scan    every lane evaluates its knots against their chords, resolves inner segments, posts the maxima of its
+//             two possible spanning runs (the one entering from the left, the one leaving to the right)
+//     claim   lanes whose run maximum equals the slot's maximum post their knot (atomic min: smallest knot wins)
+//     update  every lane reads the slots of its spanning segments and moves la / rb / its own masks
+// A lane none of whose segments changed in a level is final (a segment with a violation anywhere always gains a pin,
+// which changes something for every lane it touches); the group stops when no lane gained a pin.
+//
+// Numerics.  Decisions are taken on S, a running sum (centred by the fibre mean by the caller), so values are exact to
+// ~1e-16 |S| / piece length instead of the walker's 1e-16 |y|: 1e-14 relative on unit noise of 4096 samples.  Knots
+// whose violation is rounding noise may or may not be pinned; either way the string moves by that noise only.
+//
+// Host-testable: tests/host_harness.cpp runs the three steps for all lanes of a group in turn (a barrier is the end of
+// a loop), tests/test_pin_host.py compares with the oracle.
+#pragma once
+
+namespace ptv {
+
+#ifndef PTV_HOST_TEST
+#define PTV_PIN_FN __device__ __forceinline__
+#else
+#define PTV_PIN_FN inline
+#endif
+
+// Shared-memory side of a group (concept `Sh`):
+//     double S(int j)                          running sum at knot j (0 <= j <= n)
+//     double r(int j)                          tube half-width at interior knot j
+//     void   post(int wall, int slot, double v)     slot maximum <- max(., v)          (v > 0)
+//     double best(int wall, int slot)               slot maximum (0: nothing posted)
+//     void   claim(int wall, int slot, int j)       slot knot <- min(., j)
+//     int    knot(int wall, int slot)
+// wall 0 = upper, 1 = lower.
+
+template <int P>
+struct PinLane {
+    static_assert(P >= 1 && P <= 64, "a lane's pins live in one 64-bit mask per wall");
+    int n = 0, t = 0;
+    int j0 = 0, j1 = 0;                        // own candidate knots [j0, j1) (interior knots are 1 .. n-1)
+    unsigned long long pinU = 0, pinL = 0;     // bit k: knot j0 + k is pinned to the upper / lower wall
+    int la = 0, rb = 0;                        // nearest pinned knot before j0 / at or after j1
+    double hl = 0.0, hr = 0.0;                 // the string's height there
+    bool final_ = false;                       // no segment of this lane can change any more
+    // what the scan step found for the two runs that may span lanes
+    double eU = 0.0, eL = 0.0, xU = 0.0, xL = 0.0;   // entering run / leaving run: largest violation per wall (<= 0: none)
+    int eUk = 0, eLk = 0, xUk = 0, xLk = 0;          // ... and the knot
+    bool leaving = false;                             // the lane has pins of its own, so a second run leaves to the right
+    unsigned long long newU = 0, newL = 0;            // pins found this level inside the lane's own range
+
+    PTV_PIN_FN static int slot_of(int ja) { return ja == 0 ? 0 : (ja - 1) / P + 1; }
+
+    template <class Sh>
+    PTV_PIN_FN void init(int n_, int t_, const Sh &sh) {
+        n = n_;
+        t = t_;
+        j0 = 1 + t * P < n ? 1 + t * P : n;
+        j1 = j0 + P < n ? j0 + P : n;
+        pinU = pinL = 0;
+        la = 0;
+        hl = sh.S(0);
+        rb = n;
+        hr = sh.S(n);
+        final_ = (t * P >= n);   // a lane without samples never acts (it still passes the barriers); one with a sample
+                                 // but no knot (the fibre's last) follows its neighbours' pins
+    }
+
+    template <class Sh>
+    PTV_PIN_FN double height(const Sh &sh, int j, bool lower) const {
+        return lower ? sh.S(j) - sh.r(j) : sh.S(j) + sh.r(j);
+    }
+
+    // ---- scan -------------------------------------------------------------------------------------------------------------
+    template <class Sh>
+    PTV_PIN_FN void scan(Sh &sh) {
+        newU = newL = 0;
+        eU = eL = xU = xL = 0.0;
+        leaving = false;
+        if (final_) return;
+        const unsigned long long pinned = pinU | pinL;
+        int ca = la;
+        double cha = hl;
+        // end of the run that enters from the left: the lane's first pin, or the pin beyond its range
+        int cb;
+        double chb;
+        {
+            if (pinned) {
+                const int b = __builtin_ctzll(pinned);
+                cb = j0 + b;
+                chb = height(sh, cb, (pinL >> b) & 1ull);
+            } else {
+                cb = rb;
+                chb = hr;
+            }
+        }
+        double m = (chb - cha) / (double)(cb - ca);
+        double bu = 0.0, bl = 0.0;
+        int ku = 0, kl = 0;
+        bool entering = true;
+        const int cnt = j1 - j0;
+        for (int k = 0; k < cnt; k++) {
+            const int j = j0 + k;
+            if ((pinned >> k) & 1ull) {
+                // a run closes at this pin
+                if (entering) {
+                    eU = bu; eUk = ku; eL = bl; eLk = kl;
+                    entering = false;
+                } else {
+                    if (bu > 0.0) newU |= 1ull << (ku - j0);
+                    if (bl > 0.0) newL |= 1ull << (kl - j0);
+                }
+                ca = j;
+                cha = chb;   // (the run ended exactly here)
+                const unsigned long long rest = (k + 1 < 64) ? (pinned >> (k + 1)) : 0ull;
+                if (rest) {
+                    const int b = k + 1 + __builtin_ctzll(rest);
+                    cb = j0 + b;
+                    chb = height(sh, cb, (pinL >> b) & 1ull);
+                } else {
+                    cb = rb;
+                    chb = hr;
+                }
+                m = (chb - cha) / (double)(cb - ca);
+                bu = bl = 0.0;
+            } else {
+                const double c = cha + m * (double)(j - ca);
+                const double s = sh.S(j), w = sh.r(j);
+                const double vu = c - (s + w), vl = (s - w) - c;
+                if (vu > bu) { bu = vu; ku = j; }
+                if (vl > bl) { bl = vl; kl = j; }
+            }
+        }
+        // the last run ends at rb, beyond the lane's range
+        if (entering) {
+            eU = bu; eUk = ku; eL = bl; eLk = kl;
+        } else {
+            leaving = true;
+            xU = bu; xUk = ku; xL = bl; xLk = kl;
+        }
+        const int se = slot_of(la);
+        if (eU > 0.0) sh.post(0, se, eU);
+        if (eL > 0.0) sh.post(1, se, eL);
+        if (leaving) {
+            if (xU > 0.0) sh.post(0, t + 1, xU);
+            if (xL > 0.0) sh.post(1, t + 1, xL);
+        }
+    }
+
+    // ---- claim ------------------------------------------------------------------------------------------------------------
+    template <class Sh>
+    PTV_PIN_FN void claim(Sh &sh) {
+        if (final_) return;
+        const int se = slot_of(la);
+        if (eU > 0.0 && eU == sh.best(0, se)) sh.claim(0, se, eUk);
+        if (eL > 0.0 && eL == sh.best(1, se)) sh.claim(1, se, eLk);
+        if (leaving) {
+            if (xU > 0.0 && xU == sh.best(0, t + 1)) sh.claim(0, t + 1, xUk);
+            if (xL > 0.0 && xL == sh.best(1, t + 1)) sh.claim(1, t + 1, xLk);
+        }
+    }
+
+    // ---- update: returns true when the lane gained a pin of its own ------------------------------------------------------------
+    template <class Sh>
+    PTV_PIN_FN bool update(const Sh &sh) {
+        if (final_) return false;
+        bool moved = false;
+        const int se = slot_of(la);   // (before la moves)
+        for (int wall = 0; wall < 2; wall++) {
+            if (sh.best(wall, se) > 0.0) moved |= place(sh, sh.knot(wall, se), wall);
+            if (leaving && sh.best(wall, t + 1) > 0.0) moved |= place(sh, sh.knot(wall, t + 1), wall);
+        }
+        const bool gained = (newU | newL) != 0ull;
+        pinU |= newU;
+        pinL |= newL;
+        if (!moved && !gained) final_ = true;
+        return gained;
+    }
+
+    template <class Sh>
+    PTV_PIN_FN bool place(const Sh &sh, int k, int wall) {
+        if (k < j0) {
+            if (k > la) {
+                la = k;
+                hl = height(sh, k, wall != 0);
+                return true;
+            }
+            return false;
+        }
+        if (k >= j1) {
+            if (k < rb) {
+                rb = k;
+                hr = height(sh, k, wall != 0);
+                return true;
+            }
+            return false;
+        }
+        if (wall) newL |= 1ull << (k - j0);
+        else      newU |= 1ull << (k - j0);
+        return true;
+    }
+
+    // ---- values: slope of the string over the lane's own samples i = tP + k (between knots i and i + 1), k < P ---------------
+    // `mean` is what the caller subtracted from the samples before summing them.
+    template <class Sh, class Put>
+    PTV_PIN_FN void values(const Sh &sh, double mean, Put &&put) const {
+        const unsigned long long pinned = pinU | pinL;
+        const int i0 = t * P;
+        if (i0 >= n) return;
+        int ca = la;
+        double cha = hl;
+        int cb;
+        double chb;
+        if (pinned) {
+            const int b = __builtin_ctzll(pinned);
+            cb = j0 + b;
+            chb = height(sh, cb, (pinL >> b) & 1ull);
+        } else {
+            cb = rb;
+            chb = hr;
+        }
+        double v = (chb - cha) / (double)(cb - ca) + mean;
+        const int cnt = (i0 + P <= n ? P : n - i0);
+        for (int k = 0; k < cnt; k++) {
+            const int i = i0 + k;   // knot i = j0 + k - 1: the lane's own knot k - 1
+            if (k >= 1 && ((pinned >> (k - 1)) & 1ull)) {
+                ca = i;
+                cha = chb;
+                const unsigned long long rest = (k < 64) ? (pinned >> k) : 0ull;
+                if (rest) {
+                    const int b = k + __builtin_ctzll(rest);
+                    cb = j0 + b;
+                    chb = height(sh, cb, (pinL >> b) & 1ull);
+                } else {
+                    cb = rb;
+                    chb = hr;
+                }
+                v = (chb - cha) / (double)(cb - ca) + mean;
+            }
+            put(i, v);
+        }
+    }
+};
+
+}  // namespace ptv

@@ -14,6 +14,7 @@
 #include "../proxtv_amd/csrc/policy.hpp"
 #include "../proxtv_amd/csrc/walker.hpp"
 #include "../proxtv_amd/csrc/chunkcore.hpp"
+#include "../proxtv_amd/csrc/pincore.hpp"
 
 using namespace ptv;
 
@@ -160,6 +161,50 @@ int chunk_fibre(const double *y, const double *w, double lam, int len, int H, in
 }
 }  // namespace
 
+// The pinning solver (pincore.hpp) for one fibre, its group of lanes emulated one after the other: a group barrier is the
+// end of a loop over lanes, an atomic is a plain max / min.  P = knots per lane (16, 32 or 64).  w (n - 1 edge penalties)
+// may be null.  Returns the number of levels.
+template <int P>
+static int pin_fibre(const double *y, const double *w, double lam, double *x, int n) {
+    struct Shared {
+        std::vector<double> s, rr;
+        std::vector<double> mx[2];
+        std::vector<int> arg[2];
+        double S(int j) const { return s[(size_t)j]; }
+        double r(int j) const { return rr[(size_t)j]; }
+        void post(int wall, int slot, double v) { if (v > mx[wall][(size_t)slot]) mx[wall][(size_t)slot] = v; }
+        double best(int wall, int slot) const { return mx[wall][(size_t)slot]; }
+        void claim(int wall, int slot, int j) { if (j < arg[wall][(size_t)slot]) arg[wall][(size_t)slot] = j; }
+        int knot(int wall, int slot) const { return arg[wall][(size_t)slot]; }
+    } sh;
+    const int lanes = (n + P - 1) / P;
+    double mean = 0;
+    for (int i = 0; i < n; i++) mean += y[i];
+    mean /= n;
+    sh.s.assign((size_t)n + 1, 0.0);
+    sh.rr.assign((size_t)n + 1, 0.0);
+    for (int i = 0; i < n; i++) sh.s[(size_t)i + 1] = sh.s[(size_t)i] + (y[i] - mean);
+    for (int j = 1; j < n; j++) sh.rr[(size_t)j] = w ? w[j - 1] : lam;
+    std::vector<PinLane<P>> lane((size_t)lanes);
+    for (int t = 0; t < lanes; t++) lane[(size_t)t].init(n, t, sh);
+    int levels = 0;
+    for (;;) {
+        for (int wall = 0; wall < 2; wall++) {
+            sh.mx[wall].assign((size_t)lanes + 1, 0.0);
+            sh.arg[wall].assign((size_t)lanes + 1, 1 << 30);
+        }
+        levels++;
+        for (int t = 0; t < lanes; t++) lane[(size_t)t].scan(sh);
+        for (int t = 0; t < lanes; t++) lane[(size_t)t].claim(sh);
+        bool any = false;
+        for (int t = 0; t < lanes; t++) any |= lane[(size_t)t].update(sh);
+        if (!any) break;
+    }
+    for (int t = 0; t < lanes; t++) lane[(size_t)t].values(sh, mean, [&](int i, double v) { x[i] = v; });
+    return levels;
+}
+
+
 extern "C" {
 
 // One fibre through the speculative-chunk scheme exactly as a workgroup column does it (chunkcore.hpp): blocks of NW
@@ -302,5 +347,13 @@ int policy_sim(const double *cost, const double *frac, int switch_at, int solves
     }
     if (total_ms) *total_ms = total;
     return pl.mode;
+}
+
+int host_pin_fibre(const double *y, const double *w, double lam, double *x, int n, int P) {
+    if (P == 16) return pin_fibre<16>(y, w, lam, x, n);
+    if (P == 32) return pin_fibre<32>(y, w, lam, x, n);
+    if (P == 64) return pin_fibre<64>(y, w, lam, x, n);
+    if (P == 4) return pin_fibre<4>(y, w, lam, x, n);
+    return -1;
 }
 }

@@ -1,0 +1,97 @@
+"""The pinning solver of long pieces (proxtv_amd/csrc/pincore.hpp: "pin the worst violator of every segment, on both walls,
+until every chord fits its tube"), compiled for the host with its group of lanes emulated one after the other, against
+the oracle -- no GPU needed.  Exact for every input by construction; the tolerance is that of its running sums."""
+import ctypes as C
+import os
+import subprocess
+import tempfile
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def harness():
+    out = os.path.join(tempfile.mkdtemp(prefix="ptv_pin_"), "libpin_host.so")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-o", out,
+                    os.path.join(HERE, "host_harness.cpp")], check=True)
+    lib = C.CDLL(out)
+    lib.host_pin_fibre.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_int, C.c_int]
+    lib.host_pin_fibre.restype = C.c_int
+    return lib
+
+
+def pin(lib, y, lam, w=None, P=16):
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    x = np.full(y.size, np.nan)
+    levels = lib.host_pin_fibre(y.ctypes.data, None if w is None else w.ctypes.data, lam, x.ctypes.data, y.size, P)
+    assert levels >= 1
+    return x, levels
+
+
+def tol(y):
+    """running sums of n centred samples: 1e-16 * n * spread, relative to the data's scale"""
+    y = np.asarray(y, dtype=float)
+    return 4e-16 * y.size * max(1.0, float(np.abs(y - y.mean()).max())) + 1e-13 * max(1.0, float(np.abs(y).max()))
+
+
+FAMILIES = {
+    "noise": lambda r, n: r.standard_normal(n),
+    "blocks": lambda r, n: np.repeat(r.standard_normal(n // 37 + 1), 37)[:n] + 0.2 * r.standard_normal(n),
+    "integers": lambda r, n: r.integers(-2, 3, n).astype(float),
+    "walk": lambda r, n: np.cumsum(r.standard_normal(n)) * 0.3,
+    "ramp": lambda r, n: np.linspace(0, 10, n) + 0.1 * r.standard_normal(n),
+    "sine": lambda r, n: 5 * np.sin(np.arange(n) / 40.0),
+    "constant": lambda r, n: np.full(n, 3.0),
+    "offset": lambda r, n: 1000.0 + r.standard_normal(n),
+}
+
+
+def test_pinning_equals_oracle(harness, oracle):
+    rng = np.random.default_rng(0)
+    worst_levels = 0
+    for trial in range(400):
+        name = list(FAMILIES)[trial % len(FAMILIES)]
+        n = int(rng.choice([1, 2, 3, 5, 16, 17, 31, 33, 64, 100, 257, 1000, 1025, 4096, 4097, 5000]))
+        y = FAMILIES[name](rng, n)
+        lam = float(10 ** rng.uniform(-2, 2))
+        want = oracle.tv1_linearized(y.copy(), lam)
+        for P in (16, 64) if trial % 3 else (4, 32):
+            x, levels = pin(harness, y, lam, P=P)
+            worst_levels = max(worst_levels, levels)
+            assert np.abs(x - want).max() <= tol(y), (name, n, lam, P, np.abs(x - want).max())
+    assert worst_levels <= 64, worst_levels
+
+
+def test_pinning_weighted_equals_oracle(harness, oracle):
+    rng = np.random.default_rng(1)
+    for trial in range(200):
+        name = list(FAMILIES)[trial % len(FAMILIES)]
+        n = int(rng.choice([2, 3, 17, 64, 257, 1000, 4096]))
+        y = FAMILIES[name](rng, n)
+        w = 10 ** rng.uniform(-2, 1.5) * rng.uniform(0.2, 1.0, n - 1)
+        if trial % 5 == 0:
+            w[rng.integers(0, n - 1, max(1, n // 10))] = 0.0     # free edges: the string is cut there
+        want = oracle.tv1_weighted(y.copy(), w)
+        x, _ = pin(harness, y, 0.0, w=w, P=16)
+        assert np.abs(x - want).max() <= tol(y), (name, n, np.abs(x - want).max())
+
+
+def test_levels_stay_logarithmic_on_the_workloads(harness):
+    """What makes the solver a rung of the ladder: the level count barely moves between white noise, the long pieces of
+    a DR solve at large lambda, and a single flat piece."""
+    rng = np.random.default_rng(2)
+    y = rng.standard_normal(4096)
+    counts = {lam: pin(harness, y, lam)[1] for lam in (0.1, 1.0, 3.0, 10.0, 100.0)}
+    assert max(counts.values()) <= 24, counts
+    assert counts[100.0] <= 4, counts
+
+
+def test_special_values(harness, oracle):
+    for y, lam in (([3.0], 1.0), ([1.0, 5.0], 1.0), ([1.0, 5.0], 10.0), ([2.0, 2.0, 2.0, 2.0], 0.5),
+                   ([1.0, 4.0, 2.0, 8.0, 3.0], 0.0), ([0.0, 10.0, 0.0, 10.0, 0.0], 2.0)):
+        y = np.array(y)
+        x, _ = pin(harness, y, lam)
+        np.testing.assert_allclose(x, oracle.tv1_linearized(y.copy(), lam), atol=1e-13)
