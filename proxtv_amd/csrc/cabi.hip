@@ -411,6 +411,7 @@ int proxtv_set_option(const char *key, int value) {
     else if (!strcmp(key, "along")) slot = &o.along;
     else if (!strcmp(key, "whole")) slot = &o.whole;
     else if (!strcmp(key, "row_along")) slot = &o.row_along;
+    else if (!strcmp(key, "pin")) slot = &o.pin;
     else if (!strcmp(key, "along_min_len")) slot = &o.along_min_len;
     else if (!strcmp(key, "chunk_min_len")) slot = &o.chunk_min_len;
     else if (!strcmp(key, "rounds")) slot = &o.rounds;

@@ -44,6 +44,7 @@ struct Options {
     int along = 1;            // dimension-0 sweeps: chunks along the fibre (sweep_along_kernel); 0 = the transposed 64-fibre tile
     int along_min_len = 160;  // ... for fibres at least this long (16, 32 or 64 lanes share a fibre segment of 17-sample chunks)
     int row_along = 1;        // strided sweeps that need long zones: transpose + along-fibre kernel + transpose back (0 = 64-fibre tile)
+    int pin = 1;              // geometry rung 3: the pinning solver (pin.hip) where it applies; 0 = global-memory chunks
     int whole = 1;            // fibres shorter than chunk_min_len: whole-fibre-in-LDS kernel (0 = the sequential kernel)
     int chunk_min_len = 96;   // fibres shorter than this take the sequential kernel (measured crossover: 512x512xL volumes, L ~ 96)
     int verbose = 0;

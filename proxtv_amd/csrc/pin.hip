@@ -1,0 +1,325 @@
+// pin.hip -- the pinning solver (pincore.hpp) as a sweep kernel: the exact taut string of a fibre found by all lanes of a
+// group at once; cost ~ (12-16 levels) x n whatever the length of the pieces.  The device counterpart of the reference's
+// worst-case-linear solver behind its hybrid switch (src/TVL1opt_tautstring.cpp:256-340,
+// src/TVL1opt_hybridtautstring.cpp:31-35,73) and the top rung of the geometry ladder of sweep.hip: where speculative
+// chunks need zones of hundreds of samples (lambda >~ noise, block images, late DR iterates) this kernel takes the same
+// time as on white noise.
+//
+// One group of G lanes per fibre (G = 256: a workgroup; G = 64: a wave, four fibres per workgroup), P knots per lane.
+// LDS per group: ONE plane of doubles -- the samples as they arrive, then their running sums in place, then the prox
+// values in place -- laid out so that lane t's k-th element sits at t (P + 1) + k + 1: the lanes of an access are P + 1
+// doubles apart, an odd number, so they fall on different banks without any transposition; a second plane for the
+// penalties of a weighted sweep; and two small buffers of reduction slots (pincore.hpp), used alternately so that a
+// level can clear the buffer of the next one.
+//
+//   stage     coalesced loads through the op's input functor (every load of a batch issued before the first is waited for)
+//   sums      mean of the fibre (group reduction), centred running sums (lane-local pass + group scan), in place
+//   levels    scan / claim / update of pincore.hpp, three group barriers per level, until no lane gained a pin
+//   values    every lane turns its part of the string into slopes, in place
+//   stream    coalesced, through the op's output functor
+//
+// Fibres must be contiguous (dimension 0); a strided sweep runs on transposed copies of its operands (pointwise.hip's
+// slab_transpose), like launch_row_along in sweep.hip.  Exact for every input: no links, no repair kernel, no counters.
+#include "pin.hpp"
+
+#include <memory>
+
+#include "pincore.hpp"
+#include "pointwise.hpp"
+
+namespace ptv {
+
+namespace {
+
+constexpr int kPinThreads = 256;
+
+template <int P, int G, bool WEIGHTED>
+struct PinGeom {
+    static constexpr int PS = P + 1;                     // lane stride inside a plane
+    static constexpr int ROWS = G * PS + 2;              // knots 0 .. G P
+    static constexpr int NG = kPinThreads / G;           // fibres per workgroup
+    static constexpr int SLOTS = G + 1;
+    static constexpr size_t plane_bytes = sizeof(double) * ROWS;
+    static constexpr size_t slot_bytes = (size_t)2 * 2 * SLOTS * (sizeof(unsigned long long) + sizeof(unsigned));   // [buffer][wall][slot]
+    static constexpr size_t group_bytes = ((plane_bytes * (WEIGHTED ? 2 : 1) + slot_bytes + 15) / 16) * 16;
+    static constexpr size_t lds = group_bytes * NG;
+    static_assert(lds <= 160 * 1024, "pinning geometry does not fit the LDS of a CU");
+    // address of knot j (and of sample j - 1, which lives there until the sums replace it)
+    __device__ static __forceinline__ int sa(int j) { return j + (j > 0 ? (j - 1) / P : 0); }
+};
+
+template <int P, int G, bool WEIGHTED>
+struct PinShared {
+    using Geo = PinGeom<P, G, WEIGHTED>;
+    double *Sp, *Wp;
+    double lam;
+    unsigned long long *mx;   // [wall][slot] of the level's buffer
+    unsigned *arg;
+    __device__ __forceinline__ double S(int j) const { return Sp[Geo::sa(j)]; }
+    __device__ __forceinline__ double r(int j) const { return WEIGHTED ? Wp[Geo::sa(j)] : lam; }
+    __device__ __forceinline__ void post(int wall, int slot, double v) {
+        atomicMax(&mx[wall * Geo::SLOTS + slot], (unsigned long long)__double_as_longlong(v));   // positive doubles order like their bits
+    }
+    __device__ __forceinline__ double best(int wall, int slot) const { return __longlong_as_double((long long)mx[wall * Geo::SLOTS + slot]); }
+    __device__ __forceinline__ void claim(int wall, int slot, int j) { atomicMin(&arg[wall * Geo::SLOTS + slot], (unsigned)j); }
+    __device__ __forceinline__ int knot(int wall, int slot) const { return (int)arg[wall * Geo::SLOTS + slot]; }
+};
+
+// ---- group collectives --------------------------------------------------------------------------------------------------
+template <int G>
+__device__ __forceinline__ void group_sync() {
+    if constexpr (G == kPinThreads) {
+        __syncthreads();
+    } else {   // the group is one wave: order its LDS traffic, nothing to wait for
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
+
+template <int G>
+__device__ __forceinline__ bool group_any(bool pred) {
+    if constexpr (G == kPinThreads) {
+        return __syncthreads_or(pred ? 1 : 0) != 0;
+    } else {
+        group_sync<G>();
+        return __ballot(pred) != 0ull;
+    }
+}
+
+// inclusive scan of v over the lanes of the group; `total` = the sum over the group.  red: G / 64 doubles of LDS scratch.
+template <int G>
+__device__ __forceinline__ double group_scan(double v, int t, double *red, double &total) {
+    const int lane = t & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const double o = __shfl_up(v, d);
+        if (lane >= d) v += o;
+    }
+    if constexpr (G == 64) {
+        total = __shfl(v, 63);
+        return v;
+    } else {
+        const int wave = t >> 6;
+        if (lane == 63) red[wave] = v;
+        __syncthreads();
+        double pre = 0.0, tot = 0.0;
+#pragma unroll
+        for (int w = 0; w < G / 64; w++) {
+            const double x = red[w];
+            if (w < wave) pre += x;
+            tot += x;
+        }
+        __syncthreads();
+        total = tot;
+        return v + pre;
+    }
+}
+
+template <int OP, bool WEIGHTED, int P, int G>
+__global__ __launch_bounds__(kPinThreads) void sweep_pin_kernel(SweepArgs p, FibreGeom g) {
+    using Geo = PinGeom<P, G, WEIGHTED>;
+    using Sh = PinShared<P, G, WEIGHTED>;
+    constexpr int SLOTS = Geo::SLOTS;
+    constexpr int UB = 8;   // global loads in flight per lane
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (p.gate && *p.gate == 0) return;
+    const int tid = threadIdx.x, gi = tid / G, t = tid % G;
+    char *base = smem + Geo::group_bytes * (size_t)gi;
+    double *Sp = reinterpret_cast<double *>(base);
+    double *Wp = Sp + (WEIGHTED ? Geo::ROWS : 0);
+    unsigned long long *mx = reinterpret_cast<unsigned long long *>(base + Geo::plane_bytes * (WEIGHTED ? 2 : 1));   // [buffer][wall][slot]
+    unsigned *arg = reinterpret_cast<unsigned *>(mx + 2 * 2 * SLOTS);
+    const long fibre = (long)blockIdx.x * Geo::NG + gi;
+    if (G < kPinThreads && fibre >= g.count) return;   // (a whole wave; such groups share no barrier with the others)
+    const int n = g.len;
+    const long fbase = fibre * n, wbase = fibre * (long)(n - 1);
+
+    // ---- stage ------------------------------------------------------------------------------------------------------------------
+#pragma unroll 1
+    for (int u0 = 0; u0 < P; u0 += UB) {
+        double s0[UB], s1[UB], sw[WEIGHTED ? UB : 1];
+#pragma unroll
+        for (int u = 0; u < UB; u++) {
+            const int i = (u0 + u) * G + t;
+            s0[u] = s1[u] = 0.0;
+            if (i < n) Op<OP>::fetch_in(p, fbase + i, s0[u], s1[u]);
+            if (WEIGHTED) sw[WEIGHTED ? u : 0] = (i >= 1 && i < n) ? p.w[wbase + i - 1] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < UB; u++) {
+            const int i = (u0 + u) * G + t;
+            if (i < n) {
+                Sp[Geo::sa(i + 1)] = Op<OP>::y_of(p, s0[u], s1[u]);
+                if (WEIGHTED && i >= 1) Wp[Geo::sa(i)] = sw[WEIGHTED ? u : 0];   // penalty of the edge (i - 1, i) = half-width at knot i
+            }
+        }
+    }
+    if (t == 0) Sp[0] = 0.0;
+    group_sync<G>();
+
+    // ---- centred running sums, in place ---------------------------------------------------------------------------------------------
+    double *own = Sp + 1 + t * Geo::PS;   // own[k]: sample t P + k, then the sum at knot t P + k + 1
+    const int cnt = n - t * P < 0 ? 0 : (n - t * P < P ? n - t * P : P);
+    double *red = reinterpret_cast<double *>(mx);
+    double mean;
+    {
+        double ls = 0.0;
+        for (int k = 0; k < cnt; k++) ls += own[k];
+        double total;
+        group_scan<G>(ls, t, red, total);
+        mean = total / (double)n;
+        double lc = 0.0;
+        for (int k = 0; k < cnt; k++) lc += own[k] - mean;
+        double tot2;
+        double acc = group_scan<G>(lc, t, red, tot2) - lc;
+        for (int k = 0; k < cnt; k++) {
+            acc += own[k] - mean;
+            own[k] = acc;
+        }
+    }
+    // reduction slots: both buffers empty
+    for (int b = 0; b < 2; b++)
+        for (int wall = 0; wall < 2; wall++) {
+            mx[(b * 2 + wall) * SLOTS + t + 1] = 0ull;
+            arg[(b * 2 + wall) * SLOTS + t + 1] = ~0u;
+            if (t == 0) {
+                mx[(b * 2 + wall) * SLOTS] = 0ull;
+                arg[(b * 2 + wall) * SLOTS] = ~0u;
+            }
+        }
+    group_sync<G>();
+
+    // ---- levels ----------------------------------------------------------------------------------------------------------------------
+    PinLane<P> ln;
+    {
+        const Sh sh0{Sp, Wp, p.lam, mx, arg};
+        ln.init(n, t, sh0);
+    }
+#pragma unroll 1
+    for (int level = 0;; level++) {
+        const int cur = level & 1;
+        Sh sh{Sp, Wp, p.lam, mx + cur * 2 * SLOTS, arg + cur * 2 * SLOTS};
+        {   // the other buffer was last read before the barrier that ended the previous level: clear this lane's slots of it
+            unsigned long long *omx = mx + (cur ^ 1) * 2 * SLOTS;
+            unsigned *oarg = arg + (cur ^ 1) * 2 * SLOTS;
+            omx[t + 1] = 0ull; omx[SLOTS + t + 1] = 0ull;
+            oarg[t + 1] = ~0u; oarg[SLOTS + t + 1] = ~0u;
+            if (t == 0) {
+                omx[0] = 0ull; omx[SLOTS] = 0ull;
+                oarg[0] = ~0u; oarg[SLOTS] = ~0u;
+            }
+        }
+        ln.scan(sh);
+        group_sync<G>();
+        ln.claim(sh);
+        group_sync<G>();
+        const bool gained = ln.update(sh);
+        if (!group_any<G>(gained)) break;
+    }
+
+    // ---- values, in place (a lane reads nothing but its own part of the plane and what it cached of its neighbours') -----------------
+    {
+        const Sh sh{Sp, Wp, p.lam, mx, arg};
+        ln.values(sh, mean, [&](int i, double v) { Sp[Geo::sa(i + 1)] = v; });
+    }
+    group_sync<G>();
+
+    // ---- stream out -------------------------------------------------------------------------------------------------------------------
+#pragma unroll 1
+    for (int u0 = 0; u0 < P; u0 += UB) {
+        Ext ex[UB];
+#pragma unroll
+        for (int u = 0; u < UB; u++) {
+            const int i = (u0 + u) * G + t;
+            ex[u] = (i < n) ? Op<OP>::fetch(p, fbase + i) : Ext{0, 0};
+        }
+#pragma unroll
+        for (int u = 0; u < UB; u++) {
+            const int i = (u0 + u) * G + t;
+            if (i < n) Op<OP>::finish(p, fbase + i, ex[u], Sp[Geo::sa(i + 1)]);
+        }
+    }
+}
+
+template <int OP, bool WEIGHTED, int P, int G>
+void launch_geom(const SweepArgs &args, const FibreGeom &g, hipStream_t stream) {
+    using Geo = PinGeom<P, G, WEIGHTED>;
+    auto kern = sweep_pin_kernel<OP, WEIGHTED, P, G>;
+    if (Geo::lds > 64 * 1024) {   // above the default dynamic-LDS limit
+        static thread_local bool attr_done[kMaxDevices] = {};
+        bool &attr_set = attr_done[current_device()];
+        if (!attr_set) {
+            PTV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)Geo::lds));
+            attr_set = true;
+        }
+    }
+    const long wgs = (g.count + Geo::NG - 1) / Geo::NG;
+    hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(kPinThreads), Geo::lds, stream, args, g);
+    PTV_HIP(hipGetLastError());
+}
+
+// contiguous fibres: pick the group geometry from the fibre length
+template <int OP, bool WEIGHTED>
+void launch_contig(const SweepArgs &args, const FibreGeom &g, hipStream_t stream) {
+    if (g.len <= 64 * 16)        launch_geom<OP, WEIGHTED, 16, 64>(args, g, stream);
+    else if (g.len <= 256 * 16)  launch_geom<OP, WEIGHTED, 16, 256>(args, g, stream);
+    else if (g.len <= 256 * 32)  launch_geom<OP, WEIGHTED, 32, 256>(args, g, stream);
+    else if constexpr (!WEIGHTED) launch_geom<OP, false, 64, 256>(args, g, stream);
+}
+
+template <int OP, bool WEIGHTED>
+void launch_op(const SweepArgs &args, const FibreGeom &g, hipStream_t stream) {
+    if (g.inc == 1) {
+        launch_contig<OP, WEIGHTED>(args, g, stream);
+        return;
+    }
+    if constexpr (!WEIGHTED) {
+        // strided: transpose every operand the op reads, sweep along dimension 0, transpose every output back
+        const long slabs = g.count / g.inc;
+        const size_t bytes = sizeof(double) * (size_t)g.count * (size_t)g.len;
+        std::unique_ptr<Scratch> ta, tb, tc, to0, to1;
+        SweepArgs t = args;
+        if (Op<OP>::IN_MASK & 1u) { ta.reset(new Scratch(bytes)); slab_transpose(args.a, ta->d(), g.inc, g.len, slabs, stream); t.a = ta->d(); }
+        if (Op<OP>::IN_MASK & 2u) { tb.reset(new Scratch(bytes)); slab_transpose(args.b, tb->d(), g.inc, g.len, slabs, stream); t.b = tb->d(); }
+        if (Op<OP>::IN_MASK & 4u) { tc.reset(new Scratch(bytes)); slab_transpose(args.c, tc->d(), g.inc, g.len, slabs, stream); t.c = tc->d(); }
+        if (Op<OP>::OUT_MASK & 1u) { to0.reset(new Scratch(bytes)); t.o0 = to0->d(); }
+        if (Op<OP>::OUT_MASK & 2u) { to1.reset(new Scratch(bytes)); t.o1 = to1->d(); }
+        const FibreGeom gt{1, g.len, g.count};
+        launch_contig<OP, false>(t, gt, stream);
+        if (Op<OP>::OUT_MASK & 1u) slab_transpose(to0->d(), args.o0, g.len, g.inc, slabs, stream);
+        if (Op<OP>::OUT_MASK & 2u) slab_transpose(to1->d(), args.o1, g.len, g.inc, slabs, stream);
+    }
+}
+
+}  // namespace
+
+void launch_pin(OpId op, bool weighted, const SweepArgs &args, const FibreGeom &g, hipStream_t stream) {
+    if (!pin_supports(op, weighted, g, args.lam)) {
+        set_error("launch_pin: sweep not supported (len %d, inc %ld, weighted %d)", g.len, g.inc, (int)weighted);
+        throw HipFailure{hipErrorInvalidValue};
+    }
+#define PTV_PIN_CASE(ID)                                         \
+    case ID:                                                     \
+        if (weighted) launch_op<ID, true>(args, g, stream);      \
+        else          launch_op<ID, false>(args, g, stream);     \
+        break;
+#define PTV_PIN_CASE_U(ID) case ID: launch_op<ID, false>(args, g, stream); break;
+    switch (op) {
+        PTV_PIN_CASE(OP_PROX)
+        PTV_PIN_CASE(OP_DR_COL)
+        PTV_PIN_CASE(OP_DR_COL_FINAL)
+        PTV_PIN_CASE_U(OP_DR_ROW)
+        PTV_PIN_CASE_U(OP_DR_ROW_FINAL)
+        PTV_PIN_CASE_U(OP_PD2_A)
+        PTV_PIN_CASE_U(OP_PD2_B)
+        PTV_PIN_CASE_U(OP_YANG)
+        default:
+            set_error("launch_pin: unknown op %d", (int)op);
+            throw HipFailure{hipErrorInvalidValue};
+    }
+#undef PTV_PIN_CASE
+#undef PTV_PIN_CASE_U
+}
+
+}  // namespace ptv

@@ -1,0 +1,28 @@
+// pin.hpp -- the pinning solver as a sweep: exact 1-D TV-L1 prox of every fibre, data-parallel inside the fibre
+// (pincore.hpp has the algorithm; pin.hip the kernel).  The top rung of the geometry ladder for data with long pieces.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "common.hpp"
+#include "ops.hpp"
+
+namespace ptv {
+
+// Longest fibre the kernel holds in LDS (running sums of one fibre per lane group).
+constexpr int kPinMaxLen = 16384;
+constexpr int kPinMaxLenWeighted = 8192;   // (two planes: sums and penalties)
+
+// Does the pinning solver take this sweep?  (lam < 0 -- tvgen lets negative penalties through -- stays with the walker,
+// whose behaviour there mirrors the reference's.)
+inline bool pin_supports(OpId op, bool weighted, const FibreGeom &g, double lam) {
+    if (g.len < 2 || g.count < 1 || op == OP_DRW_ROW_FINAL) return false;
+    if (weighted)   // weighted strided sweeps are not wired (their penalties would have to be transposed as well)
+        return g.inc == 1 && g.len <= kPinMaxLenWeighted && (op == OP_PROX || op == OP_DR_COL || op == OP_DR_COL_FINAL);
+    return lam >= 0.0 && g.len <= kPinMaxLen;
+}
+
+// One sweep.  Strided fibres (g.inc > 1) go through transposed copies of the operands, like launch_row_along in sweep.hip.
+void launch_pin(OpId op, bool weighted, const SweepArgs &args, const FibreGeom &g, hipStream_t stream);
+
+}  // namespace ptv

@@ -72,7 +72,7 @@ struct PinLane {
     double hl = 0.0, hr = 0.0;                 // the string's height there
     bool final_ = false;                       // no segment of this lane can change any more
     // what the scan step found for the two runs that may span lanes
-    double eU = 0.0, eL = 0.0, xU = 0.0, xL = 0.0;   // entering run / leaving run: largest violation per wall (<= 0: none)
+    double eU = 0.0, eL = 0.0, xU = 0.0, xL = 0.0;   // entering run / leaving run: largest (scaled) violation per wall (0: none)
     int eUk = 0, eLk = 0, xUk = 0, xLk = 0;          // ... and the knot
     bool leaving = false;                             // the lane has pins of its own, so a second run leaves to the right
     unsigned long long newU = 0, newL = 0;            // pins found this level inside the lane's own range
@@ -122,7 +122,9 @@ struct PinLane {
                 chb = hr;
             }
         }
-        double m = (chb - cha) / (double)(cb - ca);
+        // Violations are compared scaled by the segment's length D = cb - ca: D (c_j - S_j) = (cha - S_j)(cb - j) + (chb - S_j)(j - ca),
+        // so a level divides nothing, and all lanes of a segment -- same ends, same heights -- compare like with like.
+        double D = (double)(cb - ca);
         double bu = 0.0, bl = 0.0;
         int ku = 0, kl = 0;
         bool entering = true;
@@ -149,12 +151,13 @@ struct PinLane {
                     cb = rb;
                     chb = hr;
                 }
-                m = (chb - cha) / (double)(cb - ca);
+                D = (double)(cb - ca);
                 bu = bl = 0.0;
             } else {
-                const double c = cha + m * (double)(j - ca);
-                const double s = sh.S(j), w = sh.r(j);
-                const double vu = c - (s + w), vl = (s - w) - c;
+                const double s = sh.S(j);
+                const double q = (cha - s) * (double)(cb - j) + (chb - s) * (double)(j - ca);
+                const double wd = sh.r(j) * D;
+                const double vu = q - wd, vl = -q - wd;
                 if (vu > bu) { bu = vu; ku = j; }
                 if (vl > bl) { bl = vl; kl = j; }
             }

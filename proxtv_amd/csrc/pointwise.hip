@@ -308,4 +308,29 @@ void ccp_step(const CcpArgs &a, bool first, hipStream_t s) {
     PTV_HIP(hipGetLastError());
 }
 
+namespace {
+__global__ __launch_bounds__(256) void slab_transpose_kernel(const double *in, double *out, long rows, long cols) {
+    __shared__ double tile[32][33];
+    const long slab = (long)blockIdx.z * rows * cols;
+    const long r0 = (long)blockIdx.x * 32, c0 = (long)blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    for (int k = ty; k < 32; k += 8) {
+        const long r = r0 + tx, c = c0 + k;
+        if (r < rows && c < cols) tile[k][tx] = in[slab + r + rows * c];
+    }
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8) {
+        const long c = c0 + tx, r = r0 + k;
+        if (r < rows && c < cols) out[slab + c + cols * r] = tile[tx][k];
+    }
+}
+}  // namespace
+
+void slab_transpose(const double *in, double *out, long rows, long cols, long slabs, hipStream_t s) {
+    if (rows <= 0 || cols <= 0 || slabs <= 0) return;
+    const dim3 grid((unsigned)((rows + 31) / 32), (unsigned)((cols + 31) / 32), (unsigned)slabs);
+    hipLaunchKernelGGL(slab_transpose_kernel, grid, dim3(256), 0, s, in, out, rows, cols);
+    PTV_HIP(hipGetLastError());
+}
+
 }  // namespace ptv

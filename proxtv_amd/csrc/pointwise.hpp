@@ -32,6 +32,10 @@ void scale_to(const double *y, double *x, double divisor, long n, hipStream_t s)
 // of the mixed-norm solvers are made of these.
 void lincomb(double *out, const double *a, double ca, const double *b, double cb, const double *c, double cc,
              const double *d, double cd, long n, hipStream_t s);
+// Tiled transpose of `slabs` column-major matrices stored back to back: out (cols x rows) = in (rows x cols)^T per slab.
+// Sweeps along a strided dimension use it to run as dimension-0 sweeps on transposed copies: fibre j = slab * inc + off
+// sits at j * len after the transposition of every (inc x len) slab.
+void slab_transpose(const double *in, double *out, long rows, long cols, long slabs, hipStream_t s);
 // dst = src, 8 bytes per lane (counter calibration only)
 void calib_copy(const double *src, double *dst, long n, hipStream_t s);
 // Yang X update (src/TV2Dopt.cpp:832-833 ; src/TVNDopt.cpp:729-730): X = (Y + sum U_k + rho sum Z_k) / (1 + D rho)

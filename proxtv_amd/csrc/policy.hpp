@@ -6,7 +6,8 @@
 //   1  the same, robust instantiation         pieces of ~5 samples: walks may run past the window (global reads), failed
 //                                             links are walked again inside the block (second-chance rounds)
 //   2  LDS window, 64-sample zones            pieces of ~10 samples
-//   3  global memory, zone 256 / chunk 64     pieces of ~50 samples
+//   3  the pinning solver (pin.hip) where it applies: exact and data-parallel inside the fibre, same cost whatever the
+//      pieces; else global memory, zone 256 / chunk 64 (pieces of ~50 samples)
 //   4  global memory, zone 1024 / chunk 256   pieces of a few hundred samples
 //   5  one sequential walk per fibre          pieces comparable to the fibre: speculation cannot pay
 //
@@ -53,9 +54,11 @@ struct GeometryPolicy {
     bool weighted = false;   // no mode 2 for weighted sweeps (two LDS windows)
     int len = 0;             // no mode 4 below 1024 samples
     long count = 0;
+    bool pin = false;        // rung 3 is the pinning solver: nothing above it is worth a trial
     int changes = 0;         // workload changes seen in this solve
 
-    bool available(int m) const { return !(m == 2 && weighted) && !(m == 4 && len < 1024); }
+    bool available(int m) const { return !(m == 2 && weighted) && !(m == 4 && (len < 1024 || pin)); }
+    int top() const { return pin ? 3 : kModeSeq; }   // where a trial jumps to when most chunks failed
     int up(int m) const {
         do m++; while (m < kModeSeq && !available(m));
         return m;
@@ -71,8 +74,8 @@ struct GeometryPolicy {
 
     // A sweep of this shape is about to be launched.  Returns true when the workload differs from the last one's
     // (explore afresh -- unless shapes keep alternating inside one solve: 4-D+ tensors share a family).
-    bool workload(int len_, long count_, bool weighted_) {
-        const bool fresh = (len != len_ || count != count_ || weighted != weighted_) && changes++ < 4;
+    bool workload(int len_, long count_, bool weighted_, bool pin_ = false) {
+        const bool fresh = (len != len_ || count != count_ || weighted != weighted_ || pin != pin_) && changes++ < 4;
         if (fresh) {
             explore = true;
             trial = -1;
@@ -81,6 +84,7 @@ struct GeometryPolicy {
         len = len_;
         count = count_;
         weighted = weighted_;
+        pin = pin_;
         return fresh;
     }
 
@@ -104,7 +108,7 @@ struct GeometryPolicy {
             t_mode = best_t = t;
             best = r;
             if (r < kModeSeq && dirty && hold_up == 0) {
-                next = (f > kJump) ? kModeSeq : up(r);
+                next = (f > kJump && top() > r) ? top() : up(r);
                 dir = (next > up(r)) ? -1 : +1;   // skipped rungs on the way up: look at them from above
             } else if (r > 0 && clean && hold_down == 0) {
                 next = down(r);

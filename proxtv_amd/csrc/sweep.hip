@@ -38,6 +38,8 @@
 #ifndef PTV_TILE_UNROLL
 #define PTV_TILE_UNROLL 1   // rows of the rebuild passes in flight together in the 64-fibre tile kernel (registers are scarce there)
 #endif
+#include "pin.hpp"
+#include "pointwise.hpp"
 #include "policy.hpp"
 #include "walker.hpp"
 
@@ -1423,29 +1425,6 @@ void launch_gchunk(const SweepArgs &args, const FibreGeom &g, int C, int H, hipS
 // contiguous; a tiled copy at HBM speed), the sweep runs as a dimension-0 sweep, and the outputs are transposed back.
 // Fibre numbering is unchanged: fibre j = slab * inc + off sits at j * len after the transposition of every
 // (inc x len) slab.
-__global__ __launch_bounds__(256) void slab_transpose_kernel(const double *in, double *out, long rows, long cols) {
-    __shared__ double tile[32][33];
-    const long slab = (long)blockIdx.z * rows * cols;
-    const long r0 = (long)blockIdx.x * 32, c0 = (long)blockIdx.y * 32;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    for (int k = ty; k < 32; k += 8) {
-        const long r = r0 + tx, c = c0 + k;
-        if (r < rows && c < cols) tile[k][tx] = in[slab + r + rows * c];
-    }
-    __syncthreads();
-    for (int k = ty; k < 32; k += 8) {
-        const long c = c0 + tx, r = r0 + k;
-        if (r < rows && c < cols) out[slab + c + cols * r] = tile[tx][k];
-    }
-}
-
-static void slab_transpose(const double *in, double *out, long rows, long cols, long slabs, hipStream_t s) {
-    if (rows <= 0 || cols <= 0 || slabs <= 0) return;
-    const dim3 grid((unsigned)((rows + 31) / 32), (unsigned)((cols + 31) / 32), (unsigned)slabs);
-    hipLaunchKernelGGL(slab_transpose_kernel, grid, dim3(256), 0, s, in, out, rows, cols);
-    PTV_HIP(hipGetLastError());
-}
-
 template <int OP, int H>
 void launch_row_along(const SweepArgs &args, const FibreGeom &g, hipStream_t stream, int fam) {
     const long slabs = g.count / g.inc;
@@ -1468,7 +1447,8 @@ void launch_chunk(const SweepArgs &args, const FibreGeom &g, hipStream_t stream,
     ChunkScratch &st = chunk_state();
     ChunkScratch::Policy &pl = st.pol[fam];
     const bool pinned = options().chunk_mode >= 0;
-    if (pl.workload(g.len, g.count, WEIGHTED) && pl.meas) {   // a new workload: the measurement in flight is of the old one
+    const bool pin_ok = options().pin && pin_supports((OpId)OP, WEIGHTED, g, args.lam);
+    if (pl.workload(g.len, g.count, WEIGHTED, pin_ok) && pl.meas) {   // a new workload: the measurement in flight is of the old one
         double t, f;
         st.evaluate(fam, t, f);
     }
@@ -1486,11 +1466,14 @@ void launch_chunk(const SweepArgs &args, const FibreGeom &g, hipStream_t stream,
     }
     const int rounds = (mode == 1) ? (options().rounds > 0 ? options().rounds : kRounds) : 0;
     // Geometry ladder.  Dimension 0 (chunks along the fibre once a fibre fills most of a lane group): 0 = 16-sample zones,
-    // 1 / 2 = 64-sample zones, 3 / 4 = chunks from global memory (zones 256 / 1024), 5 = one sequential walk per fibre.
+    // 1 / 2 = 64-sample zones, 3 = the pinning solver (pin.hip; where it does not apply: chunks from global memory, zone
+    // 256), 4 = chunks from global memory (zone 1024), 5 = one sequential walk per fibre.
     // Strided sweeps: 0 / 1 = the 64-fibre tile (1: robust instantiation), 2 = transposed copies + the along-fibre kernel
     // with 64-sample zones (or the tile with 64-sample zones), 3 / 4 / 5 as above.
     const bool along_ok = options().along && g.len >= options().along_min_len;
+    const bool pinning = (mode == 3 && pin_ok);
     if (mode >= kModeSeq)  launch_seq<OP, WEIGHTED>(args, g, stream, true);
+    else if (pinning)      launch_pin((OpId)OP, WEIGHTED, args, g, stream);
     else if (mode == 3)    launch_gchunk<OP, WEIGHTED>(args, g, 64, 256, stream, fam);
     else if (mode == 4)    launch_gchunk<OP, WEIGHTED>(args, g, 256, 1024, stream, fam);
     else if (TRANSPOSED && along_ok) {
@@ -1512,7 +1495,7 @@ void launch_chunk(const SweepArgs &args, const FibreGeom &g, hipStream_t stream,
         pl.meas = true;
         pl.meas_mode = mode;
         pl.meas_sweep = pl.sweeps;
-        pl.meas_slot = (mode < kModeSeq) ? st.enqueue_readback(stream) : -1;
+        pl.meas_slot = (mode < kModeSeq && !pinning) ? st.enqueue_readback(stream) : -1;   // (no counters behind an exact kernel)
     }
 }
 

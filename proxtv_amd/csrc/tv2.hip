@@ -22,6 +22,8 @@
 // z, dual u).  Not a hot path of the headline; exact, batched, device-resident.
 #include "tv2.hpp"
 
+#include "pointwise.hpp"
+
 namespace ptv {
 
 namespace {
@@ -152,30 +154,6 @@ __global__ __launch_bounds__(64) void tv2_fibres_kernel(Tv2Args p, FibreGeom g) 
     }
 }
 
-// out (cols x rows, column-major) = transpose of in (rows x cols, column-major), `slabs` matrices back to back
-__global__ __launch_bounds__(256) void transpose_kernel(const double *in, double *out, long rows, long cols) {
-    __shared__ double tile[32][33];
-    const long slab = (long)blockIdx.z * rows * cols;
-    const long r0 = (long)blockIdx.x * 32, c0 = (long)blockIdx.y * 32;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
-    for (int k = ty; k < 32; k += 8) {
-        const long r = r0 + tx, c = c0 + k;
-        if (r < rows && c < cols) tile[k][tx] = in[slab + r + rows * c];
-    }
-    __syncthreads();
-    for (int k = ty; k < 32; k += 8) {
-        const long c = c0 + tx, r = r0 + k;
-        if (r < rows && c < cols) out[slab + c + cols * r] = tile[tx][k];
-    }
-}
-
-void transpose(const double *in, double *out, long rows, long cols, hipStream_t s) {
-    if (rows <= 0 || cols <= 0) return;
-    const dim3 grid((unsigned)((rows + 31) / 32), (unsigned)((cols + 31) / 32), 1);
-    hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, s, in, out, rows, cols);
-    PTV_HIP(hipGetLastError());
-}
-
 }  // namespace
 
 void tv2_fibres(const double *in, double *out, const int *ns, int nds, int dim, double lam, hipStream_t s) {
@@ -189,12 +167,12 @@ void tv2_fibres(const double *in, double *out, const int *ns, int nds, int dim, 
         // dimension 0: fibres are contiguous, so lanes would stride by the fibre length -- transpose (len x count ->
         // count x len), solve along dimension 1 of the transposed array, transpose back
         Scratch tin(bytes), tout(bytes);
-        transpose(in, tin.d(), g.len, g.count, s);
+        slab_transpose(in, tin.d(), g.len, g.count, 1, s);
         const FibreGeom gt{g.count, g.len, g.count};
         const Tv2Args a{tin.d(), tout.d(), d.d(), z.d(), u.d(), lam};
         hipLaunchKernelGGL(tv2_fibres_kernel, dim3((unsigned)((gt.count + 63) / 64)), dim3(64), 0, s, a, gt);
         PTV_HIP(hipGetLastError());
-        transpose(tout.d(), out, g.count, g.len, s);
+        slab_transpose(tout.d(), out, g.count, g.len, 1, s);
         return;
     }
     const Tv2Args a{in, out, d.d(), z.d(), u.d(), lam};

@@ -1,0 +1,103 @@
+"""The pinning solver (pin.hip; geometry rung 3) on the GPU: exact 1-D prox of every fibre found data-parallel inside the
+fibre -- the rung the policy climbs to when pieces are long.  Pinned to that rung and checked against the oracle over
+fibre lengths around every group geometry, both sweep directions, weighted sweeps, and through the splitting loops."""
+import numpy as np
+import pytest
+
+from conftest import assert_close
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def rung3(clib):
+    before = clib.proxtv_set_option(b"chunk_mode", 3)
+    yield
+    clib.proxtv_set_option(b"chunk_mode", before)
+
+
+def _families(rng, n):
+    yield "noise", rng.standard_normal(n)
+    yield "blocks", np.repeat(rng.standard_normal(n // 37 + 1), 37)[:n] + 0.2 * rng.standard_normal(n)
+    yield "walk", np.cumsum(rng.standard_normal(n)) * 0.3
+    yield "constant", np.full(n, 1.25)
+    yield "offset", 1000.0 + rng.standard_normal(n)
+
+
+def test_single_fibres_every_group_geometry(ptv, oracle, rung3):
+    """One fibre per call: lengths on both sides of 64 x 16, 256 x 16, 256 x 32, 256 x 64 (beyond: the previous rung 3)."""
+    rng = np.random.default_rng(90)
+    for n in (96, 257, 1023, 1024, 1025, 4096, 4097, 8192, 8193, 16384, 16385):
+        for name, x in _families(rng, n):
+            for lam in (0.05, 1.0, 30.0):
+                assert_close(ptv.tv1_1d(x, lam), oracle.tv1_hybrid(x, lam), tol=1e-11, what=f"{name} n={n} lam={lam}")
+
+
+def test_batched_fibres_both_directions(oracle, rung3):
+    import torch
+    from proxtv_amd import device
+    rng = np.random.default_rng(91)
+    for shape in ((1500, 333), (333, 1500), (130, 97, 5), (4100, 70)):
+        X = rng.standard_normal(shape) + np.repeat(rng.standard_normal((shape[0] // 50 + 1,) + shape[1:]), 50, axis=0)[:shape[0]]
+        xd = device.to_colmajor(torch.from_numpy(X).cuda())
+        for dim in range(len(shape)):
+            for lam in (0.2, 4.0):
+                got = device.tv1_fibres(xd, lam, dim).cpu().numpy()
+                want = np.apply_along_axis(lambda v: oracle.tv1_hybrid(np.ascontiguousarray(v), lam), dim, X)
+                assert_close(got, want, tol=1e-11, what=f"{shape} dim {dim} lam {lam}")
+
+
+def test_weighted_columns(ptv, oracle, rung3):
+    rng = np.random.default_rng(92)
+    for n in (300, 1024, 1025, 5000, 8192):
+        x = np.cumsum(rng.standard_normal(n)) * 0.2 + rng.standard_normal(n)
+        w = 10 ** rng.uniform(-1.5, 1.0) * rng.uniform(0.2, 1.0, n - 1)
+        w[rng.integers(0, n - 1, 5)] = 0.0
+        assert_close(ptv.tv1w_1d(x, w), oracle.tv1_weighted(x, w), tol=1e-11, what=f"weighted n={n}")
+
+
+def test_splitting_loops_on_rung3(ptv, oracle, rung3):
+    rng = np.random.default_rng(93)
+    X = rng.standard_normal((500, 620))
+    for lam in (0.3, 3.0):
+        assert_close(ptv.tv1_2d(X, lam), oracle.dr2(X, lam)[0], tol=1e-9, what=f"DR lam={lam}")
+        assert_close(ptv.tv1_2d(X, lam, method="pd"), oracle.pd2(X, [lam, lam], [1, 2])[0], tol=1e-9, what=f"PD2 lam={lam}")
+        assert_close(ptv.tv1_2d(X, lam, method="yang"), oracle.yang2(X, lam)[0], tol=1e-9, what=f"Yang lam={lam}")
+    W1, W2 = rng.uniform(0.5, 3.0, (499, 620)), rng.uniform(0.5, 3.0, (500, 619))
+    assert_close(ptv.tv1w_2d(X, W1, W2), oracle.dr2w(X, W1, W2)[0], tol=1e-9, what="weighted DR")
+    V = rng.standard_normal((120, 110, 100))
+    assert_close(ptv.tvgen(V, [2.0, 1.0, 3.0], [1, 2, 3], [1, 1, 1]), oracle.pd(V, [2.0, 1.0, 3.0], [1, 2, 3])[0], tol=1e-9, what="PD 3-D")
+
+
+def test_policy_climbs_to_the_pinning_rung_and_back(ptv, clib, oracle):
+    """Adaptive policy: long pieces (lambda = 3 on unit noise) end on rung 3; white noise at small lambda returns to the
+    chunk kernels."""
+    before = clib.proxtv_set_option(b"chunk_mode", -1)
+    try:
+        rng = np.random.default_rng(94)
+        X = rng.standard_normal((900, 1100))
+        want = oracle.dr2(X, 3.0)[0]
+        for _ in range(3):
+            got = ptv.tv1_2d(X, 3.0)
+        assert_close(got, want, tol=1e-9, what="DR lam=3, adaptive")
+        assert clib.proxtv_chunk_mode() == 3, clib.proxtv_chunk_mode()
+        for _ in range(4):
+            got = ptv.tv1_2d(X, 0.05)
+        assert_close(got, oracle.dr2(X, 0.05)[0], tol=1e-9, what="DR lam=0.05, adaptive")
+        assert clib.proxtv_chunk_mode() <= 1, clib.proxtv_chunk_mode()
+    finally:
+        clib.proxtv_set_option(b"chunk_mode", before)
+
+
+def test_previous_rung3_still_exact(ptv, clib, oracle, rung3):
+    """option pin = 0: rung 3 is the global-memory chunk kernel again (what fibres too long for the LDS plane get)."""
+    before = clib.proxtv_set_option(b"pin", 0)
+    try:
+        rng = np.random.default_rng(95)
+        x = np.repeat(rng.standard_normal(100), 50) + 0.2 * rng.standard_normal(5000)
+        for lam in (0.5, 5.0):
+            assert_close(ptv.tv1_1d(x, lam), oracle.tv1_hybrid(x, lam), tol=1e-11, what=f"gchunk lam={lam}")
+        X = rng.standard_normal((400, 500))
+        assert_close(ptv.tv1_2d(X, 1.0), oracle.dr2(X, 1.0)[0], tol=1e-9, what="DR on the old rung 3")
+    finally:
+        clib.proxtv_set_option(b"pin", before)
