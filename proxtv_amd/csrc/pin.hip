@@ -51,12 +51,16 @@ struct PinGeom {
 template <int P, int G, bool WEIGHTED>
 struct PinShared {
     using Geo = PinGeom<P, G, WEIGHTED>;
+    static constexpr bool kWeighted = WEIGHTED;
     double *Sp, *Wp;
+    double *ownS, *ownW;      // the lane's own part of the two planes
     double lam;
     unsigned long long *mx;   // [wall][slot] of the level's buffer
     unsigned *arg;
     __device__ __forceinline__ double S(int j) const { return Sp[Geo::sa(j)]; }
     __device__ __forceinline__ double r(int j) const { return WEIGHTED ? Wp[Geo::sa(j)] : lam; }
+    __device__ __forceinline__ double own(int, int k) const { return ownS[k]; }
+    __device__ __forceinline__ double rown(int, int k) const { return WEIGHTED ? ownW[k] : lam; }
     __device__ __forceinline__ void post(int wall, int slot, double v) {
         atomicMax(&mx[wall * Geo::SLOTS + slot], (unsigned long long)__double_as_longlong(v));   // positive doubles order like their bits
     }
@@ -117,7 +121,7 @@ __device__ __forceinline__ double group_scan(double v, int t, double *red, doubl
 }
 
 template <int OP, bool WEIGHTED, int P, int G>
-__global__ __launch_bounds__(kPinThreads) void sweep_pin_kernel(SweepArgs p, FibreGeom g) {
+__global__ __launch_bounds__(kPinThreads) void sweep_pin_kernel(SweepArgs p, FibreGeom g, int *pieces) {
     using Geo = PinGeom<P, G, WEIGHTED>;
     using Sh = PinShared<P, G, WEIGHTED>;
     constexpr int SLOTS = Geo::SLOTS;
@@ -193,13 +197,13 @@ __global__ __launch_bounds__(kPinThreads) void sweep_pin_kernel(SweepArgs p, Fib
     // ---- levels ----------------------------------------------------------------------------------------------------------------------
     PinLane<P> ln;
     {
-        const Sh sh0{Sp, Wp, p.lam, mx, arg};
+        const Sh sh0{Sp, Wp, own, Wp + 1 + t * Geo::PS, p.lam, mx, arg};
         ln.init(n, t, sh0);
     }
 #pragma unroll 1
     for (int level = 0;; level++) {
         const int cur = level & 1;
-        Sh sh{Sp, Wp, p.lam, mx + cur * 2 * SLOTS, arg + cur * 2 * SLOTS};
+        Sh sh{Sp, Wp, own, Wp + 1 + t * Geo::PS, p.lam, mx + cur * 2 * SLOTS, arg + cur * 2 * SLOTS};
         {   // the other buffer was last read before the barrier that ended the previous level: clear this lane's slots of it
             unsigned long long *omx = mx + (cur ^ 1) * 2 * SLOTS;
             unsigned *oarg = arg + (cur ^ 1) * 2 * SLOTS;
@@ -220,8 +224,14 @@ __global__ __launch_bounds__(kPinThreads) void sweep_pin_kernel(SweepArgs p, Fib
 
     // ---- values, in place (a lane reads nothing but its own part of the plane and what it cached of its neighbours') -----------------
     {
-        const Sh sh{Sp, Wp, p.lam, mx, arg};
-        ln.values(sh, mean, [&](int i, double v) { Sp[Geo::sa(i + 1)] = v; });
+        const Sh sh{Sp, Wp, own, Wp + 1 + t * Geo::PS, p.lam, mx, arg};
+        ln.values(sh, mean, [&](int, int k, double v) { own[k] = v; });
+    }
+    if (pieces) {   // a measured launch: pieces of this sweep, for the geometry policy (one atomic per wave)
+        int c = __popcll(ln.pinU | ln.pinL) + (t == 0 ? 1 : 0);
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) c += __shfl_down(c, d);
+        if ((t & 63) == 0 && c > 0) atomicAdd(pieces, c);
     }
     group_sync<G>();
 
@@ -243,7 +253,7 @@ __global__ __launch_bounds__(kPinThreads) void sweep_pin_kernel(SweepArgs p, Fib
 }
 
 template <int OP, bool WEIGHTED, int P, int G>
-void launch_geom(const SweepArgs &args, const FibreGeom &g, hipStream_t stream) {
+void launch_geom(const SweepArgs &args, const FibreGeom &g, hipStream_t stream, int *pieces) {
     using Geo = PinGeom<P, G, WEIGHTED>;
     auto kern = sweep_pin_kernel<OP, WEIGHTED, P, G>;
     if (Geo::lds > 64 * 1024) {   // above the default dynamic-LDS limit
@@ -255,23 +265,23 @@ void launch_geom(const SweepArgs &args, const FibreGeom &g, hipStream_t stream) 
         }
     }
     const long wgs = (g.count + Geo::NG - 1) / Geo::NG;
-    hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(kPinThreads), Geo::lds, stream, args, g);
+    hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(kPinThreads), Geo::lds, stream, args, g, pieces);
     PTV_HIP(hipGetLastError());
 }
 
 // contiguous fibres: pick the group geometry from the fibre length
 template <int OP, bool WEIGHTED>
-void launch_contig(const SweepArgs &args, const FibreGeom &g, hipStream_t stream) {
-    if (g.len <= 64 * 16)        launch_geom<OP, WEIGHTED, 16, 64>(args, g, stream);
-    else if (g.len <= 256 * 16)  launch_geom<OP, WEIGHTED, 16, 256>(args, g, stream);
-    else if (g.len <= 256 * 32)  launch_geom<OP, WEIGHTED, 32, 256>(args, g, stream);
-    else if constexpr (!WEIGHTED) launch_geom<OP, false, 64, 256>(args, g, stream);
+void launch_contig(const SweepArgs &args, const FibreGeom &g, hipStream_t stream, int *pieces) {
+    if (g.len <= 64 * 16)        launch_geom<OP, WEIGHTED, 16, 64>(args, g, stream, pieces);
+    else if (g.len <= 256 * 16)  launch_geom<OP, WEIGHTED, 16, 256>(args, g, stream, pieces);
+    else if (g.len <= 256 * 32)  launch_geom<OP, WEIGHTED, 32, 256>(args, g, stream, pieces);
+    else if constexpr (!WEIGHTED) launch_geom<OP, false, 64, 256>(args, g, stream, pieces);
 }
 
 template <int OP, bool WEIGHTED>
-void launch_op(const SweepArgs &args, const FibreGeom &g, hipStream_t stream) {
+void launch_op(const SweepArgs &args, const FibreGeom &g, hipStream_t stream, int *pieces) {
     if (g.inc == 1) {
-        launch_contig<OP, WEIGHTED>(args, g, stream);
+        launch_contig<OP, WEIGHTED>(args, g, stream, pieces);
         return;
     }
     if constexpr (!WEIGHTED) {
@@ -286,7 +296,7 @@ void launch_op(const SweepArgs &args, const FibreGeom &g, hipStream_t stream) {
         if (Op<OP>::OUT_MASK & 1u) { to0.reset(new Scratch(bytes)); t.o0 = to0->d(); }
         if (Op<OP>::OUT_MASK & 2u) { to1.reset(new Scratch(bytes)); t.o1 = to1->d(); }
         const FibreGeom gt{1, g.len, g.count};
-        launch_contig<OP, false>(t, gt, stream);
+        launch_contig<OP, false>(t, gt, stream, pieces);
         if (Op<OP>::OUT_MASK & 1u) slab_transpose(to0->d(), args.o0, g.len, g.inc, slabs, stream);
         if (Op<OP>::OUT_MASK & 2u) slab_transpose(to1->d(), args.o1, g.len, g.inc, slabs, stream);
     }
@@ -294,17 +304,17 @@ void launch_op(const SweepArgs &args, const FibreGeom &g, hipStream_t stream) {
 
 }  // namespace
 
-void launch_pin(OpId op, bool weighted, const SweepArgs &args, const FibreGeom &g, hipStream_t stream) {
+void launch_pin(OpId op, bool weighted, const SweepArgs &args, const FibreGeom &g, hipStream_t stream, int *pieces) {
     if (!pin_supports(op, weighted, g, args.lam)) {
         set_error("launch_pin: sweep not supported (len %d, inc %ld, weighted %d)", g.len, g.inc, (int)weighted);
         throw HipFailure{hipErrorInvalidValue};
     }
 #define PTV_PIN_CASE(ID)                                         \
     case ID:                                                     \
-        if (weighted) launch_op<ID, true>(args, g, stream);      \
-        else          launch_op<ID, false>(args, g, stream);     \
+        if (weighted) launch_op<ID, true>(args, g, stream, pieces);      \
+        else          launch_op<ID, false>(args, g, stream, pieces);     \
         break;
-#define PTV_PIN_CASE_U(ID) case ID: launch_op<ID, false>(args, g, stream); break;
+#define PTV_PIN_CASE_U(ID) case ID: launch_op<ID, false>(args, g, stream, pieces); break;
     switch (op) {
         PTV_PIN_CASE(OP_PROX)
         PTV_PIN_CASE(OP_DR_COL)

@@ -23,6 +23,8 @@ inline bool pin_supports(OpId op, bool weighted, const FibreGeom &g, double lam)
 }
 
 // One sweep.  Strided fibres (g.inc > 1) go through transposed copies of the operands, like launch_row_along in sweep.hip.
-void launch_pin(OpId op, bool weighted, const SweepArgs &args, const FibreGeom &g, hipStream_t stream);
+// pieces (device, may be null): the number of pieces of the sweep's result is added to it -- the geometry policy's hint
+// for whether the chunk kernels below this rung are worth a trial.
+void launch_pin(OpId op, bool weighted, const SweepArgs &args, const FibreGeom &g, hipStream_t stream, int *pieces = nullptr);
 
 }  // namespace ptv

@@ -54,8 +54,11 @@ namespace ptv {
 #endif
 
 // Shared-memory side of a group (concept `Sh`):
+//     static constexpr bool kWeighted          per-knot half-widths (else r(j) is one constant)
 //     double S(int j)                          running sum at knot j (0 <= j <= n)
 //     double r(int j)                          tube half-width at interior knot j
+//     double own(int t, int k)                 = S(1 + tP + k): lane t's k-th knot, at a constant offset from the lane's base
+//     double rown(int t, int k)                = r(1 + tP + k)
 //     void   post(int wall, int slot, double v)     slot maximum <- max(., v)          (v > 0)
 //     double best(int wall, int slot)               slot maximum (0: nothing posted)
 //     void   claim(int wall, int slot, int j)       slot knot <- min(., j)
@@ -100,6 +103,9 @@ struct PinLane {
     }
 
     // ---- scan -------------------------------------------------------------------------------------------------------------
+    // Written for full unrolling: k is a compile-time constant in every copy of the body, so a pin test is one bit test,
+    // a knot's sum is read at a constant offset from the lane's part of the plane (sh.own), and the distances to the two
+    // ends of the run are doubles counted up and down by one (exact) instead of converted integers.
     template <class Sh>
     PTV_PIN_FN void scan(Sh &sh) {
         newU = newL = 0;
@@ -112,54 +118,62 @@ struct PinLane {
         // end of the run that enters from the left: the lane's first pin, or the pin beyond its range
         int cb;
         double chb;
-        {
-            if (pinned) {
-                const int b = __builtin_ctzll(pinned);
-                cb = j0 + b;
-                chb = height(sh, cb, (pinL >> b) & 1ull);
-            } else {
-                cb = rb;
-                chb = hr;
-            }
+        if (pinned) {
+            const int b = __builtin_ctzll(pinned);
+            cb = j0 + b;
+            chb = own_height(sh, b);
+        } else {
+            cb = rb;
+            chb = hr;
         }
         // Violations are compared scaled by the segment's length D = cb - ca: D (c_j - S_j) = (cha - S_j)(cb - j) + (chb - S_j)(j - ca),
         // so a level divides nothing, and all lanes of a segment -- same ends, same heights -- compare like with like.
         double D = (double)(cb - ca);
+        double da = (double)(cb - j0), db = (double)(j0 - ca);   // distances of the knot in hand to the run's two ends
+        double rd = Sh::kWeighted ? 0.0 : sh.r(j0) * D;
         double bu = 0.0, bl = 0.0;
         int ku = 0, kl = 0;
         bool entering = true;
         const int cnt = j1 - j0;
-        for (int k = 0; k < cnt; k++) {
-            const int j = j0 + k;
-            if ((pinned >> k) & 1ull) {
-                // a run closes at this pin
-                if (entering) {
-                    eU = bu; eUk = ku; eL = bl; eLk = kl;
-                    entering = false;
+#pragma unroll
+        for (int k = 0; k < P; k++) {
+            if (k < cnt) {   // (fewer than P knots: the fibre's last lane only)
+                const int j = j0 + k;
+                if ((pinned >> k) & 1ull) {
+                    // a run closes at this pin
+                    if (entering) {
+                        eU = bu; eUk = ku; eL = bl; eLk = kl;
+                        entering = false;
+                    } else {
+                        if (bu > 0.0) newU |= 1ull << (ku - j0);
+                        if (bl > 0.0) newL |= 1ull << (kl - j0);
+                    }
+                    ca = j;
+                    cha = chb;   // (the run ended exactly here)
+                    const unsigned long long rest = (k + 1 < 64) ? (pinned >> (k + 1)) : 0ull;
+                    if (rest) {
+                        const int b = k + 1 + __builtin_ctzll(rest);
+                        cb = j0 + b;
+                        chb = own_height(sh, b);
+                    } else {
+                        cb = rb;
+                        chb = hr;
+                    }
+                    D = (double)(cb - ca);
+                    da = D;
+                    db = 0.0;
+                    if (!Sh::kWeighted) rd = sh.r(j) * D;
+                    bu = bl = 0.0;
                 } else {
-                    if (bu > 0.0) newU |= 1ull << (ku - j0);
-                    if (bl > 0.0) newL |= 1ull << (kl - j0);
+                    const double s = sh.own(t, k);
+                    const double q = (cha - s) * da + (chb - s) * db;
+                    const double wd = Sh::kWeighted ? sh.rown(t, k) * D : rd;
+                    const double vu = q - wd, vl = -q - wd;
+                    if (vu > bu) { bu = vu; ku = j; }
+                    if (vl > bl) { bl = vl; kl = j; }
                 }
-                ca = j;
-                cha = chb;   // (the run ended exactly here)
-                const unsigned long long rest = (k + 1 < 64) ? (pinned >> (k + 1)) : 0ull;
-                if (rest) {
-                    const int b = k + 1 + __builtin_ctzll(rest);
-                    cb = j0 + b;
-                    chb = height(sh, cb, (pinL >> b) & 1ull);
-                } else {
-                    cb = rb;
-                    chb = hr;
-                }
-                D = (double)(cb - ca);
-                bu = bl = 0.0;
-            } else {
-                const double s = sh.S(j);
-                const double q = (cha - s) * (double)(cb - j) + (chb - s) * (double)(j - ca);
-                const double wd = sh.r(j) * D;
-                const double vu = q - wd, vl = -q - wd;
-                if (vu > bu) { bu = vu; ku = j; }
-                if (vl > bl) { bl = vl; kl = j; }
+                da -= 1.0;
+                db += 1.0;
             }
         }
         // the last run ends at rb, beyond the lane's range
@@ -176,6 +190,13 @@ struct PinLane {
             if (xU > 0.0) sh.post(0, t + 1, xU);
             if (xL > 0.0) sh.post(1, t + 1, xL);
         }
+    }
+
+    // height of the string at the lane's own pin k
+    template <class Sh>
+    PTV_PIN_FN double own_height(const Sh &sh, int k) const {
+        const double w = Sh::kWeighted ? sh.rown(t, k) : sh.r(j0 + k);
+        return ((pinL >> k) & 1ull) ? sh.own(t, k) - w : sh.own(t, k) + w;
     }
 
     // ---- claim ------------------------------------------------------------------------------------------------------------
@@ -245,30 +266,33 @@ struct PinLane {
         if (pinned) {
             const int b = __builtin_ctzll(pinned);
             cb = j0 + b;
-            chb = height(sh, cb, (pinL >> b) & 1ull);
+            chb = own_height(sh, b);
         } else {
             cb = rb;
             chb = hr;
         }
         double v = (chb - cha) / (double)(cb - ca) + mean;
         const int cnt = (i0 + P <= n ? P : n - i0);
-        for (int k = 0; k < cnt; k++) {
-            const int i = i0 + k;   // knot i = j0 + k - 1: the lane's own knot k - 1
-            if (k >= 1 && ((pinned >> (k - 1)) & 1ull)) {
-                ca = i;
-                cha = chb;
-                const unsigned long long rest = (k < 64) ? (pinned >> k) : 0ull;
-                if (rest) {
-                    const int b = k + __builtin_ctzll(rest);
-                    cb = j0 + b;
-                    chb = height(sh, cb, (pinL >> b) & 1ull);
-                } else {
-                    cb = rb;
-                    chb = hr;
+#pragma unroll
+        for (int k = 0; k < P; k++) {
+            if (k < cnt) {
+                const int i = i0 + k;   // knot i = j0 + k - 1: the lane's own knot k - 1
+                if (k >= 1 && ((pinned >> (k - 1)) & 1ull)) {
+                    ca = i;
+                    cha = chb;
+                    const unsigned long long rest = (k < 64) ? (pinned >> k) : 0ull;
+                    if (rest) {
+                        const int b = k + __builtin_ctzll(rest);
+                        cb = j0 + b;
+                        chb = own_height(sh, b);
+                    } else {
+                        cb = rb;
+                        chb = hr;
+                    }
+                    v = (chb - cha) / (double)(cb - ca) + mean;
                 }
-                v = (chb - cha) / (double)(cb - ca) + mean;
+                put(i, k, v);
             }
-            put(i, v);
         }
     }
 };

@@ -36,6 +36,11 @@ constexpr double kCleanAt[kModeSeq + 1] = {1e-6, 1e-6, 5e-5, 5e-5, 5e-5, 1.0};
 constexpr double kJump = 0.5;       // ... above which the trial goes straight to the sequential walk
 constexpr double kBetter = 0.9;     // a trial wins if its sweep took less than this times the incumbent's
 constexpr double kDrift = 1.5;      // steady state: re-explore when the sweep time moved by this factor
+// The pinning rung has no repair counters; it reports the pieces per sample of its result instead.  Short pieces (at least
+// kPinShort per sample) read as a clean sweep: the chunk kernels below are worth a trial.  Anything else reads as kPinHold,
+// neither clean nor dirty: stay -- a trial of 64-sample zones on long pieces costs a hundred sweeps' time in repairs.
+constexpr double kPinShort = 0.2;
+constexpr double kPinHold = 1e-4;   // (between kCleanAt[3] and kTryUpAt[3])
 constexpr int kMonitorLag = 2;      // family sweeps between a steady-state sample and its evaluation
 constexpr int kHoldSolves = 2;      // solves during which a rejected direction is not tried again
 constexpr int kQuietSolves = 16;    // one-sweep solves between explorations
@@ -157,6 +162,7 @@ struct GeometryPolicy {
 
     // a measurement arrived: exploration step or steady-state sample
     void measured(int r, double t, double f) {
+        if (r == 3 && pin) f = (f >= kPinShort) ? 0.0 : kPinHold;
         if (explore) step(r, t, f);
         else monitor(r, t, f);
     }

@@ -1473,7 +1473,15 @@ void launch_chunk(const SweepArgs &args, const FibreGeom &g, hipStream_t stream,
     const bool along_ok = options().along && g.len >= options().along_min_len;
     const bool pinning = (mode == 3 && pin_ok);
     if (mode >= kModeSeq)  launch_seq<OP, WEIGHTED>(args, g, stream, true);
-    else if (pinning)      launch_pin((OpId)OP, WEIGHTED, args, g, stream);
+    else if (pinning) {
+        int *pieces = nullptr;
+        if (measure) {   // the policy's hint from this rung: pieces per sample (numerator and denominator of evaluate())
+            st.ensure(g.count, 1, stream);
+            pieces = st.failcount + 2 * fam + 1;
+            pl.chunks_done += (long)g.len * g.count;
+        }
+        launch_pin((OpId)OP, WEIGHTED, args, g, stream, pieces);
+    }
     else if (mode == 3)    launch_gchunk<OP, WEIGHTED>(args, g, 64, 256, stream, fam);
     else if (mode == 4)    launch_gchunk<OP, WEIGHTED>(args, g, 256, 1024, stream, fam);
     else if (TRANSPOSED && along_ok) {
@@ -1495,7 +1503,7 @@ void launch_chunk(const SweepArgs &args, const FibreGeom &g, hipStream_t stream,
         pl.meas = true;
         pl.meas_mode = mode;
         pl.meas_sweep = pl.sweeps;
-        pl.meas_slot = (mode < kModeSeq && !pinning) ? st.enqueue_readback(stream) : -1;   // (no counters behind an exact kernel)
+        pl.meas_slot = (mode < kModeSeq) ? st.enqueue_readback(stream) : -1;
     }
 }
 
@@ -1563,7 +1571,8 @@ long chunk_trace_fetch(unsigned long long *dst, long max_wgs, hipStream_t s) {
 
 int chunk_stats_mode() {
     int m = 0;
-    for (int f = 0; f < FAM_COUNT; f++) m = chunk_state().pol[f].mode > m ? chunk_state().pol[f].mode : m;
+    for (int f = 0; f < FAM_COUNT; f++)   // (families the last solve did not use keep whatever an earlier workload left them)
+        if (chunk_state().pol[f].sweeps > 0 && chunk_state().pol[f].mode > m) m = chunk_state().pol[f].mode;
     return m;
 }
 

@@ -21,8 +21,9 @@ void launch_sweep(OpId op, bool weighted, const SweepArgs &args, const FibreGeom
 // Fibres that the chunked path had to re-solve sequentially (unproven chunk links) since the last reset, on this thread.
 void chunk_stats_reset(hipStream_t s);
 long chunk_stats_fixups(hipStream_t s);
-// current geometry policy of this thread (highest over the sweep families): 0 / 1 / 2 = LDS windows (16-sample zones, the
-// same with second-chance rounds, 64-sample zones), 3 / 4 = global-memory chunks, 5 = sequential
+// current geometry policy of this thread (highest over the sweep families the last solve used): 0 / 1 / 2 = LDS windows
+// (16-sample zones, the same with second-chance rounds, 64-sample zones), 3 = the pinning solver (or global-memory chunks
+// where it does not apply), 4 = global-memory chunks, 5 = sequential
 int chunk_stats_mode();
 long chunk_trace_fetch(unsigned long long *dst, long max_wgs, hipStream_t s);
 

@@ -164,28 +164,35 @@ int chunk_fibre(const double *y, const double *w, double lam, int len, int H, in
 // The pinning solver (pincore.hpp) for one fibre, its group of lanes emulated one after the other: a group barrier is the
 // end of a loop over lanes, an atomic is a plain max / min.  P = knots per lane (16, 32 or 64).  w (n - 1 edge penalties)
 // may be null.  Returns the number of levels.
-template <int P>
+template <int P, bool W>
+struct PinHostShared {
+    std::vector<double> s, rr;
+    std::vector<double> mx[2];
+    std::vector<int> arg[2];
+    static constexpr bool kWeighted = W;
+    double S(int j) const { return s[(size_t)j]; }
+    double r(int j) const { return rr[(size_t)j]; }
+    double own(int t, int k) const { return s[(size_t)(1 + t * P + k)]; }
+    double rown(int t, int k) const { return rr[(size_t)(1 + t * P + k)]; }
+    void post(int wall, int slot, double v) { if (v > mx[wall][(size_t)slot]) mx[wall][(size_t)slot] = v; }
+    double best(int wall, int slot) const { return mx[wall][(size_t)slot]; }
+    void claim(int wall, int slot, int j) { if (j < arg[wall][(size_t)slot]) arg[wall][(size_t)slot] = j; }
+    int knot(int wall, int slot) const { return arg[wall][(size_t)slot]; }
+};
+
+template <int P, bool W>
 static int pin_fibre(const double *y, const double *w, double lam, double *x, int n) {
-    struct Shared {
-        std::vector<double> s, rr;
-        std::vector<double> mx[2];
-        std::vector<int> arg[2];
-        double S(int j) const { return s[(size_t)j]; }
-        double r(int j) const { return rr[(size_t)j]; }
-        void post(int wall, int slot, double v) { if (v > mx[wall][(size_t)slot]) mx[wall][(size_t)slot] = v; }
-        double best(int wall, int slot) const { return mx[wall][(size_t)slot]; }
-        void claim(int wall, int slot, int j) { if (j < arg[wall][(size_t)slot]) arg[wall][(size_t)slot] = j; }
-        int knot(int wall, int slot) const { return arg[wall][(size_t)slot]; }
-    } sh;
+    PinHostShared<P, W> sh;
     const int lanes = (n + P - 1) / P;
     double mean = 0;
     for (int i = 0; i < n; i++) mean += y[i];
     mean /= n;
-    sh.s.assign((size_t)n + 1, 0.0);
-    sh.rr.assign((size_t)n + 1, 0.0);
+    sh.s.assign((size_t)n + 1 + P, 0.0);    // (+ P: a lane may read the slots of knots it does not have)
+    sh.rr.assign((size_t)n + 1 + P, 0.0);
     for (int i = 0; i < n; i++) sh.s[(size_t)i + 1] = sh.s[(size_t)i] + (y[i] - mean);
     for (int j = 1; j < n; j++) sh.rr[(size_t)j] = w ? w[j - 1] : lam;
     std::vector<PinLane<P>> lane((size_t)lanes);
+    (void)W;
     for (int t = 0; t < lanes; t++) lane[(size_t)t].init(n, t, sh);
     int levels = 0;
     for (;;) {
@@ -200,7 +207,7 @@ static int pin_fibre(const double *y, const double *w, double lam, double *x, in
         for (int t = 0; t < lanes; t++) any |= lane[(size_t)t].update(sh);
         if (!any) break;
     }
-    for (int t = 0; t < lanes; t++) lane[(size_t)t].values(sh, mean, [&](int i, double v) { x[i] = v; });
+    for (int t = 0; t < lanes; t++) lane[(size_t)t].values(sh, mean, [&](int i, int, double v) { x[i] = v; });
     return levels;
 }
 
@@ -350,10 +357,10 @@ int policy_sim(const double *cost, const double *frac, int switch_at, int solves
 }
 
 int host_pin_fibre(const double *y, const double *w, double lam, double *x, int n, int P) {
-    if (P == 16) return pin_fibre<16>(y, w, lam, x, n);
-    if (P == 32) return pin_fibre<32>(y, w, lam, x, n);
-    if (P == 64) return pin_fibre<64>(y, w, lam, x, n);
-    if (P == 4) return pin_fibre<4>(y, w, lam, x, n);
+    if (P == 16) return w ? pin_fibre<16, true>(y, w, lam, x, n) : pin_fibre<16, false>(y, w, lam, x, n);
+    if (P == 32) return w ? pin_fibre<32, true>(y, w, lam, x, n) : pin_fibre<32, false>(y, w, lam, x, n);
+    if (P == 64) return w ? pin_fibre<64, true>(y, w, lam, x, n) : pin_fibre<64, false>(y, w, lam, x, n);
+    if (P == 4) return w ? pin_fibre<4, true>(y, w, lam, x, n) : pin_fibre<4, false>(y, w, lam, x, n);
     return -1;
 }
 }
