@@ -7,10 +7,9 @@
 //
 // One group of G lanes per fibre (G = 256: a workgroup; G = 64: a wave, four fibres per workgroup), P knots per lane.
 // LDS per group: ONE plane of doubles -- the samples as they arrive, then their running sums in place, then the prox
-// values in place -- laid out so that lane t's k-th element sits at t (P + 1) + k + 1: the lanes of an access are P + 1
-// doubles apart, an odd number, so they fall on different banks without any transposition; a second plane for the
-// penalties of a weighted sweep; and two small buffers of reduction slots (pincore.hpp), used alternately so that a
-// level can clear the buffer of the next one.
+// values in place -- padded so that the lanes of an access (P doubles apart in the fibre) fall on different banks without
+// any transposition (PinGeom); a second plane for the penalties of a weighted sweep; and one small buffer of reduction
+// slots (pincore.hpp).  4096-sample fibres: 39 KB per workgroup, four workgroups = 16 waves per CU.
 //
 //   stage     coalesced loads through the op's input functor (every load of a batch issued before the first is waited for)
 //   sums      mean of the fibre (group reduction), centred running sums (lane-local pass + group scan), in place
@@ -22,10 +21,8 @@
 // slab_transpose), like launch_row_along in sweep.hip.  Exact for every input: no links, no repair kernel, no counters.
 #include "pin.hpp"
 
-#include <memory>
-
 #include "pincore.hpp"
-#include "pointwise.hpp"
+#include "transposed.hpp"
 
 namespace ptv {
 
@@ -35,17 +32,22 @@ constexpr int kPinThreads = 256;
 
 template <int P, int G, bool WEIGHTED>
 struct PinGeom {
-    static constexpr int PS = P + 1;                     // lane stride inside a plane
-    static constexpr int ROWS = G * PS + 2;              // knots 0 .. G P
+    // One pad double per PADK knots: lane t's part starts at t P + (t P) / PADK + 1.  For P >= 32 the lanes of an access
+    // are P + 1 doubles apart (odd); for P = 16 they alternate 16 / 17, which also puts the 32 lanes of a half-wave on 32
+    // different bank pairs (0, 16, 1, 17, ...) at half the padding -- what lets four workgroups of the 4096-sample
+    // geometry share a CU.
+    static constexpr int PADK = P < 32 ? 32 : P;
+    static constexpr int ROWS = G * P + (G * P) / PADK + 2;   // knots 0 .. G P
     static constexpr int NG = kPinThreads / G;           // fibres per workgroup
     static constexpr int SLOTS = G + 1;
     static constexpr size_t plane_bytes = sizeof(double) * ROWS;
-    static constexpr size_t slot_bytes = (size_t)2 * 2 * SLOTS * (sizeof(unsigned long long) + sizeof(unsigned));   // [buffer][wall][slot]
+    static constexpr size_t slot_bytes = (size_t)2 * SLOTS * (sizeof(unsigned long long) + sizeof(unsigned));   // [wall][slot]
     static constexpr size_t group_bytes = ((plane_bytes * (WEIGHTED ? 2 : 1) + slot_bytes + 15) / 16) * 16;
     static constexpr size_t lds = group_bytes * NG;
     static_assert(lds <= 160 * 1024, "pinning geometry does not fit the LDS of a CU");
     // address of knot j (and of sample j - 1, which lives there until the sums replace it)
-    __device__ static __forceinline__ int sa(int j) { return j + (j > 0 ? (j - 1) / P : 0); }
+    __device__ static __forceinline__ int sa(int j) { return j + (j > 0 ? (j - 1) / PADK : 0); }
+    __device__ static __forceinline__ int lane_base(int t) { return 1 + t * P + (t * P) / PADK; }   // = sa(1 + t P); the lane's P knots follow contiguously
 };
 
 template <int P, int G, bool WEIGHTED>
@@ -55,7 +57,7 @@ struct PinShared {
     double *Sp, *Wp;
     double *ownS, *ownW;      // the lane's own part of the two planes
     double lam;
-    unsigned long long *mx;   // [wall][slot] of the level's buffer
+    unsigned long long *mx;   // [wall][slot]
     unsigned *arg;
     __device__ __forceinline__ double S(int j) const { return Sp[Geo::sa(j)]; }
     __device__ __forceinline__ double r(int j) const { return WEIGHTED ? Wp[Geo::sa(j)] : lam; }
@@ -66,7 +68,9 @@ struct PinShared {
     }
     __device__ __forceinline__ double best(int wall, int slot) const { return __longlong_as_double((long long)mx[wall * Geo::SLOTS + slot]); }
     __device__ __forceinline__ void claim(int wall, int slot, int j) { atomicMin(&arg[wall * Geo::SLOTS + slot], (unsigned)j); }
-    __device__ __forceinline__ int knot(int wall, int slot) const { return (int)arg[wall * Geo::SLOTS + slot]; }
+    __device__ __forceinline__ int knot(int wall, int slot) const { return (int)arg[wall * Geo::SLOTS + slot]; }   // ~0u reads as -1
+    __device__ __forceinline__ void clear_best(int slot) { mx[slot] = 0ull; mx[Geo::SLOTS + slot] = 0ull; }
+    __device__ __forceinline__ void clear_knot(int slot) { arg[slot] = ~0u; arg[Geo::SLOTS + slot] = ~0u; }
 };
 
 // ---- group collectives --------------------------------------------------------------------------------------------------
@@ -132,8 +136,8 @@ __global__ __launch_bounds__(kPinThreads) void sweep_pin_kernel(SweepArgs p, Fib
     char *base = smem + Geo::group_bytes * (size_t)gi;
     double *Sp = reinterpret_cast<double *>(base);
     double *Wp = Sp + (WEIGHTED ? Geo::ROWS : 0);
-    unsigned long long *mx = reinterpret_cast<unsigned long long *>(base + Geo::plane_bytes * (WEIGHTED ? 2 : 1));   // [buffer][wall][slot]
-    unsigned *arg = reinterpret_cast<unsigned *>(mx + 2 * 2 * SLOTS);
+    unsigned long long *mx = reinterpret_cast<unsigned long long *>(base + Geo::plane_bytes * (WEIGHTED ? 2 : 1));   // [wall][slot]
+    unsigned *arg = reinterpret_cast<unsigned *>(mx + 2 * SLOTS);
     const long fibre = (long)blockIdx.x * Geo::NG + gi;
     if (G < kPinThreads && fibre >= g.count) return;   // (a whole wave; such groups share no barrier with the others)
     const int n = g.len;
@@ -163,7 +167,7 @@ __global__ __launch_bounds__(kPinThreads) void sweep_pin_kernel(SweepArgs p, Fib
     group_sync<G>();
 
     // ---- centred running sums, in place ---------------------------------------------------------------------------------------------
-    double *own = Sp + 1 + t * Geo::PS;   // own[k]: sample t P + k, then the sum at knot t P + k + 1
+    double *own = Sp + Geo::lane_base(t);   // own[k]: sample t P + k, then the sum at knot t P + k + 1
     const int cnt = n - t * P < 0 ? 0 : (n - t * P < P ? n - t * P : P);
     double *red = reinterpret_cast<double *>(mx);
     double mean;
@@ -182,38 +186,23 @@ __global__ __launch_bounds__(kPinThreads) void sweep_pin_kernel(SweepArgs p, Fib
             own[k] = acc;
         }
     }
-    // reduction slots: both buffers empty
-    for (int b = 0; b < 2; b++)
-        for (int wall = 0; wall < 2; wall++) {
-            mx[(b * 2 + wall) * SLOTS + t + 1] = 0ull;
-            arg[(b * 2 + wall) * SLOTS + t + 1] = ~0u;
-            if (t == 0) {
-                mx[(b * 2 + wall) * SLOTS] = 0ull;
-                arg[(b * 2 + wall) * SLOTS] = ~0u;
-            }
+    // reduction slots: empty (from here on the lanes clear what they own as the levels go: pincore.hpp)
+    for (int wall = 0; wall < 2; wall++) {
+        mx[wall * SLOTS + t + 1] = 0ull;
+        arg[wall * SLOTS + t + 1] = ~0u;
+        if (t == 0) {
+            mx[wall * SLOTS] = 0ull;
+            arg[wall * SLOTS] = ~0u;
         }
+    }
     group_sync<G>();
 
     // ---- levels ----------------------------------------------------------------------------------------------------------------------
     PinLane<P> ln;
-    {
-        const Sh sh0{Sp, Wp, own, Wp + 1 + t * Geo::PS, p.lam, mx, arg};
-        ln.init(n, t, sh0);
-    }
+    Sh sh{Sp, Wp, own, Wp + Geo::lane_base(t), p.lam, mx, arg};
+    ln.init(n, t, sh);
 #pragma unroll 1
-    for (int level = 0;; level++) {
-        const int cur = level & 1;
-        Sh sh{Sp, Wp, own, Wp + 1 + t * Geo::PS, p.lam, mx + cur * 2 * SLOTS, arg + cur * 2 * SLOTS};
-        {   // the other buffer was last read before the barrier that ended the previous level: clear this lane's slots of it
-            unsigned long long *omx = mx + (cur ^ 1) * 2 * SLOTS;
-            unsigned *oarg = arg + (cur ^ 1) * 2 * SLOTS;
-            omx[t + 1] = 0ull; omx[SLOTS + t + 1] = 0ull;
-            oarg[t + 1] = ~0u; oarg[SLOTS + t + 1] = ~0u;
-            if (t == 0) {
-                omx[0] = 0ull; omx[SLOTS] = 0ull;
-                oarg[0] = ~0u; oarg[SLOTS] = ~0u;
-            }
-        }
+    for (;;) {
         ln.scan(sh);
         group_sync<G>();
         ln.claim(sh);
@@ -223,10 +212,7 @@ __global__ __launch_bounds__(kPinThreads) void sweep_pin_kernel(SweepArgs p, Fib
     }
 
     // ---- values, in place (a lane reads nothing but its own part of the plane and what it cached of its neighbours') -----------------
-    {
-        const Sh sh{Sp, Wp, own, Wp + 1 + t * Geo::PS, p.lam, mx, arg};
-        ln.values(sh, mean, [&](int, int k, double v) { own[k] = v; });
-    }
+    ln.values(sh, mean, [&](int, int k, double v) { own[k] = v; });
     if (pieces) {   // a measured launch: pieces of this sweep, for the geometry policy (one atomic per wave)
         int c = __popcll(ln.pinU | ln.pinL) + (t == 0 ? 1 : 0);
 #pragma unroll
@@ -285,20 +271,10 @@ void launch_op(const SweepArgs &args, const FibreGeom &g, hipStream_t stream, in
         return;
     }
     if constexpr (!WEIGHTED) {
-        // strided: transpose every operand the op reads, sweep along dimension 0, transpose every output back
-        const long slabs = g.count / g.inc;
-        const size_t bytes = sizeof(double) * (size_t)g.count * (size_t)g.len;
-        std::unique_ptr<Scratch> ta, tb, tc, to0, to1;
-        SweepArgs t = args;
-        if (Op<OP>::IN_MASK & 1u) { ta.reset(new Scratch(bytes)); slab_transpose(args.a, ta->d(), g.inc, g.len, slabs, stream); t.a = ta->d(); }
-        if (Op<OP>::IN_MASK & 2u) { tb.reset(new Scratch(bytes)); slab_transpose(args.b, tb->d(), g.inc, g.len, slabs, stream); t.b = tb->d(); }
-        if (Op<OP>::IN_MASK & 4u) { tc.reset(new Scratch(bytes)); slab_transpose(args.c, tc->d(), g.inc, g.len, slabs, stream); t.c = tc->d(); }
-        if (Op<OP>::OUT_MASK & 1u) { to0.reset(new Scratch(bytes)); t.o0 = to0->d(); }
-        if (Op<OP>::OUT_MASK & 2u) { to1.reset(new Scratch(bytes)); t.o1 = to1->d(); }
-        const FibreGeom gt{1, g.len, g.count};
-        launch_contig<OP, false>(t, gt, stream, pieces);
-        if (Op<OP>::OUT_MASK & 1u) slab_transpose(to0->d(), args.o0, g.len, g.inc, slabs, stream);
-        if (Op<OP>::OUT_MASK & 2u) slab_transpose(to1->d(), args.o1, g.len, g.inc, slabs, stream);
+        // strided: the same sweep along dimension 0 of transposed copies (transposed.hpp)
+        TransposedOperands tr(args, Op<OP>::IN_MASK, Op<OP>::OUT_MASK, g, stream);
+        launch_contig<OP, false>(tr.args(), tr.geom(), stream, pieces);
+        tr.finish();
     }
 }
 

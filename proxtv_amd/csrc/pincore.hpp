@@ -49,9 +49,25 @@ namespace ptv {
 
 #ifndef PTV_HOST_TEST
 #define PTV_PIN_FN __device__ __forceinline__
+PTV_PIN_FN unsigned long long pin_bits(double v) { return (unsigned long long)__double_as_longlong(v); }
+PTV_PIN_FN double pin_double(unsigned long long b) { return __longlong_as_double((long long)b); }
+PTV_PIN_FN double pin_max(double a, double b) { return __builtin_fmax(a, b); }
 #else
 #define PTV_PIN_FN inline
+inline unsigned long long pin_bits(double v) { unsigned long long b; std::memcpy(&b, &v, 8); return b; }
+inline double pin_double(unsigned long long b) { double v; std::memcpy(&v, &b, 8); return v; }
+inline double pin_max(double a, double b) { return a > b ? a : b; }
 #endif
+
+// A violation carries the lane-local index of its knot in the lowest bits of its mantissa (log2 P bits: a relative
+// perturbation of 2^-46 at most, far below the rounding of the running sums it is computed from), so that "largest
+// violation and where" is ONE floating-point max per knot and wall instead of a compare and three selects.
+template <int P>
+struct PinTag {
+    static constexpr unsigned long long kMask = (P <= 16 ? 15ull : P <= 32 ? 31ull : 63ull);
+    PTV_PIN_FN static double tag(double v, int k) { return pin_double((pin_bits(v) & ~kMask) | (unsigned long long)k); }
+    PTV_PIN_FN static int index(double v) { return (int)(pin_bits(v) & kMask); }
+};
 
 // Shared-memory side of a group (concept `Sh`):
 //     static constexpr bool kWeighted          per-knot half-widths (else r(j) is one constant)
@@ -62,7 +78,11 @@ namespace ptv {
 //     void   post(int wall, int slot, double v)     slot maximum <- max(., v)          (v > 0)
 //     double best(int wall, int slot)               slot maximum (0: nothing posted)
 //     void   claim(int wall, int slot, int j)       slot knot <- min(., j)
-//     int    knot(int wall, int slot)
+//     int    knot(int wall, int slot)               (negative: nobody claimed)
+//     void   clear_best(int slot), clear_knot(int slot)     both walls of a slot back to "nothing"
+// One buffer of slots serves all levels: a lane clears the knots of the slots it owns (slot t + 1; lane 0 also slot 0)
+// in its scan step -- every reader of the previous level is past the barrier that ended it, the next claims come after
+// the next barrier -- and their maxima in its update step, which reads knots only.
 // wall 0 = upper, 1 = lower.
 
 template <int P>
@@ -112,6 +132,8 @@ struct PinLane {
         eU = eL = xU = xL = 0.0;
         leaving = false;
         if (final_) return;
+        sh.clear_knot(t + 1);
+        if (t == 0) sh.clear_knot(0);
         const unsigned long long pinned = pinU | pinL;
         int ca = la;
         double cha = hl;
@@ -131,8 +153,7 @@ struct PinLane {
         double D = (double)(cb - ca);
         double da = (double)(cb - j0), db = (double)(j0 - ca);   // distances of the knot in hand to the run's two ends
         double rd = Sh::kWeighted ? 0.0 : sh.r(j0) * D;
-        double bu = 0.0, bl = 0.0;
-        int ku = 0, kl = 0;
+        double bu = 0.0, bl = 0.0;   // largest violation of the run so far, per wall, tagged with its knot (PinTag)
         bool entering = true;
         const int cnt = j1 - j0;
 #pragma unroll
@@ -142,11 +163,11 @@ struct PinLane {
                 if ((pinned >> k) & 1ull) {
                     // a run closes at this pin
                     if (entering) {
-                        eU = bu; eUk = ku; eL = bl; eLk = kl;
+                        eU = bu; eL = bl;
                         entering = false;
                     } else {
-                        if (bu > 0.0) newU |= 1ull << (ku - j0);
-                        if (bl > 0.0) newL |= 1ull << (kl - j0);
+                        if (bu > 0.0) newU |= 1ull << PinTag<P>::index(bu);
+                        if (bl > 0.0) newL |= 1ull << PinTag<P>::index(bl);
                     }
                     ca = j;
                     cha = chb;   // (the run ended exactly here)
@@ -168,9 +189,8 @@ struct PinLane {
                     const double s = sh.own(t, k);
                     const double q = (cha - s) * da + (chb - s) * db;
                     const double wd = Sh::kWeighted ? sh.rown(t, k) * D : rd;
-                    const double vu = q - wd, vl = -q - wd;
-                    if (vu > bu) { bu = vu; ku = j; }
-                    if (vl > bl) { bl = vl; kl = j; }
+                    bu = pin_max(bu, PinTag<P>::tag(q - wd, k));
+                    bl = pin_max(bl, PinTag<P>::tag(-q - wd, k));
                 }
                 da -= 1.0;
                 db += 1.0;
@@ -178,11 +198,13 @@ struct PinLane {
         }
         // the last run ends at rb, beyond the lane's range
         if (entering) {
-            eU = bu; eUk = ku; eL = bl; eLk = kl;
+            eU = bu; eL = bl;
         } else {
             leaving = true;
-            xU = bu; xUk = ku; xL = bl; xLk = kl;
+            xU = bu; xL = bl;
         }
+        eUk = j0 + PinTag<P>::index(eU); eLk = j0 + PinTag<P>::index(eL);
+        xUk = j0 + PinTag<P>::index(xU); xLk = j0 + PinTag<P>::index(xL);
         const int se = slot_of(la);
         if (eU > 0.0) sh.post(0, se, eU);
         if (eL > 0.0) sh.post(1, se, eL);
@@ -214,13 +236,19 @@ struct PinLane {
 
     // ---- update: returns true when the lane gained a pin of its own ------------------------------------------------------------
     template <class Sh>
-    PTV_PIN_FN bool update(const Sh &sh) {
+    PTV_PIN_FN bool update(Sh &sh) {
         if (final_) return false;
+        sh.clear_best(t + 1);
+        if (t == 0) sh.clear_best(0);
         bool moved = false;
         const int se = slot_of(la);   // (before la moves)
         for (int wall = 0; wall < 2; wall++) {
-            if (sh.best(wall, se) > 0.0) moved |= place(sh, sh.knot(wall, se), wall);
-            if (leaving && sh.best(wall, t + 1) > 0.0) moved |= place(sh, sh.knot(wall, t + 1), wall);
+            const int ke = sh.knot(wall, se);
+            if (ke >= 0) moved |= place(sh, ke, wall);
+            if (leaving) {
+                const int kx = sh.knot(wall, t + 1);
+                if (kx >= 0) moved |= place(sh, kx, wall);
+            }
         }
         const bool gained = (newU | newL) != 0ull;
         pinU |= newU;

@@ -2,6 +2,8 @@
 // All HBM-bound: grid-stride loops, 256-thread blocks, fixed partial-sum layout so results are deterministic.
 #include "pointwise.hpp"
 
+#include "transposed.hpp"
+
 namespace ptv {
 
 namespace {
@@ -331,6 +333,68 @@ void slab_transpose(const double *in, double *out, long rows, long cols, long sl
     const dim3 grid((unsigned)((rows + 31) / 32), (unsigned)((cols + 31) / 32), (unsigned)slabs);
     hipLaunchKernelGGL(slab_transpose_kernel, grid, dim3(256), 0, s, in, out, rows, cols);
     PTV_HIP(hipGetLastError());
+}
+
+// ---- transposed operands (transposed.hpp) -----------------------------------------------------------------------------------
+static thread_local TransposeCache g_transposed[kMaxDevices];
+TransposeCache &transpose_cache() { return g_transposed[current_device()]; }
+
+Scratch *TransposeCache::find(const double *src) {
+    for (auto &e : entries)
+        if (e.src == src) return e.copy.get();
+    return nullptr;
+}
+
+void TransposeCache::remember(const double *src, std::unique_ptr<Scratch> copy) {
+    for (auto &e : entries)
+        if (e.src == src) {
+            e.copy = std::move(copy);
+            return;
+        }
+    entries.push_back(Entry{src, std::move(copy)});
+}
+
+void TransposeCache::forget(const double *p) {
+    if (!p) return;
+    for (size_t k = 0; k < entries.size(); k++)
+        if (entries[k].src == p) {
+            entries.erase(entries.begin() + (long)k);
+            return;
+        }
+}
+
+TransposedOperands::TransposedOperands(const SweepArgs &args, unsigned in_mask, unsigned out_mask, const FibreGeom &g, hipStream_t s)
+    : orig_(args), t_(args), g_(g), s_(s), out_mask_(out_mask), slabs_(g.count / g.inc),
+      bytes_(sizeof(double) * (size_t)g.count * (size_t)g.len) {
+    if (in_mask & 1u) t_.a = input(args.a, ia_);
+    if (in_mask & 2u) t_.b = input(args.b, ib_);
+    if (in_mask & 4u) t_.c = input(args.c, ic_);
+    if (out_mask & 1u) { o0_.reset(new Scratch(bytes_)); t_.o0 = o0_->d(); }
+    if (out_mask & 2u) { o1_.reset(new Scratch(bytes_)); t_.o1 = o1_->d(); }
+}
+
+const double *TransposedOperands::input(const double *src, std::unique_ptr<Scratch> &own) {
+    TransposeCache &cache = transpose_cache();
+    if (cache.active)
+        if (Scratch *c = cache.find(src)) return c->d();
+    std::unique_ptr<Scratch> copy(new Scratch(bytes_));
+    slab_transpose(src, copy->d(), g_.inc, g_.len, slabs_, s_);
+    const double *p = copy->d();
+    if (cache.active) cache.remember(src, std::move(copy));
+    else own = std::move(copy);
+    return p;
+}
+
+void TransposedOperands::finish() {
+    TransposeCache &cache = transpose_cache();
+    if (out_mask_ & 1u) {
+        slab_transpose(o0_->d(), orig_.o0, g_.len, g_.inc, slabs_, s_);
+        if (cache.active) cache.remember(orig_.o0, std::move(o0_));   // (what was just written, in the form the next strided sweep wants)
+    }
+    if (out_mask_ & 2u) {
+        slab_transpose(o1_->d(), orig_.o1, g_.len, g_.inc, slabs_, s_);
+        if (cache.active) cache.remember(orig_.o1, std::move(o1_));
+    }
 }
 
 }  // namespace ptv

@@ -41,6 +41,7 @@ constexpr double kDrift = 1.5;      // steady state: re-explore when the sweep t
 // neither clean nor dirty: stay -- a trial of 64-sample zones on long pieces costs a hundred sweeps' time in repairs.
 constexpr double kPinShort = 0.2;
 constexpr double kPinHold = 1e-4;   // (between kCleanAt[3] and kTryUpAt[3])
+constexpr double kPinMargin = 1.1;  // a chunk geometry measured slower than this times the pinning rung's sweep gives way to it
 constexpr int kMonitorLag = 2;      // family sweeps between a steady-state sample and its evaluation
 constexpr int kHoldSolves = 2;      // solves during which a rejected direction is not tried again
 constexpr int kQuietSolves = 16;    // one-sweep solves between explorations
@@ -60,6 +61,8 @@ struct GeometryPolicy {
     int len = 0;             // no mode 4 below 1024 samples
     long count = 0;
     bool pin = false;        // rung 3 is the pinning solver: nothing above it is worth a trial
+    double t_pin = 0.0;      // ... and what a sweep of this workload takes there (0: not measured yet): a yardstick whose
+                             // cost barely depends on the data, so one cheap measurement tells when the chunk kernels lose
     int changes = 0;         // workload changes seen in this solve
 
     bool available(int m) const { return !(m == 2 && weighted) && !(m == 4 && (len < 1024 || pin)); }
@@ -85,6 +88,7 @@ struct GeometryPolicy {
             explore = true;
             trial = -1;
             hold_up = hold_down = quiet = 0;
+            t_pin = 0.0;
         }
         len = len_;
         count = count_;
@@ -162,7 +166,24 @@ struct GeometryPolicy {
 
     // a measurement arrived: exploration step or steady-state sample
     void measured(int r, double t, double f) {
-        if (r == 3 && pin) f = (f >= kPinShort) ? 0.0 : kPinHold;
+        if (pin) {
+            if (r == 3) {
+                f = (f >= kPinShort) ? 0.0 : kPinHold;
+                t_pin = t;
+            } else if (t_pin > 0.0 && t > kPinMargin * t_pin) {   // no need to explore: the yardstick is known and beats this
+                mode = 3;
+                t_mode = t_pin;
+                hold_down = kHoldSolves;
+                conclude();
+                return;
+            } else if (t_pin <= 0.0 && explore && trial < 0) {    // first look at this workload: take the yardstick next
+                t_mode = best_t = t;
+                best = r;
+                trial = 3;
+                dir = +1;
+                return;
+            }
+        }
         if (explore) step(r, t, f);
         else monitor(r, t, f);
     }

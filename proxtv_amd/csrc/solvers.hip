@@ -6,6 +6,8 @@
 // for the Dykstra-type loops, the 8-byte stopping value once per iteration.
 #include "solvers.hpp"
 
+#include "transposed.hpp"
+
 #include <cfloat>
 #include <cmath>
 #include <memory>
@@ -83,6 +85,9 @@ SolveInfo dr2(size_t M, size_t N, size_t B, const double *unary, double W1, doub
     SweepArgs col, row;
     col.lam = W1; col.w = W1m; col.o0 = sp.d();
     row.lam = W2; row.w = W2m; row.a = sp.d(); row.b = unary;
+    // every array of this loop is written by sweeps only (t, s' once by dr_fill, before any row sweep): row sweeps that
+    // run on transposed copies may keep them (transposed.hpp)
+    TransposeScope keep_transposed;
     for (int it = 0; it < maxit; it++) {
         col.a = t;
         if (it == 0) {

@@ -39,8 +39,8 @@
 #define PTV_TILE_UNROLL 1   // rows of the rebuild passes in flight together in the 64-fibre tile kernel (registers are scarce there)
 #endif
 #include "pin.hpp"
-#include "pointwise.hpp"
 #include "policy.hpp"
+#include "transposed.hpp"
 #include "walker.hpp"
 
 #include <cstdio>
@@ -1427,19 +1427,9 @@ void launch_gchunk(const SweepArgs &args, const FibreGeom &g, int C, int H, hipS
 // (inc x len) slab.
 template <int OP, int H>
 void launch_row_along(const SweepArgs &args, const FibreGeom &g, hipStream_t stream, int fam) {
-    const long slabs = g.count / g.inc;
-    const size_t bytes = sizeof(double) * (size_t)g.count * (size_t)g.len;
-    std::unique_ptr<Scratch> ta, tb, tc, to0, to1;
-    SweepArgs t = args;
-    if (Op<OP>::IN_MASK & 1u) { ta.reset(new Scratch(bytes)); slab_transpose(args.a, ta->d(), g.inc, g.len, slabs, stream); t.a = ta->d(); }
-    if (Op<OP>::IN_MASK & 2u) { tb.reset(new Scratch(bytes)); slab_transpose(args.b, tb->d(), g.inc, g.len, slabs, stream); t.b = tb->d(); }
-    if (Op<OP>::IN_MASK & 4u) { tc.reset(new Scratch(bytes)); slab_transpose(args.c, tc->d(), g.inc, g.len, slabs, stream); t.c = tc->d(); }
-    if (Op<OP>::OUT_MASK & 1u) { to0.reset(new Scratch(bytes)); t.o0 = to0->d(); }
-    if (Op<OP>::OUT_MASK & 2u) { to1.reset(new Scratch(bytes)); t.o1 = to1->d(); }
-    const FibreGeom gt{1, g.len, g.count};
-    launch_along<OP, false, H>(t, gt, stream, fam);
-    if (Op<OP>::OUT_MASK & 1u) slab_transpose(to0->d(), args.o0, g.len, g.inc, slabs, stream);
-    if (Op<OP>::OUT_MASK & 2u) slab_transpose(to1->d(), args.o1, g.len, g.inc, slabs, stream);
+    TransposedOperands tr(args, Op<OP>::IN_MASK, Op<OP>::OUT_MASK, g, stream);
+    launch_along<OP, false, H>(tr.args(), tr.geom(), stream, fam);
+    tr.finish();
 }
 
 template <int OP, bool WEIGHTED, bool TRANSPOSED>
@@ -1579,6 +1569,10 @@ int chunk_stats_mode() {
 void launch_sweep(OpId op, bool weighted, const SweepArgs &args, const FibreGeom &g, hipStream_t stream, int fam,
                   bool allow_chunked) {
     if (g.count <= 0 || g.len <= 0) return;
+    if (transpose_cache().active) {   // transposed copies of what this sweep is about to write are stale
+        transpose_cache().forget(args.o0);
+        transpose_cache().forget(args.o1);
+    }
     FamilyTimer timer(fam, stream);
 #define PTV_CASE(ID)                                                                             \
     case ID:                                                                                     \

@@ -177,7 +177,9 @@ struct PinHostShared {
     void post(int wall, int slot, double v) { if (v > mx[wall][(size_t)slot]) mx[wall][(size_t)slot] = v; }
     double best(int wall, int slot) const { return mx[wall][(size_t)slot]; }
     void claim(int wall, int slot, int j) { if (j < arg[wall][(size_t)slot]) arg[wall][(size_t)slot] = j; }
-    int knot(int wall, int slot) const { return arg[wall][(size_t)slot]; }
+    int knot(int wall, int slot) const { return arg[wall][(size_t)slot] == (1 << 30) ? -1 : arg[wall][(size_t)slot]; }
+    void clear_best(int slot) { mx[0][(size_t)slot] = mx[1][(size_t)slot] = 0.0; }
+    void clear_knot(int slot) { arg[0][(size_t)slot] = arg[1][(size_t)slot] = 1 << 30; }
 };
 
 template <int P, bool W>
@@ -195,11 +197,11 @@ static int pin_fibre(const double *y, const double *w, double lam, double *x, in
     (void)W;
     for (int t = 0; t < lanes; t++) lane[(size_t)t].init(n, t, sh);
     int levels = 0;
+    for (int wall = 0; wall < 2; wall++) {   // one buffer of slots for all levels: the lanes clear what they own (pincore.hpp)
+        sh.mx[wall].assign((size_t)lanes + 1, 0.0);
+        sh.arg[wall].assign((size_t)lanes + 1, 1 << 30);
+    }
     for (;;) {
-        for (int wall = 0; wall < 2; wall++) {
-            sh.mx[wall].assign((size_t)lanes + 1, 0.0);
-            sh.arg[wall].assign((size_t)lanes + 1, 1 << 30);
-        }
         levels++;
         for (int t = 0; t < lanes; t++) lane[(size_t)t].scan(sh);
         for (int t = 0; t < lanes; t++) lane[(size_t)t].claim(sh);
