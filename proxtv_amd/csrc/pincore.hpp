@@ -51,7 +51,11 @@ namespace ptv {
 #define PTV_PIN_FN __device__ __forceinline__
 PTV_PIN_FN unsigned long long pin_bits(double v) { return (unsigned long long)__double_as_longlong(v); }
 PTV_PIN_FN double pin_double(unsigned long long b) { return __longlong_as_double((long long)b); }
-PTV_PIN_FN double pin_max(double a, double b) { return __builtin_fmax(a, b); }
+PTV_PIN_FN double pin_max(double a, double b) {   // one v_max_f64: the builtin would first quiet both operands (it cannot
+    double r;                                      // know that a tagged violation is never a signalling NaN)
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 #else
 #define PTV_PIN_FN inline
 inline unsigned long long pin_bits(double v) { unsigned long long b; std::memcpy(&b, &v, 8); return b; }

@@ -1,8 +1,8 @@
 """The speculative-chunk machinery under stress: data whose walks do NOT meet inside the warm-up zone, so links stay
 unproven, windows overflow and the repair kernel / geometry policy must keep the result exact.  Every case is
 checked against the CPU oracle and across the pinned geometry modes (0: LDS window, 16-sample zones; 1: the same with
-second-chance rounds inside a block; 2: LDS window, 64-sample zones; 3: global-memory chunks, 256-sample zones;
-4: global-memory chunks, 1024-sample zones; 5: one sequential walk per fibre)."""
+second-chance rounds inside a block; 2: LDS window, 64-sample zones; 3: the pinning solver -- or, where it does not apply,
+global-memory chunks with 256-sample zones; 4: global-memory chunks, 1024-sample zones; 5: one sequential walk per fibre)."""
 import numpy as np
 import pytest
 
