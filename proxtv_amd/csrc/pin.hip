@@ -270,12 +270,10 @@ void launch_op(const SweepArgs &args, const FibreGeom &g, hipStream_t stream, in
         launch_contig<OP, WEIGHTED>(args, g, stream, pieces);
         return;
     }
-    if constexpr (!WEIGHTED) {
-        // strided: the same sweep along dimension 0 of transposed copies (transposed.hpp)
-        TransposedOperands tr(args, Op<OP>::IN_MASK, Op<OP>::OUT_MASK, g, stream);
-        launch_contig<OP, false>(tr.args(), tr.geom(), stream, pieces);
-        tr.finish();
-    }
+    // strided: the same sweep along dimension 0 of transposed copies (transposed.hpp)
+    TransposedOperands tr(args, Op<OP>::IN_MASK, Op<OP>::OUT_MASK, g, stream);
+    launch_contig<OP, WEIGHTED>(tr.args(), tr.geom(), stream, pieces);
+    tr.finish();
 }
 
 }  // namespace
@@ -291,12 +289,14 @@ void launch_pin(OpId op, bool weighted, const SweepArgs &args, const FibreGeom &
         else          launch_op<ID, false>(args, g, stream, pieces);     \
         break;
 #define PTV_PIN_CASE_U(ID) case ID: launch_op<ID, false>(args, g, stream, pieces); break;
+#define PTV_PIN_CASE_W(ID) case ID: launch_op<ID, true>(args, g, stream, pieces); break;
     switch (op) {
         PTV_PIN_CASE(OP_PROX)
         PTV_PIN_CASE(OP_DR_COL)
         PTV_PIN_CASE(OP_DR_COL_FINAL)
-        PTV_PIN_CASE_U(OP_DR_ROW)
+        PTV_PIN_CASE(OP_DR_ROW)
         PTV_PIN_CASE_U(OP_DR_ROW_FINAL)
+        PTV_PIN_CASE_W(OP_DRW_ROW_FINAL)
         PTV_PIN_CASE_U(OP_PD2_A)
         PTV_PIN_CASE_U(OP_PD2_B)
         PTV_PIN_CASE_U(OP_YANG)
@@ -306,6 +306,7 @@ void launch_pin(OpId op, bool weighted, const SweepArgs &args, const FibreGeom &
     }
 #undef PTV_PIN_CASE
 #undef PTV_PIN_CASE_U
+#undef PTV_PIN_CASE_W
 }
 
 }  // namespace ptv

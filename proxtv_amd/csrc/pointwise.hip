@@ -366,19 +366,20 @@ void TransposeCache::forget(const double *p) {
 TransposedOperands::TransposedOperands(const SweepArgs &args, unsigned in_mask, unsigned out_mask, const FibreGeom &g, hipStream_t s)
     : orig_(args), t_(args), g_(g), s_(s), out_mask_(out_mask), slabs_(g.count / g.inc),
       bytes_(sizeof(double) * (size_t)g.count * (size_t)g.len) {
-    if (in_mask & 1u) t_.a = input(args.a, ia_);
-    if (in_mask & 2u) t_.b = input(args.b, ib_);
-    if (in_mask & 4u) t_.c = input(args.c, ic_);
+    if (in_mask & 1u) t_.a = input(args.a, ia_, g.len);
+    if (in_mask & 2u) t_.b = input(args.b, ib_, g.len);
+    if (in_mask & 4u) t_.c = input(args.c, ic_, g.len);
+    if (args.w && g.len > 1) t_.w = input(args.w, iw_, g.len - 1);
     if (out_mask & 1u) { o0_.reset(new Scratch(bytes_)); t_.o0 = o0_->d(); }
     if (out_mask & 2u) { o1_.reset(new Scratch(bytes_)); t_.o1 = o1_->d(); }
 }
 
-const double *TransposedOperands::input(const double *src, std::unique_ptr<Scratch> &own) {
+const double *TransposedOperands::input(const double *src, std::unique_ptr<Scratch> &own, int len) {
     TransposeCache &cache = transpose_cache();
     if (cache.active)
         if (Scratch *c = cache.find(src)) return c->d();
-    std::unique_ptr<Scratch> copy(new Scratch(bytes_));
-    slab_transpose(src, copy->d(), g_.inc, g_.len, slabs_, s_);
+    std::unique_ptr<Scratch> copy(new Scratch(sizeof(double) * (size_t)g_.count * (size_t)len));
+    slab_transpose(src, copy->d(), g_.inc, len, slabs_, s_);
     const double *p = copy->d();
     if (cache.active) cache.remember(src, std::move(copy));
     else own = std::move(copy);

@@ -46,21 +46,22 @@ struct TransposeScope {
 
 class TransposedOperands {
   public:
-    // in_mask: arrays the op reads (bit 0 a, 1 b, 2 c); out_mask: arrays it writes (bit 0 o0, 1 o1)
+    // in_mask: arrays the op reads (bit 0 a, 1 b, 2 c); out_mask: arrays it writes (bit 0 o0, 1 o1); args.w (per-edge
+    // penalties, len - 1 along the fibre), when set, is transposed as well
     TransposedOperands(const SweepArgs &args, unsigned in_mask, unsigned out_mask, const FibreGeom &g, hipStream_t s);
     const SweepArgs &args() const { return t_; }                       // the same sweep on the copies ...
     FibreGeom geom() const { return FibreGeom{1, g_.len, g_.count}; }   // ... whose fibres are contiguous
     void finish();                                                      // outputs back to where the caller wants them
 
   private:
-    const double *input(const double *src, std::unique_ptr<Scratch> &own);
+    const double *input(const double *src, std::unique_ptr<Scratch> &own, int len);
     SweepArgs orig_, t_;
     FibreGeom g_;
     hipStream_t s_;
     unsigned out_mask_;
     long slabs_;
     size_t bytes_;
-    std::unique_ptr<Scratch> ia_, ib_, ic_, o0_, o1_;
+    std::unique_ptr<Scratch> ia_, ib_, ic_, iw_, o0_, o1_;
 };
 
 }  // namespace ptv

@@ -61,8 +61,9 @@ def test_concurrent_host_threads_mixed_solvers(ptv, oracle):
 
 def test_device_outputs_may_alias_inputs(oracle):
     """out = x on every device entry point: the same result as the out-of-place call (the library solves through a
-    scratch array when it sees the overlap).  Compared to 1e-14: two calls may run different kernel geometries (the
-    adaptive policy explores across calls), which differ in the last ulps."""
+    scratch array when it sees the overlap).  Compared to 1e-12: two calls may run different kernel geometries (the
+    adaptive policy explores across calls) -- the chunk kernels differ among themselves in the last ulps, the pinning
+    solver works on running sums and agrees with them to ~1e-14 of the data's scale."""
     import torch
     from proxtv_amd import device
     rng = np.random.default_rng(78)
@@ -75,7 +76,7 @@ def test_device_outputs_may_alias_inputs(oracle):
         ref[method] = y.cpu().numpy().copy()
         z, info2 = device.tv1_2d(xd, 0.25, method=method, out=xd, **kw)
         assert z.data_ptr() == xd.data_ptr()
-        np.testing.assert_allclose(z.cpu().numpy(), ref[method], rtol=0, atol=1e-14)
+        np.testing.assert_allclose(z.cpu().numpy(), ref[method], rtol=0, atol=1e-12)
         assert info[0] == info2[0]
     assert_close(ref["dr"], oracle.dr2(X, 0.25)[0], tol=1e-11, what="dr")
     # weighted DR, N-D loops, single sweeps in both directions
@@ -84,19 +85,19 @@ def test_device_outputs_may_alias_inputs(oracle):
     w1, w2 = device.to_colmajor(torch.from_numpy(W1).cuda()), device.to_colmajor(torch.from_numpy(W2).cuda())
     a = device.tv1w_2d(xd, w1, w2)[0].cpu().numpy().copy()
     b = device.tv1w_2d(xd, w1, w2, out=xd)[0].cpu().numpy()
-    np.testing.assert_allclose(a, b, rtol=0, atol=1e-14)
+    np.testing.assert_allclose(a, b, rtol=0, atol=1e-12)
     V = rng.standard_normal((30, 40, 20))
     for method in (None, "pdr", "yang"):
         vd = device.to_colmajor(torch.from_numpy(V).cuda())
         a = device.tvgen(vd, [0.2, 0.1, 0.3], [1, 2, 3], method=method)[0].cpu().numpy().copy()
         b = device.tvgen(vd, [0.2, 0.1, 0.3], [1, 2, 3], method=method, out=vd)[0].cpu().numpy()
-        np.testing.assert_allclose(a, b, rtol=0, atol=1e-14)
+        np.testing.assert_allclose(a, b, rtol=0, atol=1e-12)
     big = rng.standard_normal((1500, 700))
     for dim in (0, 1):
         bd = device.to_colmajor(torch.from_numpy(big).cuda())
         a = device.tv1_fibres(bd, 0.4, dim).cpu().numpy().copy()
         b = device.tv1_fibres(bd, 0.4, dim, out=bd).cpu().numpy()
-        np.testing.assert_allclose(a, b, rtol=0, atol=1e-14)
+        np.testing.assert_allclose(a, b, rtol=0, atol=1e-12)
 
 
 def test_device_api_rejects_wrong_tensors():

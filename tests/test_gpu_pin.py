@@ -47,6 +47,28 @@ def test_batched_fibres_both_directions(oracle, rung3):
                 assert_close(got, want, tol=1e-11, what=f"{shape} dim {dim} lam {lam}")
 
 
+def test_weighted_sweeps_both_directions(oracle, rung3):
+    """Per-edge penalties along dimension 0 and along a strided dimension (the penalties are transposed with the data)."""
+    import torch
+    from proxtv_amd import device
+    rng = np.random.default_rng(96)
+    X = np.cumsum(rng.standard_normal((700, 300)), axis=0) * 0.2 + rng.standard_normal((700, 300))
+    xd = device.to_colmajor(torch.from_numpy(X).cuda())
+    for dim in (0, 1):
+        shape = list(X.shape)
+        shape[dim] -= 1
+        W = 10 ** rng.uniform(-1.5, 1.0) * rng.uniform(0.2, 1.0, shape)
+        wd = device.to_colmajor(torch.from_numpy(W).cuda())
+        got = device.tv1_fibres(xd, 0.0, dim, weights=wd).cpu().numpy()
+        want = np.empty_like(X)
+        for j in range(X.shape[1 - dim]):
+            if dim == 0:
+                want[:, j] = oracle.tv1_weighted(np.ascontiguousarray(X[:, j]), np.ascontiguousarray(W[:, j]))
+            else:
+                want[j, :] = oracle.tv1_weighted(np.ascontiguousarray(X[j, :]), np.ascontiguousarray(W[j, :]))
+        assert_close(got, want, tol=1e-11, what=f"weighted fibres dim {dim}")
+
+
 def test_weighted_columns(ptv, oracle, rung3):
     rng = np.random.default_rng(92)
     for n in (300, 1024, 1025, 5000, 8192):
