@@ -54,14 +54,17 @@ template <int P, int G, bool WEIGHTED>
 struct PinShared {
     using Geo = PinGeom<P, G, WEIGHTED>;
     static constexpr bool kWeighted = WEIGHTED;
+    static constexpr bool kCached = (P <= 16);   // the lane's sums stay in registers for all levels (32 VGPRs)
     double *Sp, *Wp;
     double *ownS, *ownW;      // the lane's own part of the two planes
+    double cached[kCached ? P : 1];
     double lam;
     unsigned long long *mx;   // [wall][slot]
     unsigned *arg;
     __device__ __forceinline__ double S(int j) const { return Sp[Geo::sa(j)]; }
     __device__ __forceinline__ double r(int j) const { return WEIGHTED ? Wp[Geo::sa(j)] : lam; }
-    __device__ __forceinline__ double own(int, int k) const { return ownS[k]; }
+    __device__ __forceinline__ double own(int, int k) const { return kCached ? cached[kCached ? k : 0] : ownS[k]; }
+    __device__ __forceinline__ double own_at(int, int k) const { return ownS[k]; }
     __device__ __forceinline__ double rown(int, int k) const { return WEIGHTED ? ownW[k] : lam; }
     __device__ __forceinline__ void post(int wall, int slot, double v) {
         atomicMax(&mx[wall * Geo::SLOTS + slot], (unsigned long long)__double_as_longlong(v));   // positive doubles order like their bits
@@ -199,7 +202,11 @@ __global__ __launch_bounds__(kPinThreads) void sweep_pin_kernel(SweepArgs p, Fib
 
     // ---- levels ----------------------------------------------------------------------------------------------------------------------
     PinLane<P> ln;
-    Sh sh{Sp, Wp, own, Wp + Geo::lane_base(t), p.lam, mx, arg};
+    Sh sh{Sp, Wp, own, Wp + Geo::lane_base(t), {}, p.lam, mx, arg};
+    if (Sh::kCached) {
+#pragma unroll
+        for (int k = 0; k < (Sh::kCached ? P : 1); k++) sh.cached[k] = own[k];
+    }
     ln.init(n, t, sh);
 #pragma unroll 1
     for (;;) {

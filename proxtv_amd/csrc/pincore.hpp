@@ -77,7 +77,9 @@ struct PinTag {
 //     static constexpr bool kWeighted          per-knot half-widths (else r(j) is one constant)
 //     double S(int j)                          running sum at knot j (0 <= j <= n)
 //     double r(int j)                          tube half-width at interior knot j
-//     double own(int t, int k)                 = S(1 + tP + k): lane t's k-th knot, at a constant offset from the lane's base
+//     double own(int t, int k)                 = S(1 + tP + k): lane t's k-th knot; k is a compile-time constant wherever this
+//                                                is called (unrolled loops), so an implementation may keep the values in registers
+//     double own_at(int t, int k)              the same for a run-time k
 //     double rown(int t, int k)                = r(1 + tP + k)
 //     void   post(int wall, int slot, double v)     slot maximum <- max(., v)          (v > 0)
 //     double best(int wall, int slot)               slot maximum (0: nothing posted)
@@ -164,7 +166,8 @@ struct PinLane {
         for (int k = 0; k < P; k++) {
             if (k < cnt) {   // (fewer than P knots: the fibre's last lane only)
                 const int j = j0 + k;
-                if ((pinned >> k) & 1ull) {
+                const bool is_pin = (pinned >> k) & 1ull;
+                if (is_pin) {
                     // a run closes at this pin
                     if (entering) {
                         eU = bu; eL = bl;
@@ -189,13 +192,15 @@ struct PinLane {
                     db = 0.0;
                     if (!Sh::kWeighted) rd = sh.r(j) * D;
                     bu = bl = 0.0;
-                } else {
-                    const double s = sh.own(t, k);
-                    const double q = (cha - s) * da + (chb - s) * db;
-                    const double wd = Sh::kWeighted ? sh.rown(t, k) * D : rd;
-                    bu = pin_max(bu, PinTag<P>::tag(q - wd, k));
-                    bl = pin_max(bl, PinTag<P>::tag(-q - wd, k));
                 }
+                // every knot is evaluated, pins included (straight-line code for the common case); a pin's own numbers
+                // are replaced by "no violation"
+                const double s = sh.own(t, k);
+                const double q = (cha - s) * da + (chb - s) * db;
+                const double wd = Sh::kWeighted ? sh.rown(t, k) * D : rd;
+                const double vu = is_pin ? -1.0 : q - wd, vl = is_pin ? -1.0 : -q - wd;
+                bu = pin_max(bu, PinTag<P>::tag(vu, k));
+                bl = pin_max(bl, PinTag<P>::tag(vl, k));
                 da -= 1.0;
                 db += 1.0;
             }
@@ -222,7 +227,7 @@ struct PinLane {
     template <class Sh>
     PTV_PIN_FN double own_height(const Sh &sh, int k) const {
         const double w = Sh::kWeighted ? sh.rown(t, k) : sh.r(j0 + k);
-        return ((pinL >> k) & 1ull) ? sh.own(t, k) - w : sh.own(t, k) + w;
+        return ((pinL >> k) & 1ull) ? sh.own_at(t, k) - w : sh.own_at(t, k) + w;
     }
 
     // ---- claim ------------------------------------------------------------------------------------------------------------

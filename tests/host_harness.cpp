@@ -173,6 +173,7 @@ struct PinHostShared {
     double S(int j) const { return s[(size_t)j]; }
     double r(int j) const { return rr[(size_t)j]; }
     double own(int t, int k) const { return s[(size_t)(1 + t * P + k)]; }
+    double own_at(int t, int k) const { return own(t, k); }
     double rown(int t, int k) const { return rr[(size_t)(1 + t * P + k)]; }
     void post(int wall, int slot, double v) { if (v > mx[wall][(size_t)slot]) mx[wall][(size_t)slot] = v; }
     double best(int wall, int slot) const { return mx[wall][(size_t)slot]; }
