@@ -131,5 +131,6 @@ def test_unknown_device_fails_cleanly_and_state_survives(clib, ptv, oracle):
     before = ptv.tv1_1d(x, 0.3)
     assert clib.proxtv_init(97) != 0
     assert clib.proxtv_init(0) == 0
-    np.testing.assert_array_equal(ptv.tv1_1d(x, 0.3), before)
+    # (not bit for bit: the adaptive policy may take its one look at the pinning rung in either call)
+    np.testing.assert_allclose(ptv.tv1_1d(x, 0.3), before, rtol=0, atol=1e-12)
     assert_close(before, oracle.tv1_hybrid(x, 0.3), tol=1e-11)
