@@ -14,13 +14,14 @@ constexpr int kPinMaxLen = 16384;
 constexpr int kPinMaxLenWeighted = 8192;   // (two planes: sums and penalties)
 
 // Does the pinning solver take this sweep?  (lam < 0 -- tvgen lets negative penalties through -- stays with the walker,
-// whose behaviour there mirrors the reference's.)
+// whose behaviour there mirrors the reference's; so does lam = 0, where the walker returns the input bit for bit and
+// this solver returns it through its running sums.)
 inline bool pin_supports(OpId op, bool weighted, const FibreGeom &g, double lam) {
     if (g.len < 2 || g.count < 1) return false;
     if (weighted)
         return g.len <= kPinMaxLenWeighted &&
                (op == OP_PROX || op == OP_DR_COL || op == OP_DR_COL_FINAL || op == OP_DR_ROW || op == OP_DRW_ROW_FINAL);
-    return op != OP_DRW_ROW_FINAL && lam >= 0.0 && g.len <= kPinMaxLen;
+    return op != OP_DRW_ROW_FINAL && lam > 0.0 && g.len <= kPinMaxLen;
 }
 
 // One sweep.  Strided fibres (g.inc > 1) go through transposed copies of the operands, like launch_row_along in sweep.hip.
