@@ -65,7 +65,11 @@ struct GeometryPolicy {
                              // cost barely depends on the data, so one cheap measurement tells when the chunk kernels lose
     int changes = 0;         // workload changes seen in this solve
 
-    bool available(int m) const { return !(m == 2 && weighted) && !(m == 4 && (len < 1024 || pin)); }
+    // (with a pinning rung the adaptive ladder is 0, 1, 3: 64-sample zones -- rung 2 -- only ever won where the pinning
+    // solver now does as well, and a trial of it on long pieces is expensive; an explicitly chosen mode still gets it)
+    bool available(int m, bool forced = false) const {
+        return !(m == 2 && (weighted || (pin && !forced))) && !(m == 4 && (len < 1024 || (pin && !forced)));
+    }
     int top() const { return pin ? 3 : kModeSeq; }   // where a trial jumps to when most chunks failed
     int up(int m) const {
         do m++; while (m < kModeSeq && !available(m));
@@ -89,6 +93,10 @@ struct GeometryPolicy {
             trial = -1;
             hold_up = hold_down = quiet = 0;
             t_pin = 0.0;
+            // Unknown data: open on the pinning rung where there is one.  Its sweep costs the same whatever the pieces and
+            // it reports how long they are, so the way down is taken only when it is worth it -- whereas one sweep of
+            // 16-sample zones on long pieces costs a hundred sweeps' time in repair walks.
+            if (pin_ && changes <= 1) mode = 3;
         }
         len = len_;
         count = count_;

@@ -1446,7 +1446,7 @@ void launch_chunk(const SweepArgs &args, const FibreGeom &g, hipStream_t stream,
     bool measure = false;
     if (pinned) {
         mode = pl.mode = options().chunk_mode < kModeSeq ? options().chunk_mode : kModeSeq;
-        if (!pl.available(mode)) mode = pl.up(mode);
+        if (!pl.available(mode, true)) mode = pl.up(mode);
     } else {
         st.ensure_host();
         if (pl.meas && (pl.explore || pl.sweeps - pl.meas_sweep >= kMonitorLag)) st.settle(fam, true);
