@@ -8,7 +8,7 @@ rm -rf $O; mkdir -p $O
 BENCH="python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-c5"
 timeout 200 rocprofv3 --kernel-trace --stats -d $O/prof_bench -o x -- $BENCH > $O/bench_under_rocprof.log 2>&1
 python $R/tools/rocprof_summary.py $(find $O/prof_bench -name "x_results.db" | head -1) > $O/r02_final_kernel_stats.txt
-for c in c3 c4 c4y dr0.5 dr1.0; do
+for c in c3 c4 c4y dr0.5 dr1.0 dr3.0; do
   timeout 200 rocprofv3 --kernel-trace --stats -d $O/prof_$c -o x -- python $R/tools/profile_cases.py $c > /dev/null 2>&1
   python $R/tools/rocprof_summary.py $(find $O/prof_$c -name "x_results.db" | head -1) > $O/r02_final_${c}_kernel_stats.txt
 done
