@@ -319,9 +319,9 @@ int host_walk_from(const double *y, const double *w, double lam, double *x, int 
 // counters).  The loop mirrors launch_chunk / chunk_stats_reset in sweep.hip: measurements are looked at before the
 // family's next launch while exploring, kMonitorLag sweeps later in the steady state, and at the next solve's start.
 // Returns the incumbent mode at the end; total_ms = time of the LAST solve; trace (if not null) = mode of every sweep
-// of the last solve.
-int policy_sim(const double *cost, const double *frac, int switch_at, int solves, int sweeps, int len, int weighted,
-               int start_mode, double *total_ms, int *trace) {
+// of the last solve.  pin: rung 3 is the pinning solver (its `frac` entry = pieces per sample of its result).
+int policy_sim_pin(const double *cost, const double *frac, int switch_at, int solves, int sweeps, int len, int weighted,
+                   int start_mode, int pin, double *total_ms, int *trace) {
     GeometryPolicy pl;
     pl.mode = start_mode;
     bool meas = false;
@@ -337,7 +337,7 @@ int policy_sim(const double *cost, const double *frac, int switch_at, int solves
         total = 0;
         for (int k = 0; k < sweeps; k++) {
             const int phase = k >= switch_at ? 1 : 0;
-            if (pl.workload(len, 4096, weighted != 0)) meas = false;
+            if (pl.workload(len, 4096, weighted != 0, pin != 0)) meas = false;
             if (meas && (pl.explore || pl.sweeps - meas_sweep >= kMonitorLag)) {
                 pl.measured(meas_mode, cost[6 * meas_phase + meas_mode], frac[6 * meas_phase + meas_mode]);
                 meas = false;
@@ -365,5 +365,11 @@ int host_pin_fibre(const double *y, const double *w, double lam, double *x, int 
     if (P == 64) return w ? pin_fibre<64, true>(y, w, lam, x, n) : pin_fibre<64, false>(y, w, lam, x, n);
     if (P == 4) return w ? pin_fibre<4, true>(y, w, lam, x, n) : pin_fibre<4, false>(y, w, lam, x, n);
     return -1;
+}
+
+// (the same without a pinning rung: rung 3 is the global-memory chunk kernel)
+int policy_sim(const double *cost, const double *frac, int switch_at, int solves, int sweeps, int len, int weighted,
+               int start_mode, double *total_ms, int *trace) {
+    return policy_sim_pin(cost, frac, switch_at, solves, sweeps, len, weighted, start_mode, 0, total_ms, trace);
 }
 }

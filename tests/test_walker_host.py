@@ -21,6 +21,8 @@ def harness():
     lib.host_walk_from.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_int, C.c_int, C.c_int]
     lib.host_walk_blocked.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_int, C.c_int, C.c_int]
     lib.policy_sim.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    lib.policy_sim_pin.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                   C.c_void_p]
     return lib
 
 
@@ -198,3 +200,37 @@ def test_policy_one_sweep_solves_explore_across_calls(harness):
     cost, frac, best = REGIMES["headline lam=0.1"]
     mode, total, trace = _simulate(harness, cost, frac, solves=8, sweeps=1, start=5)
     assert mode == best
+
+
+def _simulate_pin(lib, cost, frac, cost2=None, frac2=None, switch_at=10 ** 6, solves=4, sweeps=35, length=4096, start=0):
+    table_c = np.array(list(cost) + list(cost2 if cost2 is not None else cost), dtype=np.float64)
+    table_f = np.array(list(frac) + list(frac2 if frac2 is not None else frac), dtype=np.float64)
+    total = np.zeros(1)
+    trace = np.zeros(sweeps, dtype=np.int32)
+    mode = lib.policy_sim_pin(table_c.ctypes.data, table_f.ctypes.data, switch_at, solves, sweeps, length, 0, start, 1,
+                              total.ctypes.data, trace.ctypes.data)
+    return mode, float(total[0]), trace
+
+
+def test_policy_with_a_pinning_rung(harness):
+    """Rung 3 = the pinning solver: sweep time independent of the data, frac = pieces per sample of its result.
+    (i) a fresh workload opens on it, so long pieces never see a chunk kernel -- whose repair walks are what costs;
+    (ii) short pieces send the policy down to the chunk kernels; (iii) a chunk geometry that drifts past the pinning
+    rung's time inside a solve gives way to it."""
+    # 4096^2 DR iterates at lambda = 3: rungs 0-2 cost tens of ms in repairs
+    long_cost, long_frac = [57.0, 40.0, 9.0, 0.25, 8.0, 4.3], [0.4, 0.3, 0.01, 0.01, 0.1, -1]
+    for start in range(6):
+        mode, total, trace = _simulate_pin(harness, long_cost, long_frac, solves=1, start=start)
+        assert mode == 3 and (trace == 3).all(), (start, mode, trace)          # first solve, from any stale state: rung 3 only
+        assert abs(total - 35 * 0.25) < 1e-9
+    # headline data: white noise, lambda = 0.1 -- one piece per sample
+    short_cost, short_frac = [0.09, 0.10, 0.45, 0.55, 2.0, 6.0], [0, 0, 0, 0.9, 0, -1]
+    mode, total, trace = _simulate_pin(harness, short_cost, short_frac, solves=3)
+    assert mode == 0 and (trace == 0).all() and abs(total - 35 * 0.09) < 1e-9
+    mode, total, trace = _simulate_pin(harness, short_cost, short_frac, solves=1)
+    assert mode == 0 and total <= 35 * 0.09 + 0.55 + 0.10 + 0.01                    # first solve: one look at rung 3, one at rung 1
+    # lambda = 0.7: rung 1 starts a solve fast and ends it slow, the pinning rung takes 0.45 ms throughout
+    early, late = [0.5, 0.30, 0.6, 0.45, 2.0, 6.0], [1.2, 0.62, 0.9, 0.45, 2.0, 6.0]
+    fr = [0.01, 1e-4, 0, 0.25, 0, -1]
+    mode, total, trace = _simulate_pin(harness, early, fr, cost2=late, frac2=[0.02, 6e-4, 0, 0.15, 0, -1], switch_at=15, solves=4)
+    assert trace[-1] == 3 and total <= 15 * 0.45 + 20 * 0.45 + 2.0, (trace, total)
