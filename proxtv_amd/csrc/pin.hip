@@ -70,8 +70,11 @@ struct PinShared {
         atomicMax(&mx[wall * Geo::SLOTS + slot], (unsigned long long)__double_as_longlong(v));   // positive doubles order like their bits
     }
     __device__ __forceinline__ double best(int wall, int slot) const { return __longlong_as_double((long long)mx[wall * Geo::SLOTS + slot]); }
-    __device__ __forceinline__ void claim(int wall, int slot, int j) { atomicMin(&arg[wall * Geo::SLOTS + slot], (unsigned)j); }
-    __device__ __forceinline__ int knot(int wall, int slot) const { return (int)arg[wall * Geo::SLOTS + slot]; }   // ~0u reads as -1
+    __device__ __forceinline__ void claim(int wall, int slot, unsigned key) { atomicMin(&arg[wall * Geo::SLOTS + slot], key); }
+    __device__ __forceinline__ int knot(int wall, int slot) const {
+        const unsigned key = arg[wall * Geo::SLOTS + slot];
+        return key == ~0u ? -1 : PinLane<P>::claimed_knot(key);
+    }
     __device__ __forceinline__ void clear_best(int slot) { mx[slot] = 0ull; mx[Geo::SLOTS + slot] = 0ull; }
     __device__ __forceinline__ void clear_knot(int slot) { arg[slot] = ~0u; arg[Geo::SLOTS + slot] = ~0u; }
 };

@@ -83,8 +83,8 @@ struct PinTag {
 //     double rown(int t, int k)                = r(1 + tP + k)
 //     void   post(int wall, int slot, double v)     slot maximum <- max(., v)          (v > 0)
 //     double best(int wall, int slot)               slot maximum (0: nothing posted)
-//     void   claim(int wall, int slot, int j)       slot knot <- min(., j)
-//     int    knot(int wall, int slot)               (negative: nobody claimed)
+//     void   claim(int wall, int slot, unsigned key)   slot key <- min(., key)      (PinLane::claim_key: the knot in the low 16 bits)
+//     int    knot(int wall, int slot)               the knot of the smallest key (negative: nobody claimed)
 //     void   clear_best(int slot), clear_knot(int slot)     both walls of a slot back to "nothing"
 // One buffer of slots serves all levels: a lane clears the knots of the slots it owns (slot t + 1; lane 0 also slot 0)
 // in its scan step -- every reader of the previous level is past the barrier that ended it, the next claims come after
@@ -94,6 +94,7 @@ struct PinTag {
 template <int P>
 struct PinLane {
     static_assert(P >= 1 && P <= 64, "a lane's pins live in one 64-bit mask per wall");
+    // (fibres are at most 65535 samples long: a claim key keeps the knot in 16 bits; the kernel's LDS plane ends at 16384)
     int n = 0, t = 0;
     int j0 = 0, j1 = 0;                        // own candidate knots [j0, j1) (interior knots are 1 .. n-1)
     unsigned long long pinU = 0, pinL = 0;     // bit k: knot j0 + k is pinned to the upper / lower wall
@@ -103,6 +104,7 @@ struct PinLane {
     // what the scan step found for the two runs that may span lanes
     double eU = 0.0, eL = 0.0, xU = 0.0, xL = 0.0;   // entering run / leaving run: largest (scaled) violation per wall (0: none)
     int eUk = 0, eLk = 0, xUk = 0, xLk = 0;          // ... and the knot
+    int eEnds = 0, xEnds = 0;                         // ja + jb of the two runs' segments (twice their midpoint)
     bool leaving = false;                             // the lane has pins of its own, so a second run leaves to the right
     unsigned long long newU = 0, newL = 0;            // pins found this level inside the lane's own range
 
@@ -214,6 +216,8 @@ struct PinLane {
         }
         eUk = j0 + PinTag<P>::index(eU); eLk = j0 + PinTag<P>::index(eL);
         xUk = j0 + PinTag<P>::index(xU); xLk = j0 + PinTag<P>::index(xL);
+        eEnds = la + (pinned ? j0 + __builtin_ctzll(pinned) : rb);
+        xEnds = ca + rb;   // (ca: the lane's last pin when a run leaves)
         const int se = slot_of(la);
         if (eU > 0.0) sh.post(0, se, eU);
         if (eL > 0.0) sh.post(1, se, eL);
@@ -231,15 +235,25 @@ struct PinLane {
     }
 
     // ---- claim ------------------------------------------------------------------------------------------------------------
+    // Among the lanes that hold a segment's largest violation the one whose knot lies closest to the middle of the
+    // segment wins (then the smaller knot): on data with exact ties -- stripes, checkerboards, staircases -- a fixed
+    // preference for one end would peel one knot off a segment per level (n / 2 levels for +-a alternating samples),
+    // the middle halves it.  Key: distance to the midpoint (doubled, 16 bits) above the knot (16 bits).
+    PTV_PIN_FN static unsigned claim_key(int k, int ends) {
+        const int d = 2 * k - ends;
+        return ((unsigned)(d < 0 ? -d : d) << 16) | (unsigned)k;
+    }
+    PTV_PIN_FN static int claimed_knot(unsigned key) { return (int)(key & 0xffffu); }
+
     template <class Sh>
     PTV_PIN_FN void claim(Sh &sh) {
         if (final_) return;
         const int se = slot_of(la);
-        if (eU > 0.0 && eU == sh.best(0, se)) sh.claim(0, se, eUk);
-        if (eL > 0.0 && eL == sh.best(1, se)) sh.claim(1, se, eLk);
+        if (eU > 0.0 && eU == sh.best(0, se)) sh.claim(0, se, claim_key(eUk, eEnds));
+        if (eL > 0.0 && eL == sh.best(1, se)) sh.claim(1, se, claim_key(eLk, eEnds));
         if (leaving) {
-            if (xU > 0.0 && xU == sh.best(0, t + 1)) sh.claim(0, t + 1, xUk);
-            if (xL > 0.0 && xL == sh.best(1, t + 1)) sh.claim(1, t + 1, xLk);
+            if (xU > 0.0 && xU == sh.best(0, t + 1)) sh.claim(0, t + 1, claim_key(xUk, xEnds));
+            if (xL > 0.0 && xL == sh.best(1, t + 1)) sh.claim(1, t + 1, claim_key(xLk, xEnds));
         }
     }
 

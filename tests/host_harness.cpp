@@ -168,7 +168,7 @@ template <int P, bool W>
 struct PinHostShared {
     std::vector<double> s, rr;
     std::vector<double> mx[2];
-    std::vector<int> arg[2];
+    std::vector<unsigned> arg[2];
     static constexpr bool kWeighted = W;
     double S(int j) const { return s[(size_t)j]; }
     double r(int j) const { return rr[(size_t)j]; }
@@ -177,10 +177,10 @@ struct PinHostShared {
     double rown(int t, int k) const { return rr[(size_t)(1 + t * P + k)]; }
     void post(int wall, int slot, double v) { if (v > mx[wall][(size_t)slot]) mx[wall][(size_t)slot] = v; }
     double best(int wall, int slot) const { return mx[wall][(size_t)slot]; }
-    void claim(int wall, int slot, int j) { if (j < arg[wall][(size_t)slot]) arg[wall][(size_t)slot] = j; }
-    int knot(int wall, int slot) const { return arg[wall][(size_t)slot] == (1 << 30) ? -1 : arg[wall][(size_t)slot]; }
+    void claim(int wall, int slot, unsigned key) { if (key < arg[wall][(size_t)slot]) arg[wall][(size_t)slot] = key; }
+    int knot(int wall, int slot) const { return arg[wall][(size_t)slot] == ~0u ? -1 : PinLane<P>::claimed_knot(arg[wall][(size_t)slot]); }
     void clear_best(int slot) { mx[0][(size_t)slot] = mx[1][(size_t)slot] = 0.0; }
-    void clear_knot(int slot) { arg[0][(size_t)slot] = arg[1][(size_t)slot] = 1 << 30; }
+    void clear_knot(int slot) { arg[0][(size_t)slot] = arg[1][(size_t)slot] = ~0u; }
 };
 
 template <int P, bool W>
@@ -200,7 +200,7 @@ static int pin_fibre(const double *y, const double *w, double lam, double *x, in
     int levels = 0;
     for (int wall = 0; wall < 2; wall++) {   // one buffer of slots for all levels: the lanes clear what they own (pincore.hpp)
         sh.mx[wall].assign((size_t)lanes + 1, 0.0);
-        sh.arg[wall].assign((size_t)lanes + 1, 1 << 30);
+        sh.arg[wall].assign((size_t)lanes + 1, ~0u);
     }
     for (;;) {
         levels++;

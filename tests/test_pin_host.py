@@ -95,3 +95,21 @@ def test_special_values(harness, oracle):
         y = np.array(y)
         x, _ = pin(harness, y, lam)
         np.testing.assert_allclose(x, oracle.tv1_linearized(y.copy(), lam), atol=1e-13)
+
+
+def test_ties_split_segments_in_the_middle(harness, oracle):
+    """Exact ties (stripes, staircases): the lane nearest the middle of a segment wins the claim, so a segment of equal
+    violations is halved, not peeled from one end.  (A regular zigzag whose every sample is a bend still peels -- the worst
+    violator of a sloped chord is always next to a pin: n / 2 levels; such data have one-sample pieces and belong to the
+    chunk kernels, which is where the policy sends them.)"""
+    n = 4096
+    y = 3.0 * (-1.0) ** np.arange(n)
+    x, levels = pin(harness, y, 2.999)          # one flat piece per pair is not possible: the string is pinned everywhere ...
+    assert np.abs(x - oracle.tv1_linearized(y.copy(), 2.999)).max() <= tol(y)
+    x, levels = pin(harness, y, 3.0)            # ... at lambda = amplitude every knot ties
+    assert levels <= 24, levels
+    assert np.abs(x - oracle.tv1_linearized(y.copy(), 3.0)).max() <= tol(y)
+    stairs = np.repeat(np.arange(n // 64), 64).astype(float)
+    x, levels = pin(harness, stairs, 3.0)
+    assert levels <= 32, levels
+    assert np.abs(x - oracle.tv1_linearized(stairs.copy(), 3.0)).max() <= tol(stairs)
