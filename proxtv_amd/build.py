@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libproxtv_amd.so")
-UNITS = ["common", "sweep", "pin", "pointwise", "tv2", "solvers", "cabi"]
+UNITS = ["common", "sweep", "pin", "pinlong", "pointwise", "tv2", "solvers", "cabi"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -ffp-contract=off: keep a*b+c as two roundings so the device arithmetic matches the reference's CPU build
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-ffp-contract=off", "-fno-gpu-rdc",

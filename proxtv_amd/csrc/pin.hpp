@@ -16,17 +16,30 @@ constexpr int kPinMaxLenWeighted = 8192;   // (two planes: sums and penalties)
 // Does the pinning solver take this sweep?  (lam < 0 -- tvgen lets negative penalties through -- stays with the walker,
 // whose behaviour there mirrors the reference's; so does lam = 0, where the walker returns the input bit for bit and
 // this solver returns it through its running sums.)
+// Longer fibres are spread over a grid of workgroups that must all be resident at once (pinlong.hip, 4096 samples per
+// workgroup): what an MI355X holds of that kernel.
+constexpr int kPinLongBlock = 4096;
+constexpr long kPinLongMaxWgs = 1024, kPinLongMaxWgsWeighted = 512;
+
+inline bool pin_is_long(bool weighted, const FibreGeom &g) { return g.len > (weighted ? kPinMaxLenWeighted : kPinMaxLen); }
+
 inline bool pin_supports(OpId op, bool weighted, const FibreGeom &g, double lam) {
     if (g.len < 2 || g.count < 1) return false;
+    if (pin_is_long(weighted, g)) {
+        const long wgs = ((long)g.len + kPinLongBlock - 1) / kPinLongBlock * g.count;
+        if (wgs > (weighted ? kPinLongMaxWgsWeighted : kPinLongMaxWgs)) return false;
+        if (weighted && op != OP_PROX && op != OP_DR_COL && op != OP_DR_COL_FINAL) return false;   // (the ops pinlong.hip builds weighted)
+    }
     if (weighted)
-        return g.len <= kPinMaxLenWeighted &&
-               (op == OP_PROX || op == OP_DR_COL || op == OP_DR_COL_FINAL || op == OP_DR_ROW || op == OP_DRW_ROW_FINAL);
-    return op != OP_DRW_ROW_FINAL && lam > 0.0 && g.len <= kPinMaxLen;
+        return op == OP_PROX || op == OP_DR_COL || op == OP_DR_COL_FINAL || op == OP_DR_ROW || op == OP_DRW_ROW_FINAL;
+    return op != OP_DRW_ROW_FINAL && lam > 0.0;
 }
 
 // One sweep.  Strided fibres (g.inc > 1) go through transposed copies of the operands, like launch_row_along in sweep.hip.
 // pieces (device, may be null): the number of pieces of the sweep's result is added to it -- the geometry policy's hint
 // for whether the chunk kernels below this rung are worth a trial.
 void launch_pin(OpId op, bool weighted, const SweepArgs &args, const FibreGeom &g, hipStream_t stream, int *pieces = nullptr);
+// (the grid-wide variant behind it, for fibres beyond kPinMaxLen: pinlong.hip)
+void launch_pin_long(OpId op, bool weighted, const SweepArgs &args, const FibreGeom &g, hipStream_t stream, int *pieces);
 
 }  // namespace ptv

@@ -83,7 +83,7 @@ struct PinTag {
 //     double rown(int t, int k)                = r(1 + tP + k)
 //     void   post(int wall, int slot, double v)     slot maximum <- max(., v)          (v > 0)
 //     double best(int wall, int slot)               slot maximum (0: nothing posted)
-//     void   claim(int wall, int slot, unsigned key)   slot key <- min(., key)      (PinLane::claim_key: the knot in the low 16 bits)
+//     void   claim(int wall, int slot, Key key)     slot key <- min(., key)      (PinLane::claim_key: the knot in the low half)
 //     int    knot(int wall, int slot)               the knot of the smallest key (negative: nobody claimed)
 //     void   clear_best(int slot), clear_knot(int slot)     both walls of a slot back to "nothing"
 // One buffer of slots serves all levels: a lane clears the knots of the slots it owns (slot t + 1; lane 0 also slot 0)
@@ -91,10 +91,12 @@ struct PinTag {
 // the next barrier -- and their maxima in its update step, which reads knots only.
 // wall 0 = upper, 1 = lower.
 
-template <int P>
+// Key: the type of a claim key -- 32 bits (knot and distance in 16 bits each: fibres held in one workgroup's LDS) or 64 bits
+// (32 + 32: fibres spread over a grid of workgroups, pinlong.hip).
+template <int P, class Key = unsigned>
 struct PinLane {
     static_assert(P >= 1 && P <= 64, "a lane's pins live in one 64-bit mask per wall");
-    // (fibres are at most 65535 samples long: a claim key keeps the knot in 16 bits; the kernel's LDS plane ends at 16384)
+    // (a 32-bit claim key keeps the knot in 16 bits: fibres of at most 65535 samples -- the LDS kernel's planes end at 16384)
     int n = 0, t = 0;
     int j0 = 0, j1 = 0;                        // own candidate knots [j0, j1) (interior knots are 1 .. n-1)
     unsigned long long pinU = 0, pinL = 0;     // bit k: knot j0 + k is pinned to the upper / lower wall
@@ -238,12 +240,13 @@ struct PinLane {
     // Among the lanes that hold a segment's largest violation the one whose knot lies closest to the middle of the
     // segment wins (then the smaller knot): on data with exact ties -- stripes, checkerboards, staircases -- a fixed
     // preference for one end would peel one knot off a segment per level (n / 2 levels for +-a alternating samples),
-    // the middle halves it.  Key: distance to the midpoint (doubled, 16 bits) above the knot (16 bits).
-    PTV_PIN_FN static unsigned claim_key(int k, int ends) {
+    // the middle halves it.  Key: distance to the midpoint (doubled) in the high half, the knot in the low half.
+    static constexpr int kKeyHalf = 4 * (int)sizeof(Key);   // bits of the knot (low) and of the distance (high)
+    PTV_PIN_FN static Key claim_key(int k, int ends) {
         const int d = 2 * k - ends;
-        return ((unsigned)(d < 0 ? -d : d) << 16) | (unsigned)k;
+        return ((Key)(unsigned)(d < 0 ? -d : d) << kKeyHalf) | (Key)(unsigned)k;
     }
-    PTV_PIN_FN static int claimed_knot(unsigned key) { return (int)(key & 0xffffu); }
+    PTV_PIN_FN static int claimed_knot(Key key) { return (int)(key & (((Key)1 << kKeyHalf) - 1)); }
 
     template <class Sh>
     PTV_PIN_FN void claim(Sh &sh) {

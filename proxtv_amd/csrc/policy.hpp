@@ -56,6 +56,8 @@ struct GeometryPolicy {
     bool explore = true;
     int hold_up = 0, hold_down = 0, quiet = 0;
     long sweeps = 0;         // sweeps of this family since the solve started
+    bool single = false;     // the previous solve was ONE sweep (batched 1-D prox calls): every call is timed, so that a call whose
+                             // data got harder than the pinning rung's yardstick is the last slow one
     // the workload of the last sweep (a different shape = a different workload)
     bool weighted = false;   // no mode 2 for weighted sweeps (two LDS windows)
     int len = 0;             // no mode 4 below 1024 samples
@@ -112,7 +114,7 @@ struct GeometryPolicy {
     }
     // should the next sweep be measured?  (`pending`: a measurement is still in flight)
     bool wants_measurement(bool pending) const {
-        return !pending && (explore || (sweeps > 0 && sweeps % (mode == 0 ? 8 : 4) == 0));
+        return !pending && (explore || single || (sweeps > 0 && sweeps % (mode == 0 ? 8 : 4) == 0));
     }
 
     // one step of an exploration: the sweep just measured ran geometry r in t ms and had the fraction f of its chunks
@@ -149,7 +151,7 @@ struct GeometryPolicy {
         }
         if (trial >= 0 && best == mode) {   // looked and found nothing: leave that direction alone for a while
             if (dir > 0) hold_up = kHoldSolves;
-            else hold_down = kHoldSolves;
+            else hold_down = single ? 4 * kHoldSolves : kHoldSolves;   // (one-sweep solves: a rejected look below costs a whole call)
         }
         mode = best;
         t_mode = best_t;
@@ -192,6 +194,11 @@ struct GeometryPolicy {
                 return;
             }
         }
+        // one-sweep solves on the pinning rung whose result has short pieces: look below now, not at the next periodic exploration
+        if (pin && r == 3 && single && !explore && f == 0.0 && hold_down == 0) {
+            explore = true;
+            trial = -1;
+        }
         if (explore) step(r, t, f);
         else monitor(r, t, f);
     }
@@ -200,6 +207,7 @@ struct GeometryPolicy {
     void begin_solve() {
         if (hold_up > 0) hold_up--;
         if (hold_down > 0) hold_down--;
+        single = pin && sweeps == 1;
         if (sweeps > 1) {            // a real solve: every solve opens with a measured sweep of the incumbent
             explore = true;
             trial = -1;

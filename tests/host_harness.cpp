@@ -164,11 +164,11 @@ int chunk_fibre(const double *y, const double *w, double lam, int len, int H, in
 // The pinning solver (pincore.hpp) for one fibre, its group of lanes emulated one after the other: a group barrier is the
 // end of a loop over lanes, an atomic is a plain max / min.  P = knots per lane (16, 32 or 64).  w (n - 1 edge penalties)
 // may be null.  Returns the number of levels.
-template <int P, bool W>
+template <int P, bool W, class Key = unsigned>
 struct PinHostShared {
     std::vector<double> s, rr;
     std::vector<double> mx[2];
-    std::vector<unsigned> arg[2];
+    std::vector<Key> arg[2];
     static constexpr bool kWeighted = W;
     double S(int j) const { return s[(size_t)j]; }
     double r(int j) const { return rr[(size_t)j]; }
@@ -177,15 +177,15 @@ struct PinHostShared {
     double rown(int t, int k) const { return rr[(size_t)(1 + t * P + k)]; }
     void post(int wall, int slot, double v) { if (v > mx[wall][(size_t)slot]) mx[wall][(size_t)slot] = v; }
     double best(int wall, int slot) const { return mx[wall][(size_t)slot]; }
-    void claim(int wall, int slot, unsigned key) { if (key < arg[wall][(size_t)slot]) arg[wall][(size_t)slot] = key; }
-    int knot(int wall, int slot) const { return arg[wall][(size_t)slot] == ~0u ? -1 : PinLane<P>::claimed_knot(arg[wall][(size_t)slot]); }
+    void claim(int wall, int slot, Key key) { if (key < arg[wall][(size_t)slot]) arg[wall][(size_t)slot] = key; }
+    int knot(int wall, int slot) const { return arg[wall][(size_t)slot] == (Key)~(Key)0 ? -1 : PinLane<P, Key>::claimed_knot(arg[wall][(size_t)slot]); }
     void clear_best(int slot) { mx[0][(size_t)slot] = mx[1][(size_t)slot] = 0.0; }
-    void clear_knot(int slot) { arg[0][(size_t)slot] = arg[1][(size_t)slot] = ~0u; }
+    void clear_knot(int slot) { arg[0][(size_t)slot] = arg[1][(size_t)slot] = (Key)~(Key)0; }
 };
 
-template <int P, bool W>
+template <int P, bool W, class Key = unsigned>
 static int pin_fibre(const double *y, const double *w, double lam, double *x, int n) {
-    PinHostShared<P, W> sh;
+    PinHostShared<P, W, Key> sh;
     const int lanes = (n + P - 1) / P;
     double mean = 0;
     for (int i = 0; i < n; i++) mean += y[i];
@@ -194,13 +194,13 @@ static int pin_fibre(const double *y, const double *w, double lam, double *x, in
     sh.rr.assign((size_t)n + 1 + P, 0.0);
     for (int i = 0; i < n; i++) sh.s[(size_t)i + 1] = sh.s[(size_t)i] + (y[i] - mean);
     for (int j = 1; j < n; j++) sh.rr[(size_t)j] = w ? w[j - 1] : lam;
-    std::vector<PinLane<P>> lane((size_t)lanes);
+    std::vector<PinLane<P, Key>> lane((size_t)lanes);
     (void)W;
     for (int t = 0; t < lanes; t++) lane[(size_t)t].init(n, t, sh);
     int levels = 0;
     for (int wall = 0; wall < 2; wall++) {   // one buffer of slots for all levels: the lanes clear what they own (pincore.hpp)
         sh.mx[wall].assign((size_t)lanes + 1, 0.0);
-        sh.arg[wall].assign((size_t)lanes + 1, ~0u);
+        sh.arg[wall].assign((size_t)lanes + 1, (Key)~(Key)0);
     }
     for (;;) {
         levels++;
@@ -336,7 +336,7 @@ int policy_sim_pin(const double *cost, const double *frac, int switch_at, int so
         pl.begin_solve();
         total = 0;
         for (int k = 0; k < sweeps; k++) {
-            const int phase = k >= switch_at ? 1 : 0;
+            const int phase = (sweeps == 1 ? s : k) >= switch_at ? 1 : 0;   // (one-sweep solves: the data change at solve `switch_at`)
             if (pl.workload(len, 4096, weighted != 0, pin != 0)) meas = false;
             if (meas && (pl.explore || pl.sweeps - meas_sweep >= kMonitorLag)) {
                 pl.measured(meas_mode, cost[6 * meas_phase + meas_mode], frac[6 * meas_phase + meas_mode]);
@@ -357,6 +357,12 @@ int policy_sim_pin(const double *cost, const double *frac, int switch_at, int so
     }
     if (total_ms) *total_ms = total;
     return pl.mode;
+}
+
+// the same with 64-bit claim keys: fibres longer than one workgroup's LDS (the lanes of pinlong.hip's grid are emulated
+// exactly like the lanes of a workgroup: the protocol is the same, its barriers span the grid)
+int host_pin_fibre_long(const double *y, const double *w, double lam, double *x, int n) {
+    return w ? pin_fibre<16, true, unsigned long long>(y, w, lam, x, n) : pin_fibre<16, false, unsigned long long>(y, w, lam, x, n);
 }
 
 int host_pin_fibre(const double *y, const double *w, double lam, double *x, int n, int P) {

@@ -125,3 +125,26 @@ def test_previous_rung3_still_exact(ptv, clib, oracle, rung3):
         assert_close(ptv.tv1_2d(X, 1.0), oracle.dr2(X, 1.0)[0], tol=1e-9, what="DR on the old rung 3")
     finally:
         clib.proxtv_set_option(b"pin", before)
+
+
+def test_fibres_longer_than_a_workgroup(ptv, oracle, rung3):
+    """Beyond 16384 samples the fibre is spread over a grid of workgroups (pinlong.hip): the BASELINE config-#1 shape with
+    pieces of any length."""
+    import torch
+    from proxtv_amd import device
+    rng = np.random.default_rng(97)
+    for n in (16385, 20000, 100000, 1000000):
+        x = rng.standard_normal(n) + np.repeat(rng.standard_normal(n // 3000 + 1), 3000)[:n]
+        for lam in (0.5, 30.0, 2000.0):
+            assert_close(ptv.tv1_1d(x, lam), oracle.tv1_hybrid(x, lam), tol=1e-11, what=f"n={n} lam={lam}")
+    for n in (8193, 50000):
+        x = np.cumsum(rng.standard_normal(n)) * 0.1 + rng.standard_normal(n)
+        w = rng.uniform(0.05, 4.0, n - 1)
+        assert_close(ptv.tv1w_1d(x, w), oracle.tv1_weighted(x, w), tol=1e-11, what=f"weighted n={n}")
+    # several long fibres in one launch, contiguous and strided
+    X = rng.standard_normal((40000, 3)) + np.repeat(rng.standard_normal((20, 3)), 2000, axis=0)
+    for arr, dim in ((X, 0), (np.ascontiguousarray(X.T), 1)):
+        xd = device.to_colmajor(torch.from_numpy(arr).cuda())
+        got = device.tv1_fibres(xd, 7.0, dim).cpu().numpy()
+        want = np.apply_along_axis(lambda v: oracle.tv1_hybrid(np.ascontiguousarray(v), 7.0), dim, arr)
+        assert_close(got, want, tol=1e-11, what=f"3 fibres of 40000, dim {dim}")

@@ -20,6 +20,8 @@ def harness():
     lib = C.CDLL(out)
     lib.host_pin_fibre.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_int, C.c_int]
     lib.host_pin_fibre.restype = C.c_int
+    lib.host_pin_fibre_long.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_int]
+    lib.host_pin_fibre_long.restype = C.c_int
     return lib
 
 
@@ -113,3 +115,21 @@ def test_ties_split_segments_in_the_middle(harness, oracle):
     x, levels = pin(harness, stairs, 3.0)
     assert levels <= 32, levels
     assert np.abs(x - oracle.tv1_linearized(stairs.copy(), 3.0)).max() <= tol(stairs)
+
+
+def test_long_fibres_wide_keys(harness, oracle):
+    """Fibres beyond one workgroup's LDS (pinlong.hip: the lanes of a grid of workgroups, 64-bit claim keys): same protocol,
+    emulated the same way."""
+    rng = np.random.default_rng(6)
+    for n, lam in ((70000, 0.5), (200000, 5.0), (1000000, 30.0), (300000, 1000.0)):
+        y = rng.standard_normal(n) + np.repeat(rng.standard_normal(n // 5000 + 1), 5000)[:n]
+        x = np.full(n, np.nan)
+        levels = harness.host_pin_fibre_long(y.ctypes.data, None, lam, x.ctypes.data, n)
+        assert 1 <= levels <= 40, levels
+        assert np.abs(x - oracle.tv1_linearized(y.copy(), lam)).max() <= tol(y), (n, lam)
+    n = 50000
+    y = np.cumsum(rng.standard_normal(n)) * 0.1
+    w = rng.uniform(0.1, 3.0, n - 1)
+    x = np.full(n, np.nan)
+    harness.host_pin_fibre_long(y.ctypes.data, w.ctypes.data, 0.0, x.ctypes.data, n)
+    assert np.abs(x - oracle.tv1_weighted(y.copy(), w)).max() <= tol(y)

@@ -234,3 +234,21 @@ def test_policy_with_a_pinning_rung(harness):
     fr = [0.01, 1e-4, 0, 0.25, 0, -1]
     mode, total, trace = _simulate_pin(harness, early, fr, cost2=late, frac2=[0.02, 6e-4, 0, 0.15, 0, -1], switch_at=15, solves=4)
     assert trace[-1] == 3 and total <= 15 * 0.45 + 20 * 0.45 + 2.0, (trace, total)
+
+
+def test_policy_one_sweep_solves_react_to_harder_data(harness):
+    """Batched 1-D prox calls are one-sweep solves: with a pinning rung every call is timed, and a call that takes longer than
+    the rung's yardstick is the last slow one (a 10^6-sample fibre: 0.2 ms at lambda = 0.5 on rung 1, 800 ms there at lambda =
+    30, 0.9 ms on the pinning rung whatever lambda)."""
+    easy_c, easy_f = [0.25, 0.2, 1.0, 0.9, 50.0, 800.0], [1e-5, 0, 0, 0.9, 0, -1]
+    hard_c, hard_f = [900.0, 800.0, 700.0, 0.9, 50.0, 800.0], [0.5, 0.4, 0.3, 0.001, 0.01, -1]
+    # 12 easy calls settle on a chunk rung; from call 12 on the data are hard: one slow call, then the pinning rung
+    for calls, want_mode, want_last in ((12, None, None), (13, None, None), (14, 3, 0.9), (20, 3, 0.9)):
+        mode, last, trace = _simulate_pin(harness, easy_c, easy_f, cost2=hard_c, frac2=hard_f, switch_at=12, solves=calls, sweeps=1)
+        if calls == 12:
+            assert mode <= 1 and last <= 0.25, (mode, last)
+        elif want_mode is not None:
+            assert mode == want_mode and abs(last - want_last) < 1e-9, (calls, mode, last)
+    # and back: on the pinning rung with short pieces (data got easy again) the policy looks below within a call or two
+    mode, last, trace = _simulate_pin(harness, hard_c, hard_f, cost2=easy_c, frac2=easy_f, switch_at=6, solves=10, sweeps=1)
+    assert mode <= 1 and last <= 0.25, (mode, last)
