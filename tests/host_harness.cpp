@@ -5,6 +5,9 @@
 #define __device__
 #define __forceinline__ inline
 #include <cstring>
+#include <atomic>
+#include <thread>
+#include <pthread.h>
 
 #include <algorithm>
 #include <cmath>
@@ -215,6 +218,91 @@ static int pin_fibre(const double *y, const double *w, double lam, double *x, in
 }
 
 
+// The same protocol under REAL concurrency: the lanes are dealt to host threads, the three steps of a level are separated
+// by thread barriers, and the slots are relaxed atomics (max by compare-and-swap on the bit pattern, min on the key) -- what
+// the kernels do with ds_max_u64 / ds_min_u32 and global atomics.  The sequential emulation above cannot see an ordering
+// mistake in the one-buffer slot protocol (who clears what, between which barriers); this one can.
+template <int P, bool W>
+struct PinThreadShared {
+    using Key = unsigned long long;
+    std::vector<double> s, rr;
+    std::vector<std::atomic<unsigned long long>> mx[2];
+    std::vector<std::atomic<Key>> arg[2];
+    static constexpr bool kWeighted = W;
+    double S(int j) const { return s[(size_t)j]; }
+    double r(int j) const { return rr[(size_t)j]; }
+    double own(int t, int k) const { return s[(size_t)(1 + t * P + k)]; }
+    double own_at(int t, int k) const { return own(t, k); }
+    double rown(int t, int k) const { return rr[(size_t)(1 + t * P + k)]; }
+    void post(int wall, int slot, double v) {
+        const unsigned long long b = pin_bits(v);
+        unsigned long long cur = mx[wall][(size_t)slot].load(std::memory_order_relaxed);
+        while (cur < b && !mx[wall][(size_t)slot].compare_exchange_weak(cur, b, std::memory_order_relaxed)) {}
+    }
+    double best(int wall, int slot) const { return pin_double(mx[wall][(size_t)slot].load(std::memory_order_relaxed)); }
+    void claim(int wall, int slot, Key key) {
+        Key cur = arg[wall][(size_t)slot].load(std::memory_order_relaxed);
+        while (key < cur && !arg[wall][(size_t)slot].compare_exchange_weak(cur, key, std::memory_order_relaxed)) {}
+    }
+    int knot(int wall, int slot) const {
+        const Key key = arg[wall][(size_t)slot].load(std::memory_order_relaxed);
+        return key == ~0ull ? -1 : PinLane<P, Key>::claimed_knot(key);
+    }
+    void clear_best(int slot) { mx[0][(size_t)slot].store(0, std::memory_order_relaxed); mx[1][(size_t)slot].store(0, std::memory_order_relaxed); }
+    void clear_knot(int slot) { arg[0][(size_t)slot].store(~0ull, std::memory_order_relaxed); arg[1][(size_t)slot].store(~0ull, std::memory_order_relaxed); }
+};
+
+template <bool W>
+static int pin_fibre_threads(const double *y, const double *w, double lam, double *x, int n, int nthreads) {
+    constexpr int P = 16;
+    PinThreadShared<P, W> sh;
+    const int lanes = (n + P - 1) / P;
+    double mean = 0;
+    for (int i = 0; i < n; i++) mean += y[i];
+    mean /= n;
+    sh.s.assign((size_t)n + 1 + P, 0.0);
+    sh.rr.assign((size_t)n + 1 + P, 0.0);
+    for (int i = 0; i < n; i++) sh.s[(size_t)i + 1] = sh.s[(size_t)i] + (y[i] - mean);
+    for (int j = 1; j < n; j++) sh.rr[(size_t)j] = w ? w[j - 1] : lam;
+    for (int wall = 0; wall < 2; wall++) {
+        sh.mx[wall] = std::vector<std::atomic<unsigned long long>>((size_t)lanes + 1);
+        sh.arg[wall] = std::vector<std::atomic<unsigned long long>>((size_t)lanes + 1);
+        for (int k = 0; k <= lanes; k++) {
+            sh.mx[wall][(size_t)k].store(0);
+            sh.arg[wall][(size_t)k].store(~0ull);
+        }
+    }
+    std::vector<PinLane<P, unsigned long long>> lane((size_t)lanes);
+    for (int t = 0; t < lanes; t++) lane[(size_t)t].init(n, t, sh);
+    pthread_barrier_t bar;
+    pthread_barrier_init(&bar, nullptr, (unsigned)nthreads);
+    std::atomic<int> gained[3];
+    for (auto &g : gained) g.store(0);
+    std::atomic<int> levels{0};
+    auto body = [&](int tid) {
+        // lanes are dealt round-robin, so that neighbouring lanes (which share segments and slots) run on different threads
+        for (int level = 0;; level++) {
+            if (tid == 0) gained[(level + 1) % 3].store(0, std::memory_order_relaxed);
+            for (int t = tid; t < lanes; t += nthreads) lane[(size_t)t].scan(sh);
+            pthread_barrier_wait(&bar);
+            for (int t = tid; t < lanes; t += nthreads) lane[(size_t)t].claim(sh);
+            pthread_barrier_wait(&bar);
+            bool any = false;
+            for (int t = tid; t < lanes; t += nthreads) any |= lane[(size_t)t].update(sh);
+            if (any) gained[level % 3].store(1, std::memory_order_relaxed);
+            pthread_barrier_wait(&bar);
+            if (tid == 0) levels.store(level + 1);
+            if (gained[level % 3].load(std::memory_order_relaxed) == 0) break;
+        }
+    };
+    std::vector<std::thread> th;
+    for (int k = 0; k < nthreads; k++) th.emplace_back(body, k);
+    for (auto &t : th) t.join();
+    pthread_barrier_destroy(&bar);
+    for (int t = 0; t < lanes; t++) lane[(size_t)t].values(sh, mean, [&](int i, int, double v) { x[i] = v; });
+    return levels.load();
+}
+
 extern "C" {
 
 // One fibre through the speculative-chunk scheme exactly as a workgroup column does it (chunkcore.hpp): blocks of NW
@@ -357,6 +445,11 @@ int policy_sim_pin(const double *cost, const double *frac, int switch_at, int so
     }
     if (total_ms) *total_ms = total;
     return pl.mode;
+}
+
+// concurrent emulation (pthread barriers, atomic slots): same result as the sequential one, bit for bit
+int host_pin_fibre_threads(const double *y, const double *w, double lam, double *x, int n, int nthreads) {
+    return w ? pin_fibre_threads<true>(y, w, lam, x, n, nthreads) : pin_fibre_threads<false>(y, w, lam, x, n, nthreads);
 }
 
 // the same with 64-bit claim keys: fibres longer than one workgroup's LDS (the lanes of pinlong.hip's grid are emulated

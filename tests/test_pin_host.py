@@ -15,13 +15,15 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 @pytest.fixture(scope="module")
 def harness():
     out = os.path.join(tempfile.mkdtemp(prefix="ptv_pin_"), "libpin_host.so")
-    subprocess.run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-o", out,
+    subprocess.run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-pthread", "-o", out,
                     os.path.join(HERE, "host_harness.cpp")], check=True)
     lib = C.CDLL(out)
     lib.host_pin_fibre.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_int, C.c_int]
     lib.host_pin_fibre.restype = C.c_int
     lib.host_pin_fibre_long.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_int]
     lib.host_pin_fibre_long.restype = C.c_int
+    lib.host_pin_fibre_threads.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_int, C.c_int]
+    lib.host_pin_fibre_threads.restype = C.c_int
     return lib
 
 
@@ -133,3 +135,21 @@ def test_long_fibres_wide_keys(harness, oracle):
     x = np.full(n, np.nan)
     harness.host_pin_fibre_long(y.ctypes.data, w.ctypes.data, 0.0, x.ctypes.data, n)
     assert np.abs(x - oracle.tv1_weighted(y.copy(), w)).max() <= tol(y)
+
+
+def test_protocol_under_real_concurrency(harness):
+    """The slot protocol (one buffer: knots cleared in scan, maxima in update, three barriers per level) with the lanes on
+    8 host threads, relaxed atomics and thread barriers: bit-identical to the sequential emulation, level for level."""
+    rng = np.random.default_rng(8)
+    for trial in range(40):
+        name = list(FAMILIES)[trial % len(FAMILIES)]
+        n = int(rng.choice([100, 1000, 4096, 20000, 70000]))
+        y = FAMILIES[name](rng, n)
+        lam = float(10 ** rng.uniform(-1.5, 1.5))
+        w = 10 ** rng.uniform(-1, 1) * rng.uniform(0.2, 1.0, n - 1) if trial % 5 == 0 else None
+        a = np.full(n, np.nan)
+        la = harness.host_pin_fibre_long(y.ctypes.data, None if w is None else w.ctypes.data, lam, a.ctypes.data, n)
+        b = np.full(n, np.nan)
+        lb = harness.host_pin_fibre_threads(y.ctypes.data, None if w is None else w.ctypes.data, lam, b.ctypes.data, n, 8)
+        assert la == lb, (name, n, lam, la, lb)
+        np.testing.assert_array_equal(a, b)

@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 @pytest.fixture(scope="module")
 def harness():
     out = os.path.join(tempfile.mkdtemp(prefix="ptv_hw_"), "libwalker_host.so")
-    subprocess.run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-o", out,
+    subprocess.run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-pthread", "-o", out,
                     os.path.join(HERE, "host_harness.cpp")], check=True)
     lib = C.CDLL(out)
     lib.host_walk.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_int]
