@@ -14,9 +14,11 @@
  * PART 2 is new API (not in the reference): device-pointer entry points used by bench.py and by
  * callers that already hold data in HBM, plus the batch solver that shards independent images.
  *
- * Only the p = 1 (TV-L1) norm is implemented -- the hot path of BASELINE.json.  The TV-L2 / TV-Lp /
- * projected-Newton / 1-D Kolmogorov / Johnson-DP entry points of the reference are out of scope
- * (DESIGN.md "Out of scope") and are not exported.
+ * Norms: p = 1 (TV-L1, the hot path of BASELINE.json) and p = 2 (TV-L2) have exact device solvers.  Every function
+ * the reference's cffi cdef declares (prox_tv/prox_tv_build.py:13-76) is exported, so that cdef links against this
+ * library unmodified: the alternative 1-D TV-L1 algorithms (projected Newton, Kolmogorov's and Johnson's solvers,
+ * Condat's taut string) are entry points of the one exact solver -- the minimiser is unique -- and the general-p
+ * TV-Lp schemes report RC_ERROR for p outside {1, 2} (DESIGN.md "Out of scope").
  */
 #ifndef PROXTV_AMD_H
 #define PROXTV_AMD_H
@@ -62,6 +64,25 @@ int TV(double *y, double lambda, double *x, double *info, int n, double p, Works
 int more_TV2(double *y, double lambda, double *x, double *info, int n);
 int morePG_TV2(double *y, double lambda, double *x, double *info, int n, Workspace *ws);
 int PG_TV2(double *y, double lambda, double *x, double *info, int n);
+
+/* replace src/TVL1opt.cpp:37 and src/TVL1Wopt.cpp:37 (projected Newton; `sigma`, its sufficient-descent tolerance, has no
+   counterpart in an exact solve), src/TVL1opt_kolmogorov.cpp:133 and :38 (Kolmogorov et al.'s message passing; n <= 1
+   handled like the reference), src/condat_fast_tv.cpp:133 (Condat's taut string) and src/johnsonRyanTV.cpp:9 (Johnson's
+   dynamic programme; n == 0 / n == 1 / lam == 0 like the reference): the same unique minimiser as the entry points below,
+   served by the same exact HIP solver.  info (where present): iterations 0, gap 0, RC_OK. */
+int PN_TV1(double *y, double lambda, double *x, double *info, int n, double sigma, Workspace *ws);
+int PN_TV1_Weighted(double *Y, double *W, double *X, double *info, int n, double sigma, Workspace *ws);
+void SolveTVConvexQuadratic_a1_nw(int n, double *b, double w, double *solution);
+void SolveTVConvexQuadratic_a1(int n, double *b, double *w, double *solution);
+void TV1D_denoise_tautstring(double *input, double *output, int width, const double lambda);
+void dp(int n, double *y, double lam, double *beta);
+/* replace src/TVLPopt.cpp:37, :295, :583, :871, :1111 -- TV-Lp first-order schemes.  p == 1 and p == 2 are served by the
+   exact solvers (like TV); any other p -> prints the reason, info[2] = RC_ERROR, returns 0. */
+int GP_TVp(double *y, double lambda, double *x, double *info, int n, double p, Workspace *ws);
+int OGP_TVp(double *y, double lambda, double *x, double *info, int n, double p, Workspace *ws);
+int FISTA_TVp(double *y, double lambda, double *x, double *info, int n, double p, Workspace *ws);
+int FW_TVp(double *y, double lambda, double *x, double *info, int n, double p, Workspace *ws);
+int GPFW_TVp(double *y, double lambda, double *x, double *info, int n, double p, Workspace *ws);
 
 /* replaces src/TVL1opt.cpp:359 */
 int linearizedTautString_TV1(double *y, double lambda, double *x, int n);
@@ -211,8 +232,10 @@ long   proxtv_last_fixups(void);
 long   proxtv_debug_trace(unsigned long long *dst, long max_wgs);
 /* Geometry policy the adaptive chunk kernel currently uses on this thread (the highest over the sweep families):
    0 = 16-sample warm-up zones (noisy data, small lambda), 1 = the same, robust instantiation (walks may run past
-   the window, second-chance rounds inside a block: pieces of ~5 samples), 2 = 64-sample zones (pieces of ~10 samples), 3 / 4 = chunks walked straight from global
-   memory with 256- / 1024-sample zones (pieces of tens / hundreds of samples), 5 = one sequential walk per fibre. */
+   the window, second-chance rounds inside a block: pieces of ~5 samples), 2 = 64-sample zones (pieces of ~10 samples),
+   3 = the pinning solver (exact and data-parallel inside the fibre, any piece length; where it does not apply --
+   lambda <= 0, fibres beyond what the device holds -- chunks walked from global memory with 256-sample zones),
+   4 = chunks walked from global memory with 1024-sample zones, 5 = one sequential walk per fibre. */
 int    proxtv_chunk_mode(void);
 /* dst = src with the 8-bytes-per-lane access width of the sweep kernels: a known byte count against which the
    rocprofv3 FETCH_SIZE / WRITE_SIZE counters are calibrated (tools/pmc_traffic.py).  Device pointers. */

@@ -73,11 +73,10 @@ def _contig(x):
 def tv1_1d(x, w, method="hybridtautstring", sigma=0.05, maxbacktracks=None):
     r"""1D proximal operator for :math:`\ell_1`:  min_y 1/2 ||x-y||^2 + w sum_i |y_i - y_{i+1}|.
 
-    Mirrors prox_tv.tv1_1d (reference: prox_tv/__init__.py:124-179).  The minimiser is unique, so every
-    ``method`` name of the reference is accepted and served by the same exact HIP solver; the names that map onto
-    a C entry point of the hot path ('hybridtautstring', 'linearizedtautstring', 'classictautstring', 'condat')
-    call that entry point, the remaining ones ('pn', 'dp', 'condattautstring', 'kolmogorov': alternative CPU
-    algorithms, out of scope) are aliases of 'hybridtautstring'.
+    Mirrors prox_tv.tv1_1d (reference: prox_tv/__init__.py:124-216).  Every ``method`` name calls the C entry point
+    the reference binds for it (PN_TV1, TV1D_denoise, TV1D_denoise_tautstring, SolveTVConvexQuadratic_a1_nw, dp, the
+    three taut-string variants); the minimiser is unique, so in libproxtv_amd all of them are entry points of the one
+    exact HIP solver.
     """
     methods = ("classictautstring", "linearizedtautstring", "hybridtautstring", "pn", "condat", "dp",
                "condattautstring", "kolmogorov")
@@ -94,7 +93,16 @@ def tv1_1d(x, w, method="hybridtautstring", sigma=0.05, maxbacktracks=None):
         lib.linearizedTautString_TV1(_ptr(x), w, _ptr(y), n)
     elif method == "condat":
         lib.TV1D_denoise(_ptr(x), _ptr(y), n, w)
-    elif method == "hybridtautstring" and maxbacktracks is not None:
+    elif method == "pn":                      # prox_tv/__init__.py:197-200
+        info = np.zeros(_N_INFO)
+        lib.PN_TV1(_ptr(x), w, _ptr(y), _ptr(info), n, float(sigma), None)
+    elif method == "condattautstring":        # :206-208
+        lib.TV1D_denoise_tautstring(_ptr(x), _ptr(y), n, w)
+    elif method == "kolmogorov":              # :210-212
+        lib.SolveTVConvexQuadratic_a1_nw(n, _ptr(x), w, _ptr(y))
+    elif method == "dp":                      # :214-216
+        lib.dp(n, _ptr(x), w, _ptr(y))
+    elif maxbacktracks is not None:
         lib.hybridTautString_TV1_custom(_ptr(x), n, w, _ptr(y), float(maxbacktracks))
     else:
         lib.hybridTautString_TV1(_ptr(x), n, w, _ptr(y))
@@ -104,14 +112,18 @@ def tv1_1d(x, w, method="hybridtautstring", sigma=0.05, maxbacktracks=None):
 
 def tv1w_1d(x, w, method="tautstring", sigma=0.05):
     r"""Weighted 1D proximal operator for :math:`\ell_1` (reference: prox_tv/__init__.py:218-254).
-    Both method names ('tautstring', 'pn') run the exact weighted HIP solver."""
+    'tautstring' calls tautString_TV1_Weighted, 'pn' PN_TV1_Weighted; both are the exact weighted HIP solver."""
     assert np.all(w >= 0)
     assert np.size(x) - 1 == np.size(w)
     w = _contig(force_float_matrix(w))
     x = _contig(force_float_matrix(x))
     y = np.zeros(np.size(x))
     lib = _lib.require_device()
-    lib.tautString_TV1_Weighted(_ptr(x), _ptr(w), _ptr(y), int(np.size(x)))
+    if method == "tautstring":
+        lib.tautString_TV1_Weighted(_ptr(x), _ptr(w), _ptr(y), int(np.size(x)))
+    else:
+        info = np.zeros(_N_INFO)
+        lib.PN_TV1_Weighted(_ptr(x), _ptr(w), _ptr(y), _ptr(info), int(np.size(x)), float(sigma), None)
     _lib.check("tv1w_1d")
     return y
 
@@ -151,7 +163,8 @@ def tvp_1d(x, w, p, method="gpfw", max_iters=0):
     info = np.zeros(_N_INFO)
     y = np.zeros(np.size(x), order="F")
     lib = _lib.require_device()
-    lib.TV(_ptr(x), w, _ptr(y), _ptr(info), int(np.size(x)), float(p), None)
+    entry = {"gp": lib.GP_TVp, "fw": lib.FW_TVp, "gpfw": lib.GPFW_TVp}[method]   # prox_tv/__init__.py:343-351
+    entry(_ptr(x), w, _ptr(y), _ptr(info), int(np.size(x)), float(p), None)
     _lib.check("tvp_1d")
     return y
 

@@ -24,6 +24,17 @@ SIGNATURES = {
     "hybridTautString_TV1_custom": (None, [_dp, C.c_int, C.c_double, _dp, C.c_double]),
     "tautString_TV1_Weighted": (C.c_int, [_dp, _dp, _dp, C.c_int]),
     "TV1D_denoise": (None, [_dp, _dp, C.c_int, C.c_double]),
+    "TV1D_denoise_tautstring": (None, [_dp, _dp, C.c_int, C.c_double]),
+    "dp": (None, [C.c_int, _dp, C.c_double, _dp]),
+    "PN_TV1": (C.c_int, [_dp, C.c_double, _dp, _dp, C.c_int, C.c_double, C.c_void_p]),
+    "PN_TV1_Weighted": (C.c_int, [_dp, _dp, _dp, _dp, C.c_int, C.c_double, C.c_void_p]),
+    "SolveTVConvexQuadratic_a1_nw": (None, [C.c_int, _dp, C.c_double, _dp]),
+    "SolveTVConvexQuadratic_a1": (None, [C.c_int, _dp, _dp, _dp]),
+    "GP_TVp": (C.c_int, [_dp, C.c_double, _dp, _dp, C.c_int, C.c_double, C.c_void_p]),
+    "OGP_TVp": (C.c_int, [_dp, C.c_double, _dp, _dp, C.c_int, C.c_double, C.c_void_p]),
+    "FISTA_TVp": (C.c_int, [_dp, C.c_double, _dp, _dp, C.c_int, C.c_double, C.c_void_p]),
+    "FW_TVp": (C.c_int, [_dp, C.c_double, _dp, _dp, C.c_int, C.c_double, C.c_void_p]),
+    "GPFW_TVp": (C.c_int, [_dp, C.c_double, _dp, _dp, C.c_int, C.c_double, C.c_void_p]),
     "DR2_TV": (C.c_int, [C.c_size_t, C.c_size_t, _dp, C.c_double, C.c_double, C.c_double, C.c_double, _dp,
                          C.c_int, C.c_int, _dp]),
     "DR2L1W_TV": (C.c_int, [C.c_size_t, C.c_size_t, _dp, _dp, _dp, _dp, C.c_int, C.c_int, _dp]),

@@ -219,6 +219,72 @@ void TV1D_denoise(double *input, double *output, const int width, const double l
     guarded("TV1D_denoise", nullptr, 1, [&] { prox1d_host(input, nullptr, lambda, output, width, 0.0); });
 }
 
+// ---- the remaining 1-D entry points of the reference's cdef (prox_tv/prox_tv_build.py:13-76) -------------------------------
+// PN_TV1 (src/TVL1opt.cpp:37), PN_TV1_Weighted (src/TVL1Wopt.cpp:37), SolveTVConvexQuadratic_a1[_nw]
+// (src/TVL1opt_kolmogorov.cpp:38,133), TV1D_denoise_tautstring (src/condat_fast_tv.cpp:133) and dp (src/johnsonRyanTV.cpp:9)
+// are alternative CPU algorithms for the SAME minimiser the exact HIP solver computes: each keeps its reference argument
+// order, trivial-case behaviour and info convention and lands on prox1d_host.  (sigma, the projected-Newton descent
+// tolerance, has no counterpart in an exact solve.)
+int PN_TV1(double *y, double lambda, double *x, double *info, int n, double, Workspace *) {
+    return guarded("PN_TV1", info, 1, [&] {
+        prox1d_host(y, nullptr, lambda, x, n, 0.0);
+        if (info) { info[INFO_ITERS] = 0; info[INFO_GAP] = 0; info[INFO_RC] = RC_OK; }
+    });
+}
+
+int PN_TV1_Weighted(double *Y, double *W, double *X, double *info, int n, double, Workspace *) {
+    return guarded("PN_TV1_Weighted", info, 1, [&] {
+        prox1d_host(Y, W, 0.0, X, n, 0.0);
+        if (info) { info[INFO_ITERS] = 0; info[INFO_GAP] = 0; info[INFO_RC] = RC_OK; }
+    });
+}
+
+void SolveTVConvexQuadratic_a1_nw(int n, double *b, double w, double *solution) {
+    if (n <= 1) {                                                 // src/TVL1opt_kolmogorov.cpp:135-139
+        if (n == 1) solution[0] = b[0];
+        return;
+    }
+    guarded("SolveTVConvexQuadratic_a1_nw", nullptr, 1, [&] { prox1d_host(b, nullptr, w, solution, n, 0.0); });
+}
+
+void SolveTVConvexQuadratic_a1(int n, double *b, double *w, double *solution) {
+    if (n <= 1) {                                                 // src/TVL1opt_kolmogorov.cpp:40-44
+        if (n == 1) solution[0] = b[0];
+        return;
+    }
+    guarded("SolveTVConvexQuadratic_a1", nullptr, 1, [&] { prox1d_host(b, w, 0.0, solution, n, 0.0); });
+}
+
+void TV1D_denoise_tautstring(double *input, double *output, int width, const double lambda) {
+    if (width <= 0) return;   // (the reference allocates width + 1 work arrays and walks them: nothing to do for an empty signal)
+    guarded("TV1D_denoise_tautstring", nullptr, 1, [&] { prox1d_host(input, nullptr, lambda, output, width, 0.0); });
+}
+
+void dp(int n, double *y, double lam, double *beta) {
+    if (n <= 0) return;                                           // src/johnsonRyanTV.cpp:11
+    if (n == 1 || lam == 0) {                                     // :12-15
+        for (int i = 0; i < n; i++) beta[i] = y[i];
+        return;
+    }
+    guarded("dp", nullptr, 1, [&] { prox1d_host(y, nullptr, lam, beta, n, 0.0); });
+}
+
+// TV-Lp for general p (src/TVLPopt.cpp: GP_TVp :37, OGP_TVp :295, FISTA_TVp :583, FW_TVp :871, GPFW_TVp :1111): five
+// first-order schemes for min 1/2 ||x-y||^2 + lambda ||Dx||_p.  Out of scope for general p (SURVEY section 2 allows the
+// RC_ERROR stub); p = 1 and p = 2 have exact device solvers and are served by them, like TV().
+static int tvp_host(const char *who, double *y, double lambda, double *x, double *info, int n, double p) {
+    return guarded(who, info, 1, [&] {
+        if (p != 1 && p != 2) reject("only the p = 1 (TV-L1) and p = 2 (TV-L2) norms are implemented on the HIP path");
+        prox1d_host(y, nullptr, lambda, x, n, 0.0, p);
+        if (info) { info[INFO_ITERS] = 0; info[INFO_GAP] = 0; info[INFO_RC] = RC_OK; }
+    });
+}
+int GP_TVp(double *y, double lambda, double *x, double *info, int n, double p, Workspace *) { return tvp_host("GP_TVp", y, lambda, x, info, n, p); }
+int OGP_TVp(double *y, double lambda, double *x, double *info, int n, double p, Workspace *) { return tvp_host("OGP_TVp", y, lambda, x, info, n, p); }
+int FISTA_TVp(double *y, double lambda, double *x, double *info, int n, double p, Workspace *) { return tvp_host("FISTA_TVp", y, lambda, x, info, n, p); }
+int FW_TVp(double *y, double lambda, double *x, double *info, int n, double p, Workspace *) { return tvp_host("FW_TVp", y, lambda, x, info, n, p); }
+int GPFW_TVp(double *y, double lambda, double *x, double *info, int n, double p, Workspace *) { return tvp_host("GPFW_TVp", y, lambda, x, info, n, p); }
+
 int DR2_TV(size_t M, size_t N, double *unary, double W1, double W2, double norm1, double norm2, double *s, int,
            int maxit, double *info) {
     // returns 0 on success like the reference (src/TV2Dopt.cpp:440); failures also return 0 with info[RC]=RC_ERROR

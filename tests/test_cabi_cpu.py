@@ -36,6 +36,39 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert lib.proxtv_version().startswith(b"proxtv_amd")
 
 
+# Every function the reference's cffi cdef declares (prox_tv/prox_tv_build.py:13-76 -- names only: cffi's API mode resolves
+# each of them when the extension module is linked, so the cdef links against libproxtv_amd.so unmodified iff all resolve).
+REFERENCE_CDEF_FUNCTIONS = [
+    "TV1D_denoise", "TV1D_denoise_tautstring", "dp",
+    "PN_TV1", "linearizedTautString_TV1", "classicTautString_TV1", "hybridTautString_TV1", "hybridTautString_TV1_custom",
+    "SolveTVConvexQuadratic_a1_nw",
+    "PN_TV1_Weighted", "tautString_TV1_Weighted", "SolveTVConvexQuadratic_a1",
+    "more_TV2", "PG_TV2", "morePG_TV2",
+    "DR2L1W_TV",
+    "PD2_TV", "DR2_TV", "CondatChambollePock2_TV", "Yang2_TV", "Kolmogorov2_TV",
+    "PD_TV",
+    "GP_TVp", "OGP_TVp", "FISTA_TVp", "FW_TVp", "GPFW_TVp",
+]
+
+
+def test_every_function_of_the_reference_cdef_resolves():
+    """`nm -D` on the shipped library: all 27 cdef'd functions are defined, unmangled, in its dynamic symbol table."""
+    import subprocess
+    from proxtv_amd import _lib
+    _lib.load()
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], check=True, capture_output=True, text=True).stdout
+    defined = {line.split()[-1] for line in out.splitlines() if line.split()[1:2] == ["T"]}
+    missing = [f for f in REFERENCE_CDEF_FUNCTIONS if f not in defined]
+    assert not missing, missing
+    assert len(REFERENCE_CDEF_FUNCTIONS) == 27
+    if os.path.exists("/root/reference/prox_tv/prox_tv_build.py"):   # (this container only) the list above IS the cdef's
+        text = open("/root/reference/prox_tv/prox_tv_build.py").read()
+        cdef = text[text.index('ffi.cdef("""'):text.index('""")')]
+        cdef = re.sub(r"/\*.*?\*/|//[^\n]*", "", cdef, flags=re.S)
+        names = set(re.findall(r"\b(\w+)\s*\(", cdef)) - {"cdef"}
+        assert names == set(REFERENCE_CDEF_FUNCTIONS), names ^ set(REFERENCE_CDEF_FUNCTIONS)
+
+
 def test_code_object_is_gfx950_only():
     """The library carries hand-written gfx950 code objects and nothing else (no multi-arch / fallback bundles)."""
     from proxtv_amd import _lib

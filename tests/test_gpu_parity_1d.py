@@ -165,3 +165,57 @@ def test_c1_full_size(ptv, glarge):
     # size-independent properties of the prox: mean is preserved, TV does not increase, idempotent at lambda = 0
     assert abs(y.mean() - x.mean()) < 1e-9
     assert np.abs(np.diff(y)).sum() <= np.abs(np.diff(x)).sum()
+
+
+def test_alternative_algorithm_symbols(clib, oracle):
+    """The remaining 1-D symbols of the reference's cdef (PN_TV1, PN_TV1_Weighted, SolveTVConvexQuadratic_a1[_nw],
+    TV1D_denoise_tautstring, dp, the five *_TVp): reference argument order, trivial cases and info conventions."""
+    rng = np.random.default_rng(21)
+    x = rng.standard_normal(777)
+    w = rng.uniform(0.1, 0.9, x.size - 1)
+    want, wantw = oracle.tv1_hybrid(x, 0.4), oracle.tv1_weighted(x, w)
+    out, info = np.zeros_like(x), np.full(3, -1.0)
+    assert clib.PN_TV1(x.ctypes.data, 0.4, out.ctypes.data, info.ctypes.data, x.size, 0.05, None) == 1
+    assert list(info) == [0.0, 0.0, 0.0]
+    assert_close(out, want)
+    out[:] = 0; info[:] = -1
+    assert clib.PN_TV1_Weighted(x.ctypes.data, w.ctypes.data, out.ctypes.data, info.ctypes.data, x.size, 0.05, None) == 1
+    assert info[2] == 0
+    assert_close(out, wantw)
+    out[:] = 0
+    clib.SolveTVConvexQuadratic_a1_nw(x.size, x.ctypes.data, 0.4, out.ctypes.data)
+    assert_close(out, want)
+    out[:] = 0
+    clib.SolveTVConvexQuadratic_a1(x.size, x.ctypes.data, w.ctypes.data, out.ctypes.data)
+    assert_close(out, wantw)
+    out[:] = 0
+    clib.TV1D_denoise_tautstring(x.ctypes.data, out.ctypes.data, x.size, 0.4)
+    assert_close(out, want)
+    out[:] = 0
+    clib.dp(x.size, x.ctypes.data, 0.4, out.ctypes.data)
+    assert_close(out, want)
+    # trivial cases, as the reference handles them before any work
+    one, o1 = np.array([5.0]), np.array([-1.0])
+    clib.SolveTVConvexQuadratic_a1_nw(1, one.ctypes.data, 0.4, o1.ctypes.data)
+    assert o1[0] == 5.0
+    o1[:] = -1
+    clib.dp(1, one.ctypes.data, 0.4, o1.ctypes.data)
+    assert o1[0] == 5.0
+    out[:] = 0
+    clib.dp(x.size, x.ctypes.data, 0.0, out.ctypes.data)
+    assert (out == x).all()
+    untouched = np.full(4, 9.0)
+    clib.dp(0, x.ctypes.data, 0.4, untouched.ctypes.data)
+    clib.TV1D_denoise_tautstring(x.ctypes.data, untouched.ctypes.data, 0, 0.4)
+    clib.SolveTVConvexQuadratic_a1(0, x.ctypes.data, w.ctypes.data, untouched.ctypes.data)
+    assert (untouched == 9.0).all()
+    # TV-Lp schemes: p in {1, 2} through the exact solvers, general p -> RC_ERROR
+    for fn in (clib.GP_TVp, clib.OGP_TVp, clib.FISTA_TVp, clib.FW_TVp, clib.GPFW_TVp):
+        out[:] = 0; info[:] = -1
+        assert fn(x.ctypes.data, 0.4, out.ctypes.data, info.ctypes.data, x.size, 1.0, None) == 1 and info[2] == 0
+        assert_close(out, want)
+        info[:] = -1
+        assert fn(x.ctypes.data, 0.4, out.ctypes.data, info.ctypes.data, x.size, 1.5, None) == 0 and info[2] == 3
+    out[:] = 0; info[:] = -1
+    assert clib.GPFW_TVp(x.ctypes.data, 0.4, out.ctypes.data, info.ctypes.data, x.size, 2.0, None) == 1 and info[2] == 0
+    assert_close(out, oracle.tv(x, 0.4, 2)[0], tol=1e-10)
