@@ -21,6 +21,8 @@
 // slab_transpose), like launch_row_along in sweep.hip.  Exact for every input: no links, no repair kernel, no counters.
 #include "pin.hpp"
 
+#include <memory>
+
 #include "pin_device.hpp"
 #include "transposed.hpp"
 
@@ -31,7 +33,7 @@ namespace {
 using namespace pin;
 
 template <int OP, bool WEIGHTED, int P, int G>
-__global__ __launch_bounds__(kPinThreads) void sweep_pin_kernel(SweepArgs p, FibreGeom g, int *pieces) {
+__global__ __launch_bounds__(kPinThreads) void sweep_pin_kernel(SweepArgs p, FibreGeom g, int *pieces, int *gaveup) {
     using Geo = PinGeom<P, G, WEIGHTED>;
     using Sh = PinShared<P, G, WEIGHTED>;
     constexpr int SLOTS = Geo::SLOTS;
@@ -111,14 +113,23 @@ __global__ __launch_bounds__(kPinThreads) void sweep_pin_kernel(SweepArgs p, Fib
         for (int k = 0; k < (Sh::kCached ? P : 1); k++) sh.cached[k] = own[k];
     }
     ln.init(n, t, sh);
+    bool capped = false;
 #pragma unroll 1
-    for (;;) {
+    for (int level = 0;; level++) {
         ln.scan(sh);
         group_sync<G>();
         ln.claim(sh);
         group_sync<G>();
         const bool gained = ln.update(sh);
         if (!group_any<G>(gained)) break;
+        if (level + 1 >= kPinMaxLevels) {   // (uniform over the group) periodic ties: this fibre goes to the walker
+            capped = true;
+            break;
+        }
+    }
+    if (capped) {
+        if (t == 0) gaveup[fibre] = 1;
+        return;   // nothing of this fibre was written; groups share no barrier after this point
     }
 
     // ---- values, in place (a lane reads nothing but its own part of the plane and what it cached of its neighbours') -----------------
@@ -148,6 +159,21 @@ __global__ __launch_bounds__(kPinThreads) void sweep_pin_kernel(SweepArgs p, Fib
     }
 }
 
+// per-fibre "gave up at the level cap" flags: zero between launches (launch_seq_gated clears what it consumes)
+struct GaveUp {
+    std::unique_ptr<Scratch> buf;
+    size_t count = 0;
+    int *get(long fibres, hipStream_t s) {
+        if ((size_t)fibres > count) {
+            buf.reset(new Scratch(sizeof(int) * (size_t)fibres));
+            count = (size_t)fibres;
+            PTV_HIP(hipMemsetAsync(buf->as<int>(), 0, sizeof(int) * count, s));
+        }
+        return buf->as<int>();
+    }
+};
+static thread_local GaveUp g_gaveup[kMaxDevices];
+
 template <int OP, bool WEIGHTED, int P, int G>
 void launch_geom(const SweepArgs &args, const FibreGeom &g, hipStream_t stream, int *pieces) {
     using Geo = PinGeom<P, G, WEIGHTED>;
@@ -161,8 +187,11 @@ void launch_geom(const SweepArgs &args, const FibreGeom &g, hipStream_t stream, 
         }
     }
     const long wgs = (g.count + Geo::NG - 1) / Geo::NG;
-    hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(kPinThreads), Geo::lds, stream, args, g, pieces);
+    int *gaveup = g_gaveup[current_device()].get(g.count, stream);
+    hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(kPinThreads), Geo::lds, stream, args, g, pieces, gaveup);
     PTV_HIP(hipGetLastError());
+    // fibres that hit the level cap (none on anything but periodic data: the kernel returns at once)
+    launch_seq_gated((OpId)OP, WEIGHTED, args, g, stream, gaveup);
 }
 
 // contiguous fibres: pick the group geometry from the fibre length
@@ -188,15 +217,12 @@ void launch_op(const SweepArgs &args, const FibreGeom &g, hipStream_t stream, in
 
 }  // namespace
 
-void launch_pin(OpId op, bool weighted, const SweepArgs &args, const FibreGeom &g, hipStream_t stream, int *pieces) {
+bool launch_pin(OpId op, bool weighted, const SweepArgs &args, const FibreGeom &g, hipStream_t stream, int *pieces) {
     if (!pin_supports(op, weighted, g, args.lam)) {
         set_error("launch_pin: sweep not supported (len %d, inc %ld, weighted %d)", g.len, g.inc, (int)weighted);
         throw HipFailure{hipErrorInvalidValue};
     }
-    if (pin_is_long(weighted, g)) {
-        launch_pin_long(op, weighted, args, g, stream, pieces);
-        return;
-    }
+    if (pin_is_long(weighted, g)) return launch_pin_long(op, weighted, args, g, stream, pieces);
 #define PTV_PIN_CASE(ID)                                         \
     case ID:                                                     \
         if (weighted) launch_op<ID, true>(args, g, stream, pieces);      \
@@ -221,6 +247,7 @@ void launch_pin(OpId op, bool weighted, const SweepArgs &args, const FibreGeom &
 #undef PTV_PIN_CASE
 #undef PTV_PIN_CASE_U
 #undef PTV_PIN_CASE_W
+    return true;
 }
 
 }  // namespace ptv

@@ -41,6 +41,7 @@ using LongLane = PinLane<kLongP, LongKey>;
 struct LongCtl {             // zeroed before every launch
     unsigned barrier;        // arrivals, never reset: the k-th barrier waits for k * gridDim.x
     unsigned gained[3];      // "some lane gained a pin at level l": word l % 3
+    unsigned capped;         // the level cap was hit: nothing was written
 };
 
 struct LongArgs {
@@ -226,6 +227,10 @@ __global__ __launch_bounds__(kPinThreads) void sweep_pin_long_kernel(SweepArgs p
             __hip_atomic_fetch_or(&a.ctl->gained[level % 3], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         grid_sync(a.ctl, epoch);
         if (load_u32(&a.ctl->gained[level % 3]) == 0u) break;
+        if (level + 1 >= (unsigned)kPinMaxLevels) {   // (uniform over the grid) periodic ties: the caller takes another rung
+            if (blockIdx.x == 0 && tid == 0) __hip_atomic_store(&a.ctl->capped, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
     }
 
     // ---- values, in place; then out through the op -------------------------------------------------------------------------------------
@@ -263,8 +268,10 @@ int resident_workgroups(K kern, size_t lds) {
     return per_cu * prop.multiProcessorCount;
 }
 
+// Returns false when nothing was written: the instantiation does not fit the device at once after all (pin_supports()
+// asked about the plain-prox instantiation; another op may hold fewer workgroups per unit), or the level cap was hit.
 template <int OP, bool WEIGHTED>
-void launch_long(const SweepArgs &args, const FibreGeom &g, hipStream_t stream, int *pieces) {
+bool launch_long(const SweepArgs &args, const FibreGeom &g, hipStream_t stream, int *pieces) {
     using Geo = PinGeom<kLongP, kPinThreads, WEIGHTED>;
     constexpr size_t lds = Geo::plane_bytes * (WEIGHTED ? 2 : 1) + 64;
     auto kern = sweep_pin_long_kernel<OP, WEIGHTED>;
@@ -277,9 +284,10 @@ void launch_long(const SweepArgs &args, const FibreGeom &g, hipStream_t stream, 
     }
     const int bpf = (g.len + kLongBlock - 1) / kLongBlock;
     const long wgs = (long)bpf * g.count;
-    if (wgs > cap) {   // (pin_supports() keeps to what an MI355X holds; anything else is a caller's error)
-        set_error("launch_pin_long: %ld workgroups do not fit on the device at once (%d)", wgs, cap);
-        throw HipFailure{hipErrorInvalidValue};
+    if (wgs > cap) {
+        if (options().verbose)
+            fprintf(stderr, "[proxtv_amd] pinlong: %ld workgroups do not fit this device at once (%d): next rung\n", wgs, cap);
+        return false;
     }
     const int slots = bpf * kPinThreads + 1;
     Scratch S(sizeof(double) * (size_t)g.count * (size_t)(g.len + 1));
@@ -293,28 +301,55 @@ void launch_long(const SweepArgs &args, const FibreGeom &g, hipStream_t stream, 
     FibreGeom ga = g;
     void *params[] = {&pa, &ga, &la, &pieces};
     PTV_HIP(hipLaunchCooperativeKernel(reinterpret_cast<const void *>(kern), dim3((unsigned)wgs), dim3(kPinThreads), params, (unsigned)lds, stream));
+    // Did it finish?  One word back per launch: these are sweeps of a few very long fibres (a millisecond each), and the
+    // scratch above must outlive the kernel anyway.
+    unsigned capped = 0;
+    PTV_HIP(hipMemcpyAsync(&capped, &ctl.as<LongCtl>()->capped, sizeof(unsigned), hipMemcpyDeviceToHost, stream));
+    PTV_HIP(hipStreamSynchronize(stream));
+    if (capped && options().verbose)
+        fprintf(stderr, "[proxtv_amd] pinlong: level cap (%d) hit on fibres of %d samples: next rung\n", kPinMaxLevels, g.len);
+    return capped == 0;
 }
 
 template <int OP, bool WEIGHTED>
-void launch_long_op(const SweepArgs &args, const FibreGeom &g, hipStream_t stream, int *pieces) {
-    if (g.inc == 1) {
-        launch_long<OP, WEIGHTED>(args, g, stream, pieces);
-        return;
-    }
+bool launch_long_op(const SweepArgs &args, const FibreGeom &g, hipStream_t stream, int *pieces) {
+    if (g.inc == 1) return launch_long<OP, WEIGHTED>(args, g, stream, pieces);
     TransposedOperands tr(args, Op<OP>::IN_MASK, Op<OP>::OUT_MASK, g, stream);
-    launch_long<OP, WEIGHTED>(tr.args(), tr.geom(), stream, pieces);
+    if (!launch_long<OP, WEIGHTED>(tr.args(), tr.geom(), stream, pieces)) return false;
     tr.finish();
+    return true;
 }
 
 }  // namespace
 
-void launch_pin_long(OpId op, bool weighted, const SweepArgs &args, const FibreGeom &g, hipStream_t stream, int *pieces) {
-#define PTV_LONG_CASE(ID)                                                        \
-    case ID:                                                                     \
-        if (weighted) launch_long_op<ID, true>(args, g, stream, pieces);         \
-        else          launch_long_op<ID, false>(args, g, stream, pieces);        \
-        break;
-#define PTV_LONG_CASE_U(ID) case ID: launch_long_op<ID, false>(args, g, stream, pieces); break;
+// What the current device holds of the grid-wide kernel (the plain-prox instantiation: the others are checked at launch).
+long pin_long_capacity(bool weighted) {
+    static thread_local long cap[kMaxDevices][2] = {};
+    long &c = cap[current_device()][weighted ? 1 : 0];
+    if (c == 0) {
+        if (weighted) {
+            using Geo = PinGeom<kLongP, kPinThreads, true>;
+            constexpr size_t lds = Geo::plane_bytes * 2 + 64;
+            auto kern = sweep_pin_long_kernel<OP_PROX, true>;
+            if (lds > 64 * 1024)
+                PTV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            c = resident_workgroups(kern, lds);
+        } else {
+            using Geo = PinGeom<kLongP, kPinThreads, false>;
+            constexpr size_t lds = Geo::plane_bytes + 64;
+            c = resident_workgroups(sweep_pin_long_kernel<OP_PROX, false>, lds);
+        }
+        if (c <= 0) c = -1;   // (asked and answered: nothing fits)
+    }
+    return c > 0 ? c : 0;
+}
+
+bool launch_pin_long(OpId op, bool weighted, const SweepArgs &args, const FibreGeom &g, hipStream_t stream, int *pieces) {
+#define PTV_LONG_CASE(ID)                                                               \
+    case ID:                                                                            \
+        return weighted ? launch_long_op<ID, true>(args, g, stream, pieces)             \
+                        : launch_long_op<ID, false>(args, g, stream, pieces);
+#define PTV_LONG_CASE_U(ID) case ID: return launch_long_op<ID, false>(args, g, stream, pieces);
     switch (op) {
         PTV_LONG_CASE(OP_PROX)
         PTV_LONG_CASE(OP_DR_COL)

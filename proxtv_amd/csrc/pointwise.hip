@@ -222,6 +222,7 @@ void sum_to(const double *a, long n, long segments, double *partials, double *ou
 }
 
 void dr_fill(double *t, long n, long segments, const double *sums, double sign, hipStream_t s) {
+    if (transpose_cache().active) transpose_cache().forget(t);   // a writer inside a TransposeScope: copies of t are stale
     hipLaunchKernelGGL(dr_fill_kernel, dim3(grid_for(n, 1024), (unsigned)segments), dim3(kThreads), 0, s, t, n, sums, sign);
     PTV_HIP(hipGetLastError());
 }
@@ -264,6 +265,7 @@ __global__ void lincomb_kernel(double *out, const double *a, double ca, const do
 
 void lincomb(double *out, const double *a, double ca, const double *b, double cb, const double *c, double cc,
              const double *d, double cd, long n, hipStream_t s) {
+    if (transpose_cache().active) transpose_cache().forget(out);
     if (n <= 0) return;
     const long blocks = (n + 255) / 256;
     hipLaunchKernelGGL(lincomb_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, s, out, a, ca, b, cb, c, cc, d,
@@ -339,28 +341,25 @@ void slab_transpose(const double *in, double *out, long rows, long cols, long sl
 static thread_local TransposeCache g_transposed[kMaxDevices];
 TransposeCache &transpose_cache() { return g_transposed[current_device()]; }
 
-Scratch *TransposeCache::find(const double *src) {
+Scratch *TransposeCache::find(const double *src, const Shape &shape) {
     for (auto &e : entries)
-        if (e.src == src) return e.copy.get();
+        if (e.src == src && e.shape == shape) return e.copy.get();
     return nullptr;
 }
 
-void TransposeCache::remember(const double *src, std::unique_ptr<Scratch> copy) {
+void TransposeCache::remember(const double *src, const Shape &shape, std::unique_ptr<Scratch> copy) {
     for (auto &e : entries)
-        if (e.src == src) {
+        if (e.src == src && e.shape == shape) {
             e.copy = std::move(copy);
             return;
         }
-    entries.push_back(Entry{src, std::move(copy)});
+    entries.push_back(Entry{src, shape, std::move(copy)});
 }
 
 void TransposeCache::forget(const double *p) {
     if (!p) return;
-    for (size_t k = 0; k < entries.size(); k++)
-        if (entries[k].src == p) {
-            entries.erase(entries.begin() + (long)k);
-            return;
-        }
+    for (size_t k = entries.size(); k-- > 0;)
+        if (entries[k].src == p) entries.erase(entries.begin() + (long)k);
 }
 
 TransposedOperands::TransposedOperands(const SweepArgs &args, unsigned in_mask, unsigned out_mask, const FibreGeom &g, hipStream_t s)
@@ -377,11 +376,11 @@ TransposedOperands::TransposedOperands(const SweepArgs &args, unsigned in_mask, 
 const double *TransposedOperands::input(const double *src, std::unique_ptr<Scratch> &own, int len) {
     TransposeCache &cache = transpose_cache();
     if (cache.active)
-        if (Scratch *c = cache.find(src)) return c->d();
+        if (Scratch *c = cache.find(src, shape(len))) return c->d();
     std::unique_ptr<Scratch> copy(new Scratch(sizeof(double) * (size_t)g_.count * (size_t)len));
     slab_transpose(src, copy->d(), g_.inc, len, slabs_, s_);
     const double *p = copy->d();
-    if (cache.active) cache.remember(src, std::move(copy));
+    if (cache.active) cache.remember(src, shape(len), std::move(copy));
     else own = std::move(copy);
     return p;
 }
@@ -390,11 +389,11 @@ void TransposedOperands::finish() {
     TransposeCache &cache = transpose_cache();
     if (out_mask_ & 1u) {
         slab_transpose(o0_->d(), orig_.o0, g_.len, g_.inc, slabs_, s_);
-        if (cache.active) cache.remember(orig_.o0, std::move(o0_));   // (what was just written, in the form the next strided sweep wants)
+        if (cache.active) cache.remember(orig_.o0, shape(g_.len), std::move(o0_));   // (what was just written, in the form the next strided sweep wants)
     }
     if (out_mask_ & 2u) {
         slab_transpose(o1_->d(), orig_.o1, g_.len, g_.inc, slabs_, s_);
-        if (cache.active) cache.remember(orig_.o1, std::move(o1_));
+        if (cache.active) cache.remember(orig_.o1, shape(g_.len), std::move(o1_));
     }
 }
 

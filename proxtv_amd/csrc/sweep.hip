@@ -158,11 +158,17 @@ __device__ __forceinline__ void solve_fibre_seq(const SweepArgs &p, const FibreG
     }
 }
 
+// fibre_gate (may be null): only the fibres j with fibre_gate[j] != 0 are walked, and their flags are cleared -- the
+// mop-up of a kernel that gave some fibres up (pin.hip's level cap).
 template <int OP, bool WEIGHTED, bool PIPELINED>
-__global__ __launch_bounds__(64) void sweep_seq_kernel(SweepArgs p, FibreGeom g) {
+__global__ __launch_bounds__(64) void sweep_seq_kernel(SweepArgs p, FibreGeom g, int *fibre_gate) {
     const long j = (long)blockIdx.x * 64 + threadIdx.x;
     if (j >= g.count || g.len <= 0) return;
     if (p.gate && *p.gate == 0) return;
+    if (fibre_gate) {
+        if (fibre_gate[j] == 0) return;
+        fibre_gate[j] = 0;
+    }
     solve_fibre_seq<OP, WEIGHTED, PIPELINED>(p, g, j);
 }
 
@@ -1147,11 +1153,11 @@ __global__ __launch_bounds__(64) void sweep_repair_kernel(SweepArgs p, FibreGeom
 
 // ---- host side ---------------------------------------------------------------------------------------------------------
 template <int OP, bool WEIGHTED>
-void launch_seq(const SweepArgs &args, const FibreGeom &g, hipStream_t stream, bool long_pieces) {
+void launch_seq(const SweepArgs &args, const FibreGeom &g, hipStream_t stream, bool long_pieces, int *fibre_gate = nullptr) {
     const unsigned blocks = (unsigned)((g.count + 63) / 64);
     if (blocks == 0) return;
-    if (long_pieces) hipLaunchKernelGGL((sweep_seq_kernel<OP, WEIGHTED, true>), dim3(blocks), dim3(64), 0, stream, args, g);
-    else             hipLaunchKernelGGL((sweep_seq_kernel<OP, WEIGHTED, false>), dim3(blocks), dim3(64), 0, stream, args, g);
+    if (long_pieces) hipLaunchKernelGGL((sweep_seq_kernel<OP, WEIGHTED, true>), dim3(blocks), dim3(64), 0, stream, args, g, fibre_gate);
+    else             hipLaunchKernelGGL((sweep_seq_kernel<OP, WEIGHTED, false>), dim3(blocks), dim3(64), 0, stream, args, g, fibre_gate);
     PTV_HIP(hipGetLastError());
 }
 
@@ -1461,17 +1467,20 @@ void launch_chunk(const SweepArgs &args, const FibreGeom &g, hipStream_t stream,
     // Strided sweeps: 0 / 1 = the 64-fibre tile (1: robust instantiation), 2 = transposed copies + the along-fibre kernel
     // with 64-sample zones (or the tile with 64-sample zones), 3 / 4 / 5 as above.
     const bool along_ok = options().along && g.len >= options().along_min_len;
-    const bool pinning = (mode == 3 && pin_ok);
-    if (mode >= kModeSeq)  launch_seq<OP, WEIGHTED>(args, g, stream, true);
-    else if (pinning) {
+    bool pinned_done = false;
+    if (mode == 3 && pin_ok) {
         int *pieces = nullptr;
         if (measure) {   // the policy's hint from this rung: pieces per sample (numerator and denominator of evaluate())
             st.ensure(g.count, 1, stream);
             pieces = st.failcount + 2 * fam + 1;
-            pl.chunks_done += (long)g.len * g.count;
         }
-        launch_pin((OpId)OP, WEIGHTED, args, g, stream, pieces);
+        // false: the grid-wide variant wrote nothing (its instantiation does not fit this device at once after all, or it
+        // hit the level cap on periodic data) -- the global-memory chunks below take the sweep
+        pinned_done = launch_pin((OpId)OP, WEIGHTED, args, g, stream, pieces);
+        if (pinned_done && measure) pl.chunks_done += (long)g.len * g.count;
     }
+    if (pinned_done) {}
+    else if (mode >= kModeSeq)  launch_seq<OP, WEIGHTED>(args, g, stream, true);
     else if (mode == 3)    launch_gchunk<OP, WEIGHTED>(args, g, 64, 256, stream, fam);
     else if (mode == 4)    launch_gchunk<OP, WEIGHTED>(args, g, 256, 1024, stream, fam);
     else if (TRANSPOSED && along_ok) {
@@ -1564,6 +1573,33 @@ int chunk_stats_mode() {
     for (int f = 0; f < FAM_COUNT; f++)   // (families the last solve did not use keep whatever an earlier workload left them)
         if (chunk_state().pol[f].sweeps > 0 && chunk_state().pol[f].mode > m) m = chunk_state().pol[f].mode;
     return m;
+}
+
+void launch_seq_gated(OpId op, bool weighted, const SweepArgs &args, const FibreGeom &g, hipStream_t stream, int *flags) {
+#define PTV_GATED(ID)                                                                       \
+    case ID:                                                                                \
+        if (weighted) launch_seq<ID, true>(args, g, stream, true, flags);                   \
+        else          launch_seq<ID, false>(args, g, stream, true, flags);                  \
+        break;
+#define PTV_GATED_U(ID) case ID: launch_seq<ID, false>(args, g, stream, true, flags); break;
+#define PTV_GATED_W(ID) case ID: launch_seq<ID, true>(args, g, stream, true, flags); break;
+    switch (op) {
+        PTV_GATED(OP_PROX)
+        PTV_GATED(OP_DR_COL)
+        PTV_GATED(OP_DR_COL_FINAL)
+        PTV_GATED(OP_DR_ROW)
+        PTV_GATED_U(OP_DR_ROW_FINAL)
+        PTV_GATED_W(OP_DRW_ROW_FINAL)
+        PTV_GATED_U(OP_PD2_A)
+        PTV_GATED_U(OP_PD2_B)
+        PTV_GATED_U(OP_YANG)
+        default:
+            set_error("launch_seq_gated: unknown op %d", (int)op);
+            throw HipFailure{hipErrorInvalidValue};
+    }
+#undef PTV_GATED
+#undef PTV_GATED_U
+#undef PTV_GATED_W
 }
 
 void launch_sweep(OpId op, bool weighted, const SweepArgs &args, const FibreGeom &g, hipStream_t stream, int fam,

@@ -18,30 +18,43 @@
 namespace ptv {
 
 struct TransposeCache {
+    // A copy is the transposition of `src` under ONE slab geometry: it answers only a sweep that asks for the same
+    // (stride, fibre length, slab count) -- another dimension of the same array is another copy.
+    struct Shape {
+        long inc = 0, slabs = 0;
+        int len = 0;
+        bool operator==(const Shape &o) const { return inc == o.inc && slabs == o.slabs && len == o.len; }
+    };
     struct Entry {
         const double *src = nullptr;
+        Shape shape;
         std::unique_ptr<Scratch> copy;
     };
     bool active = false;
     std::vector<Entry> entries;
-    Scratch *find(const double *src);
-    void remember(const double *src, std::unique_ptr<Scratch> copy);
-    void forget(const double *p);
+    Scratch *find(const double *src, const Shape &shape);
+    void remember(const double *src, const Shape &shape, std::unique_ptr<Scratch> copy);
+    void forget(const double *p);   // every copy of p, whatever its shape: p is about to be written
     void clear() { entries.clear(); }
 };
 TransposeCache &transpose_cache();   // per host thread and per device, like the scratch pool
 
+// Contract of a scope: between its construction and destruction every array a strided sweep reads is written by
+// launch_sweep() only (which forgets the copies of what it writes) -- or the writer calls transpose_cache().forget().
 struct TransposeScope {
-    TransposeScope() {
-        transpose_cache().clear();
-        transpose_cache().active = true;
+    TransposeScope() : cache_(transpose_cache()) {
+        cache_.clear();
+        cache_.active = true;
     }
-    ~TransposeScope() {
-        transpose_cache().clear();
-        transpose_cache().active = false;
+    ~TransposeScope() {   // (holds the cache it opened: nothing here can throw)
+        cache_.clear();
+        cache_.active = false;
     }
     TransposeScope(const TransposeScope &) = delete;
     TransposeScope &operator=(const TransposeScope &) = delete;
+
+  private:
+    TransposeCache &cache_;
 };
 
 class TransposedOperands {
@@ -55,6 +68,7 @@ class TransposedOperands {
 
   private:
     const double *input(const double *src, std::unique_ptr<Scratch> &own, int len);
+    TransposeCache::Shape shape(int len) const { return TransposeCache::Shape{g_.inc, slabs_, len}; }
     SweepArgs orig_, t_;
     FibreGeom g_;
     hipStream_t s_;

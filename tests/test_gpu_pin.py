@@ -148,3 +148,55 @@ def test_fibres_longer_than_a_workgroup(ptv, oracle, rung3):
         got = device.tv1_fibres(xd, 7.0, dim).cpu().numpy()
         want = np.apply_along_axis(lambda v: oracle.tv1_hybrid(np.ascontiguousarray(v), 7.0), dim, arr)
         assert_close(got, want, tol=1e-11, what=f"3 fibres of 40000, dim {dim}")
+
+
+def _periodic_families(n):
+    k = np.arange(n)
+    yield "zigzag", np.where(k % 2 == 0, 1.0, -1.0)             # every sample a bend: n / 2 levels without a cap
+    yield "period3", np.array([0.0, 2.0, -1.0])[k % 3]
+    yield "sawtooth7", (k % 7).astype(float)
+    yield "stripes", np.repeat(np.where(np.arange(n // 4 + 1) % 2 == 0, 3.0, -3.0), 4)[:n]
+
+
+def test_level_cap_hands_periodic_fibres_to_the_walker(ptv, oracle, rung3):
+    """Data with exact periodic ties peel one knot per segment end and level; the kernels give such a fibre up after
+    kPinMaxLevels = 64 levels and a gated sequential sweep finishes it (pin.hpp).  Exact either way, and bounded."""
+    import time
+    for n in (1000, 4096, 16384):
+        for name, x in _periodic_families(n):
+            for lam in (0.1, 0.6):
+                t0 = time.perf_counter()
+                got = ptv.tv1_1d(x, lam)
+                dt = time.perf_counter() - t0
+                assert_close(got, oracle.tv1_hybrid(x, lam), tol=1e-11, what=f"{name} n={n} lam={lam}")
+                assert dt < 2.0, (name, n, lam, dt)
+
+
+def test_level_cap_batched_and_strided(oracle, rung3):
+    """A batch in which only some fibres are periodic (those alone go to the walker), both sweep directions, and the
+    fused DR operators through a whole solve on a striped image."""
+    import torch
+    import proxtv_amd
+    from proxtv_amd import device
+    rng = np.random.default_rng(98)
+    X = rng.standard_normal((2048, 96)) + np.repeat(rng.standard_normal((32, 96)), 64, axis=0)
+    X[:, ::5] = np.where(np.arange(2048) % 2 == 0, 1.0, -1.0)[:, None]
+    for arr, dim in ((X, 0), (np.ascontiguousarray(X.T), 1)):
+        xd = device.to_colmajor(torch.from_numpy(arr).cuda())
+        got = device.tv1_fibres(xd, 0.3, dim).cpu().numpy()
+        want = np.apply_along_axis(lambda v: oracle.tv1_hybrid(np.ascontiguousarray(v), 0.3), dim, arr)
+        assert_close(got, want, tol=1e-11, what=f"mixed batch, dim {dim}")
+    S = np.where((np.arange(600)[:, None] + np.arange(500)[None, :]) % 2 == 0, 1.0, -1.0)   # checkerboard
+    assert_close(proxtv_amd.tv1_2d(S, 0.2), oracle.dr2(S, 0.2)[0], tol=1e-9, what="DR on a checkerboard, rung 3")
+
+
+def test_level_cap_long_fibre_takes_the_next_rung(ptv, oracle, rung3):
+    """Beyond one workgroup (pinlong.hip) a capped sweep writes nothing and the global-memory chunk kernels take it."""
+    import time
+    n = 70000
+    for name, x in _periodic_families(n):
+        t0 = time.perf_counter()
+        got = ptv.tv1_1d(x, 0.4)
+        dt = time.perf_counter() - t0
+        assert_close(got, oracle.tv1_hybrid(x, 0.4), tol=1e-11, what=f"{name} n={n}")
+        assert dt < 2.0, (name, dt)
