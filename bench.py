@@ -78,6 +78,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-c5", action="store_true", help="skip the config-#5 object (64 x 2048^2 per rank, ~13 GiB of HBM)")
+    ap.add_argument("--c5-images", type=int, default=64, help="images per rank of the config-#5 object (BASELINE: 64; the "
+                    "shared-GPU plumbing test uses fewer)")
     args = ap.parse_args()
 
     import torch
@@ -157,7 +159,7 @@ def main():
     # ---- BASELINE config #5: 64 independent 2048^2 images per rank, then the gather --------------------------------------
     c5 = None
     if not args.no_c5:
-        B5, S5 = 64, 2048
+        B5, S5 = args.c5_images, 2048
         g5 = torch.Generator(device="cuda").manual_seed(1000 + rank)
         x5 = torch.randn((B5, S5, S5), dtype=torch.float64, device="cuda", generator=g5).permute(2, 1, 0)   # column-major (M, N, B)
         y5 = device.colmajor_empty((S5, S5, B5))
@@ -168,14 +170,22 @@ def main():
         barrier()
         t_solve = time.perf_counter() - ts
         t_gather = None
-        if world > 1 and not shared:
+        if world > 1:
             send = y5.permute(2, 1, 0)                      # (B, N, M) contiguous view of the same bytes
+            if shared:
+                send = send.cpu()                           # plumbing dry run: the same gather over gloo on host copies
             bufs = [torch.empty_like(send) for _ in range(world)] if rank == 0 else None
             barrier()
             ts = time.perf_counter()
             dist.gather(send, gather_list=bufs, dst=0)
             barrier()
             t_gather = time.perf_counter() - ts
+            # did every rank's block arrive intact?  (checksum of each rank's first image, sent separately)
+            sums = [None] * world
+            dist.all_gather_object(sums, float(send[0].double().sum()))
+            gather_ok = None
+            if rank == 0:
+                gather_ok = all(abs(float(bufs[r][0].double().sum()) - sums[r]) <= 1e-9 * max(1.0, abs(sums[r])) for r in range(world))
             del bufs
         if world > 1:
             tt = torch.tensor([t_solve], dtype=torch.float64, device="cpu" if shared else "cuda")
@@ -185,13 +195,20 @@ def main():
               "images": B5 * world, "solve_ms": t_solve * 1e3, "value": world * B5 * S5 * S5 / t_solve / 1e6, "unit": "Mpixel/s",
               "gather_ms": None if t_gather is None else t_gather * 1e3,
               "gather_bytes": None if t_gather is None else (world - 1) * B5 * S5 * S5 * 8,
+              "gather_checked": None if t_gather is None else gather_ok,
               "ranks": world, "backend": (dist.get_backend() if world > 1 else None)}
         del x5, y5
 
+    # who took part: what the process group itself reports, and every rank's device (rank 0 prints them)
+    ranks_info = [{"rank": 0, "device": torch.cuda.get_device_name(torch.cuda.current_device()), "index": torch.cuda.current_device()}]
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cpu" if shared else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        mine = {"rank": rank, "device": torch.cuda.get_device_name(torch.cuda.current_device()), "index": torch.cuda.current_device()}
+        ranks_info = [None] * world
+        dist.all_gather_object(ranks_info, mine)
+        assert dist.get_world_size() == world
 
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
@@ -218,9 +235,15 @@ def main():
         traffic = None
         try:
             from proxtv_amd import build as _build
-            with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as f:
-                pmc = json.load(f)
-            if pmc.get("build_id") == _build.build_id():
+            import glob
+            pmc = {}
+            for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):   # newest round first
+                with open(path) as f:
+                    cand = json.load(f)
+                if cand.get("build_id") == _build.build_id():
+                    pmc = cand
+                    break
+            if pmc:
                 label = ["column sweep (DR_COL)", "row sweep (DR_ROW)"][dom]
                 traffic = pmc["kernels"][label]["hbm_total"]
         except (OSError, KeyError, ValueError):
@@ -232,7 +255,9 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "tv1_2d (DR2_TV, 35 iterations) on one 4096x4096 float64 N(0,1) image per GPU per step, "
                                    "lambda=0.1, input and output resident in HBM", "images_per_step": world,
-                       "parallelism": f"independent images, {world} rank(s), no data-path collective"},
+                       "parallelism": f"independent images, {world} rank(s), no data-path collective",
+                       "process_group": {"world_size": dist.get_world_size() if world > 1 else 1,
+                                         "backend": dist.get_backend() if world > 1 else None, "ranks": ranks_info}},
             "roofline": {"bound": "hbm", "kernel": ["column sweep (DR_COL)", "row sweep (DR_ROW, fused reflections+combiner)"][dom],
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "avg_launch_ms": avg_ms, "launches": fam_n[dom],

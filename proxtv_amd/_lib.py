@@ -8,8 +8,11 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# PROXTV_LIB: an alternative build of the library for A/B measurements (tools/); never set in production
-LIB_PATH = os.environ.get("PROXTV_LIB") or os.path.join(_HERE, "libproxtv_amd.so")
+LIB_PATH = os.path.join(_HERE, "libproxtv_amd.so")
+# A/B measurements (tools/ab*.sh) load an alternative build of the library.  The override is honoured only together with
+# an explicit debug switch, so that a stray PROXTV_LIB in a production environment cannot redirect the load.
+if os.environ.get("PROXTV_DEBUG_ALT_LIB") == "1" and os.environ.get("PROXTV_LIB"):
+    LIB_PATH = os.environ["PROXTV_LIB"]
 
 _dp = C.c_void_p      # double* (host or device, per entry point)
 _ip = C.c_void_p      # int*

@@ -482,6 +482,7 @@ int proxtv_set_option(const char *key, int value) {
     else if (!strcmp(key, "chunk_min_len")) slot = &o.chunk_min_len;
     else if (!strcmp(key, "rounds")) slot = &o.rounds;
     else if (!strcmp(key, "chunk_mode")) slot = &o.chunk_mode;
+    else if (!strcmp(key, "deterministic")) slot = &o.deterministic;
     if (!slot) return -1;
     const int old = *slot;
     *slot = value;

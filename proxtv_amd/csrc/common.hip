@@ -30,6 +30,7 @@ Options &options() {
         if (const char *e = getenv("PROXTV_PIN")) v.pin = atoi(e);
         if (const char *e = getenv("PROXTV_ALONG_MIN_LEN")) v.along_min_len = atoi(e);
         if (const char *e = getenv("PROXTV_CHUNK_MODE")) v.chunk_mode = atoi(e);
+        if (const char *e = getenv("PROXTV_DETERMINISTIC")) v.deterministic = atoi(e);
         return v;
     }();
     return o;

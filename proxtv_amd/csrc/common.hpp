@@ -38,7 +38,9 @@ struct HipFailure {
 struct Options {
     int chunk = 16;     // non-zero: speculative-chunk kernels (16-sample chunks); 0 = sequential lane-per-fibre kernels only
     int warmup = 16;    // (reserved) warm-up zone in samples; the chunk kernels are built for kWarm = 16
-    int chunk_mode = -1;    // -1 = adaptive (see ChunkScratch); 0..5 pin the chunk geometry policy
+    int chunk_mode = -1;    // -1 = chosen per sweep (see `deterministic`); 0..5 pin the chunk geometry policy
+    int deterministic = 1;  // 1: the rung of a sweep is a function of (input statistics, lambda) only -- reproducible to the last
+                            // bit; 0: hill climb on measured sweep times, seeded by the same statistics (policy.hpp)
     int blocks_per_wg = 0;  // blocks pipelined per workgroup in the chunk kernel; 0 = pick from the problem size
     int rounds = 0;         // second-chance rounds of geometry mode 1 (0 = the built-in default)
     int along = 1;            // dimension-0 sweeps: chunks along the fibre (sweep_along_kernel); 0 = the transposed 64-fibre tile

@@ -337,6 +337,54 @@ void slab_transpose(const double *in, double *out, long rows, long cols, long sl
     PTV_HIP(hipGetLastError());
 }
 
+// ---- edge statistics (the geometry policy's seed) -------------------------------------------------------------------------------
+namespace {
+constexpr int kProbeRuns = 4096;        // runs of 64 consecutive elements sampled, at most
+constexpr int kProbeRunsPerBlock = 16;
+
+__global__ __launch_bounds__(kThreads) void edge_hist_kernel(const double *y, const double *w, long n, long inc, int len, long runs,
+                                                             long run_stride, unsigned *hist) {
+    __shared__ unsigned bins[kProbeBins + 1];
+    for (int b = threadIdx.x; b <= kProbeBins; b += kThreads) bins[b] = 0u;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int k = wv; k < kProbeRunsPerBlock; k += kThreads / 64) {
+        const long r = (long)blockIdx.x * kProbeRunsPerBlock + k;
+        if (r >= runs) break;
+        const long e = r * run_stride + lane;
+        if (e >= n) continue;
+        const long q = e / inc;
+        const int pos = (int)(q % len);
+        if (pos >= len - 1) continue;
+        double v = fabs(y[e + inc] - y[e]);
+        if (w) {
+            const double we = w[(q / len) * inc * (len - 1) + (long)pos * inc + e % inc];
+            v = we > 0.0 ? v / we : (v > 0.0 ? 1e300 : 0.0);
+        }
+        long key = (long)(((unsigned long long)__double_as_longlong(v) & 0x7fffffffffffffffull) >> 50) - ((long)kProbeLowExp << 2);
+        key = key < 0 ? 0 : (key >= kProbeBins ? kProbeBins - 1 : key);
+        atomicAdd(&bins[key], 1u);
+        atomicAdd(&bins[kProbeBins], 1u);
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b <= kProbeBins; b += kThreads)
+        if (bins[b]) atomicAdd(&hist[b], bins[b]);
+}
+}  // namespace
+
+void edge_histogram(const double *y, const double *w, long n, long inc, int len, unsigned *hist, hipStream_t s) {
+    if (n <= 0 || len < 2) return;
+    long runs = (n + 63) / 64;
+    long stride = 64;
+    if (runs > kProbeRuns) {
+        stride = (n / kProbeRuns) & ~63L;
+        runs = kProbeRuns;
+    }
+    const unsigned blocks = (unsigned)((runs + kProbeRunsPerBlock - 1) / kProbeRunsPerBlock);
+    hipLaunchKernelGGL(edge_hist_kernel, dim3(blocks), dim3(kThreads), 0, s, y, w, n, inc, len, runs, stride, hist);
+    PTV_HIP(hipGetLastError());
+}
+
 // ---- transposed operands (transposed.hpp) -----------------------------------------------------------------------------------
 static thread_local TransposeCache g_transposed[kMaxDevices];
 TransposeCache &transpose_cache() { return g_transposed[current_device()]; }

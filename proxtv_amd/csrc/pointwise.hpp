@@ -36,6 +36,20 @@ void lincomb(double *out, const double *a, double ca, const double *b, double cb
 // Sweeps along a strided dimension use it to run as dimension-0 sweeps on transposed copies: fibre j = slab * inc + off
 // sits at j * len after the transposition of every (inc x len) slab.
 void slab_transpose(const double *in, double *out, long rows, long cols, long slabs, hipStream_t s);
+// Edge statistics of an array along one dimension -- what the geometry policy (sweep.hip) is seeded with: a histogram of
+// |y[e + inc] - y[e]| (weighted: divided by the edge's penalty) over a fixed sample of edges, kProbeBins bins of a quarter
+// octave each (bin = biased exponent and two mantissa bits of the value, clamped to the window that starts at 2^-60),
+// hist[kProbeBins] = edges sampled.  Integer counts over a sample that depends on the shape only: the same array always
+// gives the same histogram.  `hist` (device, kProbeBins + 1 words) must be zero on entry.
+constexpr int kProbeBins = 512;
+constexpr int kProbeLowExp = 1023 - 60;
+inline int probe_bin(double v) {   // host side of the same binning
+    unsigned long long b;
+    memcpy(&b, &v, 8);
+    const long k = (long)((b & 0x7fffffffffffffffull) >> 50) - ((long)kProbeLowExp << 2);
+    return k < 0 ? 0 : (k >= kProbeBins ? kProbeBins - 1 : (int)k);
+}
+void edge_histogram(const double *y, const double *w, long n, long inc, int len, unsigned *hist, hipStream_t s);
 // dst = src, 8 bytes per lane (counter calibration only)
 void calib_copy(const double *src, double *dst, long n, hipStream_t s);
 // Yang X update (src/TV2Dopt.cpp:832-833 ; src/TVNDopt.cpp:729-730): X = (Y + sum U_k + rho sum Z_k) / (1 + D rho)

@@ -46,6 +46,17 @@ constexpr int kMonitorLag = 2;      // family sweeps between a steady-state samp
 constexpr int kHoldSolves = 2;      // solves during which a rejected direction is not tried again
 constexpr int kQuietSolves = 16;    // one-sweep solves between explorations
 
+// Seeding.  Before a solve the input's edges |y_k - y_{k-1}| are sampled along every dimension it sweeps (pointwise.hip's
+// edge_histogram); the fraction f of them above 4 lambda -- the edges at which the string is KNOWN to bend
+// (chunkcore.hpp) -- says which rung the data want: on unit noise f = 0.78 / 0.40 / 0.16 / 0.05 / 0.005 at lambda = 0.1 /
+// 0.3 / 0.5 / 0.7 / 1, where the pieces of a DR solve's iterates average 1.1 / 1.5 / 2.4 / 4 / 8 samples and a speculative
+// walk meets the true one within 6 / 10 / 15 / 30 / 70 samples.  With option "deterministic" (the default) the rung of a
+// sweep is this function of (input, lambda) and nothing else -- two runs on the same input take the same kernels and agree
+// to the last bit; without it the hill climb below starts from the seed instead of exploring from scratch.
+constexpr double kSeedNoisy = 0.45;   // f at or above: rung 0
+constexpr double kSeedMid = 0.02;     // f at or above: rung 1 ; below: rung 3
+inline int rung_from_certain_fraction(double f) { return f >= kSeedNoisy ? 0 : (f >= kSeedMid ? 1 : 3); }
+
 struct GeometryPolicy {
     int mode = 0;            // incumbent geometry
     double t_mode = 0.0;     // ms of its last measured sweep
@@ -88,17 +99,21 @@ struct GeometryPolicy {
 
     // A sweep of this shape is about to be launched.  Returns true when the workload differs from the last one's
     // (explore afresh -- unless shapes keep alternating inside one solve: 4-D+ tensors share a family).
-    bool workload(int len_, long count_, bool weighted_, bool pin_ = false) {
+    bool workload(int len_, long count_, bool weighted_, bool pin_ = false, int seed = -1) {
         const bool fresh = (len != len_ || count != count_ || weighted != weighted_ || pin != pin_) && changes++ < 4;
         if (fresh) {
             explore = true;
             trial = -1;
             hold_up = hold_down = quiet = 0;
             t_pin = 0.0;
-            // Unknown data: open on the pinning rung where there is one.  Its sweep costs the same whatever the pieces and
-            // it reports how long they are, so the way down is taken only when it is worth it -- whereas one sweep of
-            // 16-sample zones on long pieces costs a hundred sweeps' time in repair walks.
-            if (pin_ && changes <= 1) mode = 3;
+            // A new workload opens on the rung its input's edge statistics ask for (`seed`).  Unknown data (no statistics:
+            // tiny problems): on the pinning rung where there is one -- its sweep costs the same whatever the pieces and it
+            // reports how long they are, so the way down is taken only when it is worth it, whereas one sweep of 16-sample
+            // zones on long pieces costs a hundred sweeps' time in repair walks.
+            if (changes <= 1) {
+                if (seed >= 0) mode = seed;
+                else if (pin_) mode = 3;
+            }
         }
         len = len_;
         count = count_;

@@ -47,6 +47,7 @@ void tv1_fibres(const double *in, double *out, const int *ns, int nds, int dim, 
     a.o0 = out;
     a.lam = lam;
     a.w = weights;
+    if (in != out) policy_probe(in, &weights, ns, nds, &dim, 1, s);
     launch_sweep(OP_PROX, weights != nullptr, a, fibres_along(ns, nds, dim), s, fam_of_dim(dim), in != out);
 }
 
@@ -79,6 +80,11 @@ SolveInfo dr2(size_t M, size_t N, size_t B, const double *unary, double W1, doub
     Scratch partials(sizeof(double) * kReduceBlocks * B), sums(sizeof(double) * B);
     double *t = t0.d(), *tn = t1.d();
 
+    {   // seed of the geometry policy: the image's edge statistics along both directions (the iterates' are close to them)
+        const int both[2] = {0, 1};
+        const double *const wts[2] = {W1m, W2m};
+        policy_probe(unary, wts, ns, 3, both, 2, s);
+    }
     sum_to(unary, n1, (long)B, partials.d(), sums.d(), s);
     dr_fill(t, n1, (long)B, sums.d(), 1.0, s);
 
@@ -166,6 +172,10 @@ SolveInfo pd2(const double *y, const double *lambdas, const double *dims, double
     const int d1 = npen >= 2 ? (int)(dims[1] - 1) : 0;
     const FibreGeom g0 = fibres_along(ns, nds, d0);
     const FibreGeom g1 = fibres_along(ns, nds, d1);
+    {
+        const int swept[2] = {d0, d1};
+        policy_probe(y, nullptr, ns, nds, swept, npen >= 2 ? 2 : 1, s);
+    }
 
     double stop = DBL_MAX;
     int iters = 0;
@@ -245,6 +255,11 @@ SolveInfo pd_like(bool dr_variant, const double *y, const double *lambdas, const
     else            PTV_HIP(hipMemsetAsync(x, 0, bytes, s));          // x = 0               (:126-130)
     for (int i = 0; i < npen; i++) PTV_HIP(hipMemcpyAsync(z.pack.v[i], y, bytes, hipMemcpyDeviceToDevice, s));
 
+    {
+        int swept[kMaxTerms];
+        for (int i = 0; i < npen; i++) swept[i] = (int)(dims[i] - 1);
+        policy_probe(y, nullptr, ns, nds, swept, npen, s);
+    }
     double stop = dr_variant ? 0.0 : DBL_MAX;
     int iters = 0;
     while ((dr_variant || stop > STOP_PD) && iters < maxIters) {
@@ -303,6 +318,7 @@ SolveInfo yang(const int *ns, int nds, const int *order, const double *lambdas, 
         PTV_HIP(hipMemcpyAsync(Z.pack.v[k], Y, bytes, hipMemcpyDeviceToDevice, s));
     }
     PTV_HIP(hipMemcpyAsync(X, Y, bytes, hipMemcpyDeviceToDevice, s));
+    policy_probe(Y, nullptr, ns, nds, order, nds, s);
 
     for (int it = 1; it <= maxit; it++) {
         {
@@ -370,6 +386,10 @@ SolveInfo kolmogorov2(size_t M, size_t N, const double *Y, double lambda, double
     PTV_HIP(hipMemcpyAsync(xold, Y, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, s));
     PTV_HIP(hipMemcpyAsync(D.d(), Y, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, s));
     double theta = 1., tau = 1. / 2., sigma = 1., su = 1.;
+    {
+        const int both[2] = {0, 1};
+        policy_probe(Y, nullptr, ns, 2, both, 2, s);
+    }
 
     for (int it = 1; it <= maxit; it++) {
         const int *gate = flags.at(it - 1);

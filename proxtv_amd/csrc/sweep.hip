@@ -30,6 +30,7 @@
 // Which of these a sweep runs is the geometry policy's business (policy.hpp; plumbing in ChunkScratch below).
 #include "sweep.hpp"
 
+#include <cstddef>
 #include <memory>
 
 #include "chunkcore.hpp"
@@ -39,6 +40,7 @@
 #define PTV_TILE_UNROLL 1   // rows of the rebuild passes in flight together in the 64-fibre tile kernel (registers are scarce there)
 #endif
 #include "pin.hpp"
+#include "pointwise.hpp"
 #include "policy.hpp"
 #include "transposed.hpp"
 #include "walker.hpp"
@@ -1189,6 +1191,34 @@ struct ChunkScratch {
         int rewritten_seen = 0;
     } pol[FAM_COUNT];
 
+    // Edge statistics of this solve's input, one record per swept dimension (policy_probe): the seed of the policy.
+    struct Probe {
+        long inc = 0, count = 0;
+        int len = 0;
+        bool weighted = false;
+        unsigned hist[kProbeBins + 1] = {};
+    };
+    static constexpr int kMaxProbes = 8;
+    Probe probes[kMaxProbes];
+    int nprobes = 0;
+    std::unique_ptr<Scratch> probe_dev;   // kMaxProbes histograms
+    const Probe *find_probe(const FibreGeom &g, bool weighted) const {
+        for (int k = 0; k < nprobes; k++)
+            if (probes[k].inc == g.inc && probes[k].len == g.len && probes[k].count == g.count && probes[k].weighted == weighted)
+                return &probes[k];
+        return nullptr;
+    }
+    // rung the statistics ask for at this penalty (-1: this sweep's input was not sampled)
+    int seed(const FibreGeom &g, double lam, bool weighted) const {
+        const Probe *p = find_probe(g, weighted);
+        if (!p || p->hist[kProbeBins] == 0) return -1;
+        if (!weighted && !(lam > 0.0)) return 0;
+        const int b = probe_bin(weighted ? 4.0 : 4.0 * lam);
+        unsigned long above = p->hist[b] / 2;
+        for (int k = b + 1; k < kProbeBins; k++) above += p->hist[k];
+        return rung_from_certain_fraction((double)above / (double)p->hist[kProbeBins]);
+    }
+
     static constexpr int kSlots = 8, kCounters = 2 * FAM_COUNT;
     int *h_counts = nullptr;    // pinned: [slot][kCounters]
     hipEvent_t ev[kSlots] = {};
@@ -1444,7 +1474,8 @@ void launch_chunk(const SweepArgs &args, const FibreGeom &g, hipStream_t stream,
     ChunkScratch::Policy &pl = st.pol[fam];
     const bool pinned = options().chunk_mode >= 0;
     const bool pin_ok = options().pin && pin_supports((OpId)OP, WEIGHTED, g, args.lam);
-    if (pl.workload(g.len, g.count, WEIGHTED, pin_ok) && pl.meas) {   // a new workload: the measurement in flight is of the old one
+    const int seed = st.seed(g, args.lam, WEIGHTED);
+    if (pl.workload(g.len, g.count, WEIGHTED, pin_ok, seed) && pl.meas) {   // a new workload: the measurement in flight is of the old one
         double t, f;
         st.evaluate(fam, t, f);
     }
@@ -1453,6 +1484,15 @@ void launch_chunk(const SweepArgs &args, const FibreGeom &g, hipStream_t stream,
     if (pinned) {
         mode = pl.mode = options().chunk_mode < kModeSeq ? options().chunk_mode : kModeSeq;
         if (!pl.available(mode, true)) mode = pl.up(mode);
+    } else if (options().deterministic) {
+        // the rung is a function of the sweep's (sampled) input and penalty alone; unsampled inputs (tiny problems) take the
+        // rung whose cost and exactness do not depend on the data
+        mode = seed >= 0 ? seed : (pin_ok ? 3 : 0);
+        if (mode == 1 && WEIGHTED && !pl.available(1, true)) mode = pl.up(mode);
+        if (options().verbose && (pl.sweeps == 0 || mode != pl.mode))
+            fprintf(stderr, "[proxtv_amd] policy: family %d (len %d x %ld fibres, lambda %g): seed %d -> mode %d\n", fam, g.len, g.count,
+                    args.lam, seed, mode);
+        pl.mode = mode;
     } else {
         st.ensure_host();
         if (pl.meas && (pl.explore || pl.sweeps - pl.meas_sweep >= kMonitorLag)) st.settle(fam, true);
@@ -1547,6 +1587,36 @@ void chunk_stats_reset(hipStream_t s) {
         st.latest_chunks[f] = 0;
     }
     if (st.failcount) PTV_HIP(hipMemsetAsync(st.failcount, 0, sizeof(int) * ChunkScratch::kCounters, s));
+    st.nprobes = 0;
+}
+
+// Elements below which a dimension is not sampled: the rung hardly matters there, a stream synchronisation does.
+constexpr long kProbeMinElements = 4096;
+
+void policy_probe(const double *y, const double *const *weights, const int *ns, int nds, const int *dims, int ndims, hipStream_t s) {
+    if (options().chunk <= 0 || options().chunk_mode >= 0) return;   // sequential kernels only / a pinned rung: nothing to decide
+    ChunkScratch &st = chunk_state();
+    constexpr size_t kWords = kProbeBins + 1;
+    int first = st.nprobes;
+    for (int k = 0; k < ndims && st.nprobes < ChunkScratch::kMaxProbes; k++) {
+        const FibreGeom g = fibres_along(ns, nds, dims[k]);
+        const double *w = weights ? weights[k] : nullptr;
+        if (g.len < options().chunk_min_len || g.count < 1 || (long)g.len * g.count < kProbeMinElements) continue;
+        if (st.find_probe(g, w != nullptr)) continue;
+        if (!st.probe_dev) st.probe_dev.reset(new Scratch(sizeof(unsigned) * kWords * ChunkScratch::kMaxProbes));
+        unsigned *dev = st.probe_dev->as<unsigned>() + kWords * (size_t)st.nprobes;
+        if (st.nprobes == first) PTV_HIP(hipMemsetAsync(dev, 0, sizeof(unsigned) * kWords * (size_t)(ChunkScratch::kMaxProbes - first), s));
+        edge_histogram(y, w, (long)g.len * g.count, g.inc, g.len, dev, s);
+        ChunkScratch::Probe &p = st.probes[st.nprobes++];
+        p.inc = g.inc; p.len = g.len; p.count = g.count; p.weighted = (w != nullptr);
+    }
+    if (st.nprobes == first) return;
+    // one copy for all the dimensions sampled by this call (the records are contiguous on both sides)
+    static_assert(offsetof(ChunkScratch::Probe, hist) % sizeof(unsigned) == 0, "layout");
+    for (int k = first; k < st.nprobes; k++)
+        PTV_HIP(hipMemcpyAsync(st.probes[k].hist, st.probe_dev->as<unsigned>() + kWords * (size_t)k, sizeof(unsigned) * kWords,
+                               hipMemcpyDeviceToHost, s));
+    PTV_HIP(hipStreamSynchronize(s));
 }
 
 long chunk_stats_fixups(hipStream_t s) {
@@ -1561,7 +1631,7 @@ long chunk_stats_fixups(hipStream_t s) {
 
 // option "trace": copy the phase timestamps of the last chunk-kernel launch of this thread (8 words per workgroup) to the host
 long chunk_trace_fetch(unsigned long long *dst, long max_wgs, hipStream_t s) {
-    if (!chunk_state().trace) return 0;
+    if (!chunk_state().trace || max_wgs <= 0) return 0;
     const long n = (long)chunk_state().trace_wgs < max_wgs ? (long)chunk_state().trace_wgs : max_wgs;
     PTV_HIP(hipMemcpyAsync(dst, chunk_state().trace->as<unsigned long long>(), (size_t)n * 64, hipMemcpyDeviceToHost, s));
     PTV_HIP(hipStreamSynchronize(s));

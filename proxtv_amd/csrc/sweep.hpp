@@ -18,6 +18,12 @@ namespace ptv {
 void launch_sweep(OpId op, bool weighted, const SweepArgs &args, const FibreGeom &g, hipStream_t stream, int fam,
                   bool allow_chunked);
 
+// Seed of the geometry policy for the solve that is starting: samples the edge statistics of `y` along each of the `ndims`
+// dimensions `dims` (0-based; weights[k], when non-null, are the per-edge penalties of a weighted sweep along dims[k]) and
+// reads them back (one small copy + stream synchronisation per call).  Dimensions whose fibres never reach the chunked
+// kernels, or that this solve has already sampled, are skipped.  Call after chunk_stats_reset(), before the first sweep.
+void policy_probe(const double *y, const double *const *weights, const int *ns, int nds, const int *dims, int ndims, hipStream_t s);
+
 // Fibres that the chunked path had to re-solve sequentially (unproven chunk links) since the last reset, on this thread.
 void chunk_stats_reset(hipStream_t s);
 long chunk_stats_fixups(hipStream_t s);

@@ -61,9 +61,8 @@ def test_concurrent_host_threads_mixed_solvers(ptv, oracle):
 
 def test_device_outputs_may_alias_inputs(oracle):
     """out = x on every device entry point: the same result as the out-of-place call (the library solves through a
-    scratch array when it sees the overlap).  Compared to 1e-12: two calls may run different kernel geometries (the
-    adaptive policy explores across calls) -- the chunk kernels differ among themselves in the last ulps, the pinning
-    solver works on running sums and agrees with them to ~1e-14 of the data's scale."""
+    scratch array when it sees the overlap) -- bit for bit: which kernels a sweep runs is a function of its input
+    (option "deterministic", the default), so two calls on the same data take the same path."""
     import torch
     from proxtv_amd import device
     rng = np.random.default_rng(78)
@@ -76,7 +75,7 @@ def test_device_outputs_may_alias_inputs(oracle):
         ref[method] = y.cpu().numpy().copy()
         z, info2 = device.tv1_2d(xd, 0.25, method=method, out=xd, **kw)
         assert z.data_ptr() == xd.data_ptr()
-        np.testing.assert_allclose(z.cpu().numpy(), ref[method], rtol=0, atol=1e-12)
+        np.testing.assert_array_equal(z.cpu().numpy(), ref[method])
         assert info[0] == info2[0]
     assert_close(ref["dr"], oracle.dr2(X, 0.25)[0], tol=1e-11, what="dr")
     # weighted DR, N-D loops, single sweeps in both directions
@@ -85,19 +84,19 @@ def test_device_outputs_may_alias_inputs(oracle):
     w1, w2 = device.to_colmajor(torch.from_numpy(W1).cuda()), device.to_colmajor(torch.from_numpy(W2).cuda())
     a = device.tv1w_2d(xd, w1, w2)[0].cpu().numpy().copy()
     b = device.tv1w_2d(xd, w1, w2, out=xd)[0].cpu().numpy()
-    np.testing.assert_allclose(a, b, rtol=0, atol=1e-12)
+    np.testing.assert_array_equal(a, b)
     V = rng.standard_normal((30, 40, 20))
     for method in (None, "pdr", "yang"):
         vd = device.to_colmajor(torch.from_numpy(V).cuda())
         a = device.tvgen(vd, [0.2, 0.1, 0.3], [1, 2, 3], method=method)[0].cpu().numpy().copy()
         b = device.tvgen(vd, [0.2, 0.1, 0.3], [1, 2, 3], method=method, out=vd)[0].cpu().numpy()
-        np.testing.assert_allclose(a, b, rtol=0, atol=1e-12)
+        np.testing.assert_array_equal(a, b)
     big = rng.standard_normal((1500, 700))
     for dim in (0, 1):
         bd = device.to_colmajor(torch.from_numpy(big).cuda())
         a = device.tv1_fibres(bd, 0.4, dim).cpu().numpy().copy()
         b = device.tv1_fibres(bd, 0.4, dim, out=bd).cpu().numpy()
-        np.testing.assert_allclose(a, b, rtol=0, atol=1e-12)
+        np.testing.assert_array_equal(a, b)
 
 
 def test_device_api_rejects_wrong_tensors():
@@ -131,6 +130,63 @@ def test_unknown_device_fails_cleanly_and_state_survives(clib, ptv, oracle):
     before = ptv.tv1_1d(x, 0.3)
     assert clib.proxtv_init(97) != 0
     assert clib.proxtv_init(0) == 0
-    # (not bit for bit: the adaptive policy may take its one look at the pinning rung in either call)
-    np.testing.assert_allclose(ptv.tv1_1d(x, 0.3), before, rtol=0, atol=1e-12)
+    np.testing.assert_array_equal(ptv.tv1_1d(x, 0.3), before)
     assert_close(before, oracle.tv1_hybrid(x, 0.3), tol=1e-11)
+
+
+def test_results_are_reproducible_bit_for_bit(ptv, clib, oracle):
+    """The reference is bit-identical from run to run whatever its thread count; so is this library by
+    default: the geometry a sweep runs is a function of (input statistics, lambda), not of what the thread solved before or
+    of measured times.  Same calls, other workloads in between, three passes -- every result equals the first pass's."""
+    rng = np.random.default_rng(80)
+    X = rng.standard_normal((700, 900))
+    B = np.kron(rng.standard_normal((7, 9)), np.ones((100, 100))) + 0.1 * rng.standard_normal((700, 900))
+    x1 = rng.standard_normal(200000)
+    V = rng.standard_normal((120, 100, 40))
+    W1, W2 = rng.uniform(0.05, 1.0, (699, 900)), rng.uniform(0.05, 1.0, (700, 899))
+
+    def calls():
+        yield "dr 0.1", lambda: ptv.tv1_2d(X, 0.1)
+        yield "1d 0.5", lambda: ptv.tv1_1d(x1, 0.5)
+        yield "dr 0.6", lambda: ptv.tv1_2d(X, 0.6)
+        yield "blocks", lambda: ptv.tv1_2d(B, 0.5)
+        yield "dr 2.0", lambda: ptv.tv1_2d(X, 2.0)
+        yield "1d 30", lambda: ptv.tv1_1d(x1, 30.0)
+        yield "pd", lambda: ptv.tvgen(V, [0.3, 0.2, 0.4], [1, 2, 3], [1, 1, 1])
+        yield "drw", lambda: ptv.tv1w_2d(X, W1, W2)
+        yield "yang", lambda: ptv.tv1_2d(X, 0.3, method="yang")
+    assert clib.proxtv_set_option(b"deterministic", 1) == 1      # the default
+    first = {}
+    for rep in range(3):
+        order = list(calls())
+        if rep:
+            order = [order[k] for k in rng.permutation(len(order))]
+        for name, fn in order:
+            got = fn()
+            if rep == 0:
+                first[name] = got.copy()
+            else:
+                np.testing.assert_array_equal(got, first[name], err_msg=name)
+    assert_close(first["dr 0.6"], oracle.dr2(X, 0.6)[0], tol=1e-10)
+    assert_close(first["blocks"], oracle.dr2(B, 0.5)[0], tol=1e-10)
+    assert_close(first["1d 30"], oracle.tv1_hybrid(x1, 30.0), tol=1e-10)
+
+
+def test_adaptive_policy_is_still_exact(ptv, clib, oracle):
+    """deterministic = 0: the hill climb on measured sweep times (seeded by the same statistics).  Results stay exact; two
+    calls may differ in the last bits (different rungs round differently)."""
+    before = clib.proxtv_set_option(b"deterministic", 0)
+    try:
+        rng = np.random.default_rng(81)
+        X = rng.standard_normal((700, 900))
+        for lam in (0.1, 0.6, 2.0, 0.1):
+            want = oracle.dr2(X, lam)[0]
+            for _ in range(3):
+                assert_close(ptv.tv1_2d(X, lam), want, tol=1e-10, what=f"adaptive lam={lam}")
+        x1 = rng.standard_normal(300000)
+        for lam in (0.5, 30.0, 0.5):
+            want = oracle.tv1_hybrid(x1, lam)
+            for _ in range(4):
+                assert_close(ptv.tv1_1d(x1, lam), want, tol=1e-10, what=f"adaptive 1-D lam={lam}")
+    finally:
+        clib.proxtv_set_option(b"deterministic", before)

@@ -93,11 +93,21 @@ def test_global_chunks_long_pieces(ptv, clib, oracle, modes):
             assert_close(device.tv1_fibres(bd, lam, 1).cpu().numpy(), want.T, tol=1e-11, what=f"dim1 lam={lam} mode={m}")
 
 
-def test_policy_escalates_and_recovers(ptv, clib, oracle, modes):
-    """Adaptive policy: easy data runs the 16-sample-zone LDS geometry (mode 0, or its robust instantiation 1 when the
-    timing of a trial on so small an image is a toss-up); moderate lambda moves up the ladder; an easy problem
-    afterwards comes back down.  Results are exact throughout."""
+@pytest.mark.parametrize("deterministic", [1, 0])
+def test_policy_escalates_and_recovers(ptv, clib, oracle, modes, deterministic):
+    """The policy, seeded from the input's statistics (deterministic = 1: the default) or hill-climbing on measured times
+    (0): easy data runs the 16-sample-zone LDS geometry (mode 0, or its robust instantiation 1 when the timing of a trial
+    on so small an image is a toss-up); moderate lambda moves up the ladder; an easy problem afterwards comes back down.
+    Results are exact throughout."""
     modes(-1)
+    det = clib.proxtv_set_option(b"deterministic", deterministic)
+    try:
+        _escalates_and_recovers(ptv, clib, oracle)
+    finally:
+        clib.proxtv_set_option(b"deterministic", det)
+
+
+def _escalates_and_recovers(ptv, clib, oracle):
     rng = np.random.default_rng(43)
     X = rng.standard_normal((600, 640))
     assert_close(ptv.tv1_2d(X, 0.1), oracle.dr2(X, 0.1)[0], tol=1e-11)

@@ -115,3 +115,64 @@ def test_sweep_kernel_properties_full_size(ptv):
         # the fibre TV never grows and the dual certificate holds: |cumsum(x - y)| <= lambda along the fibre
         u = torch.cumsum(xd - y, dim=dim)
         assert float(u.abs().max()) <= 0.1 * (1 + 1e-9)
+
+
+def test_c5_full_shard_one_batched_call(glarge):
+    """Config #5 at the per-GPU shard size: B = 64 independent 2048x2048 images in ONE batched solve.  The three images the
+    fixture holds reference fingerprints for sit at scattered batch positions; ten sampled images are also solved alone
+    through the single-image entry point and must match the batched result bit for bit (batch-invariant kernels and
+    reductions, and a geometry choice that is a function of the input's statistics)."""
+    import torch
+    from proxtv_amd import device
+    B, S = 64, 2048
+    place = {0: 5, 1: 40, 2: 63}                      # fixture image k -> batch position
+    g = torch.Generator(device="cuda").manual_seed(77)
+    x = torch.randn((B, S, S), dtype=torch.float64, device="cuda", generator=g)        # (B, N, M): image b column-major
+    for k, pos in place.items():
+        img = np.random.default_rng(k).standard_normal((S, S))
+        x[pos] = torch.from_numpy(np.ascontiguousarray(img.T)).cuda()
+    xb = x.permute(2, 1, 0)                            # column-major (M, N, B) view of the same bytes
+    yb, info = device.tv1_2d_batch(xb, 0.1)
+    assert int(info[0]) == 35
+    for k, pos in place.items():
+        _check_digest(np.asfortranarray(yb[:, :, pos].cpu().numpy()), glarge, f"c5/{k}/dr2")
+    for pos in (0, 5, 9, 17, 26, 31, 40, 48, 55, 63):
+        one, _ = device.tv1_2d(device.to_colmajor(xb[:, :, pos].contiguous()), 0.1)
+        assert torch.equal(one, yb[:, :, pos]), f"image {pos}: batched and single-image results differ"
+    # size-independent properties over the whole shard: per-image mean preserved, each pixel moved by at most 4 lambda
+    assert float((yb.mean(dim=(0, 1)) - xb.mean(dim=(0, 1))).abs().max()) < 1e-9
+    assert float((yb - xb).abs().max()) <= 0.4 + 1e-6
+
+
+def test_bench_two_ranks_on_one_gpu_dry_run():
+    """bench.py's N > 1 path end to end on a one-GPU box: torch.distributed.run, two ranks sharing device 0
+    (PROXTV_BENCH_SHARED_GPU=1: gloo instead of RCCL -- plumbing, not a measurement).  Exercises the rank environment, the
+    barriers, the max-over-ranks all-reduce, the config-#5 object with its gather (checked on arrival) and the JSON line."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, PROXTV_BENCH_SHARED_GPU="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--c5-images", "4"]
+    out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["unit"] == "Mpixel/s"
+    assert d["config"]["images_per_step"] == 2
+    pg = d["config"]["process_group"]
+    assert pg["world_size"] == 2 and pg["backend"] == "gloo" and [r["rank"] for r in pg["ranks"]] == [0, 1]
+    assert d["value"] == pytest.approx(2 * 4096 * 4096 * 2 / (d["ms_per_step"] * 2 * 1e-3) / 1e6, rel=1e-6)
+    assert "cpu_baseline" not in d                      # rank 0 at N = 1 only
+    c5 = d["c5"]
+    assert c5["ranks"] == 2 and c5["images"] == 8 and c5["gather_checked"] is True and c5["gather_ms"] > 0
+    assert c5["gather_bytes"] == 4 * 2048 * 2048 * 8
+    assert d["roofline"]["frac"] > 0

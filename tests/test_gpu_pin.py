@@ -92,10 +92,17 @@ def test_splitting_loops_on_rung3(ptv, oracle, rung3):
 
 
 def test_policy_climbs_to_the_pinning_rung_and_back(ptv, clib, oracle):
-    """Adaptive policy: long pieces (lambda = 3 on unit noise) end on rung 3; white noise at small lambda returns to the
-    chunk kernels."""
+    """Adaptive policy (deterministic = 0): long pieces (lambda = 3 on unit noise) end on rung 3; white noise at small lambda
+    returns to the chunk kernels.  The default policy takes the same rungs straight from the input's statistics."""
     before = clib.proxtv_set_option(b"chunk_mode", -1)
+    det = clib.proxtv_set_option(b"deterministic", 1)
     try:
+        X = np.random.default_rng(94).standard_normal((900, 1100))
+        assert_close(ptv.tv1_2d(X, 3.0), oracle.dr2(X, 3.0)[0], tol=1e-9, what="DR lam=3, seeded")
+        assert clib.proxtv_chunk_mode() == 3, clib.proxtv_chunk_mode()
+        assert_close(ptv.tv1_2d(X, 0.05), oracle.dr2(X, 0.05)[0], tol=1e-9, what="DR lam=0.05, seeded")
+        assert clib.proxtv_chunk_mode() == 0, clib.proxtv_chunk_mode()
+        clib.proxtv_set_option(b"deterministic", 0)
         rng = np.random.default_rng(94)
         X = rng.standard_normal((900, 1100))
         want = oracle.dr2(X, 3.0)[0]
@@ -111,6 +118,7 @@ def test_policy_climbs_to_the_pinning_rung_and_back(ptv, clib, oracle):
         assert clib.proxtv_chunk_mode() <= 1, clib.proxtv_chunk_mode()
     finally:
         clib.proxtv_set_option(b"chunk_mode", before)
+        clib.proxtv_set_option(b"deterministic", det)
 
 
 def test_previous_rung3_still_exact(ptv, clib, oracle, rung3):

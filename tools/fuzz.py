@@ -41,6 +41,7 @@ def run(budget=60.0, seed=0, tol=1e-9, sizes=(2, 3, 17, 95, 96, 97, 130, 257, 40
             lam = float(10 ** rng.uniform(-3, 2))
             mode = int(rng.integers(-1, 6))
             lib.proxtv_set_option(b"chunk_mode", mode)
+            lib.proxtv_set_option(b"deterministic", int(rng.integers(0, 2)))   # (mode -1: seeded-deterministic or hill-climbing policy)
             what = int(rng.integers(0, 6))
             if what == 0:
                 got, want, name = ptv.tv1_2d(X, lam), orc.dr2(X, lam)[0], "dr2"
@@ -67,6 +68,7 @@ def run(budget=60.0, seed=0, tol=1e-9, sizes=(2, 3, 17, 95, 96, 97, 130, 257, 40
             assert e <= tol, f"MISMATCH {desc}: relative error {e:.3e}"
     finally:
         lib.proxtv_set_option(b"chunk_mode", before)
+        lib.proxtv_set_option(b"deterministic", 1)
     return cases, worst, worst_case
 
 
@@ -88,6 +90,7 @@ def run_nd(budget=30.0, seed=0, tol=1e-9, sizes=(2, 5, 33, 96, 130, 210)):
                                   np.cumsum(rng.standard_normal(shape), axis=int(rng.integers(0, 3))) * 0.2)
             mode = int(rng.integers(-1, 6))
             lib.proxtv_set_option(b"chunk_mode", mode)
+            lib.proxtv_set_option(b"deterministic", int(rng.integers(0, 2)))
             what = int(rng.integers(0, 3))
             if what == 0:
                 npen = int(rng.integers(1, 5))
@@ -119,6 +122,7 @@ def run_nd(budget=30.0, seed=0, tol=1e-9, sizes=(2, 5, 33, 96, 130, 210)):
             assert e <= tol, f"MISMATCH {desc}: relative error {e:.3e}"
     finally:
         lib.proxtv_set_option(b"chunk_mode", before)
+        lib.proxtv_set_option(b"deterministic", 1)
     return cases, worst, worst_case
 
 
