@@ -45,7 +45,9 @@ struct Options {
     int rounds = 0;         // second-chance rounds of geometry mode 1 (0 = the built-in default)
     int along = 1;            // dimension-0 sweeps: chunks along the fibre (sweep_along_kernel); 0 = the transposed 64-fibre tile
     int along_min_len = 160;  // ... for fibres at least this long (16, 32 or 64 lanes share a fibre segment of 17-sample chunks)
-    int row_along = 1;        // strided sweeps that need long zones: transpose + along-fibre kernel + transpose back (0 = 64-fibre tile)
+    int row_along = 1;        // strided sweeps through transposed copies + the along-fibre kernel: bit 0 = rung 2 (64-sample zones),
+                              // bit 1 = rung 1 as well (0 = the 64-fibre tile for both)
+    int seed_noisy_e4 = 0, seed_mid_e4 = 0;   // tuning aid: the policy seed's thresholds (policy.hpp) in units of 1e-4 ; 0 = built in
     int pin = 1;              // geometry rung 3: the pinning solver (pin.hip) where it applies; 0 = global-memory chunks
     int whole = 1;            // fibres shorter than chunk_min_len: whole-fibre-in-LDS kernel (0 = the sequential kernel)
     int chunk_min_len = 96;   // fibres shorter than this take the sequential kernel (measured crossover: 512x512xL volumes, L ~ 96)

@@ -564,7 +564,17 @@ constexpr int kAlongC = 17;
 constexpr int kAlongWaves = 4;
 
 // G lanes share one segment of G chunks: 64 for long fibres; 32 or 16 pack two or four shorter fibres into a wave.
-template <int OP, bool WEIGHTED, int H, int G>
+// ROBUST (geometry mode 1: pieces of a few samples, walks that need the whole zone -- or more -- to meet): like the tile
+// kernel's robust instantiation, nothing a failed link needs leaves the kernel if it can be helped:
+//   * a walk may run past the segment's look-ahead rows (global reads, a few samples, only the lanes that need it);
+//   * second chances inside the wave: a lane whose link fails while its predecessor's holds walks its chunk again from the
+//     predecessor's last bend (one lane shuffle tells it which); links are re-examined after every round, plan.rounds rounds;
+//   * the first lane of a segment, whose predecessor is the last lane of ANOTHER wave, looks that wave's final code up
+//     through LDS when both waves sit in the same workgroup (4096-sample fibres: 4 segments = the 4 waves of a workgroup)
+//     and gets its second chance from it.
+// What is still unproven goes to the repair kernel as before, which also re-checks every link between segments from the
+// codes the waves finally publish -- so none of the above is load-bearing for exactness.
+template <int OP, bool WEIGHTED, int H, int G, bool ROBUST>
 __global__ __launch_bounds__(64 * kAlongWaves) void sweep_along_kernel(SweepArgs p, FibreGeom g, ChunkPlan plan, link_t *code_mine,
                                                                         link_t *code_next, int *failflags) {
     constexpr int C = kAlongC, SEG = G * C, T = tail_rows(H), ROWS = H + SEG + T, NG = 64 / G;
@@ -576,6 +586,12 @@ __global__ __launch_bounds__(64 * kAlongWaves) void sweep_along_kernel(SweepArgs
     const int gi = lane / G, gl = lane % G;
     double *Yp = reinterpret_cast<double *>(smem) + (size_t)(wave * NG + gi) * (ROWS + 2) * (WEIGHTED ? 2 : 1);
     double *Wp = Yp + (WEIGHTED ? ROWS + 2 : 0);   // per-edge penalties, same rows (weighted sweeps)
+    // ROBUST: what a wave's last lane ends up with, for the first lane of the next wave: [kAlongWaves] codes, [kAlongWaves] "ready"
+    unsigned *xwave = reinterpret_cast<unsigned *>(reinterpret_cast<double *>(smem) + (size_t)kAlongWaves * NG * (ROWS + 2) * (WEIGHTED ? 2 : 1));
+    if (ROBUST && G == 64) {
+        if (lane == 0) xwave[kAlongWaves + wave] = 0u;
+        __syncthreads();   // (the only workgroup barrier of the kernel: before anything else happens)
+    }
     const int len = g.len;
     const int nseg = (len + SEG - 1) / SEG, NC = (len + C - 1) / C;
     const long wid = (long)blockIdx.x * kAlongWaves + wave;
@@ -639,14 +655,67 @@ __global__ __launch_bounds__(64 * kAlongWaves) void sweep_along_kernel(SweepArgs
         } else {
             walker_start<WEIGHTED>(w, win, start, p.lam);
         }
-        walk_chunk<OP, WEIGHTED, 1, false>(w, rec, win, far, hi, cs, ce, len, p.lam);
+        walk_chunk<OP, WEIGHTED, 1, ROBUST>(w, rec, win, far, hi, cs, ce, len, p.lam);
     }
     if (plan.trace && lane == 0) plan.trace[8 * (size_t)wid + 3] = wall_clock64();
 
     // ---- links: the predecessor is the lane before (a group's first lane: in another group or wave, left to the repair kernel) ----
-    const link_t prev_next = (link_t)__shfl_up((int)rec.next, 1);
-    const bool linked = has_chunk && !(start == 0 || certain) && gl > 0;
-    const bool bad = has_chunk && (rec.failed || (linked && (rec.mine == 0 || rec.mine != prev_next)));
+    bool bad;
+    bool head_linked = false, head_bad = false;   // ROBUST: the group's first lane hangs on another wave's last lane / and that link failed
+    auto examine = [&]() {
+        const link_t prev_next = (link_t)__shfl_up((int)rec.next, 1);
+        const bool linked = has_chunk && !(start == 0 || certain) && gl > 0;
+        bad = has_chunk && (rec.failed || (linked && (rec.mine == 0 || rec.mine != prev_next)) || (gl == 0 && head_bad));
+        return prev_next;
+    };
+    // one more walk of this lane's chunk from a bend of its predecessor's walk (a bend of the true walk if the predecessor is true)
+    auto second_chance = [&](link_t from) {
+        const int at = (int)(from >> 1);
+        if (from == 0 || at <= max(lo, 0)) return;
+        ChunkRec again;
+        Walker w;
+        walker_restart_with<WEIGHTED>(w, at, (int)(from & 1u), len, p.lam, win.y(at), WEIGHTED ? win.r(at - 1) : 0.0,
+                                      (WEIGHTED && at < len - 1) ? win.r(at) : 0.0);
+        again.mine = again.next = again.last = from;
+        walk_chunk<OP, WEIGHTED, 1, ROBUST>(w, again, win, far, hi, cs, ce, len, p.lam);
+        if (!again.failed) {
+            rec = again;
+            certain = false;   // from now on the chunk hangs on its predecessor like any other
+        }
+    };
+    auto rounds = [&]() {
+        for (int round = 0; round < plan.rounds; round++) {
+            const link_t prev_next = examine();
+            if (__ballot(bad) == 0ull) break;
+            const bool prev_bad = __shfl_up((int)bad, 1) != 0;
+            if (bad && gl > 0 && !prev_bad) second_chance(prev_next);
+        }
+    };
+    if constexpr (ROBUST) {
+        rounds();
+        if constexpr (G == 64) {
+            examine();
+            // the wave's last lane, as it stands now, for the next wave's first lane
+            if (lane == 63) xwave[wave] = (bad || !has_chunk) ? rec.next : (rec.next | kLinkCertain);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 63) __hip_atomic_store(&xwave[kAlongWaves + wave], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            head_linked = has_chunk && lane == 0 && wave > 0 && sg > 0 && !(certain || rec.failed);
+            if (head_linked) {
+                while (__hip_atomic_load(&xwave[kAlongWaves + wave - 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0u)
+                    __builtin_amdgcn_s_sleep(1);
+                const link_t praw = xwave[wave - 1];
+                const link_t prev = praw & ~kLinkCertain;
+                head_bad = rec.mine == 0 || rec.mine != prev;
+                if (head_bad && (praw & kLinkCertain)) {
+                    second_chance(prev);
+                    head_bad = rec.failed || rec.mine == 0 || rec.mine != prev;
+                }
+            }
+            if (__ballot(head_linked) != 0ull) rounds();   // (the first lane may have walked again: its successors' links are looked at afresh)
+        }
+    }
+    examine();
+    if (gl == 0 && head_bad && !rec.failed) bad = false;   // (not this kernel's to flag: the repair kernel checks the links between segments)
     if (has_chunk) {
         if (rec.failed) {
             rec.mine = kLinkBad;
@@ -659,8 +728,8 @@ __global__ __launch_bounds__(64 * kAlongWaves) void sweep_along_kernel(SweepArgs
     }
     // a lane's writes stop at the nearest unproven chunk before it (see GUARD in sweep_chunk_kernel; needed for H > C)
     int wlo = seg_s;
-    if (H > C) {
-        const unsigned long long all = __ballot(bad);
+    if (H > C || ROBUST) {
+        const unsigned long long all = __ballot(bad || (gl == 0 && head_bad));
         const unsigned long long grp = (G == 64) ? all : ((all >> (gi * G)) & ((1ull << (G & 63)) - 1ull));
         const unsigned long long below = grp & ((1ull << gl) - 1ull);
         if (below) wlo = seg_s + (63 - __clzll((long long)below)) * C;
@@ -1216,7 +1285,13 @@ struct ChunkScratch {
         const int b = probe_bin(weighted ? 4.0 : 4.0 * lam);
         unsigned long above = p->hist[b] / 2;
         for (int k = b + 1; k < kProbeBins; k++) above += p->hist[k];
-        return rung_from_certain_fraction((double)above / (double)p->hist[kProbeBins]);
+        const double f = (double)above / (double)p->hist[kProbeBins];
+        if (options().seed_noisy_e4 > 0 || options().seed_mid_e4 > 0) {   // tuning aid: thresholds in units of 1e-4
+            const double noisy = options().seed_noisy_e4 > 0 ? options().seed_noisy_e4 * 1e-4 : kSeedNoisy;
+            const double mid = options().seed_mid_e4 > 0 ? options().seed_mid_e4 * 1e-4 : kSeedMid;
+            return f >= noisy ? 0 : (f >= mid ? 1 : 3);
+        }
+        return rung_from_certain_fraction(f);
     }
 
     static constexpr int kSlots = 8, kCounters = 2 * FAM_COUNT;
@@ -1390,8 +1465,8 @@ void launch_chunk_h(const SweepArgs &args, const FibreGeom &g, hipStream_t strea
 
 // Chunks along the fibre (kernel 2a): dimension-0 sweeps, unweighted.  Codes are laid out [fibre][chunk] (a wave writes
 // the codes of 64 consecutive chunks of one fibre).
-template <int OP, bool WEIGHTED, int H, int G>
-void launch_along_g(const SweepArgs &args, const FibreGeom &g, hipStream_t stream, int fam) {
+template <int OP, bool WEIGHTED, int H, int G, bool ROBUST>
+void launch_along_g(const SweepArgs &args, const FibreGeom &g, hipStream_t stream, int fam, int rounds_wanted) {
     constexpr int C = kAlongC, SEG = G * C, ROWS = H + SEG + tail_rows(H), NG = 64 / G;
     const int nseg = (g.len + SEG - 1) / SEG;
     const int NC = (g.len + C - 1) / C;
@@ -1399,11 +1474,12 @@ void launch_along_g(const SweepArgs &args, const FibreGeom &g, hipStream_t strea
     const long waves = (units + NG - 1) / NG;
     ChunkPlan plan{};
     plan.ablate = options().ablate;
+    plan.rounds = ROBUST ? rounds_wanted : 0;
     chunk_state().ensure(g.count, NC, stream);
     plan.trace = options().trace ? chunk_state().trace_buffer((size_t)waves) : nullptr;
-    constexpr size_t lds = sizeof(double) * (size_t)(ROWS + 2) * NG * kAlongWaves * (WEIGHTED ? 2 : 1);
+    constexpr size_t lds = sizeof(double) * (size_t)(ROWS + 2) * NG * kAlongWaves * (WEIGHTED ? 2 : 1) + (ROBUST ? 64 : 0);
     static_assert(lds <= 160 * 1024, "along-fibre geometry does not fit the LDS of a CU");
-    auto kern = sweep_along_kernel<OP, WEIGHTED, H, G>;
+    auto kern = sweep_along_kernel<OP, WEIGHTED, H, G, ROBUST>;
     if (lds > 64 * 1024) {   // above the default dynamic-LDS limit
         static thread_local bool attr_done[kMaxDevices] = {};
         bool &attr_set = attr_done[current_device()];
@@ -1433,11 +1509,11 @@ void launch_along_g(const SweepArgs &args, const FibreGeom &g, hipStream_t strea
 // Chunks along the fibre (kernel 2a): dimension-0 sweeps, unweighted.  Codes are laid out [fibre][chunk] (a group writes
 // the codes of consecutive chunks of one fibre).  Lanes per segment: a whole wave for long fibres; half or a quarter of
 // one when the fibre fits 32 or 16 chunks.
-template <int OP, bool WEIGHTED, int H>
-void launch_along(const SweepArgs &args, const FibreGeom &g, hipStream_t stream, int fam) {
-    if (g.len <= 16 * kAlongC)      launch_along_g<OP, WEIGHTED, H, 16>(args, g, stream, fam);
-    else if (g.len <= 32 * kAlongC) launch_along_g<OP, WEIGHTED, H, 32>(args, g, stream, fam);
-    else                            launch_along_g<OP, WEIGHTED, H, 64>(args, g, stream, fam);
+template <int OP, bool WEIGHTED, int H, bool ROBUST>
+void launch_along(const SweepArgs &args, const FibreGeom &g, hipStream_t stream, int fam, int rounds) {
+    if (g.len <= 16 * kAlongC)      launch_along_g<OP, WEIGHTED, H, 16, ROBUST>(args, g, stream, fam, rounds);
+    else if (g.len <= 32 * kAlongC) launch_along_g<OP, WEIGHTED, H, 32, ROBUST>(args, g, stream, fam, rounds);
+    else                            launch_along_g<OP, WEIGHTED, H, 64, ROBUST>(args, g, stream, fam, rounds);
 }
 
 // Global-memory chunks (kernel 2b): chunk C and zone H are run-time values; every link is checked by the repair kernel.
@@ -1462,9 +1538,9 @@ void launch_gchunk(const SweepArgs &args, const FibreGeom &g, int C, int H, hipS
 // Fibre numbering is unchanged: fibre j = slab * inc + off sits at j * len after the transposition of every
 // (inc x len) slab.
 template <int OP, int H>
-void launch_row_along(const SweepArgs &args, const FibreGeom &g, hipStream_t stream, int fam) {
+void launch_row_along(const SweepArgs &args, const FibreGeom &g, hipStream_t stream, int fam, int rounds) {
     TransposedOperands tr(args, Op<OP>::IN_MASK, Op<OP>::OUT_MASK, g, stream);
-    launch_along<OP, false, H>(tr.args(), tr.geom(), stream, fam);
+    launch_along<OP, false, H, true>(tr.args(), tr.geom(), stream, fam, rounds);
     tr.finish();
 }
 
@@ -1500,7 +1576,7 @@ void launch_chunk(const SweepArgs &args, const FibreGeom &g, hipStream_t stream,
         measure = pl.wants_measurement(pl.meas);
         if (measure) PTV_HIP(hipEventRecord(pl.t0, stream));
     }
-    const int rounds = (mode == 1) ? (options().rounds > 0 ? options().rounds : kRounds) : 0;
+    const int rounds = (mode == 1 || mode == 2) ? (options().rounds > 0 ? options().rounds : kRounds) : 0;
     // Geometry ladder.  Dimension 0 (chunks along the fibre once a fibre fills most of a lane group): 0 = 16-sample zones,
     // 1 / 2 = 64-sample zones, 3 = the pinning solver (pin.hip; where it does not apply: chunks from global memory, zone
     // 256), 4 = chunks from global memory (zone 1024), 5 = one sequential walk per fibre.
@@ -1524,11 +1600,17 @@ void launch_chunk(const SweepArgs &args, const FibreGeom &g, hipStream_t stream,
     else if (mode == 3)    launch_gchunk<OP, WEIGHTED>(args, g, 64, 256, stream, fam);
     else if (mode == 4)    launch_gchunk<OP, WEIGHTED>(args, g, 256, 1024, stream, fam);
     else if (TRANSPOSED && along_ok) {
-        if (mode == 0) launch_along<OP, WEIGHTED, kWarm>(args, g, stream, fam);
-        else           launch_along<OP, WEIGHTED, kWarmLong>(args, g, stream, fam);
+        // chunks along the fibre: 0 = 16-sample zones ; 1 = the same, robust (second chances inside the wave and across the
+        // waves of a workgroup, walks past the look-ahead rows) ; 2 = 64-sample zones, robust
+        if (mode == 0)      launch_along<OP, WEIGHTED, kWarm, false>(args, g, stream, fam, 0);
+        else if (mode == 1) launch_along<OP, WEIGHTED, kWarm, true>(args, g, stream, fam, rounds);
+        else                launch_along<OP, WEIGHTED, kWarmLong, true>(args, g, stream, fam, rounds);
     }
-    else if (!TRANSPOSED && !WEIGHTED && along_ok && options().row_along && mode == 2) {
-        if constexpr (!WEIGHTED) launch_row_along<OP, kWarmLong>(args, g, stream, fam);
+    else if (!TRANSPOSED && !WEIGHTED && along_ok && (options().row_along & 1) && mode == 2) {
+        if constexpr (!WEIGHTED) launch_row_along<OP, kWarmLong>(args, g, stream, fam, rounds);
+    }
+    else if (!TRANSPOSED && !WEIGHTED && along_ok && (options().row_along & 2) && mode == 1) {
+        if constexpr (!WEIGHTED) launch_row_along<OP, kWarm>(args, g, stream, fam, rounds);
     }
     else if constexpr (!WEIGHTED) {
         if (mode == 2) launch_chunk_h<OP, false, TRANSPOSED, kWarmLong>(args, g, stream, fam, 0);
