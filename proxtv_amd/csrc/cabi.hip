@@ -46,16 +46,39 @@ int guarded(const char *who, double *info, int ok_ret, F &&body) {
     throw HipFailure{hipErrorInvalidValue};
 }
 
+// Option "host_register" (default 0): page-lock the caller's arrays around the transfer (hipHostRegister) when they are
+// large.  Measured (tools/host_api_time.py): the pageable copies already run at the link's rate and
+// locking 134 MB costs more than it saves -- the switch stays for hosts where that differs.
+struct HostPin {
+    void *p = nullptr;
+    HostPin(const void *host, size_t bytes) {
+        if (options().host_register && bytes >= (size_t)8 << 20 &&
+            hipHostRegister(const_cast<void *>(host), bytes, hipHostRegisterDefault) == hipSuccess)
+            p = const_cast<void *>(host);
+        else
+            (void)hipGetLastError();
+    }
+    ~HostPin() {
+        if (p) (void)hipHostUnregister(p);
+    }
+    HostPin(const HostPin &) = delete;
+    HostPin &operator=(const HostPin &) = delete;
+};
+
 // host array staged into HBM scratch
 struct Staged {
     Scratch buf;
     Staged(const double *host, size_t count, hipStream_t s) : buf(sizeof(double) * (count ? count : 1)) {
-        if (count) PTV_HIP(hipMemcpyAsync(buf.d(), host, sizeof(double) * count, hipMemcpyHostToDevice, s));
+        if (!count) return;
+        HostPin pin(host, sizeof(double) * count);
+        PTV_HIP(hipMemcpyAsync(buf.d(), host, sizeof(double) * count, hipMemcpyHostToDevice, s));
+        if (pin.p) PTV_HIP(hipStreamSynchronize(s));   // (the lock is released when `pin` goes out of scope)
     }
     double *d() const { return buf.d(); }
 };
 
 void download(double *host, const double *dev, size_t count, hipStream_t s) {
+    HostPin pin(host, sizeof(double) * count);
     if (count) PTV_HIP(hipMemcpyAsync(host, dev, sizeof(double) * count, hipMemcpyDeviceToHost, s));
     PTV_HIP(hipStreamSynchronize(s));
 }
@@ -483,6 +506,7 @@ int proxtv_set_option(const char *key, int value) {
     else if (!strcmp(key, "rounds")) slot = &o.rounds;
     else if (!strcmp(key, "chunk_mode")) slot = &o.chunk_mode;
     else if (!strcmp(key, "deterministic")) slot = &o.deterministic;
+    else if (!strcmp(key, "host_register")) slot = &o.host_register;
     else if (!strcmp(key, "seed_noisy_e4")) slot = &o.seed_noisy_e4;
     else if (!strcmp(key, "seed_mid_e4")) slot = &o.seed_mid_e4;
     if (!slot) return -1;

@@ -73,6 +73,16 @@ static void probe_device(int dev) {
         return;
     }
     g_dev_ok[dev] = true;
+    // load the code objects now (the device is current: probe_device runs under ensure_device on the calling thread)
+    try {
+        warm_sweep();
+        warm_pin();
+        warm_pinlong();
+        warm_pointwise();
+        warm_tv2();
+    } catch (const HipFailure &) {
+        (void)hipGetLastError();   // not fatal: the first launch will load (or report) what this could not
+    }
 }
 
 void ensure_device() {

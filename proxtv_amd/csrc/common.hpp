@@ -49,8 +49,10 @@ struct Options {
                               // bit 1 = rung 1 as well (0 = the 64-fibre tile for both)
     int seed_noisy_e4 = 0, seed_mid_e4 = 0;   // tuning aid: the policy seed's thresholds (policy.hpp) in units of 1e-4 ; 0 = built in
     int pin = 1;              // geometry rung 3: the pinning solver (pin.hip) where it applies; 0 = global-memory chunks
-    int whole = 1;            // fibres shorter than chunk_min_len: whole-fibre-in-LDS kernel (0 = the sequential kernel)
+    int whole = 1;            // fibres of 16 .. chunk_min_len samples: 1 = by length and data (sequential up to 32 samples; one block of the
+                              // chunk kernel on noisy data, else whole fibres in LDS), 2 = the whole-fibre-in-LDS kernel, 0 = the sequential kernel
     int chunk_min_len = 96;   // fibres shorter than this take the sequential kernel (measured crossover: 512x512xL volumes, L ~ 96)
+    int host_register = 0;    // host-pointer entry points: page-lock large caller arrays around their transfers (see cabi.hip)
     int verbose = 0;
     int profile = 0;    // per-kernel-family hipEvent timing
     int trace = 0;      // profiling aid: per-workgroup phase timestamps of the chunk kernel (proxtv_debug_trace)
@@ -64,6 +66,14 @@ Options &options();
 constexpr int kMaxDevices = 16;
 int current_device();
 void ensure_device();
+// One-time costs belong to initialisation, not to the first solve: each translation unit's code object is uploaded to the
+// device the first time one of its kernels is touched (milliseconds apiece); ensure_device() touches one kernel per unit
+// the first time a device is used.  (Defined next to the kernels: sweep.hip, pin.hip, pinlong.hip, pointwise.hip, tv2.hip.)
+void warm_sweep();
+void warm_pin();
+void warm_pinlong();
+void warm_pointwise();
+void warm_tv2();
 hipStream_t thread_stream();
 
 // ---- HBM scratch pool ------------------------------------------------------------------------------------------

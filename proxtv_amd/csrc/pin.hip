@@ -250,4 +250,10 @@ bool launch_pin(OpId op, bool weighted, const SweepArgs &args, const FibreGeom &
     return true;
 }
 
+
+void warm_pin() {
+    hipFuncAttributes attr;
+    PTV_HIP(hipFuncGetAttributes(&attr, reinterpret_cast<const void *>((sweep_pin_kernel<OP_PROX, false, 16, 256>))));
+}
+
 }  // namespace ptv

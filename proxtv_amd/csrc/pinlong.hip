@@ -367,4 +367,10 @@ bool launch_pin_long(OpId op, bool weighted, const SweepArgs &args, const FibreG
 #undef PTV_LONG_CASE_U
 }
 
+
+void warm_pinlong() {
+    hipFuncAttributes attr;
+    PTV_HIP(hipFuncGetAttributes(&attr, reinterpret_cast<const void *>((sweep_pin_long_kernel<OP_PROX, false>))));
+}
+
 }  // namespace ptv

@@ -70,10 +70,52 @@ __global__ __launch_bounds__(kThreads) void scale_kernel(const double *y, double
     for (long i = (long)blockIdx.x * kThreads + threadIdx.x; i < n; i += (long)gridDim.x * kThreads) x[i] = y[i] / divisor;
 }
 
-__global__ __launch_bounds__(kThreads) void pd_combine_kernel(PtrPack p, PtrPack z, const double *x, double *xo, int P,
+// The combine kernels stream 2 P + 1 arrays in and P + 1 out (P = 3: eleven streams).  Two adjacent elements per lane (16-byte
+// accesses: half as many, twice as large memory requests per stream) and the term count as a template parameter (pointers in
+// scalar registers, every load of an iteration issued before the first use); PT = 0 is the run-time-P form for P > 4.
+// Arithmetic and its order per element are the reference's (src/TVNDopt.cpp:212-227); the partial sums of the stopping value
+// keep a fixed layout (kReduceBlocks blocks, a fixed element -> lane map): run-to-run deterministic.
+template <int PT>
+__global__ __launch_bounds__(kThreads) void pd_combine_kernel(PtrPack p, PtrPack z, const double *x, double *xo, int Prt,
                                                                 long n, double *partials) {
+    const int P = PT > 0 ? PT : Prt;
     double acc = 0;
-    for (long k = (long)blockIdx.x * kThreads + threadIdx.x; k < n; k += (long)gridDim.x * kThreads) {
+    const long pairs = n / 2;
+    for (long k = (long)blockIdx.x * kThreads + threadIdx.x; k < pairs; k += (long)gridDim.x * kThreads) {
+        const double2 xold = reinterpret_cast<const double2 *>(x)[k];
+        double2 pv[PT > 0 ? PT : 1], zv[PT > 0 ? PT : 1];
+        double2 xn{0, 0};
+        if (PT > 0) {
+#pragma unroll
+            for (int i = 0; i < PT; i++) pv[i] = reinterpret_cast<const double2 *>(p.v[i])[k];
+#pragma unroll
+            for (int i = 0; i < PT; i++) zv[i] = reinterpret_cast<const double2 *>(z.v[i])[k];
+#pragma unroll
+            for (int i = 0; i < PT; i++) { xn.x += pv[i].x / P; xn.y += pv[i].y / P; }
+#pragma unroll
+            for (int i = 0; i < PT; i++) {
+                zv[i].x += xn.x - pv[i].x;
+                zv[i].y += xn.y - pv[i].y;
+                reinterpret_cast<double2 *>(z.v[i])[k] = zv[i];
+            }
+        } else {
+            for (int i = 0; i < P; i++) {
+                const double2 q = reinterpret_cast<const double2 *>(p.v[i])[k];
+                xn.x += q.x / P; xn.y += q.y / P;
+            }
+            for (int i = 0; i < P; i++) {
+                const double2 q = reinterpret_cast<const double2 *>(p.v[i])[k];
+                double2 w = reinterpret_cast<const double2 *>(z.v[i])[k];
+                w.x += xn.x - q.x; w.y += xn.y - q.y;
+                reinterpret_cast<double2 *>(z.v[i])[k] = w;
+            }
+        }
+        reinterpret_cast<double2 *>(xo)[k] = xn;
+        acc += fabs(xn.x - xold.x);
+        acc += fabs(xn.y - xold.y);
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {   // odd length: the last element
+        const long k = n - 1;
         const double xold = x[k];
         double xn = 0;
         for (int i = 0; i < P; i++) xn += p.v[i][k] / P;
@@ -106,11 +148,25 @@ __global__ __launch_bounds__(kThreads) void pdr_combine_kernel(PtrPack p, PtrPac
 template <int D>
 __global__ __launch_bounds__(kThreads) void yang_x_kernel(const double *Y, PtrPack U, PtrPack Z, double *X, double rho,
                                                             long n) {
-    for (long i = (long)blockIdx.x * kThreads + threadIdx.x; i < n; i += (long)gridDim.x * kThreads) {
+    const long pairs = n / 2;   // two adjacent elements per lane (see pd_combine_kernel)
+    for (long i = (long)blockIdx.x * kThreads + threadIdx.x; i < pairs; i += (long)gridDim.x * kThreads) {
+        const double2 y = reinterpret_cast<const double2 *>(Y)[i];
+        double2 u[D], zz[D];
+#pragma unroll
+        for (int k = 0; k < D; k++) u[k] = reinterpret_cast<const double2 *>(U.v[k])[i];
+#pragma unroll
+        for (int k = 0; k < D; k++) zz[k] = reinterpret_cast<const double2 *>(Z.v[k])[i];
+        double2 su = y, sz = zz[0];
+#pragma unroll
+        for (int k = 0; k < D; k++) { su.x += u[k].x; su.y += u[k].y; }
+#pragma unroll
+        for (int k = 1; k < D; k++) { sz.x += zz[k].x; sz.y += zz[k].y; }
+        reinterpret_cast<double2 *>(X)[i] = double2{(su.x + rho * sz.x) / (1 + D * rho), (su.y + rho * sz.y) / (1 + D * rho)};
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+        const long i = n - 1;
         double su = Y[i], sz = Z.v[0][i];
-#pragma unroll
         for (int k = 0; k < D; k++) su += U.v[k][i];
-#pragma unroll
         for (int k = 1; k < D; k++) sz += Z.v[k][i];
         X[i] = (su + rho * sz) / (1 + D * rho);
     }
@@ -235,7 +291,14 @@ void absdiff_to(const double *a, const double *b, long n, double *partials, doub
 
 void pd_combine(const PtrPack &p, const PtrPack &z, const double *x, double *xo, int P, long n, double *partials,
                 double *out, hipStream_t s) {
-    hipLaunchKernelGGL(pd_combine_kernel, dim3(kReduceBlocks), dim3(kThreads), 0, s, p, z, x, xo, P, n, partials);
+    const dim3 grid(kReduceBlocks), block(kThreads);
+    switch (P) {
+        case 1: hipLaunchKernelGGL(pd_combine_kernel<1>, grid, block, 0, s, p, z, x, xo, P, n, partials); break;
+        case 2: hipLaunchKernelGGL(pd_combine_kernel<2>, grid, block, 0, s, p, z, x, xo, P, n, partials); break;
+        case 3: hipLaunchKernelGGL(pd_combine_kernel<3>, grid, block, 0, s, p, z, x, xo, P, n, partials); break;
+        case 4: hipLaunchKernelGGL(pd_combine_kernel<4>, grid, block, 0, s, p, z, x, xo, P, n, partials); break;
+        default: hipLaunchKernelGGL(pd_combine_kernel<0>, grid, block, 0, s, p, z, x, xo, P, n, partials); break;
+    }
     hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(kThreads), 0, s, partials, kReduceBlocks, out);
     PTV_HIP(hipGetLastError());
 }
@@ -443,6 +506,12 @@ void TransposedOperands::finish() {
         slab_transpose(o1_->d(), orig_.o1, g_.len, g_.inc, slabs_, s_);
         if (cache.active) cache.remember(orig_.o1, shape(g_.len), std::move(o1_));
     }
+}
+
+
+void warm_pointwise() {
+    hipFuncAttributes attr;
+    PTV_HIP(hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(calib_copy_kernel)));
 }
 
 }  // namespace ptv

@@ -54,7 +54,8 @@ constexpr int kQuietSolves = 16;    // one-sweep solves between explorations
 // sweep is this function of (input, lambda) and nothing else -- two runs on the same input take the same kernels and agree
 // to the last bit; without it the hill climb below starts from the seed instead of exploring from scratch.
 constexpr double kSeedNoisy = 0.45;   // f at or above: rung 0
-constexpr double kSeedMid = 0.02;     // f at or above: rung 1 ; below: rung 3
+constexpr double kSeedMid = 0.03;     // f at or above: rung 1 ; below: rung 3  (0.024 = lambda 0.8 on unit noise: 35.0 ms on rung 1, 34.0 on rung 3)
+constexpr double kSeedRowAlong = 0.1; // rung 1, strided sweeps, f below: through transposed copies and the along-fibre kernel
 inline int rung_from_certain_fraction(double f) { return f >= kSeedNoisy ? 0 : (f >= kSeedMid ? 1 : 3); }
 
 struct GeometryPolicy {

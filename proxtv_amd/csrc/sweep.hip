@@ -244,15 +244,21 @@ __device__ __forceinline__ void walk_chunk(Walker &w, ChunkRec &rec, const LdsWi
 //      the block's rows are streamed out: straight from LDS for fused ops, otherwise through the op's output functor
 //      (an operand that was staged for the walk and is needed again stays in registers: Op::KEEP).
 // LDS carve (dynamic, 16-byte aligned base): Y window | Wt window (weighted) | link codes.
-template <int OP, bool WEIGHTED, bool TRANSPOSED, int C, int NW, int H, bool ROUNDS>
-__global__ __launch_bounds__(64 * NW, ((WEIGHTED || H > 16) ? NW / 4 : NW / 2)) void sweep_chunk_kernel(SweepArgs p, FibreGeom g, ChunkPlan plan,
+// SHORT: fibres no longer than one block (len <= NW * C: the 64-sample dimension of a 512 x 512 x 64 volume).  The window is
+// the fibre itself -- no zone rows before it, no look-ahead rows after it are allocated (HA = TA = 0: chunks still start
+// their walks H samples early, inside the block) -- so a workgroup of NW = 4 waves holds 32 KB of LDS and four or five of
+// them share a CU; there are no links between workgroups, and the HBM traffic is exactly the algorithmic one.
+template <int OP, bool WEIGHTED, bool TRANSPOSED, int C, int NW, int H, bool ROUNDS, int T = tail_rows(H), bool SHORT = false>
+__global__ __launch_bounds__(64 * NW, SHORT ? 16 / NW : ((WEIGHTED || H > 16) ? NW / 4 : NW / 2)) void sweep_chunk_kernel(SweepArgs p, FibreGeom g, ChunkPlan plan,
                                                                                    link_t *code_mine, link_t *code_next,
                                                                                    int *failflags) {
     constexpr int PITCH = TRANSPOSED ? 65 : 64;
-    constexpr int T = tail_rows(H), ROWS = H + NW * C + T;
-    static_assert(H % NW == 0 && T % NW == 0, "the staging shares of the waves are whole rows");
+    constexpr int HA = SHORT ? 0 : H, TA = SHORT ? 0 : T;   // zone / look-ahead rows the window really has
+    constexpr int ROWS = HA + NW * C + TA;
+    static_assert(HA % NW == 0 && TA % NW == 0, "the staging shares of the waves are whole rows");
     constexpr int RB = (ROWS + 63) / 64;                                      // transposed: 64-row blocks per fibre
-    constexpr int NST = TRANSPOSED ? (64 / NW) * RB : ROWS / NW;              // staged window elements per thread
+    constexpr int FPW = (64 + NW - 1) / NW;                                   // transposed: fibres per wave (the last wave's share may be short)
+    constexpr int NST = TRANSPOSED ? FPW * RB : ROWS / NW;                    // staged window elements per thread
     constexpr int UL = 8;                                                     // epilogue rows in flight per lane
     constexpr bool KEEP = !TRANSPOSED && Op<OP>::KEEP;                        // a staged operand is reused by the epilogue
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -305,7 +311,7 @@ __global__ __launch_bounds__(64 * NW, ((WEIGHTED || H > 16) ? NW / 4 : NW / 2)) 
     double kept[KEEP ? C : 1];
     auto stage = [&](int q) {
         const int cs_wg = q * NW * C;
-        const int lo = cs_wg - H, hi = min(len, cs_wg + NW * C + T);
+        const int lo = cs_wg - HA, hi = min(len, cs_wg + NW * C + TA);
 #pragma unroll
         for (int u0 = 0; u0 < NST; u0 += NB) {
             double s0[NB], s1[NB], sw[NB];
@@ -323,7 +329,7 @@ __global__ __launch_bounds__(64 * NW, ((WEIGHTED || H > 16) ? NW / 4 : NW / 2)) 
                 } else {
                     const long jf = j0 + wave + NW * (u / RB);
                     r = lo + (u % RB) * 64 + lane;
-                    ok = jf < g.count && r >= 0 && r < hi;
+                    ok = wave + NW * (u / RB) < 64 && jf < g.count && r >= 0 && r < hi;
                     idx = jf * len + r;
                     widx = jf * (len - 1) + r;
                 }
@@ -344,13 +350,13 @@ __global__ __launch_bounds__(64 * NW, ((WEIGHTED || H > 16) ? NW / 4 : NW / 2)) 
                 } else {
                     col = wave + NW * (u / RB);
                     r = lo + (u % RB) * 64 + lane;
-                    ok = j0 + col < g.count && r >= 0 && r < hi;
+                    ok = col < 64 && j0 + col < g.count && r >= 0 && r < hi;
                 }
                 if (ok && u < NST) {
                     Yp[(r - lo) * PITCH + col] = Op<OP>::y_of(p, s0[v], s1[v]);
                     if (WEIGHTED) Wp[(r - lo) * PITCH + col] = sw[v];
                 }
-                if (KEEP && u >= H / NW && u < H / NW + C) kept[KEEP ? u - H / NW : 0] = s1[v];
+                if (KEEP && u >= HA / NW && u < HA / NW + C) kept[KEEP ? u - HA / NW : 0] = s1[v];
             }
         }
     };
@@ -370,8 +376,8 @@ __global__ __launch_bounds__(64 * NW, ((WEIGHTED || H > 16) ? NW / 4 : NW / 2)) 
         if (kb == 0) trace_mark(plan, 2);
 
         const int cs_wg = q * NW * C;
-        const int lo = cs_wg - H;
-        const int hi = min(len, cs_wg + NW * C + T);
+        const int lo = cs_wg - HA;
+        const int hi = min(len, cs_wg + NW * C + TA);
 
         // ---- speculative walk of this wave's chunk --------------------------------------------------------------------
         const int cs = cs_wg + wave * C;
@@ -518,7 +524,7 @@ __global__ __launch_bounds__(64 * NW, ((WEIGHTED || H > 16) ? NW / 4 : NW / 2)) 
                 }
             } else {
                 constexpr int ERB = (NW * C + 63) / 64;
-                constexpr int items = (64 / NW) * ERB;
+                constexpr int items = FPW * ERB;
 #pragma unroll
                 for (int t0 = 0; t0 < items; t0 += UL) {
                     Ext ex[UL];
@@ -527,7 +533,7 @@ __global__ __launch_bounds__(64 * NW, ((WEIGHTED || H > 16) ? NW / 4 : NW / 2)) 
                         const int t = t0 + u;
                         const long jf = j0 + wave + NW * (t / ERB);
                         const int k = cs_wg + (t % ERB) * 64 + lane;
-                        const bool ok = t < items && jf < g.count && k < ce_wg;
+                        const bool ok = t < items && wave + NW * (t / ERB) < 64 && jf < g.count && k < ce_wg;
                         ex[u] = (ok && !Op<OP>::FUSED) ? Op<OP>::fetch(p, jf * len + k) : Ext{0, 0};
                     }
 #pragma unroll
@@ -535,7 +541,7 @@ __global__ __launch_bounds__(64 * NW, ((WEIGHTED || H > 16) ? NW / 4 : NW / 2)) 
                         const int t = t0 + u;
                         const int f = wave + NW * (t / ERB);
                         const int k = cs_wg + (t % ERB) * 64 + lane;
-                        if (t < items && j0 + f < g.count && k < ce_wg) {
+                        if (t < items && f < 64 && j0 + f < g.count && k < ce_wg) {
                             const double v = Yp[(k - lo) * PITCH + f];
                             if (Op<OP>::FUSED) Op<OP>::store_fused(p, (j0 + f) * len + k, v);
                             else               Op<OP>::finish(p, (j0 + f) * len + k, ex[u], v);
@@ -562,6 +568,11 @@ __global__ __launch_bounds__(64 * NW, ((WEIGHTED || H > 16) ? NW / 4 : NW / 2)) 
 // hit two).
 constexpr int kAlongC = 17;
 constexpr int kAlongWaves = 4;
+// Look-ahead rows after a segment.  Only the segment's LAST lane reads them -- to close the piece that covers its last
+// sample -- and a segment is 1088 samples, so they cost next to nothing here: the robust instantiation takes 64 (on DR
+// iterates at lambda = 0.5 / 0.7 / 1 on unit noise a walk needs more than 8 rows past its chunk in 2 % / 20 % / 70 % of
+// the cases, more than 32 in 0 / 0.01 % / 7 %), where every further sample would be a dependent global read.
+constexpr int along_tail_rows(int H, bool robust) { return robust ? 64 : tail_rows(H); }
 
 // G lanes share one segment of G chunks: 64 for long fibres; 32 or 16 pack two or four shorter fibres into a wave.
 // ROBUST (geometry mode 1: pieces of a few samples, walks that need the whole zone -- or more -- to meet): like the tile
@@ -577,7 +588,7 @@ constexpr int kAlongWaves = 4;
 template <int OP, bool WEIGHTED, int H, int G, bool ROBUST>
 __global__ __launch_bounds__(64 * kAlongWaves) void sweep_along_kernel(SweepArgs p, FibreGeom g, ChunkPlan plan, link_t *code_mine,
                                                                         link_t *code_next, int *failflags) {
-    constexpr int C = kAlongC, SEG = G * C, T = tail_rows(H), ROWS = H + SEG + T, NG = 64 / G;
+    constexpr int C = kAlongC, SEG = G * C, T = along_tail_rows(H, ROBUST), ROWS = H + SEG + T, NG = 64 / G;
     constexpr int NU = (ROWS + G - 1) / G;   // staged elements per lane
     constexpr int UL = 9;                    // epilogue operand fetches in flight per lane (C = 17 rows per lane: 9 + 8)
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -644,7 +655,8 @@ __global__ __launch_bounds__(64 * kAlongWaves) void sweep_along_kernel(SweepArgs
     bool certain = false;
     if (has_chunk && !(plan.ablate & 1)) {
         Walker w;
-        constexpr int kLook = 8;
+        // (robust: the whole zone is searched -- a lane that starts at a bend known a priori has no link that could fail)
+        constexpr int kLook = ROBUST ? kWarm - 2 : 8;
         int cat = -1, ctype = 0;
         if (start > 0 && H <= kWarm && (WEIGHTED || p.lam > 0.0)) cat = certain_bend_before<WEIGHTED, kLook>(win, cs, len, p.lam, ctype);
         if (cat >= 0) {
@@ -1277,15 +1289,20 @@ struct ChunkScratch {
                 return &probes[k];
         return nullptr;
     }
-    // rung the statistics ask for at this penalty (-1: this sweep's input was not sampled)
-    int seed(const FibreGeom &g, double lam, bool weighted) const {
+    // fraction of the sampled edges at which the string is known to bend at this penalty (-1: this sweep's input was not sampled)
+    double certain_fraction(const FibreGeom &g, double lam, bool weighted) const {
         const Probe *p = find_probe(g, weighted);
-        if (!p || p->hist[kProbeBins] == 0) return -1;
-        if (!weighted && !(lam > 0.0)) return 0;
+        if (!p || p->hist[kProbeBins] == 0) return -1.0;
+        if (!weighted && !(lam > 0.0)) return 1.0;
         const int b = probe_bin(weighted ? 4.0 : 4.0 * lam);
         unsigned long above = p->hist[b] / 2;
         for (int k = b + 1; k < kProbeBins; k++) above += p->hist[k];
-        const double f = (double)above / (double)p->hist[kProbeBins];
+        return (double)above / (double)p->hist[kProbeBins];
+    }
+    // rung the statistics ask for at this penalty (-1: not sampled)
+    int seed(const FibreGeom &g, double lam, bool weighted) const {
+        const double f = certain_fraction(g, lam, weighted);
+        if (f < 0.0) return -1;
         if (options().seed_noisy_e4 > 0 || options().seed_mid_e4 > 0) {   // tuning aid: thresholds in units of 1e-4
             const double noisy = options().seed_noisy_e4 > 0 ? options().seed_noisy_e4 * 1e-4 : kSeedNoisy;
             const double mid = options().seed_mid_e4 > 0 ? options().seed_mid_e4 * 1e-4 : kSeedMid;
@@ -1405,10 +1422,16 @@ static ChunkScratch &chunk_state() { return g_chunks[current_device()]; }
 // Chunk geometry: C = 16 samples per chunk, 8 waves (chunks) per block of 128 samples.  LDS per workgroup = one window
 // of H + 128 + 8 rows x 512 B: ~77 KiB for H = 16 -> two workgroups = 16 waves per CU; ~101 KiB for H = 64 -> one.
 // Weighted sweeps carry a second (penalty) window and exist for H = 16 only.
-template <int OP, bool WEIGHTED, bool TRANSPOSED, int H, int C = 16, int NW = 8>
+// The robust instantiation (ROBUST; geometry mode 1) cuts the block into chunks of 14 samples and spends the 16 rows that
+// saves on look-ahead: H 16 / 8 x 14 / T 24 -- the same 152 rows.  The walks of a block's LAST chunk must close the piece
+// that covers its last sample inside the window, or read on from global memory one dependent access per sample; all 64
+// lanes of that wave are in that position, and on DR iterates at lambda = 0.5 (0.7) on unit noise 2 % (20 %) of them need
+// more than 8 rows, 0.02 % (2 %) more than 16, none (0.1 %) more than 24.
+template <int OP, bool WEIGHTED, bool TRANSPOSED, int H, bool ROBUST = false, int C = (ROBUST ? 14 : 16), int NW = 8,
+          int T = (ROBUST ? 24 : tail_rows(H)), bool SHORT = false>
 void launch_chunk_h(const SweepArgs &args, const FibreGeom &g, hipStream_t stream, int fam, int rounds_wanted) {
     constexpr int PITCH = TRANSPOSED ? 65 : 64;
-    constexpr int ROWS = H + NW * C + tail_rows(H);
+    constexpr int ROWS = SHORT ? NW * C : H + NW * C + T;
     ChunkPlan plan;
     plan.Q = (g.len + NW * C - 1) / (NW * C);
     // blocks per workgroup: enough workgroups to fill the chip a few times over
@@ -1425,26 +1448,27 @@ void launch_chunk_h(const SweepArgs &args, const FibreGeom &g, hipStream_t strea
     const int WQ = (plan.Q + plan.qpw - 1) / plan.qpw;
     constexpr size_t lds = sizeof(double) * PITCH * (size_t)ROWS * (WEIGHTED ? 2 : 1) + sizeof(link_t) * ((NW + 2) * 64 + 32);
     static_assert(WEIGHTED || H > kWarm || 2 * lds <= 160 * 1024, "the short-zone geometry is meant to run two workgroups per CU");
+    if (SHORT && g.len > NW * C) {
+        set_error("launch_chunk_h: a fibre of %d samples does not fit the single-block geometry (%d)", g.len, NW * C);
+        throw HipFailure{hipErrorInvalidValue};
+    }
     static_assert(lds <= 160 * 1024, "chunk geometry does not fit the LDS of a CU");
     const int NC = (g.len + C - 1) / C;
     chunk_state().ensure(g.count, NC, stream);
     // the second-chance rounds are a separate instantiation: their live state costs the plain kernel registers it
     // does not have (it sits at the 128-VGPR budget of two workgroups per CU)
-    constexpr bool kCanRound = (H <= kWarm) && C == 16;
-    const bool rounds = kCanRound && plan.rounds > 0;
-    auto kern = sweep_chunk_kernel<OP, WEIGHTED, TRANSPOSED, C, NW, H, false>;
-    auto kern_r = sweep_chunk_kernel<OP, WEIGHTED, TRANSPOSED, C, NW, H, kCanRound>;
+    static_assert(!ROBUST || H <= kWarm, "second chances exist for the short-zone geometry");
+    if (!ROBUST) plan.rounds = 0;
+    auto kern = sweep_chunk_kernel<OP, WEIGHTED, TRANSPOSED, C, NW, H, ROBUST, T, SHORT>;
     static thread_local bool attr_done[kMaxDevices] = {};   // function attributes are per device
     bool &attr_set = attr_done[current_device()];
     if (!attr_set) {
         PTV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     160 * 1024));
-        PTV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern_r), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    160 * 1024));
         attr_set = true;
     }
     const dim3 grid((unsigned)groups, (unsigned)WQ);
-    hipLaunchKernelGGL(rounds ? kern_r : kern, grid, dim3(64 * NW), lds, stream, args, g, plan, chunk_state().code_mine,
+    hipLaunchKernelGGL(kern, grid, dim3(64 * NW), lds, stream, args, g, plan, chunk_state().code_mine,
                        chunk_state().code_next, chunk_state().failflags);
     if (!plan.ablate) {
         constexpr size_t rlds = sizeof(double) * (2 + (WEIGHTED ? 1 : 0)) * kRepairWindow * 64;
@@ -1467,7 +1491,7 @@ void launch_chunk_h(const SweepArgs &args, const FibreGeom &g, hipStream_t strea
 // the codes of 64 consecutive chunks of one fibre).
 template <int OP, bool WEIGHTED, int H, int G, bool ROBUST>
 void launch_along_g(const SweepArgs &args, const FibreGeom &g, hipStream_t stream, int fam, int rounds_wanted) {
-    constexpr int C = kAlongC, SEG = G * C, ROWS = H + SEG + tail_rows(H), NG = 64 / G;
+    constexpr int C = kAlongC, SEG = G * C, ROWS = H + SEG + along_tail_rows(H, ROBUST), NG = 64 / G;
     const int nseg = (g.len + SEG - 1) / SEG;
     const int NC = (g.len + C - 1) / C;
     const long units = g.count * nseg;
@@ -1551,6 +1575,7 @@ void launch_chunk(const SweepArgs &args, const FibreGeom &g, hipStream_t stream,
     const bool pinned = options().chunk_mode >= 0;
     const bool pin_ok = options().pin && pin_supports((OpId)OP, WEIGHTED, g, args.lam);
     const int seed = st.seed(g, args.lam, WEIGHTED);
+    const double seed_f = st.certain_fraction(g, args.lam, WEIGHTED);
     if (pl.workload(g.len, g.count, WEIGHTED, pin_ok, seed) && pl.meas) {   // a new workload: the measurement in flight is of the old one
         double t, f;
         st.evaluate(fam, t, f);
@@ -1609,14 +1634,19 @@ void launch_chunk(const SweepArgs &args, const FibreGeom &g, hipStream_t stream,
     else if (!TRANSPOSED && !WEIGHTED && along_ok && (options().row_along & 1) && mode == 2) {
         if constexpr (!WEIGHTED) launch_row_along<OP, kWarmLong>(args, g, stream, fam, rounds);
     }
-    else if (!TRANSPOSED && !WEIGHTED && along_ok && (options().row_along & 2) && mode == 1) {
+    else if (!TRANSPOSED && !WEIGHTED && along_ok && mode == 1 &&
+             ((options().row_along & 2) || ((options().row_along & 1) && seed_f >= 0.0 && seed_f < kSeedRowAlong))) {
+        // rung 1 near its upper end (pieces of ~4 samples): the 64-fibre tile leaves the links between its workgroups to the
+        // repair kernel, and those start to fail; chunks along transposed copies settle nearly all links inside the kernel
         if constexpr (!WEIGHTED) launch_row_along<OP, kWarm>(args, g, stream, fam, rounds);
     }
     else if constexpr (!WEIGHTED) {
-        if (mode == 2) launch_chunk_h<OP, false, TRANSPOSED, kWarmLong>(args, g, stream, fam, 0);
-        else           launch_chunk_h<OP, false, TRANSPOSED, kWarm>(args, g, stream, fam, rounds);
+        if (mode == 2)      launch_chunk_h<OP, false, TRANSPOSED, kWarmLong>(args, g, stream, fam, 0);
+        else if (mode == 1) launch_chunk_h<OP, false, TRANSPOSED, kWarm, true>(args, g, stream, fam, rounds);
+        else                launch_chunk_h<OP, false, TRANSPOSED, kWarm>(args, g, stream, fam, 0);
     } else {
-        launch_chunk_h<OP, true, TRANSPOSED, kWarm>(args, g, stream, fam, rounds);
+        if (mode == 1) launch_chunk_h<OP, true, TRANSPOSED, kWarm, true>(args, g, stream, fam, rounds);
+        else           launch_chunk_h<OP, true, TRANSPOSED, kWarm>(args, g, stream, fam, 0);
     }
     pl.sweeps++;
     if (measure) {
@@ -1636,7 +1666,26 @@ void launch_op_w(const SweepArgs &args, const FibreGeom &g, hipStream_t stream, 
         // penalties -- tvgen lets them through -- keep the sequential kernel, whose reads past the fibre mirror the reference's;
         // so do fibres of a handful of samples: that kernel divides like the CPU, bit for bit, and loops that end at a
         // bitwise fixed point -- Kolmogorov2_TV -- count their iterations on the last bit)
-        // short fibres: whole in LDS (kernel 1b)
+        // Three kernels for short fibres.  Measured on 512 x 512 x L volumes, unit noise (tools/short_probe.py): up to 32
+        // samples the sequential walk wins (0.084 ms per sweep at L = 32 against 0.093 / 0.120); beyond, with pieces of a few
+        // samples (the policy's seed says rung 0), ONE block of the chunk kernel -- 4 or 6 chunks of 16 samples walk in
+        // parallel -- beats the whole-fibre kernel, which walks 64-96 samples in sequence at five waves per CU (L = 64:
+        // 0.136 against 0.206 ms); with longer pieces the whole-fibre kernel, which has no links to lose (0.300 against 0.356).
+        if (options().whole == 1 && g.len <= 32) {
+            launch_seq<OP, WEIGHTED>(args, g, stream, false);
+            return;
+        }
+        if (options().whole == 1 && chunk_state().seed(g, args.lam, false) == 0) {
+            if (g.len <= 64) {
+                if (g.inc == 1) launch_chunk_h<OP, false, true, kWarm, false, 16, 4, kTail, true>(args, g, stream, fam, 0);
+                else            launch_chunk_h<OP, false, false, kWarm, false, 16, 4, kTail, true>(args, g, stream, fam, 0);
+            } else {
+                if (g.inc == 1) launch_chunk_h<OP, false, true, kWarm, false, 16, 6, kTail, true>(args, g, stream, fam, 0);
+                else            launch_chunk_h<OP, false, false, kWarm, false, 16, 6, kTail, true>(args, g, stream, fam, 0);
+            }
+            return;
+        }
+        // short fibres whole in LDS, one lane per fibre (kernel 1b)
         const unsigned blocks = (unsigned)((g.count + 63) / 64);
         if (g.inc == 1) {
             hipLaunchKernelGGL((sweep_whole_kernel<OP, true>), dim3(blocks), dim3(64), sizeof(double) * 65 * (size_t)g.len, stream, args, g);
@@ -1683,7 +1732,7 @@ void policy_probe(const double *y, const double *const *weights, const int *ns, 
     for (int k = 0; k < ndims && st.nprobes < ChunkScratch::kMaxProbes; k++) {
         const FibreGeom g = fibres_along(ns, nds, dims[k]);
         const double *w = weights ? weights[k] : nullptr;
-        if (g.len < options().chunk_min_len || g.count < 1 || (long)g.len * g.count < kProbeMinElements) continue;
+        if (g.len < 16 || g.count < 1 || (long)g.len * g.count < kProbeMinElements) continue;   // (below 16 samples: the sequential kernel, always)
         if (st.find_probe(g, w != nullptr)) continue;
         if (!st.probe_dev) st.probe_dev.reset(new Scratch(sizeof(unsigned) * kWords * ChunkScratch::kMaxProbes));
         unsigned *dev = st.probe_dev->as<unsigned>() + kWords * (size_t)st.nprobes;
@@ -1792,6 +1841,12 @@ void launch_sweep(OpId op, bool weighted, const SweepArgs &args, const FibreGeom
 #undef PTV_CASE
 #undef PTV_CASE_U
 #undef PTV_CASE_W
+}
+
+
+void warm_sweep() {
+    hipFuncAttributes attr;
+    PTV_HIP(hipFuncGetAttributes(&attr, reinterpret_cast<const void *>((sweep_seq_kernel<OP_PROX, false, false>))));
 }
 
 }  // namespace ptv

@@ -180,4 +180,10 @@ void tv2_fibres(const double *in, double *out, const int *ns, int nds, int dim, 
     PTV_HIP(hipGetLastError());
 }
 
+
+void warm_tv2() {
+    hipFuncAttributes attr;
+    PTV_HIP(hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(tv2_fibres_kernel)));
+}
+
 }  // namespace ptv

@@ -1,7 +1,7 @@
 """Per-workgroup phase timeline of the chunk kernels (option "trace"): where every workgroup of a sweep ran and when
 its phases ended.  Answers: do the workgroups sharing a CU run in lockstep?  which phase is the long one?
 
-    python tools/wg_trace.py [lambda] > gpurun_out/wg_trace.txt
+    python tools/wg_trace.py [lambda [pinned mode]] > gpurun_out/wg_trace.txt
 """
 import sys, os
 import numpy as np
@@ -11,6 +11,8 @@ from proxtv_amd import _lib, device
 
 lam = float(sys.argv[1]) if len(sys.argv) > 1 else 0.1
 lib = _lib.require_device()
+if len(sys.argv) > 2:
+    lib.proxtv_set_option(b"chunk_mode", int(sys.argv[2]))
 x = device.to_colmajor(torch.from_numpy(np.random.default_rng(0).standard_normal((4096, 4096))).cuda())
 y = device.colmajor_empty((4096, 4096))
 device.tv1_2d(x, lam, out=y)
