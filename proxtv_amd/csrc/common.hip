@@ -31,6 +31,7 @@ Options &options() {
         if (const char *e = getenv("PROXTV_ALONG_MIN_LEN")) v.along_min_len = atoi(e);
         if (const char *e = getenv("PROXTV_CHUNK_MODE")) v.chunk_mode = atoi(e);
         if (const char *e = getenv("PROXTV_DETERMINISTIC")) v.deterministic = atoi(e);
+        if (const char *e = getenv("PROXTV_XLINK")) v.xlink = atoi(e);
         if (const char *e = getenv("PROXTV_SEED_NOISY_E4")) v.seed_noisy_e4 = atoi(e);
         if (const char *e = getenv("PROXTV_SEED_MID_E4")) v.seed_mid_e4 = atoi(e);
         return v;

@@ -52,6 +52,8 @@ struct Options {
     int whole = 1;            // fibres of 16 .. chunk_min_len samples: 1 = by length and data (sequential up to 32 samples; one block of the
                               // chunk kernel on noisy data, else whole fibres in LDS), 2 = the whole-fibre-in-LDS kernel, 0 = the sequential kernel
     int chunk_min_len = 96;   // fibres shorter than this take the sequential kernel (measured crossover: 512x512xL volumes, L ~ 96)
+    int xlink = 1;            // chunk kernels check the links across their workgroups themselves and tell the repair kernel, in one word,
+                              // whether anything is left for it (0: the repair kernel checks every boundary after every sweep)
     int host_register = 0;    // host-pointer entry points: page-lock large caller arrays around their transfers (see cabi.hip)
     int verbose = 0;
     int profile = 0;    // per-kernel-family hipEvent timing

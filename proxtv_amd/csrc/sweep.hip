@@ -57,9 +57,32 @@ constexpr link_t kLinkCertain = 0x80000000u;    // flag on a published `mine` co
 
 // Per fibre, two words tell the repair kernel where the chunk kernels left work: the first and the last chunk with an
 // unproven link (both as maxima, so that 0 = none: NC - first and last + 1).  Only failing lanes touch them.
-__device__ __forceinline__ void flag_chunk(int *failflags, long j, int chunk, int NC) {
+// A sweep that leaves anything to the repair kernel says so in ONE word, *dirty = the launch's epoch: the repair kernel's
+// common case -- nothing to do -- is then a single load.  (Every launch has its own epoch, so nothing is ever reset.)
+struct DirtyMark {
+    unsigned *word;   // null: the repair kernel always does its full check (global-memory chunks)
+    unsigned epoch;
+    __device__ __forceinline__ void set() const {
+        if (word) __hip_atomic_store(word, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+};
+__device__ __forceinline__ void flag_chunk(int *failflags, long j, int chunk, int NC, const DirtyMark &dirty) {
     atomicMax(failflags + 2 * j, NC - chunk);
     atomicMax(failflags + 2 * j + 1, chunk + 1);
+    dirty.set();
+}
+
+// The link between two workgroups (tile kernel) or two segments (along-fibre kernel) is checked by the LATER one at its
+// very end, against what the earlier one published for it: (epoch << 32 | its last chunk's `next` code), one 8-byte word
+// per fibre and boundary.  The earlier workgroup was dispatched first and publishes half-way through its life, so the
+// word is almost always there; when it is not (or the codes differ) the sweep is marked dirty and the repair kernel runs
+// its own check of every boundary, from the codes both sides publish in full, as before.
+__device__ __forceinline__ void xlink_publish(unsigned long long *slot, unsigned epoch, link_t next) {
+    __hip_atomic_store(slot, ((unsigned long long)epoch << 32) | next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ bool xlink_matches(const unsigned long long *slot, unsigned epoch, link_t mine) {
+    const unsigned long long v = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return (unsigned)(v >> 32) == epoch && mine != 0 && (link_t)v == mine;
 }
 
 // ---- kernel 1: sequential walk straight from / to global memory --------------------------------------------------
@@ -181,6 +204,8 @@ struct ChunkPlan {
     int ablate; // profiling aid (option "ablate"): 1 = skip the walk, 2 = skip the epilogue, 4 = skip the window loads
     int rounds; // second-chance rounds inside a block (0 = none): see the link-proof step of sweep_chunk_kernel
     unsigned long long *trace;   // option "trace": 8 words per workgroup -- where it ran and when its phases ended (100 MHz clock)
+    DirtyMark dirty;             // this launch's "something is left for the repair kernel" word
+    unsigned long long *xlink;   // links across workgroups / segments: [boundary][fibre] (tile) or [fibre][segment] (along)
 };
 
 __device__ __forceinline__ void trace_mark(const ChunkPlan &plan, int slot) {
@@ -255,10 +280,10 @@ __global__ __launch_bounds__(64 * NW, SHORT ? 16 / NW : ((WEIGHTED || H > 16) ? 
     constexpr int PITCH = TRANSPOSED ? 65 : 64;
     constexpr int HA = SHORT ? 0 : H, TA = SHORT ? 0 : T;   // zone / look-ahead rows the window really has
     constexpr int ROWS = HA + NW * C + TA;
-    static_assert(HA % NW == 0 && TA % NW == 0, "the staging shares of the waves are whole rows");
+    static_assert(!(!TRANSPOSED && Op<OP>::KEEP) || (HA % NW == 0 && TA % NW == 0), "Op::KEEP relies on whole staging shares");
     constexpr int RB = (ROWS + 63) / 64;                                      // transposed: 64-row blocks per fibre
     constexpr int FPW = (64 + NW - 1) / NW;                                   // transposed: fibres per wave (the last wave's share may be short)
-    constexpr int NST = TRANSPOSED ? FPW * RB : ROWS / NW;                    // staged window elements per thread
+    constexpr int NST = TRANSPOSED ? FPW * RB : (ROWS + NW - 1) / NW;         // staged window elements per thread (the last may fall past the window)
     constexpr int UL = 8;                                                     // epilogue rows in flight per lane
     constexpr bool KEEP = !TRANSPOSED && Op<OP>::KEEP;                        // a staged operand is reused by the epilogue
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -274,7 +299,12 @@ __global__ __launch_bounds__(64 * NW, SHORT ? 16 / NW : ((WEIGHTED || H > 16) ? 
     // PROVEN chunks before an unproven one -- rows the repair kernel will not touch -- so those instantiations stop a
     // lane's writes at the nearest unproven chunk before it (GUARD: one flag per lane through LDS, one more barrier).
     constexpr bool GUARD = ROUNDS || H > C;
-    unsigned long long *unproven = reinterpret_cast<unsigned long long *>(anybad + 2);   // [NW] lane masks (GUARD); NW <= 14
+    unsigned long long *unproven = reinterpret_cast<unsigned long long *>(anybad + 2);   // [NW] lane masks (GUARD)
+    // what the first chunk of the workgroup's first block began with, kept for the check at the kernel's end: an LDS row ([64];
+    // the pitch-65 tile has no room left for one at two workgroups per CU and keeps it in a register)
+    link_t *stash = reinterpret_cast<link_t *>(unproven + NW);
+    constexpr link_t kNoCheck = 0xffffffffu;
+    link_t began_reg = kNoCheck;
 
     if (p.gate && *p.gate == 0) return;   // uniform over the grid
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -323,7 +353,7 @@ __global__ __launch_bounds__(64 * NW, SHORT ? 16 / NW : ((WEIGHTED || H > 16) ? 
                 bool ok;
                 if (!TRANSPOSED) {
                     r = lo + wave + NW * u;
-                    ok = active && r >= 0 && r < hi;
+                    ok = active && r >= 0 && r < hi && r - lo < ROWS;
                     idx = base + (long)r * g.inc;
                     widx = wbase + (long)r * g.inc;
                 } else {
@@ -346,7 +376,7 @@ __global__ __launch_bounds__(64 * NW, SHORT ? 16 / NW : ((WEIGHTED || H > 16) ? 
                 if (!TRANSPOSED) {
                     r = lo + wave + NW * u;
                     col = lane;
-                    ok = active && r >= 0 && r < hi;
+                    ok = active && r >= 0 && r < hi && r - lo < ROWS;
                 } else {
                     col = wave + NW * (u / RB);
                     r = lo + (u % RB) * 64 + lane;
@@ -454,12 +484,21 @@ __global__ __launch_bounds__(64 * NW, SHORT ? 16 / NW : ((WEIGHTED || H > 16) ? 
                 rec.mine = kLinkBad;
                 rec.next = 0;
             }
-            if (bad) flag_chunk(failflags, j, q * NW + wave, (len + C - 1) / C);
+            if (bad) flag_chunk(failflags, j, q * NW + wave, (len + C - 1) / C, plan.dirty);
             // Every chunk publishes its two codes: sweep_repair_kernel proves the links between workgroups with them
             // and, for a fibre with an unproven link, finds where a repair walk may stop.
             const long slot = (long)(q * NW + wave) * g.count + j;
             code_mine[slot] = (certain && rec.mine != kLinkBad) ? (rec.mine | kLinkCertain) : rec.mine;
             code_next[slot] = rec.next;
+            // ... and the workgroup's last chunk, right now, what the next workgroup's first chunk must have begun with
+            if (plan.xlink && kb == nblk - 1 && wave == NW - 1)
+                xlink_publish(plan.xlink + (size_t)blockIdx.y * g.count + j, plan.dirty.epoch, rec.next);
+        }
+        // (the link INTO this workgroup is checked at the very end, when the workgroup before has surely published)
+        if (kb == 0 && wave == 0) {
+            const link_t began = (has_chunk && !certain) ? rec.mine : kNoCheck;
+            if (TRANSPOSED) began_reg = began;
+            else stash[lane] = began;
         }
         // carried to the next block's first chunk; two slots in turn, so that no barrier is needed before the write
         if (wave == NW - 1) codes[(NW + (kb & 1)) * 64 + lane] = (bad || !has_chunk) ? rec.next : (rec.next | kLinkCertain);
@@ -551,6 +590,11 @@ __global__ __launch_bounds__(64 * NW, SHORT ? 16 / NW : ((WEIGHTED || H > 16) ? 
             }
         }
         if (kb + 1 < nblk) __syncthreads();   // every wave is done reading this block's window
+    }
+    if (plan.xlink && blockIdx.y > 0 && wave == 0 && active) {
+        const link_t began = TRANSPOSED ? began_reg : stash[lane];   // (written by this very thread)
+        if (began != kNoCheck && !xlink_matches(plan.xlink + (size_t)(blockIdx.y - 1) * g.count + j, plan.dirty.epoch, began))
+            plan.dirty.set();
     }
     trace_mark(plan, 5);
 }
@@ -734,9 +778,11 @@ __global__ __launch_bounds__(64 * kAlongWaves) void sweep_along_kernel(SweepArgs
             rec.next = 0;
         }
         const int chunk = sg * G + gl;
-        if (bad) flag_chunk(failflags, j, chunk, NC);
+        if (bad) flag_chunk(failflags, j, chunk, NC, plan.dirty);
         code_mine[j * NC + chunk] = (certain && rec.mine != kLinkBad) ? (rec.mine | kLinkCertain) : rec.mine;
         code_next[j * NC + chunk] = rec.next;
+        // the segment's last chunk: what the next segment's first chunk must have begun with (checked by that segment at its end)
+        if (plan.xlink && gl == G - 1 && sg + 1 < nseg) xlink_publish(plan.xlink + (size_t)j * nseg + sg, plan.dirty.epoch, rec.next);
     }
     // a lane's writes stop at the nearest unproven chunk before it (see GUARD in sweep_chunk_kernel; needed for H > C)
     int wlo = seg_s;
@@ -773,6 +819,11 @@ __global__ __launch_bounds__(64 * kAlongWaves) void sweep_along_kernel(SweepArgs
             }
         }
     }
+    // the link into this segment, against what the segment before published (it was dispatched earlier and published before its
+    // rebuild: almost always there by now -- else the sweep is marked dirty and the repair kernel checks every boundary itself)
+    if (plan.xlink && has_chunk && gl == 0 && sg > 0 && !certain &&
+        !xlink_matches(plan.xlink + (size_t)j * nseg + sg - 1, plan.dirty.epoch, rec.mine))
+        plan.dirty.set();
     if (plan.trace && lane == 0) plan.trace[8 * (size_t)wid + 5] = wall_clock64();
 }
 
@@ -958,7 +1009,7 @@ __global__ __launch_bounds__(64) void sweep_gchunk_kernel(SweepArgs p, FibreGeom
     walker_start<WEIGHTED>(w, src, max(0, cs - H), p.lam);
     walker_run_blocked<WEIGHTED, kGlobalBlock>(w, src, len, p.lam);
     if (src.failed) {   // nothing this lane recorded may be trusted; the repair walk rewrites its chunk
-        flag_chunk(failflags, j, c, (len + C - 1) / C);
+        flag_chunk(failflags, j, c, (len + C - 1) / C, DirtyMark{nullptr, 0u});
         src.mine = kLinkBad;
         src.next = 0;
     }
@@ -1116,8 +1167,11 @@ struct WindowRepairSource : RepairBook {
 template <int OP, bool WEIGHTED>
 __global__ __launch_bounds__(64) void sweep_repair_kernel(SweepArgs p, FibreGeom g, int C, int H, int chunks_per_wg,
                                                            const link_t *code_mine, const link_t *code_next,
-                                                           int *failflags, int *failcount, long cstride, long fstride) {
+                                                           int *failflags, int *failcount, long cstride, long fstride,
+                                                           DirtyMark dirty) {
     extern __shared__ __attribute__((aligned(16))) double repair_lds[];   // (2 + WEIGHTED) planes of kRepairWindow x 64 (LDS geometries only)
+    // the common case: the chunk kernel proved every link itself, across its workgroups too, and said so by NOT marking the sweep
+    if (dirty.word && __hip_atomic_load(dirty.word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != dirty.epoch) return;
     const long j = (long)blockIdx.x * 64 + threadIdx.x;
     if (j >= g.count) return;
     if (p.gate && *p.gate == 0) return;
@@ -1258,6 +1312,28 @@ struct ChunkScratch {
         return trace->as<unsigned long long>();
     }
     int *failcount = nullptr;   // [family][2]: fibres that needed repair, chunks rewritten by repair walks (cumulative per solve)
+    // one "dirty" word for all launches (each launch has its own epoch) and the cross-workgroup link words
+    unsigned epoch = 0;
+    std::unique_ptr<Scratch> dirty_word, xlink;
+    size_t xlink_words = 0;
+    DirtyMark next_dirty(hipStream_t s) {
+        if (!options().xlink) return DirtyMark{nullptr, 0u};
+        if (!dirty_word) {
+            dirty_word.reset(new Scratch(sizeof(unsigned)));
+            PTV_HIP(hipMemsetAsync(dirty_word->as<unsigned>(), 0, sizeof(unsigned), s));
+        }
+        if (++epoch == 0u) ++epoch;   // (0 is what freshly allocated words hold)
+        return DirtyMark{dirty_word->as<unsigned>(), epoch};
+    }
+    unsigned long long *xlink_for(size_t words, hipStream_t s) {
+        if (!options().xlink) return nullptr;
+        if (words > xlink_words) {
+            xlink.reset(new Scratch(sizeof(unsigned long long) * words));
+            xlink_words = words;
+            PTV_HIP(hipMemsetAsync(xlink->as<unsigned long long>(), 0, sizeof(unsigned long long) * words, s));
+        }
+        return xlink->as<unsigned long long>();
+    }
 
     // Geometry policy (policy.hpp), one per sweep family -- fibres along dim 0 / along the other dims see different
     // data: in a DR solve at large lambda the column pieces are several times longer than the row pieces -- plus the
@@ -1439,14 +1515,21 @@ void launch_chunk_h(const SweepArgs &args, const FibreGeom &g, hipStream_t strea
     int qpw = options().blocks_per_wg;
     if (qpw <= 0) {
         qpw = 8;
-        while (qpw > 1 && groups * ((plan.Q + qpw - 1) / qpw) < 2048) qpw >>= 1;
+        // (weighted strided sweeps run ONE workgroup per CU -- two LDS planes: as many blocks per workgroup as still gives
+        // every CU one; 14.5 -> 14.05 ms on the 4096^2 weighted solve.  Keeping the next block's window share in registers
+        // while the current one is processed -- the waves own 256 VGPRs there -- was tried and hid the staging phase, but the
+        // sweep did not get faster: at 8 waves per CU it is the walk's dependent-instruction latency that bounds it)
+        const long want = (WEIGHTED && !TRANSPOSED && !SHORT) ? 256 : 2048;
+        while (qpw > 1 && groups * ((plan.Q + qpw - 1) / qpw) < want) qpw >>= 1;
     }
     plan.qpw = qpw < plan.Q ? qpw : plan.Q;
     plan.ablate = options().ablate;
     plan.rounds = rounds_wanted;
     plan.trace = options().trace ? chunk_state().trace_buffer((size_t)groups * (size_t)((plan.Q + plan.qpw - 1) / plan.qpw)) : nullptr;
     const int WQ = (plan.Q + plan.qpw - 1) / plan.qpw;
-    constexpr size_t lds = sizeof(double) * PITCH * (size_t)ROWS * (WEIGHTED ? 2 : 1) + sizeof(link_t) * ((NW + 2) * 64 + 32);
+    plan.dirty = chunk_state().next_dirty(stream);
+    plan.xlink = chunk_state().xlink_for((size_t)WQ * (size_t)g.count, stream);
+    constexpr size_t lds = sizeof(double) * PITCH * (size_t)ROWS * (WEIGHTED ? 2 : 1) + sizeof(link_t) * ((NW + (TRANSPOSED ? 2 : 3)) * 64 + 4 + 2 * NW);
     static_assert(WEIGHTED || H > kWarm || 2 * lds <= 160 * 1024, "the short-zone geometry is meant to run two workgroups per CU");
     if (SHORT && g.len > NW * C) {
         set_error("launch_chunk_h: a fibre of %d samples does not fit the single-block geometry (%d)", g.len, NW * C);
@@ -1481,7 +1564,8 @@ void launch_chunk_h(const SweepArgs &args, const FibreGeom &g, hipStream_t strea
             rattr_set = true;
         }
         hipLaunchKernelGGL(rkern, dim3((unsigned)groups), dim3(64), rlds, stream, args, g, C, H, plan.qpw * NW,
-                           chunk_state().code_mine, chunk_state().code_next, chunk_state().failflags, chunk_state().failcount + 2 * fam, (long)g.count, 1L);
+                           chunk_state().code_mine, chunk_state().code_next, chunk_state().failflags, chunk_state().failcount + 2 * fam, (long)g.count, 1L,
+                           plan.dirty);
     }
     PTV_HIP(hipGetLastError());
     chunk_state().pol[fam].chunks_done += (long)NC * g.count;
@@ -1501,6 +1585,8 @@ void launch_along_g(const SweepArgs &args, const FibreGeom &g, hipStream_t strea
     plan.rounds = ROBUST ? rounds_wanted : 0;
     chunk_state().ensure(g.count, NC, stream);
     plan.trace = options().trace ? chunk_state().trace_buffer((size_t)waves) : nullptr;
+    plan.dirty = chunk_state().next_dirty(stream);
+    plan.xlink = chunk_state().xlink_for((size_t)g.count * (size_t)nseg, stream);
     constexpr size_t lds = sizeof(double) * (size_t)(ROWS + 2) * NG * kAlongWaves * (WEIGHTED ? 2 : 1) + (ROBUST ? 64 : 0);
     static_assert(lds <= 160 * 1024, "along-fibre geometry does not fit the LDS of a CU");
     auto kern = sweep_along_kernel<OP, WEIGHTED, H, G, ROBUST>;
@@ -1524,7 +1610,7 @@ void launch_along_g(const SweepArgs &args, const FibreGeom &g, hipStream_t strea
             rattr_set = true;
         }
         hipLaunchKernelGGL(rkern, dim3((unsigned)((g.count + 63) / 64)), dim3(64), rlds, stream, args, g, C, H, G, chunk_state().code_mine,
-                           chunk_state().code_next, chunk_state().failflags, chunk_state().failcount + 2 * fam, 1L, (long)NC);
+                           chunk_state().code_next, chunk_state().failflags, chunk_state().failcount + 2 * fam, 1L, (long)NC, plan.dirty);
     }
     PTV_HIP(hipGetLastError());
     chunk_state().pol[fam].chunks_done += (long)NC * g.count;
@@ -1549,7 +1635,8 @@ void launch_gchunk(const SweepArgs &args, const FibreGeom &g, int C, int H, hipS
     hipLaunchKernelGGL((sweep_gchunk_kernel<OP, WEIGHTED>), dim3((unsigned)groups, (unsigned)NC), dim3(64), 0, stream, args,
                        g, C, H, chunk_state().code_mine, chunk_state().code_next, chunk_state().failflags);
     hipLaunchKernelGGL((sweep_repair_kernel<OP, WEIGHTED>), dim3((unsigned)groups), dim3(64), 0, stream, args, g, C, H, 1,
-                       chunk_state().code_mine, chunk_state().code_next, chunk_state().failflags, chunk_state().failcount + 2 * fam, (long)g.count, 1L);
+                       chunk_state().code_mine, chunk_state().code_next, chunk_state().failflags, chunk_state().failcount + 2 * fam, (long)g.count, 1L,
+                       DirtyMark{nullptr, 0u});
     PTV_HIP(hipGetLastError());
     chunk_state().pol[fam].chunks_done += (long)NC * g.count;
 }
@@ -1819,7 +1906,14 @@ void launch_sweep(OpId op, bool weighted, const SweepArgs &args, const FibreGeom
 #define PTV_CASE_U(ID) case ID: launch_op_w<ID, false>(args, g, stream, allow_chunked, fam); break;
 #define PTV_CASE_W(ID) case ID: launch_op_w<ID, true>(args, g, stream, allow_chunked, fam); break;
     switch (op) {
-#ifdef PTV_FAST_BUILD   // experiments only: the headline's three unweighted sweeps (a full build takes two minutes)
+#if defined(PTV_FAST_BUILD) && defined(PTV_FAST_WEIGHTED)   // experiments only: ... and their weighted forms
+        PTV_CASE(OP_PROX)
+        PTV_CASE(OP_DR_COL)
+        PTV_CASE(OP_DR_COL_FINAL)
+        PTV_CASE(OP_DR_ROW)
+        PTV_CASE_U(OP_DR_ROW_FINAL)
+        PTV_CASE_W(OP_DRW_ROW_FINAL)
+#elif defined(PTV_FAST_BUILD)   // experiments only: the headline's three unweighted sweeps (a full build takes two minutes)
         PTV_CASE_U(OP_PROX)
         PTV_CASE_U(OP_DR_COL)
         PTV_CASE_U(OP_DR_ROW)

@@ -44,6 +44,17 @@ def report(title, rows=16):
 
 
 lib.proxtv_set_option(b"trace", 1)
+if os.environ.get("WG_TRACE_WEIGHTED") == "1":
+    rng = np.random.default_rng(1)
+    w1 = device.to_colmajor(torch.from_numpy(rng.uniform(0.05, 0.15, (4095, 4096))).cuda())
+    w2 = device.to_colmajor(torch.from_numpy(rng.uniform(0.05, 0.15, (4096, 4095))).cuda())
+    device.tv1w_2d(x, w1, w2, out=y)
+    report("weighted row sweep, DRW_ROW_FINAL")
+    device.tv1_fibres(x, 0.0, 1, weights=w2, out=y)
+    report("weighted row sweep, OP_PROX")
+    device.tv1_fibres(x, 0.0, 0, weights=w1, out=y)
+    report("weighted column sweep (along the fibre), OP_PROX")
+    sys.exit(0)
 device.tv1_2d(x, lam, out=y)     # the last launch of a DR solve is the final row sweep (OP_DR_ROW_FINAL: two-operand input, epilogue fetches)
 report("row sweep, DR_ROW_FINAL")
 device.tv1_fibres(x, lam, 0, out=y)
