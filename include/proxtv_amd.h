@@ -230,6 +230,10 @@ long   proxtv_last_fixups(void);
    8 words each: [0] = XCC_ID << 32 | HW_ID (where it ran), [1..5] = 100 MHz timestamps at start, window staged, walk
    done, rebuild done, end.  Returns the number of workgroups copied to `dst` (at most max_wgs). */
 long   proxtv_debug_trace(unsigned long long *dst, long max_wgs);
+/* Tuning aid (option "why" = 1): what left work to the repair kernel since the last call, 8 counters: [0] walks that ran off
+   their window, [1] links inside a workgroup / wave that stayed unproven, [2] links across workgroups / segments whose codes
+   differ, [3] ... that were not published in time.  Returns 8, or <= 0. */
+int    proxtv_debug_why(unsigned *dst);
 /* Geometry policy the adaptive chunk kernel currently uses on this thread (the highest over the sweep families):
    0 = 16-sample warm-up zones (noisy data, small lambda), 1 = the same, robust instantiation (walks may run past
    the window, second-chance rounds inside a block: pieces of ~5 samples), 2 = 64-sample zones (pieces of ~10 samples),

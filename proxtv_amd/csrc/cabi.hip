@@ -508,6 +508,7 @@ int proxtv_set_option(const char *key, int value) {
     else if (!strcmp(key, "deterministic")) slot = &o.deterministic;
     else if (!strcmp(key, "host_register")) slot = &o.host_register;
     else if (!strcmp(key, "xlink")) slot = &o.xlink;
+    else if (!strcmp(key, "why")) slot = &o.why;
     else if (!strcmp(key, "seed_noisy_e4")) slot = &o.seed_noisy_e4;
     else if (!strcmp(key, "seed_mid_e4")) slot = &o.seed_mid_e4;
     if (!slot) return -1;
@@ -527,6 +528,9 @@ long proxtv_debug_trace(unsigned long long *dst, long max_wgs) {
     try { return chunk_trace_fetch(dst, max_wgs, thread_stream()); } catch (...) { return -1; }
 }
 long proxtv_last_kernel_launches(int which) { return timing_launches(which); }
+int proxtv_debug_why(unsigned *dst) {
+    try { return chunk_why_fetch(dst, thread_stream()); } catch (...) { return -1; }
+}
 
 int proxtv_DR2_TV_batch_dev(size_t M, size_t N, size_t B, const double *unary, double W1, double W2, double *s,
                             int maxit, double *info, void *stream) {

@@ -57,6 +57,7 @@ struct Options {
     int host_register = 0;    // host-pointer entry points: page-lock large caller arrays around their transfers (see cabi.hip)
     int verbose = 0;
     int profile = 0;    // per-kernel-family hipEvent timing
+    int why = 0;        // tuning aid: count what marks sweeps dirty (proxtv_debug_why)
     int trace = 0;      // profiling aid: per-workgroup phase timestamps of the chunk kernel (proxtv_debug_trace)
     int ablate = 0;     // profiling aid, see ChunkPlan::ablate (results are WRONG when non-zero)
 };

@@ -133,6 +133,7 @@ __global__ __launch_bounds__(kPinThreads) void sweep_pin_kernel(SweepArgs p, Fib
     }
 
     // ---- values, in place (a lane reads nothing but its own part of the plane and what it cached of its neighbours') -----------------
+    ln.settle(sh);
     ln.values(sh, mean, [&](int, int k, double v) { own[k] = v; });
     if (pieces) {   // a measured launch: pieces of this sweep, for the geometry policy (one atomic per wave)
         int c = __popcll(ln.pinU | ln.pinL) + (t == 0 ? 1 : 0);

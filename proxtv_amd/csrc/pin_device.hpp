@@ -47,6 +47,7 @@ struct PinShared {
     __device__ __forceinline__ double r(int j) const { return WEIGHTED ? Wp[Geo::sa(j)] : lam; }
     __device__ __forceinline__ double own(int, int k) const { return kCached ? cached[kCached ? k : 0] : ownS[k]; }
     __device__ __forceinline__ double own_at(int, int k) const { return ownS[k]; }
+    __device__ __forceinline__ void set_own(int, int k, double v) { ownS[k] = v; }
     __device__ __forceinline__ double rown(int, int k) const { return WEIGHTED ? ownW[k] : lam; }
     __device__ __forceinline__ void post(int wall, int slot, double v) {
         atomicMax(&mx[wall * Geo::SLOTS + slot], (unsigned long long)__double_as_longlong(v));   // positive doubles order like their bits

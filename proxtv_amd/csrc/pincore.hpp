@@ -79,7 +79,10 @@ struct PinTag {
 //     double r(int j)                          tube half-width at interior knot j
 //     double own(int t, int k)                 = S(1 + tP + k): lane t's k-th knot; k is a compile-time constant wherever this
 //                                                is called (unrolled loops), so an implementation may keep the values in registers
-//     double own_at(int t, int k)              the same for a run-time k
+//     double own_at(int t, int k)              the same for a run-time k -- EXCEPT at a knot the lane has pinned and settled
+//                                                (PinLane::settle): there the slot holds the string's height S -+ r, which is
+//                                                all anybody ever asks of a pinned knot again
+//     void   set_own(int t, int k, double v)   overwrite that slot (settle only)
 //     double rown(int t, int k)                = r(1 + tP + k)
 //     void   post(int wall, int slot, double v)     slot maximum <- max(., v)          (v > 0)
 //     double best(int wall, int slot)               slot maximum (0: nothing posted)
@@ -91,15 +94,22 @@ struct PinTag {
 // the next barrier -- and their maxima in its update step, which reads knots only.
 // wall 0 = upper, 1 = lower.
 
+template <bool SMALL> struct PinMask { using type = unsigned long long; };
+template <> struct PinMask<true> { using type = unsigned; };
+
 // Key: the type of a claim key -- 32 bits (knot and distance in 16 bits each: fibres held in one workgroup's LDS) or 64 bits
 // (32 + 32: fibres spread over a grid of workgroups, pinlong.hip).
 template <int P, class Key = unsigned>
 struct PinLane {
     static_assert(P >= 1 && P <= 64, "a lane's pins live in one 64-bit mask per wall");
     // (a 32-bit claim key keeps the knot in 16 bits: fibres of at most 65535 samples -- the LDS kernel's planes end at 16384)
+    // a lane's pins: one bit per own knot and wall -- 32-bit words where they suffice (half the instructions per shift / scan)
+    using Mask = typename PinMask<(P <= 32)>::type;
+    PTV_PIN_FN static int ctz(Mask m) { return sizeof(Mask) == 4 ? __builtin_ctz((unsigned)m) : __builtin_ctzll((unsigned long long)m); }
     int n = 0, t = 0;
     int j0 = 0, j1 = 0;                        // own candidate knots [j0, j1) (interior knots are 1 .. n-1)
-    unsigned long long pinU = 0, pinL = 0;     // bit k: knot j0 + k is pinned to the upper / lower wall
+    Mask pinU = 0, pinL = 0;                   // bit k: knot j0 + k is pinned to the upper / lower wall
+    Mask pendU = 0, pendL = 0;                 // ... gained in the last update: their slots still hold the running sum (settle)
     int la = 0, rb = 0;                        // nearest pinned knot before j0 / at or after j1
     double hl = 0.0, hr = 0.0;                 // the string's height there
     bool final_ = false;                       // no segment of this lane can change any more
@@ -108,7 +118,7 @@ struct PinLane {
     int eUk = 0, eLk = 0, xUk = 0, xLk = 0;          // ... and the knot
     int eEnds = 0, xEnds = 0;                         // ja + jb of the two runs' segments (twice their midpoint)
     bool leaving = false;                             // the lane has pins of its own, so a second run leaves to the right
-    unsigned long long newU = 0, newL = 0;            // pins found this level inside the lane's own range
+    Mask newU = 0, newL = 0;                          // pins found this level inside the lane's own range
 
     PTV_PIN_FN static int slot_of(int ja) { return ja == 0 ? 0 : (ja - 1) / P + 1; }
 
@@ -119,6 +129,7 @@ struct PinLane {
         j0 = 1 + t * P < n ? 1 + t * P : n;
         j1 = j0 + P < n ? j0 + P : n;
         pinU = pinL = 0;
+        pendU = pendL = 0;
         la = 0;
         hl = sh.S(0);
         rb = n;
@@ -136,22 +147,40 @@ struct PinLane {
     // Written for full unrolling: k is a compile-time constant in every copy of the body, so a pin test is one bit test,
     // a knot's sum is read at a constant offset from the lane's part of the plane (sh.own), and the distances to the two
     // ends of the run are doubles counted up and down by one (exact) instead of converted integers.
+    // The slots of the knots this lane pinned in the last update take the string's height there (S + r at the upper wall,
+    // S - r at the lower): from now on a run that ends at such a knot reads its height with one load, no sign to work out.
+    // Every lane runs this at the start of a level (final lanes included) and once more after the last one: nobody reads a
+    // knot's sum after the level in which it was claimed (a pinned knot never violates, and place() looks at this level's
+    // claims only).
+    template <class Sh>
+    PTV_PIN_FN void settle(Sh &sh) {
+        Mask m = pendU | pendL;
+        while (m) {
+            const int k = ctz(m);
+            m &= m - 1;
+            const double w = Sh::kWeighted ? sh.rown(t, k) : sh.r(j0 + k);
+            sh.set_own(t, k, ((pendL >> k) & 1) ? sh.own_at(t, k) - w : sh.own_at(t, k) + w);
+        }
+        pendU = pendL = 0;
+    }
+
     template <class Sh>
     PTV_PIN_FN void scan(Sh &sh) {
+        settle(sh);
         newU = newL = 0;
         eU = eL = xU = xL = 0.0;
         leaving = false;
         if (final_) return;
         sh.clear_knot(t + 1);
         if (t == 0) sh.clear_knot(0);
-        const unsigned long long pinned = pinU | pinL;
+        const Mask pinned = pinU | pinL;
         int ca = la;
         double cha = hl;
         // end of the run that enters from the left: the lane's first pin, or the pin beyond its range
         int cb;
         double chb;
         if (pinned) {
-            const int b = __builtin_ctzll(pinned);
+            const int b = ctz(pinned);
             cb = j0 + b;
             chb = own_height(sh, b);
         } else {
@@ -170,21 +199,21 @@ struct PinLane {
         for (int k = 0; k < P; k++) {
             if (k < cnt) {   // (fewer than P knots: the fibre's last lane only)
                 const int j = j0 + k;
-                const bool is_pin = (pinned >> k) & 1ull;
+                const bool is_pin = (pinned >> k) & 1;
                 if (is_pin) {
                     // a run closes at this pin
                     if (entering) {
                         eU = bu; eL = bl;
                         entering = false;
                     } else {
-                        if (bu > 0.0) newU |= 1ull << PinTag<P>::index(bu);
-                        if (bl > 0.0) newL |= 1ull << PinTag<P>::index(bl);
+                        if (bu > 0.0) newU |= (Mask)1 << PinTag<P>::index(bu);
+                        if (bl > 0.0) newL |= (Mask)1 << PinTag<P>::index(bl);
                     }
                     ca = j;
                     cha = chb;   // (the run ended exactly here)
-                    const unsigned long long rest = (k + 1 < 64) ? (pinned >> (k + 1)) : 0ull;
+                    const Mask rest = (k + 1 < (int)(8 * sizeof(Mask))) ? (Mask)(pinned >> (k + 1)) : (Mask)0;
                     if (rest) {
-                        const int b = k + 1 + __builtin_ctzll(rest);
+                        const int b = k + 1 + ctz(rest);
                         cb = j0 + b;
                         chb = own_height(sh, b);
                     } else {
@@ -218,7 +247,7 @@ struct PinLane {
         }
         eUk = j0 + PinTag<P>::index(eU); eLk = j0 + PinTag<P>::index(eL);
         xUk = j0 + PinTag<P>::index(xU); xLk = j0 + PinTag<P>::index(xL);
-        eEnds = la + (pinned ? j0 + __builtin_ctzll(pinned) : rb);
+        eEnds = la + (pinned ? j0 + ctz(pinned) : rb);
         xEnds = ca + rb;   // (ca: the lane's last pin when a run leaves)
         const int se = slot_of(la);
         if (eU > 0.0) sh.post(0, se, eU);
@@ -229,12 +258,9 @@ struct PinLane {
         }
     }
 
-    // height of the string at the lane's own pin k
+    // height of the string at the lane's own (settled) pin k
     template <class Sh>
-    PTV_PIN_FN double own_height(const Sh &sh, int k) const {
-        const double w = Sh::kWeighted ? sh.rown(t, k) : sh.r(j0 + k);
-        return ((pinL >> k) & 1ull) ? sh.own_at(t, k) - w : sh.own_at(t, k) + w;
-    }
+    PTV_PIN_FN double own_height(const Sh &sh, int k) const { return sh.own_at(t, k); }
 
     // ---- claim ------------------------------------------------------------------------------------------------------------
     // Among the lanes that hold a segment's largest violation the one whose knot lies closest to the middle of the
@@ -276,9 +302,11 @@ struct PinLane {
                 if (kx >= 0) moved |= place(sh, kx, wall);
             }
         }
-        const bool gained = (newU | newL) != 0ull;
+        const bool gained = (newU | newL) != 0;
         pinU |= newU;
         pinL |= newL;
+        pendU |= newU;
+        pendL |= newL;
         if (!moved && !gained) final_ = true;
         return gained;
     }
@@ -301,16 +329,16 @@ struct PinLane {
             }
             return false;
         }
-        if (wall) newL |= 1ull << (k - j0);
-        else      newU |= 1ull << (k - j0);
+        if (wall) newL |= (Mask)1 << (k - j0);
+        else      newU |= (Mask)1 << (k - j0);
         return true;
     }
 
     // ---- values: slope of the string over the lane's own samples i = tP + k (between knots i and i + 1), k < P ---------------
     // `mean` is what the caller subtracted from the samples before summing them.
     template <class Sh, class Put>
-    PTV_PIN_FN void values(const Sh &sh, double mean, Put &&put) const {
-        const unsigned long long pinned = pinU | pinL;
+    PTV_PIN_FN void values(const Sh &sh, double mean, Put &&put) const {   // (after a last settle())
+        const Mask pinned = pinU | pinL;
         const int i0 = t * P;
         if (i0 >= n) return;
         int ca = la;
@@ -318,7 +346,7 @@ struct PinLane {
         int cb;
         double chb;
         if (pinned) {
-            const int b = __builtin_ctzll(pinned);
+            const int b = ctz(pinned);
             cb = j0 + b;
             chb = own_height(sh, b);
         } else {
@@ -331,12 +359,12 @@ struct PinLane {
         for (int k = 0; k < P; k++) {
             if (k < cnt) {
                 const int i = i0 + k;   // knot i = j0 + k - 1: the lane's own knot k - 1
-                if (k >= 1 && ((pinned >> (k - 1)) & 1ull)) {
+                if (k >= 1 && ((pinned >> (k - 1)) & 1)) {
                     ca = i;
                     cha = chb;
-                    const unsigned long long rest = (k < 64) ? (pinned >> k) : 0ull;
+                    const Mask rest = (k < (int)(8 * sizeof(Mask))) ? (Mask)(pinned >> k) : (Mask)0;
                     if (rest) {
-                        const int b = k + __builtin_ctzll(rest);
+                        const int b = k + ctz(rest);
                         cb = j0 + b;
                         chb = own_height(sh, b);
                     } else {

@@ -88,7 +88,8 @@ struct LongShared {
     static constexpr bool kWeighted = WEIGHTED;
     const double *Sg;            // the fibre's sums in global memory
     const double *wg;            // the fibre's penalties (weighted): half-width at knot j = wg[j - 1]
-    const double *ownS, *ownW;   // the lane's own knots in the block's LDS planes
+    double *ownS;                // the lane's own knots in the block's LDS planes (a settled pin's slot holds the string's height)
+    const double *ownW;
     double lam;
     unsigned long long *mx;      // the fibre's slots: [wall][slots]
     LongKey *arg;
@@ -97,6 +98,7 @@ struct LongShared {
     __device__ __forceinline__ double r(int j) const { return WEIGHTED ? wg[j - 1] : lam; }
     __device__ __forceinline__ double own(int, int k) const { return ownS[k]; }
     __device__ __forceinline__ double own_at(int, int k) const { return ownS[k]; }
+    __device__ __forceinline__ void set_own(int, int k, double v) { ownS[k] = v; }
     __device__ __forceinline__ double rown(int, int k) const { return WEIGHTED ? ownW[k] : lam; }
     __device__ __forceinline__ void post(int wall, int slot, double v) {
         __hip_atomic_fetch_max(&mx[(size_t)wall * slots + slot], (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
@@ -234,6 +236,7 @@ __global__ __launch_bounds__(kPinThreads) void sweep_pin_long_kernel(SweepArgs p
     }
 
     // ---- values, in place; then out through the op -------------------------------------------------------------------------------------
+    ln.settle(sh);
     ln.values(sh, mean, [&](int, int k, double v) { own[k] = v; });
     if (pieces) {   // a measured launch: pieces of this sweep, for the geometry policy (one atomic per wave)
         int c = __popcll(ln.pinU | ln.pinL) + (T == 0 ? 1 : 0);

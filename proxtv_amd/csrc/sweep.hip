@@ -62,14 +62,21 @@ constexpr link_t kLinkCertain = 0x80000000u;    // flag on a published `mine` co
 struct DirtyMark {
     unsigned *word;   // null: the repair kernel always does its full check (global-memory chunks)
     unsigned epoch;
-    __device__ __forceinline__ void set() const {
+    unsigned *why;    // option "why" (tuning aid): counters of what marked sweeps dirty -- [0] a walk ran off its window,
+                      // [1] a link inside a workgroup / wave stayed unproven, [2] a link across workgroups / segments did not match,
+                      // [3] ... was not published in time, [4] second chances taken across workgroups
+    __device__ __forceinline__ void set(int reason) const {
         if (word) __hip_atomic_store(word, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (why) atomicAdd(why + reason, 1u);
+    }
+    __device__ __forceinline__ void note(int reason) const {
+        if (why) atomicAdd(why + reason, 1u);
     }
 };
-__device__ __forceinline__ void flag_chunk(int *failflags, long j, int chunk, int NC, const DirtyMark &dirty) {
+__device__ __forceinline__ void flag_chunk(int *failflags, long j, int chunk, int NC, const DirtyMark &dirty, bool ran_off = false) {
     atomicMax(failflags + 2 * j, NC - chunk);
     atomicMax(failflags + 2 * j + 1, chunk + 1);
-    dirty.set();
+    dirty.set(ran_off ? 0 : 1);
 }
 
 // The link between two workgroups (tile kernel) or two segments (along-fibre kernel) is checked by the LATER one at its
@@ -77,12 +84,19 @@ __device__ __forceinline__ void flag_chunk(int *failflags, long j, int chunk, in
 // per fibre and boundary.  The earlier workgroup was dispatched first and publishes half-way through its life, so the
 // word is almost always there; when it is not (or the codes differ) the sweep is marked dirty and the repair kernel runs
 // its own check of every boundary, from the codes both sides publish in full, as before.
-__device__ __forceinline__ void xlink_publish(unsigned long long *slot, unsigned epoch, link_t next) {
-    __hip_atomic_store(slot, ((unsigned long long)epoch << 32) | next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+// (A second chance ACROSS workgroups of the tile kernel -- the next workgroup's first chunk waiting for a provisional word
+// published right after the walk, and walking again from it -- was built and measured: 33 walks taken per 4096^2 solve at
+// lambda = 0.5, fibres left to the repair kernel 104 -> 71, and every row sweep 35 us slower for the wait.  Not kept.)
+constexpr link_t kLinkFinal = 0x80000000u;   // marks a published word (restart indices are below 2^30: the bit is free in a `next` code)
+__device__ __forceinline__ void xlink_publish(unsigned long long *slot, unsigned epoch, link_t next, bool final_word = true) {
+    __hip_atomic_store(slot, ((unsigned long long)epoch << 32) | next | (final_word ? kLinkFinal : 0u), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ bool xlink_matches(const unsigned long long *slot, unsigned epoch, link_t mine) {
+// 0: the link holds ; 2: the codes differ ; 3: no final word of this launch yet
+__device__ __forceinline__ int xlink_check(const unsigned long long *slot, unsigned epoch, link_t mine) {
     const unsigned long long v = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return (unsigned)(v >> 32) == epoch && mine != 0 && (link_t)v == mine;
+    if ((unsigned)(v >> 32) != epoch || !((link_t)v & kLinkFinal)) return 3;
+    return (mine != 0 && (link_t)v == (mine | kLinkFinal)) ? 0 : 2;
 }
 
 // ---- kernel 1: sequential walk straight from / to global memory --------------------------------------------------
@@ -437,7 +451,6 @@ __global__ __launch_bounds__(64 * NW, SHORT ? 16 / NW : ((WEIGHTED || H > 16) ? 
             }
             walk_chunk<OP, WEIGHTED, PITCH, ROUNDS>(w, rec, win, far, hi, cs, ce, len, p.lam);
         }
-
         // ---- prove the links between consecutive chunks ------------------------------------------------------------------
         codes[wave * 64 + lane] = rec.next;
         if (ROUNDS && tid == 0) anybad[0] = anybad[1] = 0;
@@ -484,7 +497,7 @@ __global__ __launch_bounds__(64 * NW, SHORT ? 16 / NW : ((WEIGHTED || H > 16) ? 
                 rec.mine = kLinkBad;
                 rec.next = 0;
             }
-            if (bad) flag_chunk(failflags, j, q * NW + wave, (len + C - 1) / C, plan.dirty);
+            if (bad) flag_chunk(failflags, j, q * NW + wave, (len + C - 1) / C, plan.dirty, rec.failed);
             // Every chunk publishes its two codes: sweep_repair_kernel proves the links between workgroups with them
             // and, for a fibre with an unproven link, finds where a repair walk may stop.
             const long slot = (long)(q * NW + wave) * g.count + j;
@@ -593,8 +606,10 @@ __global__ __launch_bounds__(64 * NW, SHORT ? 16 / NW : ((WEIGHTED || H > 16) ? 
     }
     if (plan.xlink && blockIdx.y > 0 && wave == 0 && active) {
         const link_t began = TRANSPOSED ? began_reg : stash[lane];   // (written by this very thread)
-        if (began != kNoCheck && !xlink_matches(plan.xlink + (size_t)(blockIdx.y - 1) * g.count + j, plan.dirty.epoch, began))
-            plan.dirty.set();
+        if (began != kNoCheck) {
+            const int why = xlink_check(plan.xlink + (size_t)(blockIdx.y - 1) * g.count + j, plan.dirty.epoch, began);
+            if (why) plan.dirty.set(why);
+        }
     }
     trace_mark(plan, 5);
 }
@@ -617,6 +632,10 @@ constexpr int kAlongWaves = 4;
 // iterates at lambda = 0.5 / 0.7 / 1 on unit noise a walk needs more than 8 rows past its chunk in 2 % / 20 % / 70 % of
 // the cases, more than 32 in 0 / 0.01 % / 7 %), where every further sample would be a dependent global read.
 constexpr int along_tail_rows(int H, bool robust) { return robust ? 64 : tail_rows(H); }
+// Rows kept BEFORE a segment.  The walks start H samples early whatever this is; the robust instantiation keeps 64 so that
+// a second chance can start from a bend that lies further back than the zone (the predecessor's last bend sits more than
+// 16 samples before the boundary in ~1 % of the cases at lambda = 0.7: a third of the links it still left to the repair kernel).
+constexpr int along_zone_rows(int H, bool robust) { return robust && H < 64 ? 64 : H; }
 
 // G lanes share one segment of G chunks: 64 for long fibres; 32 or 16 pack two or four shorter fibres into a wave.
 // ROBUST (geometry mode 1: pieces of a few samples, walks that need the whole zone -- or more -- to meet): like the tile
@@ -632,7 +651,7 @@ constexpr int along_tail_rows(int H, bool robust) { return robust ? 64 : tail_ro
 template <int OP, bool WEIGHTED, int H, int G, bool ROBUST>
 __global__ __launch_bounds__(64 * kAlongWaves) void sweep_along_kernel(SweepArgs p, FibreGeom g, ChunkPlan plan, link_t *code_mine,
                                                                         link_t *code_next, int *failflags) {
-    constexpr int C = kAlongC, SEG = G * C, T = along_tail_rows(H, ROBUST), ROWS = H + SEG + T, NG = 64 / G;
+    constexpr int C = kAlongC, SEG = G * C, T = along_tail_rows(H, ROBUST), HZ = along_zone_rows(H, ROBUST), ROWS = HZ + SEG + T, NG = 64 / G;
     constexpr int NU = (ROWS + G - 1) / G;   // staged elements per lane
     constexpr int UL = 9;                    // epilogue operand fetches in flight per lane (C = 17 rows per lane: 9 + 8)
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -663,7 +682,7 @@ __global__ __launch_bounds__(64 * kAlongWaves) void sweep_along_kernel(SweepArgs
     }
     const long fbase = live ? j * len : 0, wbase = live ? j * (len - 1) : 0;
     const int seg_s = sg * SEG, seg_e = live ? min(len, seg_s + SEG) : seg_s;
-    const int lo = seg_s - H, hi = min(len, seg_s + SEG + T);
+    const int lo = seg_s - HZ, hi = min(len, seg_s + SEG + T);
 
     // ---- stage: the segment as it lies in memory ---------------------------------------------------------------------------
     if (live && !(plan.ablate & 4)) {
@@ -778,7 +797,7 @@ __global__ __launch_bounds__(64 * kAlongWaves) void sweep_along_kernel(SweepArgs
             rec.next = 0;
         }
         const int chunk = sg * G + gl;
-        if (bad) flag_chunk(failflags, j, chunk, NC, plan.dirty);
+        if (bad) flag_chunk(failflags, j, chunk, NC, plan.dirty, rec.failed);
         code_mine[j * NC + chunk] = (certain && rec.mine != kLinkBad) ? (rec.mine | kLinkCertain) : rec.mine;
         code_next[j * NC + chunk] = rec.next;
         // the segment's last chunk: what the next segment's first chunk must have begun with (checked by that segment at its end)
@@ -821,9 +840,10 @@ __global__ __launch_bounds__(64 * kAlongWaves) void sweep_along_kernel(SweepArgs
     }
     // the link into this segment, against what the segment before published (it was dispatched earlier and published before its
     // rebuild: almost always there by now -- else the sweep is marked dirty and the repair kernel checks every boundary itself)
-    if (plan.xlink && has_chunk && gl == 0 && sg > 0 && !certain &&
-        !xlink_matches(plan.xlink + (size_t)j * nseg + sg - 1, plan.dirty.epoch, rec.mine))
-        plan.dirty.set();
+    if (plan.xlink && has_chunk && gl == 0 && sg > 0 && !certain) {
+        const int why = xlink_check(plan.xlink + (size_t)j * nseg + sg - 1, plan.dirty.epoch, rec.mine);
+        if (why) plan.dirty.set(why);
+    }
     if (plan.trace && lane == 0) plan.trace[8 * (size_t)wid + 5] = wall_clock64();
 }
 
@@ -1009,7 +1029,7 @@ __global__ __launch_bounds__(64) void sweep_gchunk_kernel(SweepArgs p, FibreGeom
     walker_start<WEIGHTED>(w, src, max(0, cs - H), p.lam);
     walker_run_blocked<WEIGHTED, kGlobalBlock>(w, src, len, p.lam);
     if (src.failed) {   // nothing this lane recorded may be trusted; the repair walk rewrites its chunk
-        flag_chunk(failflags, j, c, (len + C - 1) / C, DirtyMark{nullptr, 0u});
+        flag_chunk(failflags, j, c, (len + C - 1) / C, DirtyMark{nullptr, 0u, nullptr});
         src.mine = kLinkBad;
         src.next = 0;
     }
@@ -1089,8 +1109,8 @@ struct RepairSource : RepairBook {
 
 // Repair walk through a per-lane LDS window (the LDS geometries: short stretches of short pieces, where a dependent
 // global access per sample AND per piece is all the cost -- 200 us for a 100-sample repair).  The lane fetches
-// kRepairWindow samples of its fibre in batches of 16 independent loads, walks them out of LDS, parks the piece values
-// in a second LDS plane and writes the outputs of the whole stretch at the end, 8 operand fetches in flight.
+// kRepairWindow samples of its fibre in batches of 32 independent loads, walks them out of LDS, parks the piece values
+// in a second LDS plane and writes the outputs of the whole stretch at the end, 16 operand fetches in flight.
 constexpr int kRepairWindow = 64;
 constexpr int kRepairBack = 8;   // samples kept before the one that triggered a refill (short rewinds stay inside)
 
@@ -1106,18 +1126,18 @@ struct WindowRepairSource : RepairBook {
         : RepairBook(b), p(p_), base(base_), inc(inc_), wbase(wbase_), Yw(lds + lane),
           Xw(lds + kRepairWindow * 64 + lane), Rw(lds + 2 * kRepairWindow * 64 + lane) {}
 
+    // (this kernel is a handful of waves, each as slow as its slowest lane's chain of memory round trips: the batches are as
+    // large as the registers of a wave that has the SIMD to itself allow)
+    static constexpr int kFlushBatch = 16, kFillBatch = WEIGHTED ? 16 : 32;
     __device__ __forceinline__ void flush() {
-        int k = xlo;
-        for (; k + 8 <= xhi; k += 8) {
-            Ext e[8];
+        for (int k = xlo; k < xhi; k += kFlushBatch) {
+            Ext e[kFlushBatch];
 #pragma unroll
-            for (int u = 0; u < 8; u++) e[u] = Op<OP>::fetch(p, base + (long)(k + u) * inc);
+            for (int u = 0; u < kFlushBatch; u++)
+                if (k + u < xhi) e[u] = Op<OP>::fetch(p, base + (long)(k + u) * inc);
 #pragma unroll
-            for (int u = 0; u < 8; u++) Op<OP>::finish(p, base + (long)(k + u) * inc, e[u], Xw[(k + u - wlo) * 64]);
-        }
-        for (; k < xhi; k++) {
-            const long idx = base + (long)k * inc;
-            Op<OP>::finish(p, idx, Op<OP>::fetch(p, idx), Xw[(k - wlo) * 64]);
+            for (int u = 0; u < kFlushBatch; u++)
+                if (k + u < xhi) Op<OP>::finish(p, base + (long)(k + u) * inc, e[u], Xw[(k + u - wlo) * 64]);
         }
         xlo = xhi = 0;
     }
@@ -1125,18 +1145,18 @@ struct WindowRepairSource : RepairBook {
         flush();   // the parked outputs are addressed relative to the window
         wlo = max(0, i - kRepairBack);
         whi = min(len, wlo + kRepairWindow);
-        for (int b = 0; b < kRepairWindow; b += 16) {
-            double t[16], rr[16];
+        for (int b = 0; b < kRepairWindow; b += kFillBatch) {
+            double t[kFillBatch], rr[WEIGHTED ? kFillBatch : 1];
 #pragma unroll
-            for (int u = 0; u < 16; u++) {
+            for (int u = 0; u < kFillBatch; u++) {
                 const int k = wlo + b + u;
                 t[u] = (k < whi) ? Op<OP>::load_y(p, base + (long)k * inc) : 0.0;
-                if (WEIGHTED) rr[u] = (k < whi && k < len - 1) ? p.w[wbase + (long)k * inc] : 0.0;
+                if (WEIGHTED) rr[WEIGHTED ? u : 0] = (k < whi && k < len - 1) ? p.w[wbase + (long)k * inc] : 0.0;
             }
 #pragma unroll
-            for (int u = 0; u < 16; u++) {
+            for (int u = 0; u < kFillBatch; u++) {
                 Yw[(b + u) * 64] = t[u];
-                if (WEIGHTED) Rw[(b + u) * 64] = rr[u];
+                if (WEIGHTED) Rw[(b + u) * 64] = rr[WEIGHTED ? u : 0];
             }
         }
     }
@@ -1317,13 +1337,13 @@ struct ChunkScratch {
     std::unique_ptr<Scratch> dirty_word, xlink;
     size_t xlink_words = 0;
     DirtyMark next_dirty(hipStream_t s) {
-        if (!options().xlink) return DirtyMark{nullptr, 0u};
-        if (!dirty_word) {
-            dirty_word.reset(new Scratch(sizeof(unsigned)));
-            PTV_HIP(hipMemsetAsync(dirty_word->as<unsigned>(), 0, sizeof(unsigned), s));
+        if (!options().xlink) return DirtyMark{nullptr, 0u, nullptr};
+        if (!dirty_word) {   // [0] the word, [1..8] option "why" counters
+            dirty_word.reset(new Scratch(sizeof(unsigned) * 9));
+            PTV_HIP(hipMemsetAsync(dirty_word->as<unsigned>(), 0, sizeof(unsigned) * 9, s));
         }
         if (++epoch == 0u) ++epoch;   // (0 is what freshly allocated words hold)
-        return DirtyMark{dirty_word->as<unsigned>(), epoch};
+        return DirtyMark{dirty_word->as<unsigned>(), epoch, options().why ? dirty_word->as<unsigned>() + 1 : nullptr};
     }
     unsigned long long *xlink_for(size_t words, hipStream_t s) {
         if (!options().xlink) return nullptr;
@@ -1498,13 +1518,14 @@ static ChunkScratch &chunk_state() { return g_chunks[current_device()]; }
 // Chunk geometry: C = 16 samples per chunk, 8 waves (chunks) per block of 128 samples.  LDS per workgroup = one window
 // of H + 128 + 8 rows x 512 B: ~77 KiB for H = 16 -> two workgroups = 16 waves per CU; ~101 KiB for H = 64 -> one.
 // Weighted sweeps carry a second (penalty) window and exist for H = 16 only.
-// The robust instantiation (ROBUST; geometry mode 1) cuts the block into chunks of 14 samples and spends the 16 rows that
-// saves on look-ahead: H 16 / 8 x 14 / T 24 -- the same 152 rows.  The walks of a block's LAST chunk must close the piece
-// that covers its last sample inside the window, or read on from global memory one dependent access per sample; all 64
-// lanes of that wave are in that position, and on DR iterates at lambda = 0.5 (0.7) on unit noise 2 % (20 %) of them need
-// more than 8 rows, 0.02 % (2 %) more than 16, none (0.1 %) more than 24.
-template <int OP, bool WEIGHTED, bool TRANSPOSED, int H, bool ROBUST = false, int C = (ROBUST ? 14 : 16), int NW = 8,
-          int T = (ROBUST ? 24 : tail_rows(H)), bool SHORT = false>
+// (Tried for the robust instantiation and not kept: chunks of 14 samples with the 16 rows that saves spent on look-ahead --
+// H 16 / 8 x 14 / T 24, the same 152 rows -- so that the walks of a block's last chunk close their last piece inside the
+// window instead of reading on from global memory: on DR iterates at lambda = 0.5 on unit noise 2 % of them need more than
+// 8 rows, 0.02 % more than 16.  The row sweep got 13 % slower, 180 -> 203 us: 37 blocks per fibre instead of 32 cost more
+// than the reads past the window did.  What makes these sweeps slow is the walk itself -- at lambda = 0.5 the linearized
+// taut string re-walks every piece about once: 2.6 x the trips of the headline.)
+template <int OP, bool WEIGHTED, bool TRANSPOSED, int H, bool ROBUST = false, int C = 16, int NW = 8,
+          int T = tail_rows(H), bool SHORT = false>
 void launch_chunk_h(const SweepArgs &args, const FibreGeom &g, hipStream_t stream, int fam, int rounds_wanted) {
     constexpr int PITCH = TRANSPOSED ? 65 : 64;
     constexpr int ROWS = SHORT ? NW * C : H + NW * C + T;
@@ -1575,7 +1596,7 @@ void launch_chunk_h(const SweepArgs &args, const FibreGeom &g, hipStream_t strea
 // the codes of 64 consecutive chunks of one fibre).
 template <int OP, bool WEIGHTED, int H, int G, bool ROBUST>
 void launch_along_g(const SweepArgs &args, const FibreGeom &g, hipStream_t stream, int fam, int rounds_wanted) {
-    constexpr int C = kAlongC, SEG = G * C, ROWS = H + SEG + along_tail_rows(H, ROBUST), NG = 64 / G;
+    constexpr int C = kAlongC, SEG = G * C, ROWS = along_zone_rows(H, ROBUST) + SEG + along_tail_rows(H, ROBUST), NG = 64 / G;
     const int nseg = (g.len + SEG - 1) / SEG;
     const int NC = (g.len + C - 1) / C;
     const long units = g.count * nseg;
@@ -1636,7 +1657,7 @@ void launch_gchunk(const SweepArgs &args, const FibreGeom &g, int C, int H, hipS
                        g, C, H, chunk_state().code_mine, chunk_state().code_next, chunk_state().failflags);
     hipLaunchKernelGGL((sweep_repair_kernel<OP, WEIGHTED>), dim3((unsigned)groups), dim3(64), 0, stream, args, g, C, H, 1,
                        chunk_state().code_mine, chunk_state().code_next, chunk_state().failflags, chunk_state().failcount + 2 * fam, (long)g.count, 1L,
-                       DirtyMark{nullptr, 0u});
+                       DirtyMark{nullptr, 0u, nullptr});
     PTV_HIP(hipGetLastError());
     chunk_state().pol[fam].chunks_done += (long)NC * g.count;
 }
@@ -1651,7 +1672,7 @@ void launch_gchunk(const SweepArgs &args, const FibreGeom &g, int C, int H, hipS
 template <int OP, int H>
 void launch_row_along(const SweepArgs &args, const FibreGeom &g, hipStream_t stream, int fam, int rounds) {
     TransposedOperands tr(args, Op<OP>::IN_MASK, Op<OP>::OUT_MASK, g, stream);
-    launch_along<OP, false, H, true>(tr.args(), tr.geom(), stream, fam, rounds);
+    launch_along<OP, false, H, true>(tr.args(), tr.geom(), stream, fam, 2 * rounds);
     tr.finish();
 }
 
@@ -1714,9 +1735,10 @@ void launch_chunk(const SweepArgs &args, const FibreGeom &g, hipStream_t stream,
     else if (TRANSPOSED && along_ok) {
         // chunks along the fibre: 0 = 16-sample zones ; 1 = the same, robust (second chances inside the wave and across the
         // waves of a workgroup, walks past the look-ahead rows) ; 2 = 64-sample zones, robust
+        // (second chances cost the along-fibre kernel a wave's re-walk, and only in waves that need one: twice the rounds of the tile)
         if (mode == 0)      launch_along<OP, WEIGHTED, kWarm, false>(args, g, stream, fam, 0);
-        else if (mode == 1) launch_along<OP, WEIGHTED, kWarm, true>(args, g, stream, fam, rounds);
-        else                launch_along<OP, WEIGHTED, kWarmLong, true>(args, g, stream, fam, rounds);
+        else if (mode == 1) launch_along<OP, WEIGHTED, kWarm, true>(args, g, stream, fam, 2 * rounds);
+        else                launch_along<OP, WEIGHTED, kWarmLong, true>(args, g, stream, fam, 2 * rounds);
     }
     else if (!TRANSPOSED && !WEIGHTED && along_ok && (options().row_along & 1) && mode == 2) {
         if constexpr (!WEIGHTED) launch_row_along<OP, kWarmLong>(args, g, stream, fam, rounds);
@@ -1854,6 +1876,16 @@ long chunk_trace_fetch(unsigned long long *dst, long max_wgs, hipStream_t s) {
     PTV_HIP(hipMemcpyAsync(dst, chunk_state().trace->as<unsigned long long>(), (size_t)n * 64, hipMemcpyDeviceToHost, s));
     PTV_HIP(hipStreamSynchronize(s));
     return n;
+}
+
+// option "why": read (and clear) the counters of what marked sweeps dirty on this thread
+int chunk_why_fetch(unsigned *dst, hipStream_t s) {
+    ChunkScratch &st = chunk_state();
+    if (!st.dirty_word) return 0;
+    PTV_HIP(hipMemcpyAsync(dst, st.dirty_word->as<unsigned>() + 1, sizeof(unsigned) * 8, hipMemcpyDeviceToHost, s));
+    PTV_HIP(hipMemsetAsync(st.dirty_word->as<unsigned>() + 1, 0, sizeof(unsigned) * 8, s));
+    PTV_HIP(hipStreamSynchronize(s));
+    return 8;
 }
 
 int chunk_stats_mode() {

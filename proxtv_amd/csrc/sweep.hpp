@@ -32,5 +32,6 @@ long chunk_stats_fixups(hipStream_t s);
 // where it does not apply), 4 = global-memory chunks, 5 = sequential
 int chunk_stats_mode();
 long chunk_trace_fetch(unsigned long long *dst, long max_wgs, hipStream_t s);
+int chunk_why_fetch(unsigned *dst /*[8]*/, hipStream_t s);
 
 }  // namespace ptv

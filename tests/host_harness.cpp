@@ -177,6 +177,7 @@ struct PinHostShared {
     double r(int j) const { return rr[(size_t)j]; }
     double own(int t, int k) const { return s[(size_t)(1 + t * P + k)]; }
     double own_at(int t, int k) const { return own(t, k); }
+    void set_own(int t, int k, double v) { s[(size_t)(1 + t * P + k)] = v; }
     double rown(int t, int k) const { return rr[(size_t)(1 + t * P + k)]; }
     void post(int wall, int slot, double v) { if (v > mx[wall][(size_t)slot]) mx[wall][(size_t)slot] = v; }
     double best(int wall, int slot) const { return mx[wall][(size_t)slot]; }
@@ -213,6 +214,7 @@ static int pin_fibre(const double *y, const double *w, double lam, double *x, in
         for (int t = 0; t < lanes; t++) any |= lane[(size_t)t].update(sh);
         if (!any) break;
     }
+    for (int t = 0; t < lanes; t++) lane[(size_t)t].settle(sh);   // (all lanes, then a barrier, on the device)
     for (int t = 0; t < lanes; t++) lane[(size_t)t].values(sh, mean, [&](int i, int, double v) { x[i] = v; });
     return levels;
 }
@@ -233,6 +235,7 @@ struct PinThreadShared {
     double r(int j) const { return rr[(size_t)j]; }
     double own(int t, int k) const { return s[(size_t)(1 + t * P + k)]; }
     double own_at(int t, int k) const { return own(t, k); }
+    void set_own(int t, int k, double v) { s[(size_t)(1 + t * P + k)] = v; }
     double rown(int t, int k) const { return rr[(size_t)(1 + t * P + k)]; }
     void post(int wall, int slot, double v) {
         const unsigned long long b = pin_bits(v);
@@ -299,6 +302,7 @@ static int pin_fibre_threads(const double *y, const double *w, double lam, doubl
     for (int k = 0; k < nthreads; k++) th.emplace_back(body, k);
     for (auto &t : th) t.join();
     pthread_barrier_destroy(&bar);
+    for (int t = 0; t < lanes; t++) lane[(size_t)t].settle(sh);   // (all lanes, then a barrier, on the device)
     for (int t = 0; t < lanes; t++) lane[(size_t)t].values(sh, mean, [&](int i, int, double v) { x[i] = v; });
     return levels.load();
 }

@@ -42,6 +42,12 @@ for mode in [int(m) for m in args.modes.split(",")]:
         fam = [lib.proxtv_last_kernel_ms(f) for f in range(3)]
         cnt = [max(lib.proxtv_last_kernel_launches(f), 1) for f in range(3)]
         lib.proxtv_set_option(b"profile", 0)
+        lib.proxtv_set_option(b"why", 1)
+        why = np.zeros(8, dtype=np.uint32)
+        lib.proxtv_debug_why(why.ctypes.data)
+        device.tv1_2d(X, lam, out=out)
+        lib.proxtv_debug_why(why.ctypes.data)
+        lib.proxtv_set_option(b"why", 0)
         print(f"mode {mode:2d} lambda={lam:<5} {ms:8.2f} ms  fixups {fx:6d}  ran {md}   col {fam[0] / cnt[0] * 1e3:7.1f} us x{cnt[0]}  "
-              f"row {fam[1] / cnt[1] * 1e3:7.1f} us x{cnt[1]}  other {fam[2]:.2f} ms", flush=True)
+              f"row {fam[1] / cnt[1] * 1e3:7.1f} us x{cnt[1]}  other {fam[2]:.2f} ms  why(off-window, in-wg, x-mismatch, x-late) {why[:4].tolist()}", flush=True)
 lib.proxtv_set_option(b"chunk_mode", -1)
