@@ -20,7 +20,7 @@ lib.proxtv_set_option(b"host_register", 1)      # page-lock the caller's arrays 
 thr = time_host()
 lib.proxtv_set_option(b"host_register", 0)
 # the ceiling: the same two transfers from / to memory that is already page-locked (what a caller who owns pinned buffers gets)
-hp = torch.from_numpy(X).pin_memory(); hq = torch.empty_like(hp).pin_memory(); dd = torch.empty((4096, 4096), dtype=torch.float64, device="cuda")
+hp = torch.from_numpy(X.ravel(order="K").copy()).pin_memory(); hq = torch.empty_like(hp).pin_memory(); dd = torch.empty(4096 * 4096, dtype=torch.float64, device="cuda")
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(5):
     dd.copy_(hp, non_blocking=True); hq.copy_(dd, non_blocking=True); torch.cuda.synchronize()
