@@ -405,38 +405,127 @@ namespace {
 constexpr int kProbeRuns = 4096;        // runs of 64 consecutive elements sampled, at most
 constexpr int kProbeRunsPerBlock = 16;
 
+__device__ __forceinline__ int probe_key(double v) {
+    long key = (long)(((unsigned long long)__double_as_longlong(v) & 0x7fffffffffffffffull) >> 49) - ((long)kProbeLowExp << 3);
+    return (int)(key < 0 ? 0 : (key >= kProbeBins ? kProbeBins - 1 : key));
+}
+
 __global__ __launch_bounds__(kThreads) void edge_hist_kernel(const double *y, const double *w, long n, long inc, int len, long runs,
                                                              long run_stride, unsigned *hist) {
-    __shared__ unsigned bins[kProbeBins + 1];
-    for (int b = threadIdx.x; b <= kProbeBins; b += kThreads) bins[b] = 0u;
+    __shared__ unsigned bins[2 * (kProbeBins + 1)];
+    for (int b = threadIdx.x; b < 2 * (kProbeBins + 1); b += kThreads) bins[b] = 0u;
     __syncthreads();
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     for (int k = wv; k < kProbeRunsPerBlock; k += kThreads / 64) {
         const long r = (long)blockIdx.x * kProbeRunsPerBlock + k;
         if (r >= runs) break;
         const long e = r * run_stride + lane;
-        if (e >= n) continue;
-        const long q = e / inc;
-        const int pos = (int)(q % len);
-        if (pos >= len - 1) continue;
-        double v = fabs(y[e + inc] - y[e]);
-        if (w) {
-            const double we = w[(q / len) * inc * (len - 1) + (long)pos * inc + e % inc];
-            v = we > 0.0 ? v / we : (v > 0.0 ? 1e300 : 0.0);
+        bool valid = false;
+        double v = 0.0;
+        long fibre = -1;
+        if (e < n) {
+            const long q = e / inc;
+            const int pos = (int)(q % len);
+            if (pos < len - 1) {
+                valid = true;
+                v = fabs(y[e + inc] - y[e]);
+                if (w) {
+                    const double we = w[(q / len) * inc * (len - 1) + (long)pos * inc + e % inc];
+                    v = we > 0.0 ? v / we : (v > 0.0 ? 1e300 : 0.0);
+                }
+                // (which fibre the edge belongs to: dimension 0 -- inc == 1 -- runs ALONG a fibre, other dimensions across fibres)
+                fibre = inc == 1 ? q / len : -2;
+            }
         }
-        long key = (long)(((unsigned long long)__double_as_longlong(v) & 0x7fffffffffffffffull) >> 50) - ((long)kProbeLowExp << 2);
-        key = key < 0 ? 0 : (key >= kProbeBins ? kProbeBins - 1 : key);
-        atomicAdd(&bins[key], 1u);
-        atomicAdd(&bins[kProbeBins], 1u);
+        if (valid) {
+            atomicAdd(&bins[probe_key(v)], 1u);
+            atomicAdd(&bins[kProbeBins], 1u);
+        }
+        // second histogram, dimension 0 only: the total variation of every stretch of 16 consecutive edges of one fibre
+        // (sum over 16 lanes) -- a stretch whose variation is small against lambda has nothing for a speculative walk to
+        // meet the true walk at, however lively the rest of the array is
+        if (inc == 1) {
+            double tv = valid ? v : 0.0;
+            long fmin = fibre, fmax = fibre;
+            bool all = valid;
+#pragma unroll
+            for (int d = 1; d < 16; d <<= 1) {
+                tv += __shfl_xor(tv, d);
+                const long fo = __shfl_xor(fmin, d), fx = __shfl_xor(fmax, d);
+                fmin = fo < fmin ? fo : fmin;
+                fmax = fx > fmax ? fx : fmax;
+                all = all && (__shfl_xor((int)all, d) != 0);
+            }
+            if ((lane & 15) == 0 && all && fmin == fmax) {
+                atomicAdd(&bins[kProbeBins + 1 + probe_key(tv)], 1u);
+                atomicAdd(&bins[2 * kProbeBins + 1], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < 2 * (kProbeBins + 1); b += kThreads)
+        if (bins[b]) atomicAdd(&hist[b], bins[b]);
+}
+}  // namespace
+
+namespace {
+// The stretch statistic for strided dimensions: lanes run over 64 adjacent fibres (coalesced), each lane adds up 16
+// consecutive edges of ITS fibre.  Sampled: up to kProbeRuns (fibre group, position) sites spread evenly.
+__global__ __launch_bounds__(kThreads) void stretch_hist_kernel(const double *y, const double *w, long inc, int len, long slabs,
+                                                                long sites, long groups_per_slab, int starts_per_fibre,
+                                                                unsigned *hist) {
+    __shared__ unsigned bins[kProbeBins + 1];
+    for (int b = threadIdx.x; b <= kProbeBins; b += kThreads) bins[b] = 0u;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const long site = (long)blockIdx.x * (kThreads / 64) + wv;
+    if (site < sites) {
+        const long per_slab = groups_per_slab * starts_per_fibre;
+        const long slab = site / per_slab, rem = site % per_slab;
+        const long grp = rem / starts_per_fibre;
+        const int st = (int)(rem % starts_per_fibre);
+        const long off = grp * 64 + lane;                        // position inside the slab's inc
+        const int pos0 = (int)(((long)st * (len - 17)) / (starts_per_fibre > 1 ? starts_per_fibre - 1 : 1));
+        if (off < inc && slab < slabs) {
+            const long base = slab * inc * len + off, wbase = slab * inc * (len - 1) + off;
+            double tv = 0.0, prev = y[base + (long)pos0 * inc];
+#pragma unroll 4
+            for (int k = 1; k <= 16; k++) {
+                const double cur = y[base + (long)(pos0 + k) * inc];
+                double v = fabs(cur - prev);
+                if (w) {
+                    const double we = w[wbase + (long)(pos0 + k - 1) * inc];
+                    v = we > 0.0 ? v / we : (v > 0.0 ? 1e300 : 0.0);
+                }
+                tv += v;
+                prev = cur;
+            }
+            atomicAdd(&bins[probe_key(tv)], 1u);
+            atomicAdd(&bins[kProbeBins], 1u);
+        }
     }
     __syncthreads();
     for (int b = threadIdx.x; b <= kProbeBins; b += kThreads)
-        if (bins[b]) atomicAdd(&hist[b], bins[b]);
+        if (bins[b]) atomicAdd(&hist[kProbeBins + 1 + b], bins[b]);
 }
 }  // namespace
 
 void edge_histogram(const double *y, const double *w, long n, long inc, int len, unsigned *hist, hipStream_t s) {
     if (n <= 0 || len < 2) return;
+    if (inc > 1 && len >= 18) {
+        const long slabs = n / (inc * (long)len), groups = (inc + 63) / 64;
+        int starts = (int)(kProbeRuns / 4 / (slabs * groups > 0 ? slabs * groups : 1));
+        starts = starts < 1 ? 1 : (starts > len / 16 ? len / 16 : starts);
+        long sites = slabs * groups * starts;
+        long slabs_used = slabs;
+        if (sites > kProbeRuns) {   // (many slabs: the first ones of an evenly strided subset would need a stride; keep it simple -- cap)
+            slabs_used = kProbeRuns / (groups * starts) > 0 ? kProbeRuns / (groups * starts) : 1;
+            sites = slabs_used * groups * starts;
+        }
+        hipLaunchKernelGGL(stretch_hist_kernel, dim3((unsigned)((sites + kThreads / 64 - 1) / (kThreads / 64))), dim3(kThreads), 0, s, y, w,
+                           inc, len, slabs_used, sites, groups, starts, hist);
+        PTV_HIP(hipGetLastError());
+    }
     long runs = (n + 63) / 64;
     long stride = 64;
     if (runs > kProbeRuns) {

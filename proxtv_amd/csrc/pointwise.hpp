@@ -37,16 +37,20 @@ void lincomb(double *out, const double *a, double ca, const double *b, double cb
 // sits at j * len after the transposition of every (inc x len) slab.
 void slab_transpose(const double *in, double *out, long rows, long cols, long slabs, hipStream_t s);
 // Edge statistics of an array along one dimension -- what the geometry policy (sweep.hip) is seeded with: a histogram of
-// |y[e + inc] - y[e]| (weighted: divided by the edge's penalty) over a fixed sample of edges, kProbeBins bins of a quarter
-// octave each (bin = biased exponent and two mantissa bits of the value, clamped to the window that starts at 2^-60),
-// hist[kProbeBins] = edges sampled.  Integer counts over a sample that depends on the shape only: the same array always
-// gives the same histogram.  `hist` (device, kProbeBins + 1 words) must be zero on entry.
-constexpr int kProbeBins = 512;
+// |y[e + inc] - y[e]| (weighted: divided by the edge's penalty) over a fixed sample of edges, kProbeBins bins of an eighth
+// of an octave each (bin = biased exponent and three mantissa bits of the value, clamped to the window that starts at 2^-60),
+// hist[kProbeBins] = edges sampled.  A second histogram of the same layout follows (hist + kProbeBins + 1): the total
+// variation of sampled STRETCHES of 16 consecutive edges of one fibre -- where that is small against lambda a speculative
+// walk finds nothing to meet the true walk at, however lively the array is elsewhere.  Integer counts over a sample that
+// depends on the shape only: the same array always gives the same histograms.  `hist` (device, kProbeWords words) must be
+// zero on entry.
+constexpr int kProbeBins = 1024;
+constexpr int kProbeWords = 2 * (kProbeBins + 1);
 constexpr int kProbeLowExp = 1023 - 60;
 inline int probe_bin(double v) {   // host side of the same binning
     unsigned long long b;
     memcpy(&b, &v, 8);
-    const long k = (long)((b & 0x7fffffffffffffffull) >> 50) - ((long)kProbeLowExp << 2);
+    const long k = (long)((b & 0x7fffffffffffffffull) >> 49) - ((long)kProbeLowExp << 3);
     return k < 0 ? 0 : (k >= kProbeBins ? kProbeBins - 1 : (int)k);
 }
 void edge_histogram(const double *y, const double *w, long n, long inc, int len, unsigned *hist, hipStream_t s);

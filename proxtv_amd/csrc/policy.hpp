@@ -50,12 +50,16 @@ constexpr int kQuietSolves = 16;    // one-sweep solves between explorations
 // edge_histogram); the fraction f of them above 4 lambda -- the edges at which the string is KNOWN to bend
 // (chunkcore.hpp) -- says which rung the data want: on unit noise f = 0.78 / 0.40 / 0.16 / 0.05 / 0.005 at lambda = 0.1 /
 // 0.3 / 0.5 / 0.7 / 1, where the pieces of a DR solve's iterates average 1.1 / 1.5 / 2.4 / 4 / 8 samples and a speculative
-// walk meets the true one within 6 / 10 / 15 / 30 / 70 samples.  With option "deterministic" (the default) the rung of a
+// walk meets the true one within 6 / 10 / 15 / 30 / 70 samples.  A second statistic guards against spatially uneven data:
+// the total variation of sampled stretches of 16 edges -- where it is below 2 lambda the string runs (all but) flat, a
+// speculative walk has nothing to meet the true walk at, and an average over the lively rest of the array would not tell.
+// With option "deterministic" (the default) the rung of a
 // sweep is this function of (input, lambda) and nothing else -- two runs on the same input take the same kernels and agree
 // to the last bit; without it the hill climb below starts from the seed instead of exploring from scratch.
 constexpr double kSeedNoisy = 0.45;   // f at or above: rung 0
-constexpr double kSeedMid = 0.03;     // f at or above: rung 1 ; below: rung 3  (0.024 = lambda 0.8 on unit noise: 35.0 ms on rung 1, 34.0 on rung 3)
-constexpr double kSeedRowAlong = 0.1; // rung 1, strided sweeps, f below: through transposed copies and the along-fibre kernel
+constexpr double kSeedMid = 0.03;     // f at or above: rung 1 ; below: rung 3  (as sampled -- edges in the threshold's own eighth-octave bin do not count -- lambda = 0.7 on unit noise gives 0.034, 0.75-0.8 gives 0.022; at 0.8: 35.0 ms on rung 1, 34.0 on rung 3)
+constexpr double kSeedFlat = 0.02;     // more than this fraction of the sampled 16-edge stretches (all but) flat at lambda: rung 3
+constexpr double kSeedRowAlong = 0.06; // rung 1, strided sweeps, f below (lambda >= 0.65 on unit noise): through transposed copies and the along-fibre kernel
 inline int rung_from_certain_fraction(double f) { return f >= kSeedNoisy ? 0 : (f >= kSeedMid ? 1 : 3); }
 
 struct GeometryPolicy {

@@ -1373,7 +1373,7 @@ struct ChunkScratch {
         long inc = 0, count = 0;
         int len = 0;
         bool weighted = false;
-        unsigned hist[kProbeBins + 1] = {};
+        unsigned hist[kProbeWords] = {};   // edges | stretches (pointwise.hpp)
     };
     static constexpr int kMaxProbes = 8;
     Probe probes[kMaxProbes];
@@ -1390,15 +1390,32 @@ struct ChunkScratch {
         const Probe *p = find_probe(g, weighted);
         if (!p || p->hist[kProbeBins] == 0) return -1.0;
         if (!weighted && !(lam > 0.0)) return 1.0;
+        // (edges in the threshold's own bin do not count: an edge of exactly 4 lambda -- a checkerboard of +-2 lambda -- is not a
+        // bend known a priori, and the kernels' test is strict)
         const int b = probe_bin(weighted ? 4.0 : 4.0 * lam);
-        unsigned long above = p->hist[b] / 2;
+        unsigned long above = 0;
         for (int k = b + 1; k < kProbeBins; k++) above += p->hist[k];
         return (double)above / (double)p->hist[kProbeBins];
+    }
+    // fraction of the sampled 16-edge stretches whose total variation is below 2 lambda: stretches the string crosses (all
+    // but) flat -- nothing there for a speculative walk to meet the true one at (-1: not sampled)
+    double flat_fraction(const FibreGeom &g, double lam, bool weighted) const {
+        const Probe *p = find_probe(g, weighted);
+        const unsigned *h = p ? p->hist + kProbeBins + 1 : nullptr;
+        if (!p || h[kProbeBins] == 0) return -1.0;
+        if (!weighted && !(lam > 0.0)) return 0.0;
+        const int b = probe_bin(weighted ? 2.0 : 2.0 * lam);
+        unsigned long below = 0;
+        for (int k = 0; k < b; k++) below += h[k];
+        return (double)below / (double)h[kProbeBins];
     }
     // rung the statistics ask for at this penalty (-1: not sampled)
     int seed(const FibreGeom &g, double lam, bool weighted) const {
         const double f = certain_fraction(g, lam, weighted);
         if (f < 0.0) return -1;
+        // Spatially uneven data (half an image flat, sparse spikes on a constant background): whatever the average says, the
+        // quiet stretches have pieces far longer than any zone and every chunk in them would go to the repair kernel.
+        if (flat_fraction(g, lam, weighted) > kSeedFlat) return 3;
         if (options().seed_noisy_e4 > 0 || options().seed_mid_e4 > 0) {   // tuning aid: thresholds in units of 1e-4
             const double noisy = options().seed_noisy_e4 > 0 ? options().seed_noisy_e4 * 1e-4 : kSeedNoisy;
             const double mid = options().seed_mid_e4 > 0 ? options().seed_mid_e4 * 1e-4 : kSeedMid;
@@ -1836,7 +1853,7 @@ constexpr long kProbeMinElements = 4096;
 void policy_probe(const double *y, const double *const *weights, const int *ns, int nds, const int *dims, int ndims, hipStream_t s) {
     if (options().chunk <= 0 || options().chunk_mode >= 0) return;   // sequential kernels only / a pinned rung: nothing to decide
     ChunkScratch &st = chunk_state();
-    constexpr size_t kWords = kProbeBins + 1;
+    constexpr size_t kWords = kProbeWords;
     int first = st.nprobes;
     for (int k = 0; k < ndims && st.nprobes < ChunkScratch::kMaxProbes; k++) {
         const FibreGeom g = fibres_along(ns, nds, dims[k]);
