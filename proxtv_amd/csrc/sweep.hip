@@ -288,7 +288,7 @@ __device__ __forceinline__ void walk_chunk(Walker &w, ChunkRec &rec, const LdsWi
 // their walks H samples early, inside the block) -- so a workgroup of NW = 4 waves holds 32 KB of LDS and four or five of
 // them share a CU; there are no links between workgroups, and the HBM traffic is exactly the algorithmic one.
 template <int OP, bool WEIGHTED, bool TRANSPOSED, int C, int NW, int H, bool ROUNDS, int T = tail_rows(H), bool SHORT = false>
-__global__ __launch_bounds__(64 * NW, SHORT ? 16 / NW : ((WEIGHTED || H > 16) ? NW / 4 : NW / 2)) void sweep_chunk_kernel(SweepArgs p, FibreGeom g, ChunkPlan plan,
+__global__ __launch_bounds__(64 * NW, SHORT ? 16 / NW : ((WEIGHTED || H > 16 || NW > 8) ? NW / 4 : NW / 2)) void sweep_chunk_kernel(SweepArgs p, FibreGeom g, ChunkPlan plan,
                                                                                    link_t *code_mine, link_t *code_next,
                                                                                    int *failflags) {
     constexpr int PITCH = TRANSPOSED ? 65 : 64;
@@ -626,7 +626,13 @@ __global__ __launch_bounds__(64 * NW, SHORT ? 16 / NW : ((WEIGHTED || H > 16) ? 
 // of a read hit 32 different bank pairs -- the floor for 8-byte accesses -- without any padding (with 16 they would
 // hit two).
 constexpr int kAlongC = 17;
-constexpr int kAlongWaves = 4;
+#ifndef PTV_ALONG_WAVES
+#define PTV_ALONG_WAVES 4
+#endif
+#ifndef PTV_ALONG_UNROLL
+#define PTV_ALONG_UNROLL 4
+#endif
+constexpr int kAlongWaves = PTV_ALONG_WAVES;
 // Look-ahead rows after a segment.  Only the segment's LAST lane reads them -- to close the piece that covers its last
 // sample -- and a segment is 1088 samples, so they cost next to nothing here: the robust instantiation takes 64 (on DR
 // iterates at lambda = 0.5 / 0.7 / 1 on unit noise a walk needs more than 8 rows past its chunk in 2 % / 20 % / 70 % of
@@ -812,7 +818,7 @@ __global__ __launch_bounds__(64 * kAlongWaves) void sweep_along_kernel(SweepArgs
         if (below) wlo = seg_s + (63 - __clzll((long long)below)) * C;
     }
     if (has_chunk && !(plan.ablate & 1))
-        rebuild_owned<Op<OP>, WEIGHTED, C, 4>(win, rec, cs, ce, len, start, !bad, wlo, gl == G - 1 || ce == len, p.lam);
+        rebuild_owned<Op<OP>, WEIGHTED, C, PTV_ALONG_UNROLL>(win, rec, cs, ce, len, start, !bad, wlo, gl == G - 1 || ce == len, p.lam);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     if (plan.trace && lane == 0) plan.trace[8 * (size_t)wid + 4] = wall_clock64();
@@ -1568,7 +1574,7 @@ void launch_chunk_h(const SweepArgs &args, const FibreGeom &g, hipStream_t strea
     plan.dirty = chunk_state().next_dirty(stream);
     plan.xlink = chunk_state().xlink_for((size_t)WQ * (size_t)g.count, stream);
     constexpr size_t lds = sizeof(double) * PITCH * (size_t)ROWS * (WEIGHTED ? 2 : 1) + sizeof(link_t) * ((NW + (TRANSPOSED ? 2 : 3)) * 64 + 4 + 2 * NW);
-    static_assert(WEIGHTED || H > kWarm || 2 * lds <= 160 * 1024, "the short-zone geometry is meant to run two workgroups per CU");
+    static_assert(WEIGHTED || H > kWarm || NW > 8 || 2 * lds <= 160 * 1024, "the short-zone geometry is meant to run two workgroups per CU");
     if (SHORT && g.len > NW * C) {
         set_error("launch_chunk_h: a fibre of %d samples does not fit the single-block geometry (%d)", g.len, NW * C);
         throw HipFailure{hipErrorInvalidValue};
@@ -1962,10 +1968,12 @@ void launch_sweep(OpId op, bool weighted, const SweepArgs &args, const FibreGeom
         PTV_CASE(OP_DR_ROW)
         PTV_CASE_U(OP_DR_ROW_FINAL)
         PTV_CASE_W(OP_DRW_ROW_FINAL)
-#elif defined(PTV_FAST_BUILD)   // experiments only: the headline's three unweighted sweeps (a full build takes two minutes)
+#elif defined(PTV_FAST_BUILD)   // experiments only: the headline's unweighted sweeps (a full build takes three minutes)
         PTV_CASE_U(OP_PROX)
         PTV_CASE_U(OP_DR_COL)
+        PTV_CASE_U(OP_DR_COL_FINAL)
         PTV_CASE_U(OP_DR_ROW)
+        PTV_CASE_U(OP_DR_ROW_FINAL)
 #else
         PTV_CASE(OP_PROX)
         PTV_CASE(OP_DR_COL)
