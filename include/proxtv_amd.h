@@ -155,12 +155,18 @@ void proxtv_release_scratch(void);
 /* Knobs (process-wide; returns the previous value, -1 for an unknown key).  Each also has an environment variable
    PROXTV_<KEY> read at load time.
      "chunk"          non-zero: speculative-chunk kernels ; 0: sequential lane-per-fibre kernels only
-     "chunk_mode"     -1: adaptive geometry policy (default) ; 0..5: pin a rung of the ladder (see proxtv_chunk_mode)
-     "chunk_min_len"  fibres shorter than this take the sequential kernel (default 96)
-     "rounds"         second-chance rounds of geometry mode 1 (0 = built-in default, 4)
+     "chunk_mode"     -1: the geometry policy chooses per sweep (default) ; 0..5: pin a rung of the ladder (see proxtv_chunk_mode)
+     "deterministic"  1 (default): the rung of a sweep is a function of sampled statistics of its input and of lambda alone --
+                      the same call gives the same bits whatever ran before ; 0: hill climb on measured sweep times, seeded by
+                      the same statistics (results then agree to ~1e-13 between calls, not bit for bit)
+     "chunk_min_len"  fibres shorter than this do not take the multi-block chunk kernels (default 96)
+     "whole"          fibres of 16 .. chunk_min_len samples: 1 (default) by length and data, 2 whole fibres in LDS, 0 sequential
+     "rounds"         second-chance rounds of geometry mode 1 (0 = built-in default: 4 in the tile, 8 along the fibre)
+     "xlink"          1 (default): chunk kernels check the links across their workgroups themselves ; 0: the repair kernel does
+     "host_register"  1: page-lock large caller arrays around the transfers of the host-pointer entry points (default 0: no gain measured)
      "verbose"        1: log every decision of the geometry policy to stderr
      "profile"        1: hipEvent pair around every sweep launch (proxtv_last_kernel_ms / _launches)
-     "ablate", "blocks_per_wg", "warmup"   profiling aids (tools/) */
+     "why", "trace", "ablate", "blocks_per_wg", "seed_noisy_e4", "seed_mid_e4", "warmup"   tuning / profiling aids (tools/) */
 int proxtv_set_option(const char *key, int value);
 
 /* Device-pointer solvers: every double* is an HBM pointer valid on the current device, `stream` is

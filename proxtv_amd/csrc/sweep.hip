@@ -25,9 +25,14 @@
 // known a priori (|dy| > 4 lambda) just before its chunk starts there instead: exact by construction, nothing to prove.
 // A second, "robust" instantiation lets walks run past the window and gives failed links second chances in the block.
 //
+// Kernel 2a, `sweep_along_kernel`: the same scheme for contiguous fibres -- 64 consecutive chunks of ONE fibre per wave, no
+// workgroup barrier; its robust instantiation settles failed links inside the wave and across the waves of a workgroup.
+// Short fibres (one block) run as a single-block instantiation of kernel 2 (SHORT) or whole in LDS (kernel 1b).
 // Kernel 2b, `sweep_gchunk_kernel`: the same scheme straight from global memory with run-time chunk / zone sizes, for
-// pieces of tens to hundreds of samples.  Kernel 3, `sweep_repair_kernel`, finishes what kernels 2 / 2b left unproven.
-// Which of these a sweep runs is the geometry policy's business (policy.hpp; plumbing in ChunkScratch below).
+// pieces of tens to hundreds of samples.  Kernel 3, `sweep_repair_kernel`, finishes what kernels 2 / 2a / 2b left unproven;
+// kernels 2 / 2a check the links across their workgroups themselves and tell it in one word whether anything is left.
+// Which of these a sweep runs is the geometry policy's business (policy.hpp; plumbing in ChunkScratch below): by default
+// a function of sampled statistics of the sweep's input (policy_probe) and of lambda alone.
 #include "sweep.hpp"
 
 #include <cstddef>

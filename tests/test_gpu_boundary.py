@@ -190,3 +190,35 @@ def test_adaptive_policy_is_still_exact(ptv, clib, oracle):
                 assert_close(ptv.tv1_1d(x1, lam), want, tol=1e-10, what=f"adaptive 1-D lam={lam}")
     finally:
         clib.proxtv_set_option(b"deterministic", before)
+
+
+def test_seed_sends_uneven_data_to_the_pinning_rung(ptv, clib, oracle):
+    """The policy's seed looks at more than an average: an image whose right half is flat (or that is flat but for sparse
+    spikes) has stretches no speculative walk can be proven on -- rung 3, whatever the lively half says; white noise of the
+    same size takes the chunk kernels.  Results exact either way."""
+    rng = np.random.default_rng(82)
+    Z = rng.standard_normal((640, 900))
+    half = Z.copy(); half[:, 450:] = 0.0
+    spikes = np.zeros((640, 900)); m = rng.random((640, 900)) < 0.05; spikes[m] = 10.0 * rng.standard_normal(int(m.sum()))
+    assert clib.proxtv_set_option(b"deterministic", 1) == 1
+    assert_close(ptv.tv1_2d(Z, 0.1), oracle.dr2(Z, 0.1)[0], tol=1e-10)
+    assert clib.proxtv_chunk_mode() == 0
+    for name, X in (("half flat", half), ("spikes", spikes)):
+        assert_close(ptv.tv1_2d(X, 0.1), oracle.dr2(X, 0.1)[0], tol=1e-10, what=name)
+        assert clib.proxtv_chunk_mode() == 3, (name, clib.proxtv_chunk_mode())
+
+
+def test_why_counters(ptv, clib):
+    """Tuning aid: what left work to the repair kernel.  Nothing on white noise at small lambda; something at lambda = 0.6."""
+    import ctypes as C
+    X = np.random.default_rng(83).standard_normal((1500, 1500))
+    why = (C.c_uint * 8)()
+    clib.proxtv_set_option(b"why", 1)
+    try:
+        clib.proxtv_debug_why(why)
+        ptv.tv1_2d(X, 0.1)
+        assert clib.proxtv_debug_why(why) == 8 and sum(why[:4]) == 0, list(why)
+        ptv.tv1_2d(X, 0.6)
+        assert clib.proxtv_debug_why(why) == 8 and sum(why[:4]) > 0, list(why)
+    finally:
+        clib.proxtv_set_option(b"why", 0)
