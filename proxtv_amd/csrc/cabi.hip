@@ -507,6 +507,7 @@ int proxtv_set_option(const char *key, int value) {
     else if (!strcmp(key, "chunk_mode")) slot = &o.chunk_mode;
     else if (!strcmp(key, "deterministic")) slot = &o.deterministic;
     else if (!strcmp(key, "host_register")) slot = &o.host_register;
+    else if (!strcmp(key, "dr_form")) slot = &o.dr_form;
     else if (!strcmp(key, "xlink")) slot = &o.xlink;
     else if (!strcmp(key, "why")) slot = &o.why;
     else if (!strcmp(key, "seed_noisy_e4")) slot = &o.seed_noisy_e4;

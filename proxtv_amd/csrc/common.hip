@@ -27,6 +27,7 @@ Options &options() {
         if (const char *e = getenv("PROXTV_ALONG")) v.along = atoi(e);
         if (const char *e = getenv("PROXTV_WHOLE")) v.whole = atoi(e);
         if (const char *e = getenv("PROXTV_ROW_ALONG")) v.row_along = atoi(e);
+        if (const char *e = getenv("PROXTV_DR_FORM")) v.dr_form = atoi(e);
         if (const char *e = getenv("PROXTV_PIN")) v.pin = atoi(e);
         if (const char *e = getenv("PROXTV_ALONG_MIN_LEN")) v.along_min_len = atoi(e);
         if (const char *e = getenv("PROXTV_CHUNK_MODE")) v.chunk_mode = atoi(e);

@@ -54,6 +54,9 @@ struct Options {
     int chunk_min_len = 96;   // fibres shorter than this take the sequential kernel (measured crossover: 512x512xL volumes, L ~ 96)
     int xlink = 1;            // chunk kernels check the links across their workgroups themselves and tell the repair kernel, in one word,
                               // whether anything is left for it (0: the repair kernel checks every boundary after every sweep)
+    int dr_form = 1;          // DR2 / DR2L1W: 1 = the column sweep leaves the row sweep's input and epilogue operand (OP_DR_COL_V / OP_DR_ROW_V)
+                              // when the row sweep runs on the robust 64-fibre tile (rung 1); 2 = on rung 0 too; 0 = always the
+                              // reference's split (OP_DR_COL / OP_DR_ROW)
     int host_register = 0;    // host-pointer entry points: page-lock large caller arrays around their transfers (see cabi.hip)
     int verbose = 0;
     int profile = 0;    // per-kernel-family hipEvent timing

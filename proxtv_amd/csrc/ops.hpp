@@ -39,6 +39,8 @@ enum OpId : int {
     OP_PD2_A,          // first Dykstra term
     OP_PD2_B,          // second Dykstra term
     OP_YANG,           // Z/U update of Yang's ADMM
+    OP_DR_COL_V,       // reflection through B_cols, leaving the row sweep's input and its epilogue operand (see Op<OP_DR_COL_V>)
+    OP_DR_ROW_V,       // row sweep of that form
     OP_COUNT
 };
 
@@ -150,6 +152,28 @@ template <> struct Op<OP_DR_ROW> : InBminusA, NotFused {
         const double tb = e.e0 + 2 * x;
         p.o0[idx] = 0.5 * (e.e1 + tb);
     }
+};
+// The same iteration with the work split the other way round (round 3; dr2 in solvers.hip picks it when the row sweep runs
+// on the 64-fibre tile).  The row tile is the kernel with barriers, halos and two workgroups per CU; the along-fibre column
+// kernel is bound by its instruction count and has HBM bandwidth to spare.  So the column sweep does all the pointwise work
+// (a = t, b = U, o0 = v, o1 = s):   s = t - prox(t) ; s' = 2 s - t ; v = U - s'      (:408-411 and the gather of :514)
+// and the row sweep (a = v, b = s, o0 = t) is a one-operand walk with a one-operand epilogue:   t = s + prox(v)
+// -- 0.5 (t + s' + 2 prox(v)) with t + s' = 2 s, a few ulps from OP_DR_ROW's order.  Array passes per iteration: column
+// 2 R + 2 W, row 2 R + 1 W (7, against 6 + the second read of s' above), and the row sweep's halo is read for ONE array.
+template <> struct Op<OP_DR_COL_V> : InA, NotFused {
+    static constexpr unsigned IN_MASK = 3, OUT_MASK = 3;
+    __device__ static __forceinline__ Ext fetch(const SweepArgs &p, long idx) { return Ext{p.a[idx], p.b[idx]}; }
+    __device__ static __forceinline__ void finish(const SweepArgs &p, long idx, const Ext &e, double x) {
+        const double s = e.e0 - x;
+        const double sp = 2 * s - e.e0;
+        p.o0[idx] = e.e1 - sp;
+        p.o1[idx] = s;
+    }
+};
+template <> struct Op<OP_DR_ROW_V> : InA, NotFused {
+    static constexpr unsigned IN_MASK = 3, OUT_MASK = 1;
+    __device__ static __forceinline__ Ext fetch(const SweepArgs &p, long idx) { return Ext{p.b[idx], 0}; }
+    __device__ static __forceinline__ void finish(const SweepArgs &p, long idx, const Ext &e, double x) { p.o0[idx] = e.e0 + x; }
 };
 // recovery (a = s, b = unary): out = (U - (v - prox(v))) - s                         (src/TV2Dopt.cpp:429-430)
 template <> struct Op<OP_DR_ROW_FINAL> : InBminusA, NotFused {

@@ -241,6 +241,8 @@ bool launch_pin(OpId op, bool weighted, const SweepArgs &args, const FibreGeom &
         PTV_PIN_CASE_U(OP_PD2_A)
         PTV_PIN_CASE_U(OP_PD2_B)
         PTV_PIN_CASE_U(OP_YANG)
+        PTV_PIN_CASE(OP_DR_COL_V)
+        PTV_PIN_CASE(OP_DR_ROW_V)
         default:
             set_error("launch_pin: unknown op %d", (int)op);
             throw HipFailure{hipErrorInvalidValue};

@@ -35,10 +35,11 @@ inline bool pin_supports(OpId op, bool weighted, const FibreGeom &g, double lam)
     if (pin_is_long(weighted, g)) {
         const long wgs = ((long)g.len + kPinLongBlock - 1) / kPinLongBlock * g.count;
         if (wgs > pin_long_capacity(weighted)) return false;
-        if (weighted && op != OP_PROX && op != OP_DR_COL && op != OP_DR_COL_FINAL) return false;   // (the ops pinlong.hip builds weighted)
+        if (weighted && op != OP_PROX && op != OP_DR_COL && op != OP_DR_COL_FINAL && op != OP_DR_COL_V) return false;   // (the ops pinlong.hip builds weighted)
     }
     if (weighted)
-        return op == OP_PROX || op == OP_DR_COL || op == OP_DR_COL_FINAL || op == OP_DR_ROW || op == OP_DRW_ROW_FINAL;
+        return op == OP_PROX || op == OP_DR_COL || op == OP_DR_COL_FINAL || op == OP_DR_ROW || op == OP_DRW_ROW_FINAL || op == OP_DR_COL_V ||
+               op == OP_DR_ROW_V;
     return op != OP_DRW_ROW_FINAL && lam > 0.0;
 }
 

@@ -362,6 +362,8 @@ bool launch_pin_long(OpId op, bool weighted, const SweepArgs &args, const FibreG
         PTV_LONG_CASE_U(OP_PD2_A)
         PTV_LONG_CASE_U(OP_PD2_B)
         PTV_LONG_CASE_U(OP_YANG)
+        PTV_LONG_CASE(OP_DR_COL_V)
+        PTV_LONG_CASE_U(OP_DR_ROW_V)
         default:
             set_error("launch_pin_long: unsupported op %d", (int)op);
             throw HipFailure{hipErrorInvalidValue};

@@ -94,6 +94,32 @@ SolveInfo dr2(size_t M, size_t N, size_t B, const double *unary, double W1, doub
     // every array of this loop is written by sweeps only (t, s' once by dr_fill, before any row sweep): row sweeps that
     // run on transposed copies may keep them (transposed.hpp)
     TransposeScope keep_transposed;
+    const int tile_rung = options().dr_form ? strided_tile_rung(rows, W2, weighted) : -1;
+    if (tile_rung == 1 || (tile_rung == 0 && options().dr_form == 2)) {
+        // The row sweep runs on the robust 64-fibre tile: the column sweep does all the pointwise work (ops.hpp, OP_DR_COL_V):
+        // R t, R U, W v, W s | R v, R s, W t.  Measured on 4096^2, unit noise: the column sweep, bound by its walk there, takes
+        // the two extra passes for nothing (lambda = 0.5: 150 -> 153 us) and the row sweep loses a staged operand and a fetch
+        // (235 -> 200 us); on rung 0 the column sweep is short enough to become bandwidth-bound (84 -> 120 us against
+        // 134 -> 110 for the rows), so the reference's split stays there (option dr_form = 2 forces this form on rung 0 too).
+        // No array is read and written by the same sweep, so t needs no second buffer: `tn` holds s, `sp` holds v = U - s'.
+        double *v = sp.d(), *sarr = tn;
+        for (int it = 0; it < maxit; it++) {
+            if (it == 0) {
+                // s = t - prox(t) = 0 for the constant t, s' = -t, v = U - s'
+                FamilyTimer tm(FAM_OTHER, s);
+                dr_fill(v, n1, (long)B, sums.d(), -1.0, s);
+                lincomb(v, unary, 1.0, v, -1.0, nullptr, 0.0, nullptr, 0.0, n, s);
+                PTV_HIP(hipMemsetAsync(sarr, 0, sizeof(double) * n, s));
+            } else {
+                col.a = t; col.b = unary; col.o0 = v; col.o1 = sarr;
+                launch_sweep(OP_DR_COL_V, weighted, col, cols, s, FAM_COL, true);
+            }
+            row.a = v; row.b = sarr; row.c = nullptr; row.o0 = t;
+            launch_sweep(OP_DR_ROW_V, weighted, row, rows, s, FAM_ROW, true);
+        }
+        col.b = nullptr; col.o0 = sp.d(); col.o1 = nullptr;
+        row.a = sp.d(); row.b = unary;
+    } else
     for (int it = 0; it < maxit; it++) {
         col.a = t;
         if (it == 0) {

@@ -1887,6 +1887,22 @@ void policy_probe(const double *y, const double *const *weights, const int *ns, 
     PTV_HIP(hipStreamSynchronize(s));
 }
 
+// The rung (0 or 1) a strided sweep of this geometry will take on the 64-fibre tile, -1 when it will not run there (transposed
+// copies, the pinning solver, sequential kernels).  dr2 asks before it chooses the form of its iteration: a function of the
+// seed alone, like the rung itself under the default policy.  Call after policy_probe.
+int strided_tile_rung(const FibreGeom &g, double lam, bool weighted) {
+    if (options().chunk <= 0 || g.inc == 1 || g.len < options().chunk_min_len) return -1;
+    ChunkScratch &st = chunk_state();
+    int mode = options().chunk_mode;
+    if (mode < 0) mode = st.seed(g, lam, weighted);   // (the hill climb starts from the seed too)
+    if (mode == 0) return 0;
+    if (mode != 1) return -1;                         // (unsampled: the pinning rung)
+    if (weighted || !(options().along && g.len >= options().along_min_len)) return 1;
+    if (options().row_along & 2) return -1;
+    const double f = st.certain_fraction(g, lam, weighted);
+    return ((options().row_along & 1) && f >= 0.0 && f < kSeedRowAlong) ? -1 : 1;
+}
+
 long chunk_stats_fixups(hipStream_t s) {
     if (!chunk_state().failcount) return 0;
     int h[ChunkScratch::kCounters] = {};
@@ -1941,6 +1957,8 @@ void launch_seq_gated(OpId op, bool weighted, const SweepArgs &args, const Fibre
         PTV_GATED_U(OP_PD2_A)
         PTV_GATED_U(OP_PD2_B)
         PTV_GATED_U(OP_YANG)
+        PTV_GATED(OP_DR_COL_V)
+        PTV_GATED(OP_DR_ROW_V)
         default:
             set_error("launch_seq_gated: unknown op %d", (int)op);
             throw HipFailure{hipErrorInvalidValue};
@@ -1973,12 +1991,16 @@ void launch_sweep(OpId op, bool weighted, const SweepArgs &args, const FibreGeom
         PTV_CASE(OP_DR_ROW)
         PTV_CASE_U(OP_DR_ROW_FINAL)
         PTV_CASE_W(OP_DRW_ROW_FINAL)
+        PTV_CASE(OP_DR_COL_V)
+        PTV_CASE(OP_DR_ROW_V)
 #elif defined(PTV_FAST_BUILD)   // experiments only: the headline's unweighted sweeps (a full build takes three minutes)
         PTV_CASE_U(OP_PROX)
         PTV_CASE_U(OP_DR_COL)
         PTV_CASE_U(OP_DR_COL_FINAL)
         PTV_CASE_U(OP_DR_ROW)
         PTV_CASE_U(OP_DR_ROW_FINAL)
+        PTV_CASE_U(OP_DR_COL_V)
+        PTV_CASE_U(OP_DR_ROW_V)
 #else
         PTV_CASE(OP_PROX)
         PTV_CASE(OP_DR_COL)
@@ -1989,6 +2011,8 @@ void launch_sweep(OpId op, bool weighted, const SweepArgs &args, const FibreGeom
         PTV_CASE_U(OP_PD2_A)
         PTV_CASE_U(OP_PD2_B)
         PTV_CASE_U(OP_YANG)
+        PTV_CASE(OP_DR_COL_V)
+        PTV_CASE(OP_DR_ROW_V)
 #endif
         default:
             set_error("launch_sweep: unknown op %d", (int)op);

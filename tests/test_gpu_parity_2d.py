@@ -278,3 +278,30 @@ def test_batch_equals_loop(ptv, oracle):
     for b in range(5):
         assert_close(ys[b], oracle.dr2(xs[b], 0.2)[0], what=f"batch item {b}")
         np.testing.assert_array_equal(ys[b], ptv.tv1_2d(xs[b], 0.2))   # bit-identical to the single-image path
+
+
+@pytest.mark.parametrize("mode", [-1, 0, 1, 3, 5])
+def test_both_forms_of_the_dr_iteration(ptv, clib, oracle, mode):
+    """DR2 / DR2L1W run their iteration in one of two forms (ops.hpp: OP_DR_COL / OP_DR_ROW -- the reference's split -- or
+    OP_DR_COL_V / OP_DR_ROW_V, where the column sweep leaves the row sweep's input and its epilogue operand), chosen from the
+    rung the row sweep will take.  Both forms, on every kind of kernel (policy's choice, the tile rungs, the pinning
+    solver, the sequential walk), against the oracle; weighted, batched and short-iteration calls included."""
+    rng = np.random.default_rng(101 + mode)
+    before = (clib.proxtv_set_option(b"chunk_mode", mode), clib.proxtv_set_option(b"dr_form", 2))
+    try:
+        for M, N, lam in [(300, 700, 0.1), (700, 300, 0.5), (1100, 130, 0.1), (2200, 1500, 0.15)]:
+            X = rng.standard_normal((M, N))
+            W1, W2 = rng.uniform(0, 2 * lam, (M - 1, N)), rng.uniform(0, 2 * lam, (M, N - 1))
+            want, want_w, want_3 = oracle.dr2(X, lam)[0], oracle.dr2w(X, W1, W2)[0], oracle.dr2(X, lam, max_iters=3)[0]
+            got = {}
+            for form in (2, 1, 0):
+                clib.proxtv_set_option(b"dr_form", form)
+                got[form] = ptv.tv1_2d(X, lam)
+                assert_close(got[form], want, tol=1e-10, what=f"dr2 {M}x{N} form {form} mode {mode}")
+                assert_close(ptv.tv1w_2d(X, W1, W2), want_w, tol=1e-10, what=f"dr2w {M}x{N} form {form} mode {mode}")
+                assert_close(ptv.tv1_2d(X, lam, max_iters=3), want_3, tol=1e-10, what=f"dr2 3 its {M}x{N} form {form}")
+                np.testing.assert_array_equal(ptv.tv1_2d(X, lam), got[form])
+            assert_close(got[2], got[0], tol=1e-12, what="form 2 against form 0")
+    finally:
+        clib.proxtv_set_option(b"chunk_mode", before[0])
+        clib.proxtv_set_option(b"dr_form", before[1])
