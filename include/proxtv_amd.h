@@ -163,6 +163,10 @@ void proxtv_release_scratch(void);
      "whole"          fibres of 16 .. chunk_min_len samples: 1 (default) by length and data, 2 whole fibres in LDS, 0 sequential
      "rounds"         second-chance rounds of geometry mode 1 (0 = built-in default: 4 in the tile, 8 along the fibre)
      "xlink"          1 (default): chunk kernels check the links across their workgroups themselves ; 0: the repair kernel does
+     "dr_form"        DR2_TV / DR2L1W_TV: which sweep does the pointwise work of an iteration.  1 (default): the column sweep leaves
+                      the row sweep's input and epilogue operand when the row sweep will run on the robust 64-fibre tile (decided
+                      from the same sampled statistics as the rung) ; 2: on the plain tile too ; 0: never (the reference's split).
+                      Same iterates either way, to a few ulps
      "host_register"  1: page-lock large caller arrays around the transfers of the host-pointer entry points (default 0: no gain measured)
      "verbose"        1: log every decision of the geometry policy to stderr
      "profile"        1: hipEvent pair around every sweep launch (proxtv_last_kernel_ms / _launches)

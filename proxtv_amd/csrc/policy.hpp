@@ -60,6 +60,9 @@ constexpr double kSeedNoisy = 0.45;   // f at or above: rung 0
 constexpr double kSeedMid = 0.03;     // f at or above: rung 1 ; below: rung 3  (as sampled -- edges in the threshold's own eighth-octave bin do not count -- lambda = 0.7 on unit noise gives 0.034, 0.75-0.8 gives 0.022; at 0.8: 35.0 ms on rung 1, 34.0 on rung 3)
 constexpr double kSeedFlat = 0.02;     // more than this fraction of the sampled 16-edge stretches (all but) flat at lambda: rung 3
 constexpr double kSeedRowAlong = 0.06; // rung 1, strided sweeps, f below (lambda >= 0.65 on unit noise): through transposed copies and the along-fibre kernel
+// DR2L1W: the second form of the iteration (ops.hpp, OP_DR_COL_V) pays below this certain fraction only -- the weighted column
+// sweep is the heavier one to begin with (4096^2, weights U(0.5, 1.5) lambda: lambda = 0.4: 17.4 -> 18.1 ms, 0.6: 25.3 -> 24.0)
+constexpr double kSeedDrFormWeighted = 0.2;
 inline int rung_from_certain_fraction(double f) { return f >= kSeedNoisy ? 0 : (f >= kSeedMid ? 1 : 3); }
 
 struct GeometryPolicy {

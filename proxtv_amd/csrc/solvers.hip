@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "pointwise.hpp"
+#include "policy.hpp"
 #include "sweep.hpp"
 #include "tv2.hpp"
 
@@ -94,8 +95,9 @@ SolveInfo dr2(size_t M, size_t N, size_t B, const double *unary, double W1, doub
     // every array of this loop is written by sweeps only (t, s' once by dr_fill, before any row sweep): row sweeps that
     // run on transposed copies may keep them (transposed.hpp)
     TransposeScope keep_transposed;
-    const int tile_rung = options().dr_form ? strided_tile_rung(rows, W2, weighted) : -1;
-    if (tile_rung == 1 || (tile_rung == 0 && options().dr_form == 2)) {
+    double row_f = -1.0;
+    const int tile_rung = options().dr_form ? strided_tile_rung(rows, W2, weighted, &row_f) : -1;
+    if (options().dr_form == 2 ? tile_rung >= 0 : (tile_rung == 1 && (!weighted || (row_f >= 0.0 && row_f < kSeedDrFormWeighted)))) {
         // The row sweep runs on the robust 64-fibre tile: the column sweep does all the pointwise work (ops.hpp, OP_DR_COL_V):
         // R t, R U, W v, W s | R v, R s, W t.  Measured on 4096^2, unit noise: the column sweep, bound by its walk there, takes
         // the two extra passes for nothing (lambda = 0.5: 150 -> 153 us) and the row sweep loses a staged operand and a fetch

@@ -1890,11 +1890,13 @@ void policy_probe(const double *y, const double *const *weights, const int *ns, 
 // The rung (0 or 1) a strided sweep of this geometry will take on the 64-fibre tile, -1 when it will not run there (transposed
 // copies, the pinning solver, sequential kernels).  dr2 asks before it chooses the form of its iteration: a function of the
 // seed alone, like the rung itself under the default policy.  Call after policy_probe.
-int strided_tile_rung(const FibreGeom &g, double lam, bool weighted) {
+int strided_tile_rung(const FibreGeom &g, double lam, bool weighted, double *certain_fraction) {
+    if (certain_fraction) *certain_fraction = -1.0;
     if (options().chunk <= 0 || g.inc == 1 || g.len < options().chunk_min_len) return -1;
     ChunkScratch &st = chunk_state();
     int mode = options().chunk_mode;
     if (mode < 0) mode = st.seed(g, lam, weighted);   // (the hill climb starts from the seed too)
+    if (certain_fraction) *certain_fraction = st.certain_fraction(g, lam, weighted);
     if (mode == 0) return 0;
     if (mode != 1) return -1;                         // (unsampled: the pinning rung)
     if (weighted || !(options().along && g.len >= options().along_min_len)) return 1;

@@ -28,7 +28,8 @@ void policy_probe(const double *y, const double *const *weights, const int *ns, 
 void chunk_stats_reset(hipStream_t s);
 long chunk_stats_fixups(hipStream_t s);
 // the rung (0 / 1) a strided sweep of this geometry will take on the 64-fibre tile, -1 if it will not run there.  Call after policy_probe.
-int strided_tile_rung(const FibreGeom &g, double lam, bool weighted);
+// (*certain_fraction: the seed statistic of that sweep's input, -1 when it was not sampled)
+int strided_tile_rung(const FibreGeom &g, double lam, bool weighted, double *certain_fraction = nullptr);
 // current geometry policy of this thread (highest over the sweep families the last solve used): 0 / 1 / 2 = LDS windows
 // (16-sample zones, the same with second-chance rounds, 64-sample zones), 3 = the pinning solver (or global-memory chunks
 // where it does not apply), 4 = global-memory chunks, 5 = sequential

@@ -42,6 +42,8 @@ def run(budget=60.0, seed=0, tol=1e-9, sizes=(2, 3, 17, 95, 96, 97, 130, 257, 40
             mode = int(rng.integers(-1, 6))
             lib.proxtv_set_option(b"chunk_mode", mode)
             lib.proxtv_set_option(b"deterministic", int(rng.integers(0, 2)))   # (mode -1: seeded-deterministic or hill-climbing policy)
+            form = int(rng.integers(0, 3))
+            lib.proxtv_set_option(b"dr_form", form)                            # (which of the two forms of the DR iteration: never / rung 1 / rungs 0, 1)
             what = int(rng.integers(0, 6))
             if what == 0:
                 got, want, name = ptv.tv1_2d(X, lam), orc.dr2(X, lam)[0], "dr2"
@@ -61,7 +63,7 @@ def run(budget=60.0, seed=0, tol=1e-9, sizes=(2, 3, 17, 95, 96, 97, 130, 257, 40
                 want = np.apply_along_axis(lambda f: orc.tv1_hybrid(np.ascontiguousarray(f), lam), d - 1, X)
                 name = f"prox dim {d}"
             e = rel(got, want)
-            desc = f"{name} {M}x{N} lam={lam:.4g} mode={mode}"
+            desc = f"{name} {M}x{N} lam={lam:.4g} mode={mode} dr_form={form}"
             if e > worst:
                 worst, worst_case = e, desc
             cases += 1
@@ -69,6 +71,7 @@ def run(budget=60.0, seed=0, tol=1e-9, sizes=(2, 3, 17, 95, 96, 97, 130, 257, 40
     finally:
         lib.proxtv_set_option(b"chunk_mode", before)
         lib.proxtv_set_option(b"deterministic", 1)
+        lib.proxtv_set_option(b"dr_form", 1)
     return cases, worst, worst_case
 
 

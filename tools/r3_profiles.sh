@@ -28,7 +28,7 @@ python $R/tools/pmc_traffic.py report $O/pmc > $O/r03_pmc_traffic.json 2> $O/pmc
 cd $R
 timeout 60 python tools/wg_trace.py > $O/r03_wg_trace.txt 2>&1
 timeout 300 python tools/time_cases.py > $O/r03_time_cases.txt 2>&1
-timeout 300 python tools/lambda_probe.py --modes -1 --lams 0.1,0.3,0.5,0.6,0.7,0.8,1.0,3.0,10.0,30.0 > $O/r03_lambda_sweep.txt 2>&1
+timeout 300 python tools/lambda_probe.py --modes -1 --lams 0.1,0.3,0.4,0.5,0.6,0.7,0.8,1.0,3.0,10.0,30.0 > $O/r03_lambda_sweep.txt 2>&1
 timeout 200 python tools/lambda_probe.py --modes -1 --lams 0.1,0.5,1.0,3.0 --opt deterministic=0 > $O/r03_lambda_sweep_adaptive.txt 2>&1
 for w in dr fibre; do timeout 100 python tools/first_call.py $w >> $O/r03_first_call.txt 2>&1; done
 timeout 100 python tools/first_call.py dr 3.0 >> $O/r03_first_call.txt 2>&1

@@ -12,7 +12,7 @@ dev = lambda a: device.to_colmajor(torch.from_numpy(np.ascontiguousarray(a)).cud
 X = dev(rng.standard_normal((4096, 4096)))
 out = device.colmajor_empty((4096, 4096))
 if which in ("c3", "wprox0", "wprox1"):
-    W1, W2 = dev(rng.uniform(0.05, 0.15, (4095, 4096))), dev(rng.uniform(0.05, 0.15, (4096, 4095)))
+    W1, W2 = dev(rng.uniform(0.5 * lam, 1.5 * lam, (4095, 4096))), dev(rng.uniform(0.5 * lam, 1.5 * lam, (4096, 4095)))   # (default lambda 0.1: BASELINE config #3)
 run = {"c2": lambda: device.tv1_2d(X, lam, out=out), "c3": lambda: device.tv1w_2d(X, W1, W2, out=out),
        "prox0": lambda: device.tv1_fibres(X, lam, 0, out=out), "prox1": lambda: device.tv1_fibres(X, lam, 1, out=out),
        "wprox0": lambda: device.tv1_fibres(X, 0.0, 0, weights=W1, out=out),
