@@ -287,7 +287,8 @@ def test_both_forms_of_the_dr_iteration(ptv, clib, oracle, mode):
     rung the row sweep will take.  Both forms, on every kind of kernel (policy's choice, the tile rungs, the pinning
     solver, the sequential walk), against the oracle; weighted, batched and short-iteration calls included."""
     rng = np.random.default_rng(101 + mode)
-    before = (clib.proxtv_set_option(b"chunk_mode", mode), clib.proxtv_set_option(b"dr_form", 2))
+    before = (clib.proxtv_set_option(b"chunk_mode", mode), clib.proxtv_set_option(b"dr_form", 2),
+              clib.proxtv_set_option(b"deterministic", 1))   # (bit-for-bit repeats below: the seeded policy, whatever the environment says)
     try:
         for M, N, lam in [(300, 700, 0.1), (700, 300, 0.5), (1100, 130, 0.1), (2200, 1500, 0.15)]:
             X = rng.standard_normal((M, N))
@@ -305,3 +306,4 @@ def test_both_forms_of_the_dr_iteration(ptv, clib, oracle, mode):
     finally:
         clib.proxtv_set_option(b"chunk_mode", before[0])
         clib.proxtv_set_option(b"dr_form", before[1])
+        clib.proxtv_set_option(b"deterministic", before[2])

@@ -22,8 +22,11 @@ def data(rng, kind, shape):
     return np.round(rng.standard_normal(shape) * 3)          # many exact ties
 
 
-def rel(a, b):
-    return float(np.max(np.abs(a - b))) / max(float(np.max(np.abs(b))), 1e-300)
+def rel(a, b, scale=0.0):
+    """Largest difference relative to the size of the expected result -- or of the INPUT when that is larger: with a huge
+    penalty on integer data whose mean is exactly zero the expected result is rounding noise around zero (4e-15), and a
+    difference of that size is not an error of 100 %."""
+    return float(np.max(np.abs(a - b))) / max(float(np.max(np.abs(b))), float(scale), 1e-300)
 
 
 def run(budget=60.0, seed=0, tol=1e-9, sizes=(2, 3, 17, 95, 96, 97, 130, 257, 400, 700, 1100)):
@@ -62,7 +65,7 @@ def run(budget=60.0, seed=0, tol=1e-9, sizes=(2, 3, 17, 95, 96, 97, 130, 257, 40
                 got = ptv.tvgen(X, [lam], [d], [1])
                 want = np.apply_along_axis(lambda f: orc.tv1_hybrid(np.ascontiguousarray(f), lam), d - 1, X)
                 name = f"prox dim {d}"
-            e = rel(got, want)
+            e = rel(got, want, np.max(np.abs(X)))
             desc = f"{name} {M}x{N} lam={lam:.4g} mode={mode} dr_form={form}"
             if e > worst:
                 worst, worst_case = e, desc
@@ -117,7 +120,7 @@ def run_nd(budget=30.0, seed=0, tol=1e-9, sizes=(2, 5, 33, 96, 130, 210)):
                 out, info = np.zeros(shape, order="F"), np.zeros(3)
                 lib.Yang3_TV(shape[0], shape[1], shape[2], V.ctypes.data, lam, out.ctypes.data, its, info.ctypes.data)
                 got, name = out, f"Yang3_TV {its} its"
-            e = rel(got, want)
+            e = rel(got, want, np.max(np.abs(V)))
             desc = f"{name} {shape} mode={mode}"
             if e > worst:
                 worst, worst_case = e, desc
