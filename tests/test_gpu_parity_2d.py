@@ -307,3 +307,26 @@ def test_both_forms_of_the_dr_iteration(ptv, clib, oracle, mode):
         clib.proxtv_set_option(b"chunk_mode", before[0])
         clib.proxtv_set_option(b"dr_form", before[1])
         clib.proxtv_set_option(b"deterministic", before[2])
+
+
+def test_anisotropic_image_mixes_rungs_and_forms(ptv, clib, oracle):
+    """Columns that hardly vary next to rows of independent noise: the seeded policy sends the column sweep to the pinning
+    solver and the row sweep to the robust tile, so the second form of the DR iteration (chosen from the ROW sweep's rung)
+    runs its column op on the pinning kernels -- and, transposed, the other way round with the first form."""
+    rng = np.random.default_rng(314)
+    before = (clib.proxtv_set_option(b"chunk_mode", -1), clib.proxtv_set_option(b"deterministic", 1),
+              clib.proxtv_set_option(b"dr_form", 1))
+    try:
+        base = np.tile(rng.standard_normal((1, 1200)), (1500, 1)) + 1e-3 * rng.standard_normal((1500, 1200))
+        for X in (base, np.ascontiguousarray(base.T)):
+            for lam in (0.45, 0.3):
+                got = ptv.tv1_2d(X, lam)
+                assert clib.proxtv_chunk_mode() == 3          # (the highest rung any sweep family of the solve took)
+                assert_close(got, oracle.dr2(X, lam)[0], tol=1e-10, what=f"anisotropic {X.shape} lambda {lam}")
+                np.testing.assert_array_equal(ptv.tv1_2d(X, lam), got)
+            W1 = rng.uniform(0.2, 0.7, (X.shape[0] - 1, X.shape[1]))
+            W2 = rng.uniform(0.2, 0.7, (X.shape[0], X.shape[1] - 1))
+            assert_close(ptv.tv1w_2d(X, W1, W2), oracle.dr2w(X, W1, W2)[0], tol=1e-10, what=f"anisotropic weighted {X.shape}")
+    finally:
+        for k, v in zip((b"chunk_mode", b"deterministic", b"dr_form"), before):
+            clib.proxtv_set_option(k, v)
