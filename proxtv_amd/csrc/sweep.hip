@@ -631,6 +631,16 @@ __global__ __launch_bounds__(64 * NW, SHORT ? 16 / NW : ((WEIGHTED || H > 16 || 
 // of a read hit 32 different bank pairs -- the floor for 8-byte accesses -- without any padding (with 16 they would
 // hit two).
 constexpr int kAlongC = 17;
+// The robust instantiation (rungs 1 / 2: pieces of a few samples) takes chunks of 31 samples where one LDS plane suffices:
+// the zone is walked once per 31 samples instead of once per 17, and -- what matters more -- a wave's walk lasts as long as
+// its slowest lane's, and the spread between lanes shrinks with the chunk: on the inputs of DR sweeps a wave walks
+// 2.70 -> 2.03 trips per sample at lambda = 0.5 and 4.24 -> 3.03 at 0.7 (host model: tools/study/links_study.py).  The
+// price is LDS: 16.9 KB per wave instead of 9.7, eight waves per CU instead of sixteen.  (31 is odd, see above, and a
+// chunk's piece ends fit the 32-bit masks of ChunkRec.)
+#ifndef PTV_ALONG_ROBUST_C
+#define PTV_ALONG_ROBUST_C 31
+#endif
+constexpr int along_chunk(bool robust, bool weighted) { return robust && !weighted ? PTV_ALONG_ROBUST_C : kAlongC; }
 #ifndef PTV_ALONG_WAVES
 #define PTV_ALONG_WAVES 4
 #endif
@@ -662,7 +672,7 @@ constexpr int along_zone_rows(int H, bool robust) { return robust && H < 64 ? 64
 template <int OP, bool WEIGHTED, int H, int G, bool ROBUST>
 __global__ __launch_bounds__(64 * kAlongWaves) void sweep_along_kernel(SweepArgs p, FibreGeom g, ChunkPlan plan, link_t *code_mine,
                                                                         link_t *code_next, int *failflags) {
-    constexpr int C = kAlongC, SEG = G * C, T = along_tail_rows(H, ROBUST), HZ = along_zone_rows(H, ROBUST), ROWS = HZ + SEG + T, NG = 64 / G;
+    constexpr int C = along_chunk(ROBUST, WEIGHTED), SEG = G * C, T = along_tail_rows(H, ROBUST), HZ = along_zone_rows(H, ROBUST), ROWS = HZ + SEG + T, NG = 64 / G;
     constexpr int NU = (ROWS + G - 1) / G;   // staged elements per lane
     constexpr int UL = 9;                    // epilogue operand fetches in flight per lane (C = 17 rows per lane: 9 + 8)
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -697,20 +707,26 @@ __global__ __launch_bounds__(64 * kAlongWaves) void sweep_along_kernel(SweepArgs
 
     // ---- stage: the segment as it lies in memory ---------------------------------------------------------------------------
     if (live && !(plan.ablate & 4)) {
-        double s0[NU], s1[NU], sw[WEIGHTED ? NU : 1];
+        // every load of a batch is issued before the first is waited for; NB rows per lane and batch (the 31-sample chunks stage
+        // 34 rows per lane: in one batch a two-operand op would hold 136 registers)
+        constexpr int NB = NU <= 20 ? NU : (NU + 1) / 2;
 #pragma unroll
-        for (int u = 0; u < NU; u++) {
-            const int r = lo + G * u + gl;
-            s0[u] = s1[u] = 0.0;
-            if (r >= 0 && r < hi) Op<OP>::fetch_in(p, fbase + r, s0[u], s1[u]);
-            if (WEIGHTED) sw[WEIGHTED ? u : 0] = (r >= 0 && r < hi && r < len - 1) ? p.w[wbase + r] : 0.0;
-        }
+        for (int b0 = 0; b0 < NU; b0 += NB) {
+            double s0[NB], s1[NB], sw[WEIGHTED ? NB : 1];
 #pragma unroll
-        for (int u = 0; u < NU; u++) {
-            const int r = lo + G * u + gl;
-            if (r >= 0 && r < hi) {
-                Yp[r - lo] = Op<OP>::y_of(p, s0[u], s1[u]);
-                if (WEIGHTED) Wp[r - lo] = sw[WEIGHTED ? u : 0];
+            for (int u = 0; u < NB; u++) {
+                const int r = lo + G * (b0 + u) + gl;
+                s0[u] = s1[u] = 0.0;
+                if (b0 + u < NU && r >= 0 && r < hi) Op<OP>::fetch_in(p, fbase + r, s0[u], s1[u]);
+                if (WEIGHTED) sw[WEIGHTED ? u : 0] = (b0 + u < NU && r >= 0 && r < hi && r < len - 1) ? p.w[wbase + r] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < NB; u++) {
+                const int r = lo + G * (b0 + u) + gl;
+                if (b0 + u < NU && r >= 0 && r < hi) {
+                    Yp[r - lo] = Op<OP>::y_of(p, s0[u], s1[u]);
+                    if (WEIGHTED) Wp[r - lo] = sw[WEIGHTED ? u : 0];
+                }
             }
         }
     }
@@ -1624,7 +1640,7 @@ void launch_chunk_h(const SweepArgs &args, const FibreGeom &g, hipStream_t strea
 // the codes of 64 consecutive chunks of one fibre).
 template <int OP, bool WEIGHTED, int H, int G, bool ROBUST>
 void launch_along_g(const SweepArgs &args, const FibreGeom &g, hipStream_t stream, int fam, int rounds_wanted) {
-    constexpr int C = kAlongC, SEG = G * C, ROWS = along_zone_rows(H, ROBUST) + SEG + along_tail_rows(H, ROBUST), NG = 64 / G;
+    constexpr int C = along_chunk(ROBUST, WEIGHTED), SEG = G * C, ROWS = along_zone_rows(H, ROBUST) + SEG + along_tail_rows(H, ROBUST), NG = 64 / G;
     const int nseg = (g.len + SEG - 1) / SEG;
     const int NC = (g.len + C - 1) / C;
     const long units = g.count * nseg;
@@ -1670,8 +1686,9 @@ void launch_along_g(const SweepArgs &args, const FibreGeom &g, hipStream_t strea
 // one when the fibre fits 32 or 16 chunks.
 template <int OP, bool WEIGHTED, int H, bool ROBUST>
 void launch_along(const SweepArgs &args, const FibreGeom &g, hipStream_t stream, int fam, int rounds) {
-    if (g.len <= 16 * kAlongC)      launch_along_g<OP, WEIGHTED, H, 16, ROBUST>(args, g, stream, fam, rounds);
-    else if (g.len <= 32 * kAlongC) launch_along_g<OP, WEIGHTED, H, 32, ROBUST>(args, g, stream, fam, rounds);
+    constexpr int C = along_chunk(ROBUST, WEIGHTED);
+    if (g.len <= 16 * C)      launch_along_g<OP, WEIGHTED, H, 16, ROBUST>(args, g, stream, fam, rounds);
+    else if (g.len <= 32 * C) launch_along_g<OP, WEIGHTED, H, 32, ROBUST>(args, g, stream, fam, rounds);
     else                            launch_along_g<OP, WEIGHTED, H, 64, ROBUST>(args, g, stream, fam, rounds);
 }
 
