@@ -1714,6 +1714,9 @@ void launch_gchunk(const SweepArgs &args, const FibreGeom &g, int C, int H, hipS
 // contiguous; a tiled copy at HBM speed), the sweep runs as a dimension-0 sweep, and the outputs are transposed back.
 // Fibre numbering is unchanged: fibre j = slab * inc + off sits at j * len after the transposition of every
 // (inc x len) slab.
+// (tuning aid: option seed_row_along_e4 overrides policy.hpp's kSeedRowAlong)
+static inline double seed_row_along() { return options().seed_row_along_e4 > 0 ? options().seed_row_along_e4 * 1e-4 : kSeedRowAlong; }
+
 template <int OP, int H>
 void launch_row_along(const SweepArgs &args, const FibreGeom &g, hipStream_t stream, int fam, int rounds) {
     TransposedOperands tr(args, Op<OP>::IN_MASK, Op<OP>::OUT_MASK, g, stream);
@@ -1789,7 +1792,7 @@ void launch_chunk(const SweepArgs &args, const FibreGeom &g, hipStream_t stream,
         if constexpr (!WEIGHTED) launch_row_along<OP, kWarmLong>(args, g, stream, fam, rounds);
     }
     else if (!TRANSPOSED && !WEIGHTED && along_ok && mode == 1 &&
-             ((options().row_along & 2) || ((options().row_along & 1) && seed_f >= 0.0 && seed_f < kSeedRowAlong))) {
+             ((options().row_along & 2) || ((options().row_along & 1) && seed_f >= 0.0 && seed_f < seed_row_along()))) {
         // rung 1 near its upper end (pieces of ~4 samples): the 64-fibre tile leaves the links between its workgroups to the
         // repair kernel, and those start to fail; chunks along transposed copies settle nearly all links inside the kernel
         if constexpr (!WEIGHTED) launch_row_along<OP, kWarm>(args, g, stream, fam, rounds);
@@ -1919,7 +1922,7 @@ int strided_tile_rung(const FibreGeom &g, double lam, bool weighted, double *cer
     if (weighted || !(options().along && g.len >= options().along_min_len)) return 1;
     if (options().row_along & 2) return -1;
     const double f = st.certain_fraction(g, lam, weighted);
-    return ((options().row_along & 1) && f >= 0.0 && f < kSeedRowAlong) ? -1 : 1;
+    return ((options().row_along & 1) && f >= 0.0 && f < seed_row_along()) ? -1 : 1;
 }
 
 long chunk_stats_fixups(hipStream_t s) {
