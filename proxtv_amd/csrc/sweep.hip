@@ -264,11 +264,12 @@ constexpr int kOverflow = 48;   // samples a walk of the robust instantiation ma
 
 // One chunk's walk from a given walker state: the branch-free interior loop (chunkcore.hpp), then walker_run for what
 // is left -- the fibre's last sample, the window's end (PAST: up to kOverflow samples beyond it from global memory).
-template <int OP, bool WEIGHTED, int PITCH, bool PAST>
+template <int OP, bool WEIGHTED, int PITCH, bool PAST, bool TAB = false>
 __device__ __forceinline__ void walk_chunk(Walker &w, ChunkRec &rec, const LdsWin<WEIGHTED, PITCH> &win, const FarFibre<OP> &far,
-                                           int hi, int cs, int ce, int len, double lam) {
+                                           int hi, int cs, int ce, int len, double lam, unsigned rtab = 0u) {
 #ifndef PTV_NO_ASM_WALK
-    if constexpr (!WEIGHTED) walk_interior_asm<PITCH>(w, rec, win, min(len - 1, hi), cs, ce, lam);
+    if constexpr (!WEIGHTED && TAB) walk_interior_asm_tab<PITCH>(w, rec, win, min(len - 1, hi), cs, ce, lam, rtab);   // (spans bounded: see walk_asm.hpp)
+    else if constexpr (!WEIGHTED) walk_interior_asm<PITCH>(w, rec, win, min(len - 1, hi), cs, ce, lam);
     else                     walk_interior_asm_w<PITCH>(w, rec, win, min(len - 1, hi), cs, ce);
 #else
     walk_interior<WEIGHTED>(w, rec, win, min(len - 1, hi), cs, ce, lam);
@@ -683,6 +684,17 @@ __global__ __launch_bounds__(64 * kAlongWaves) void sweep_along_kernel(SweepArgs
     double *Wp = Yp + (WEIGHTED ? ROWS + 2 : 0);   // per-edge penalties, same rows (weighted sweeps)
     // ROBUST: what a wave's last lane ends up with, for the first lane of the next wave: [kAlongWaves] codes, [kAlongWaves] "ready"
     unsigned *xwave = reinterpret_cast<unsigned *>(reinterpret_cast<double *>(smem) + (size_t)kAlongWaves * NG * (ROWS + 2) * (WEIGHTED ? 2 : 1));
+    // plain instantiation: the pull-backs of the walk divide by table (walk_asm.hpp: walk_interior_asm_tab); one table per workgroup
+#ifdef PTV_WALK_TABLE
+    constexpr bool TAB = !ROBUST && !WEIGHTED && H <= kWarm && H + kAlongC + T < kRecipTable;
+#else
+    constexpr bool TAB = false;
+#endif
+    double *rtab = reinterpret_cast<double *>(xwave);
+    if constexpr (TAB) {
+        if (threadIdx.x < kRecipTable) rtab[threadIdx.x] = threadIdx.x ? 1.0 / (double)threadIdx.x : 0.0;
+        __syncthreads();   // (before anything else happens: every wave of the workgroup is here)
+    }
     if (ROBUST && G == 64) {
         if (lane == 0) xwave[kAlongWaves + wave] = 0u;
         __syncthreads();   // (the only workgroup barrier of the kernel: before anything else happens)
@@ -757,7 +769,7 @@ __global__ __launch_bounds__(64 * kAlongWaves) void sweep_along_kernel(SweepArgs
         } else {
             walker_start<WEIGHTED>(w, win, start, p.lam);
         }
-        walk_chunk<OP, WEIGHTED, 1, ROBUST>(w, rec, win, far, hi, cs, ce, len, p.lam);
+        walk_chunk<OP, WEIGHTED, 1, ROBUST, TAB>(w, rec, win, far, hi, cs, ce, len, p.lam, (unsigned)(unsigned long long)rtab);
     }
     if (plan.trace && lane == 0) plan.trace[8 * (size_t)wid + 3] = wall_clock64();
 
@@ -1652,7 +1664,7 @@ void launch_along_g(const SweepArgs &args, const FibreGeom &g, hipStream_t strea
     plan.trace = options().trace ? chunk_state().trace_buffer((size_t)waves) : nullptr;
     plan.dirty = chunk_state().next_dirty(stream);
     plan.xlink = chunk_state().xlink_for((size_t)g.count * (size_t)nseg, stream);
-    constexpr size_t lds = sizeof(double) * (size_t)(ROWS + 2) * NG * kAlongWaves * (WEIGHTED ? 2 : 1) + (ROBUST ? 64 : 0);
+    constexpr size_t lds = sizeof(double) * (size_t)(ROWS + 2) * NG * kAlongWaves * (WEIGHTED ? 2 : 1) + (ROBUST ? 64 : sizeof(double) * kRecipTable);
     static_assert(lds <= 160 * 1024, "along-fibre geometry does not fit the LDS of a CU");
     auto kern = sweep_along_kernel<OP, WEIGHTED, H, G, ROBUST>;
     if (lds > 64 * 1024) {   // above the default dynamic-LDS limit
