@@ -216,11 +216,16 @@ struct NoFar {
 // workgroups per CU; more where the LDS latency of a row would otherwise be paid row by row).
 // TAB / rt: piece lengths are bounded by the window (plain geometries: zone + chunk + look-ahead rows), so the division by the
 // length is one product with rt[length] = the correctly rounded 1.0 / length (see walk_asm.hpp: walk_interior_asm_tab).
-template <class F, bool WEIGHTED, int C, int UNROLL = 1, bool TAB = false, class RT = const double *, class Win>
+// TSZ > 0: the table has TSZ entries and longer pieces are possible (robust instantiations): those divide.
+template <class F, bool WEIGHTED, int C, int UNROLL = 1, bool TAB = false, class RT = const double *, int TSZ = 0, class Win>
 __device__ __forceinline__ void rebuild_owned(Win &win, const ChunkRec &rec, int cs, int ce, int len, int start, bool link_ok,
                                               int wlo, bool block_last, double lam, RT rt = RT()) {
     auto quotient = [&](double num, double count) {
         if constexpr (TAB) {
+            if (TSZ > 0 && count >= (double)TSZ) {
+                const SpanDiv over(count);
+                return over(num);
+            }
             return num * rt[(int)count];
         } else {
             const SpanDiv over(count);

@@ -268,7 +268,7 @@ template <int OP, bool WEIGHTED, int PITCH, bool PAST, bool TAB = false>
 __device__ __forceinline__ void walk_chunk(Walker &w, ChunkRec &rec, const LdsWin<WEIGHTED, PITCH> &win, const FarFibre<OP> &far,
                                            int hi, int cs, int ce, int len, double lam, unsigned rtab = 0u) {
 #ifndef PTV_NO_ASM_WALK
-    if constexpr (!WEIGHTED && TAB) walk_interior_asm_tab<PITCH>(w, rec, win, min(len - 1, hi), cs, ce, lam, rtab);   // (spans bounded: see walk_asm.hpp)
+    if constexpr (!WEIGHTED && TAB) walk_interior_asm_tab<PITCH, PAST>(w, rec, win, min(len - 1, hi), cs, ce, lam, rtab);   // (spans bounded: see walk_asm.hpp)
     else if constexpr (!WEIGHTED) walk_interior_asm<PITCH>(w, rec, win, min(len - 1, hi), cs, ce, lam);
     else                     walk_interior_asm_w<PITCH>(w, rec, win, min(len - 1, hi), cs, ce);
 #else
@@ -686,14 +686,16 @@ __global__ __launch_bounds__(64 * kAlongWaves) void sweep_along_kernel(SweepArgs
     unsigned *xwave = reinterpret_cast<unsigned *>(reinterpret_cast<double *>(smem) + (size_t)kAlongWaves * NG * (ROWS + 2) * (WEIGHTED ? 2 : 1));
     // plain instantiation: the pull-backs of the walk divide by table (walk_asm.hpp: walk_interior_asm_tab); one table per workgroup
 #ifdef PTV_WALK_TABLE
-    constexpr bool TAB = !ROBUST && !WEIGHTED && H <= kWarm && H + kAlongC + T < kRecipTable;
+    constexpr bool TAB = !WEIGHTED && H <= kWarm && (ROBUST || H + kAlongC + T < kRecipTable);
 #else
     constexpr bool TAB = false;
 #endif
-    double *rtab = reinterpret_cast<double *>(xwave);
+    constexpr int TS = ROBUST ? kRecipTableRobust : kRecipTable;
+    double *rtab = reinterpret_cast<double *>(xwave + (ROBUST ? 16 : 0));
     if constexpr (TAB) {
-        if (threadIdx.x < kRecipTable) rtab[threadIdx.x] = threadIdx.x ? 1.0 / (double)threadIdx.x : 0.0;
-        __syncthreads();   // (before anything else happens: every wave of the workgroup is here)
+        if (threadIdx.x < TS) rtab[threadIdx.x] = threadIdx.x ? 1.0 / (double)threadIdx.x : 0.0;
+        if (!ROBUST || G != 64) __syncthreads();   // (before anything else happens: every wave of the workgroup is here; the robust
+                                                   //  64-lane instantiation has its own barrier right below)
     }
     if (ROBUST && G == 64) {
         if (lane == 0) xwave[kAlongWaves + wave] = 0u;
@@ -791,7 +793,7 @@ __global__ __launch_bounds__(64 * kAlongWaves) void sweep_along_kernel(SweepArgs
         walker_restart_with<WEIGHTED>(w, at, (int)(from & 1u), len, p.lam, win.y(at), WEIGHTED ? win.r(at - 1) : 0.0,
                                       (WEIGHTED && at < len - 1) ? win.r(at) : 0.0);
         again.mine = again.next = again.last = from;
-        walk_chunk<OP, WEIGHTED, 1, ROBUST>(w, again, win, far, hi, cs, ce, len, p.lam);
+        walk_chunk<OP, WEIGHTED, 1, ROBUST, TAB>(w, again, win, far, hi, cs, ce, len, p.lam, (unsigned)(unsigned long long)rtab);
         if (!again.failed) {
             rec = again;
             certain = false;   // from now on the chunk hangs on its predecessor like any other
@@ -851,7 +853,7 @@ __global__ __launch_bounds__(64 * kAlongWaves) void sweep_along_kernel(SweepArgs
         if (below) wlo = seg_s + (63 - __clzll((long long)below)) * C;
     }
     if (has_chunk && !(plan.ablate & 1))
-        rebuild_owned<Op<OP>, WEIGHTED, C, PTV_ALONG_UNROLL, TAB, lds_double *>(win, rec, cs, ce, len, start, !bad, wlo, gl == G - 1 || ce == len, p.lam,
+        rebuild_owned<Op<OP>, WEIGHTED, C, PTV_ALONG_UNROLL, TAB, lds_double *, (ROBUST ? TS : 0)>(win, rec, cs, ce, len, start, !bad, wlo, gl == G - 1 || ce == len, p.lam,
                                                                                 (lds_double *)rtab);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -1665,7 +1667,7 @@ void launch_along_g(const SweepArgs &args, const FibreGeom &g, hipStream_t strea
     plan.trace = options().trace ? chunk_state().trace_buffer((size_t)waves) : nullptr;
     plan.dirty = chunk_state().next_dirty(stream);
     plan.xlink = chunk_state().xlink_for((size_t)g.count * (size_t)nseg, stream);
-    constexpr size_t lds = sizeof(double) * (size_t)(ROWS + 2) * NG * kAlongWaves * (WEIGHTED ? 2 : 1) + (ROBUST ? 64 : sizeof(double) * kRecipTable);
+    constexpr size_t lds = sizeof(double) * (size_t)(ROWS + 2) * NG * kAlongWaves * (WEIGHTED ? 2 : 1) + (ROBUST ? 64 + sizeof(double) * kRecipTableRobust : sizeof(double) * kRecipTable);
     static_assert(lds <= 160 * 1024, "along-fibre geometry does not fit the LDS of a CU");
     auto kern = sweep_along_kernel<OP, WEIGHTED, H, G, ROBUST>;
     if (lds > 64 * 1024) {   // above the default dynamic-LDS limit

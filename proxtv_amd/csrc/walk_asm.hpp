@@ -159,17 +159,22 @@ __device__ __forceinline__ void walk_interior_asm(Walker &w, ChunkRec &rec, cons
 // product with the correctly rounded reciprocal of s -- within one ulp of the division, like the v_rcp_f64 + Newton +
 // residual sequence above (host study, -DPTV_TABLE_RECIP in walker.hpp: worst deviation from the oracle 4.9e-16 against
 // 4.0e-16, same links proven), for 9 vector instructions instead of 16 and no transcendental.  `rtab`: LDS byte address of a
-// table with rtab[s] = 1.0 / s for 1 <= s < kRecipTable, filled by the kernel before any walk.  Only the plain (not robust)
-// instantiations use it: there a walk never leaves its window, so the span is bounded by construction.
+// table with rtab[s] = 1.0 / s for 1 <= s < TS, filled by the kernel before any walk.  In the plain instantiations a walk never
+// leaves its window, so the span is bounded by construction (TS = kRecipTable); the robust ones (SPAN_EXIT) leave the loop when
+// a lane's span reaches TS -- a piece of 64 samples on the rung for pieces of a few -- and that lane goes on in the slow tail
+// (walker_run through TailSource, which divides), exactly as a lane that reaches the window's end does.
 // The read is issued first in the trip and used last: the corrections moved behind the bend's bookkeeping (different lanes:
 // a lane either bends or is pulled back), so one wait covers all four LDS reads of a trip.
 // STAGED FOR THE NEXT ROUND -- assembles, not yet run on a GPU.
-constexpr int kRecipTable = 48;
+constexpr int kRecipTable = 48;        // plain geometries: zone 16 + chunk 17 + look-ahead 8 = 41 rows at most
+constexpr int kRecipTableRobust = 64;
 
-template <int PITCH, class Win>
+template <int PITCH, bool SPAN_EXIT, class Win>
 __device__ __forceinline__ void walk_interior_asm_tab(Walker &w, ChunkRec &rec, const Win &win, int lim, int cs, int ce, double lam,
                                                       unsigned rtab) {
     if (w.i >= lim || rec.done) return;
+    constexpr int TS = SPAN_EXIT ? kRecipTableRobust : kRecipTable;
+    if (SPAN_EXIT && w.i - w.k0 >= TS) return;   // (the slow tail takes it)
     constexpr int PB = PITCH * 8;
     const int wlo = win.lo;
     const unsigned abase = (unsigned)(unsigned long long)win.Y;
@@ -182,7 +187,9 @@ __device__ __forceinline__ void walk_interior_asm_tab(Walker &w, ChunkRec &rec, 
     const double nlam = -lam, lam2 = 2 * lam, nlam2 = 2 * (-lam);
     const int lim_r = lim - wlo, cs_r = cs - wlo, ce_r = ce - wlo, cem1_r = ce - 1 - wlo, span = ce - cs, pbs = PB;
     double ynx, t0, h1, h2, inv, q;
-    int brk, at, aat, sp, code, sh, bit;
+    int brk, at, aat, code, sh, bit;
+    int sp = i - k0;
+    const int tsz = TS;
     unsigned atab;
     unsigned long long msave, mlive, mcv, mfv, mb, mth, mtl, mdone, m1, m2, m3;
     asm volatile(
@@ -190,7 +197,6 @@ __device__ __forceinline__ void walk_interior_asm_tab(Walker &w, ChunkRec &rec, 
         "s_mov_b64 %[mlive], exec\n"
         "s_mov_b64 %[mdone], 0\n"
         ".Lptv_walkt_%=:\n"
-        "v_sub_u32 %[sp], %[i], %[k0]\n"
         "ds_read_b64 %[ynx], %[ai] offset:%[pb]\n"
         "v_lshl_add_u32 %[atab], %[sp], 3, %[rtab]\n"
         "v_add_f64 %[h1], %[lo], -%[yi]\n"
@@ -267,7 +273,10 @@ __device__ __forceinline__ void walk_interior_asm_tab(Walker &w, ChunkRec &rec, 
         "v_add_u32 %[i], 1, %[i]\n"
         "v_add_u32 %[ai], %[pbs], %[ai]\n"
         "v_mov_b64 %[yi], %[ynx]\n"
+        "v_sub_u32 %[sp], %[i], %[k0]\n"               // the span of the next trip: its table index ...
         "v_cmp_gt_i32 vcc, %[limr], %[i]\n"
+        "v_cmp_gt_u32 %[m1], %[tsz], %[sp]\n"          // ... and the lane leaves the loop where the table ends (robust instantiations;
+        "s_and_b64 vcc, vcc, %[m1]\n"                  //     never true in the plain ones)
         "s_andn2_b64 vcc, vcc, %[mdone]\n"
         "s_and_b64 exec, %[mlive], vcc\n"
         "s_mov_b64 %[mlive], exec\n"
@@ -277,15 +286,15 @@ __device__ __forceinline__ void walk_interior_asm_tab(Walker &w, ChunkRec &rec, 
         "v_cndmask_b32_e64 %[doneflag], 0, 1, %[mdone]\n"
         : [lo] "+v"(lo), [hi] "+v"(hi), [hlo] "+v"(hlo), [hhi] "+v"(hhi), [yi] "+v"(yi), [i] "+v"(i), [k0] "+v"(k0),
           [klo] "+v"(klo), [khi] "+v"(khi), [ai] "+v"(ai), [ends] "+v"(ends), [types] "+v"(types), [mine] "+v"(mine),
-          [next] "+v"(next), [last] "+v"(last), [doneflag] "+v"(doneflag),
+          [next] "+v"(next), [last] "+v"(last), [doneflag] "+v"(doneflag), [sp] "+v"(sp),
           [ynx] "=&v"(ynx), [t0] "=&v"(t0), [h1] "=&v"(h1), [h2] "=&v"(h2),
           [inv] "=&v"(inv), [q] "=&v"(q), [brk] "=&v"(brk), [at] "=&v"(at), [aat] "=&v"(aat),
-          [sp] "=&v"(sp), [code] "=&v"(code), [sh] "=&v"(sh), [bit] "=&v"(bit), [atab] "=&v"(atab),
+          [code] "=&v"(code), [sh] "=&v"(sh), [bit] "=&v"(bit), [atab] "=&v"(atab),
           [msave] "=&s"(msave), [mlive] "=&s"(mlive), [mcv] "=&s"(mcv), [mfv] "=&s"(mfv), [mb] "=&s"(mb), [mth] "=&s"(mth),
           [mtl] "=&s"(mtl), [mdone] "=&s"(mdone), [m1] "=&s"(m1), [m2] "=&s"(m2), [m3] "=&s"(m3)
         : [lam] "s"(lam), [nlam] "s"(nlam), [lam2] "s"(lam2), [nlam2] "s"(nlam2), [pbs] "s"(pbs), [limr] "s"(lim_r),
           [csr] "s"(cs_r), [cer] "s"(ce_r), [cem1r] "s"(cem1_r), [span] "s"(span), [wlo] "s"(wlo), [abase] "v"(abase),
-          [rtab] "s"(rtab), [pb] "n"(PB)
+          [rtab] "s"(rtab), [tsz] "s"(tsz), [pb] "n"(PB)
         : "vcc", "scc", "memory");
     w.lo = lo;
     w.hi = hi;
