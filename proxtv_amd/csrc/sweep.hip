@@ -325,6 +325,18 @@ __global__ __launch_bounds__(64 * NW, SHORT ? 16 / NW : ((WEIGHTED || H > 16 || 
     link_t *stash = reinterpret_cast<link_t *>(unproven + NW);
     constexpr link_t kNoCheck = 0xffffffffu;
     link_t began_reg = kNoCheck;
+    // the walk's reciprocal table (walk_asm.hpp: walk_interior_asm_tab), after the stash row: the strided short-zone tiles only
+    // (the pitch-65 tile has no LDS left for it at two workgroups per CU)
+#ifdef PTV_WALK_TABLE
+    constexpr bool TAB = !WEIGHTED && !TRANSPOSED && !SHORT && H <= kWarm && NW <= 8 && (ROUNDS || H + C + T < kRecipTable);
+#else
+    constexpr bool TAB = false;
+#endif
+    constexpr int TS = ROUNDS ? kRecipTableRobust : kRecipTable;
+    double *rtab = reinterpret_cast<double *>(stash + 64);
+    if constexpr (TAB) {
+        if (threadIdx.x < TS) rtab[threadIdx.x] = threadIdx.x ? 1.0 / (double)threadIdx.x : 0.0;   // (visible after the staging barrier)
+    }
 
     if (p.gate && *p.gate == 0) return;   // uniform over the grid
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -455,7 +467,7 @@ __global__ __launch_bounds__(64 * NW, SHORT ? 16 / NW : ((WEIGHTED || H > 16 || 
             } else {
                 walker_start<WEIGHTED>(w, win, start, p.lam);
             }
-            walk_chunk<OP, WEIGHTED, PITCH, ROUNDS>(w, rec, win, far, hi, cs, ce, len, p.lam);
+            walk_chunk<OP, WEIGHTED, PITCH, ROUNDS, TAB>(w, rec, win, far, hi, cs, ce, len, p.lam, (unsigned)(unsigned long long)rtab);
         }
         // ---- prove the links between consecutive chunks ------------------------------------------------------------------
         codes[wave * 64 + lane] = rec.next;
@@ -488,7 +500,7 @@ __global__ __launch_bounds__(64 * NW, SHORT ? 16 / NW : ((WEIGHTED || H > 16 || 
                     walker_restart_with<WEIGHTED>(w, at, (int)(prev & 1u), len, p.lam, win.y(at), WEIGHTED ? win.r(at - 1) : 0.0,
                                                   (WEIGHTED && at < len - 1) ? win.r(at) : 0.0);
                     again.mine = again.next = again.last = prev;
-                    walk_chunk<OP, WEIGHTED, PITCH, ROUNDS>(w, again, win, far, hi, cs, ce, len, p.lam);
+                    walk_chunk<OP, WEIGHTED, PITCH, ROUNDS, TAB>(w, again, win, far, hi, cs, ce, len, p.lam, (unsigned)(unsigned long long)rtab);
                     if (!again.failed) {
                         rec = again;
                         certain = false;   // from now on the chunk hangs on its predecessor like any other
@@ -550,7 +562,8 @@ __global__ __launch_bounds__(64 * NW, SHORT ? 16 / NW : ((WEIGHTED || H > 16 || 
                 }
         }
         if (has_chunk && !(plan.ablate & 1))
-            rebuild_owned<Op<OP>, WEIGHTED, C, PTV_TILE_UNROLL>(win, rec, cs, ce, len, start, !bad, wlo, wave == NW - 1 || ce == len, p.lam);
+            rebuild_owned<Op<OP>, WEIGHTED, C, PTV_TILE_UNROLL, TAB, lds_double *, (ROUNDS ? TS : 0)>(win, rec, cs, ce, len, start, !bad, wlo,
+                                                                                                    wave == NW - 1 || ce == len, p.lam, (lds_double *)rtab);
         __syncthreads();
         if (kb == 0) trace_mark(plan, 4);
 
@@ -1609,7 +1622,12 @@ void launch_chunk_h(const SweepArgs &args, const FibreGeom &g, hipStream_t strea
     const int WQ = (plan.Q + plan.qpw - 1) / plan.qpw;
     plan.dirty = chunk_state().next_dirty(stream);
     plan.xlink = chunk_state().xlink_for((size_t)WQ * (size_t)g.count, stream);
-    constexpr size_t lds = sizeof(double) * PITCH * (size_t)ROWS * (WEIGHTED ? 2 : 1) + sizeof(link_t) * ((NW + (TRANSPOSED ? 2 : 3)) * 64 + 4 + 2 * NW);
+#ifdef PTV_WALK_TABLE
+    constexpr size_t tab_bytes = (!WEIGHTED && !TRANSPOSED && !SHORT && H <= kWarm && NW <= 8) ? sizeof(double) * (ROBUST ? kRecipTableRobust : kRecipTable) : 0;
+#else
+    constexpr size_t tab_bytes = 0;
+#endif
+    constexpr size_t lds = sizeof(double) * PITCH * (size_t)ROWS * (WEIGHTED ? 2 : 1) + sizeof(link_t) * ((NW + (TRANSPOSED ? 2 : 3)) * 64 + 4 + 2 * NW) + tab_bytes;
     static_assert(WEIGHTED || H > kWarm || NW > 8 || 2 * lds <= 160 * 1024, "the short-zone geometry is meant to run two workgroups per CU");
     if (SHORT && g.len > NW * C) {
         set_error("launch_chunk_h: a fibre of %d samples does not fit the single-block geometry (%d)", g.len, NW * C);
