@@ -269,6 +269,7 @@ __device__ __forceinline__ void walk_chunk(Walker &w, ChunkRec &rec, const LdsWi
                                            int hi, int cs, int ce, int len, double lam, unsigned rtab = 0u) {
 #ifndef PTV_NO_ASM_WALK
     if constexpr (!WEIGHTED && TAB) walk_interior_asm_tab<PITCH, PAST>(w, rec, win, min(len - 1, hi), cs, ce, lam, rtab);   // (spans bounded: see walk_asm.hpp)
+    else if constexpr (WEIGHTED && TAB) walk_interior_asm_w_tab<PITCH, PAST>(w, rec, win, min(len - 1, hi), cs, ce, rtab);
     else if constexpr (!WEIGHTED) walk_interior_asm<PITCH>(w, rec, win, min(len - 1, hi), cs, ce, lam);
     else                     walk_interior_asm_w<PITCH>(w, rec, win, min(len - 1, hi), cs, ce);
 #else
@@ -328,7 +329,7 @@ __global__ __launch_bounds__(64 * NW, SHORT ? 16 / NW : ((WEIGHTED || H > 16 || 
     // the walk's reciprocal table (walk_asm.hpp: walk_interior_asm_tab), after the stash row: the strided short-zone tiles only
     // (the pitch-65 tile has no LDS left for it at two workgroups per CU)
 #ifdef PTV_WALK_TABLE
-    constexpr bool TAB = !WEIGHTED && !TRANSPOSED && !SHORT && H <= kWarm && NW <= 8 && (ROUNDS || H + C + T < kRecipTable);
+    constexpr bool TAB = (WEIGHTED || !TRANSPOSED) && !SHORT && H <= kWarm && NW <= 8 && (ROUNDS || H + C + T < kRecipTable);
 #else
     constexpr bool TAB = false;
 #endif
@@ -699,7 +700,7 @@ __global__ __launch_bounds__(64 * kAlongWaves) void sweep_along_kernel(SweepArgs
     unsigned *xwave = reinterpret_cast<unsigned *>(reinterpret_cast<double *>(smem) + (size_t)kAlongWaves * NG * (ROWS + 2) * (WEIGHTED ? 2 : 1));
     // plain instantiation: the pull-backs of the walk divide by table (walk_asm.hpp: walk_interior_asm_tab); one table per workgroup
 #ifdef PTV_WALK_TABLE
-    constexpr bool TAB = !WEIGHTED && H <= kWarm && (ROBUST || H + kAlongC + T < kRecipTable);
+    constexpr bool TAB = H <= kWarm && (ROBUST || H + kAlongC + T < kRecipTable);
 #else
     constexpr bool TAB = false;
 #endif
@@ -1623,7 +1624,7 @@ void launch_chunk_h(const SweepArgs &args, const FibreGeom &g, hipStream_t strea
     plan.dirty = chunk_state().next_dirty(stream);
     plan.xlink = chunk_state().xlink_for((size_t)WQ * (size_t)g.count, stream);
 #ifdef PTV_WALK_TABLE
-    constexpr size_t tab_bytes = (!WEIGHTED && !TRANSPOSED && !SHORT && H <= kWarm && NW <= 8) ? sizeof(double) * (ROBUST ? kRecipTableRobust : kRecipTable) : 0;
+    constexpr size_t tab_bytes = ((WEIGHTED || !TRANSPOSED) && !SHORT && H <= kWarm && NW <= 8) ? sizeof(double) * (ROBUST ? kRecipTableRobust : kRecipTable) : 0;
 #else
     constexpr size_t tab_bytes = 0;
 #endif
