@@ -252,3 +252,44 @@ def test_policy_one_sweep_solves_react_to_harder_data(harness):
     # and back: on the pinning rung with short pieces (data got easy again) the policy looks below within a call or two
     mode, last, trace = _simulate_pin(harness, hard_c, hard_f, cost2=easy_c, frac2=easy_f, switch_at=6, solves=10, sweeps=1)
     assert mode <= 1 and last <= 0.25, (mode, last)
+
+
+def test_both_forms_of_the_dr_iteration_on_the_host(harness, oracle):
+    """The arithmetic of the two forms of the DR iteration (proxtv_amd/csrc/ops.hpp: OP_DR_COL / OP_DR_ROW -- the reference's
+    split -- and OP_DR_COL_V / OP_DR_ROW_V -- the column sweep leaves v = U - s' and s, the row sweep returns t = s + prox(v)),
+    restated with numpy around the host build of the device walker: both must reproduce the reference's DR2_TV, and each
+    other to rounding, for any iteration count (weighted form included: same recurrence, src/TV2DWopt.cpp:114-126)."""
+    rng = np.random.default_rng(77)
+
+    def prox(A, lam, axis, W=None):
+        A = np.ascontiguousarray(np.moveaxis(A, axis, -1))
+        Wm = None if W is None else np.ascontiguousarray(np.moveaxis(W, axis, -1))
+        out = np.empty_like(A)
+        for j in range(A.shape[0]):
+            out[j] = walk(harness, A[j], lam, None if Wm is None else np.ascontiguousarray(Wm[j]))
+        return np.moveaxis(out, -1, axis)
+
+    def dr(U, l1, l2, its, form, W1=None, W2=None):
+        t = np.full(U.shape, 2 * (U.sum() / U.size))
+        for _ in range(its):
+            p = prox(t, l1, 0, W1)
+            s = t - p
+            sp = 2 * s - t
+            v = U - sp
+            x = prox(v, l2, 1, W2)
+            t = (s + x) if form else 0.5 * (t + (sp + 2 * x))
+        s = t - prox(t, l1, 0, W1)
+        v = U - s
+        return (U - (v - prox(v, l2, 1, W2))) - s
+
+    for (M, N), lam in (((37, 53), 0.3), ((64, 20), 1.5), ((9, 120), 0.05)):
+        U = np.asfortranarray(rng.standard_normal((M, N)) * 2)
+        for its in (1, 4, 35):
+            a, b = dr(U, lam, lam, its, 0), dr(U, lam, lam, its, 1)
+            ref = oracle.dr2(U, lam, max_iters=its)[0]
+            scale = np.max(np.abs(U))
+            assert np.max(np.abs(a - ref)) <= 1e-12 * scale and np.max(np.abs(b - ref)) <= 1e-12 * scale, (M, N, lam, its)
+        W1, W2 = rng.uniform(0, 2 * lam, (M - 1, N)), rng.uniform(0, 2 * lam, (M, N - 1))
+        ref = oracle.dr2w(U, W1, W2)[0]
+        for form in (0, 1):
+            assert np.max(np.abs(dr(U, 0.0, 0.0, 35, form, W1, W2) - ref)) <= 1e-12 * np.max(np.abs(U)), (M, N, form)

@@ -131,6 +131,25 @@ int study_fibre(const double *y, int len, double lam, int C, int H, int look, in
     return done;
 }
 
+// The true walk's trip counter at every bend: out_at[k] = restart sample, out_trip[k] = trips walked when that bend was made
+// (the walk restarts there in closed form).  Returns the number of bends (at most cap are stored).
+int study_bends(const double *y, int len, double lam, int *out_at, long *out_trip, int cap) {
+    struct Log {
+        const double *yy;
+        int *at; long *trip; int cap, n = 0;
+        mutable long trips = 0;
+        double y(int i) const { return yy[i]; }
+        double r(int) const { return 0.0; }
+        void piece(int, int, double) {}
+        void bend(int a, int) { if (n < cap) { at[n] = a; trip[n] = trips; } n++; }
+        bool keep_going(int) const { trips++; return true; }
+    } log{y, out_at, out_trip, cap};
+    Walker w;
+    walker_start<false>(w, log, 0, lam);
+    walker_run<false>(w, log, len, lam);
+    return log.n;
+}
+
 // sequential walk of one fibre (to generate DR iterates without the oracle)
 void study_prox(const double *y, int n, double lam, double *x) {
     struct Src {

@@ -15,6 +15,7 @@ subprocess.run(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", so, os.pat
 lib = C.CDLL(so)
 lib.study_fibre.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int, C.c_void_p]
 lib.study_prox.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_void_p]
+lib.study_bends.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_int]
 
 
 def prox_along(A, lam, axis):
@@ -80,6 +81,33 @@ def report(name, W):
           f" | samples past the chunk end today: mean {over.mean():.1f}, wave max {over.max(axis=1).mean():.1f}")
 
 
+def pool_model(arrays, lam, seg=1088, overhead=2):
+    """A wave-wide pool instead of one chunk per lane: the stretches between consecutive bends known a priori are independent
+    problems (the string is pinned at both ends); 64 lanes draw them in fibre order, `overhead` trips per draw (closed-form
+    restart, bookkeeping).  Returns (trips per sample of the sequential walk, mean makespan of a 1088-sample segment)."""
+    import heapq
+    spans, seq = [], []
+    for a in arrays:
+        for f in np.ascontiguousarray(a):
+            n = f.size
+            at, tr = np.zeros(n, np.int32), np.zeros(n, np.int64)
+            nb = lib.study_bends(f.ctypes.data, n, lam, at.ctypes.data, tr.ctypes.data, n)
+            at, tr = at[:nb], tr[:nb]
+            known = np.flatnonzero(np.abs(np.diff(f)) > 4.0000001 * lam) + 1
+            keep = np.isin(at, known)
+            ca, ct = at[keep], tr[keep]
+            for s0 in range(seg, n - 2 * seg, seg):
+                m = (ca >= s0) & (ca < s0 + seg)
+                if m.sum() < 3: continue
+                cost = np.diff(ct[m])
+                lanes = [0] * 64
+                for c in cost:
+                    heapq.heappush(lanes, heapq.heappop(lanes) + int(c) + overhead)
+                spans.append(max(lanes))
+                seq.append(cost.sum() / (ca[m][-1] - ca[m][0]))
+    return float(np.mean(seq)), float(np.mean(spans))
+
+
 if __name__ == "__main__":
     lams = [float(v) for v in sys.argv[1:]] or [0.1, 0.3, 0.4, 0.5, 0.6, 0.7]
     rng = np.random.default_rng(5)
@@ -91,3 +119,7 @@ if __name__ == "__main__":
         for look in (8, 14):
             report(f"column inputs, look-back {look}", np.concatenate([study(a.T, lam, look=look) for a in cols]))
             report(f"row inputs,    look-back {look}", np.concatenate([study(a, lam, look=look) for a in rows]))
+        for oh in (2, 0):
+            seq, span = pool_model([a.T for a in cols], lam, overhead=oh)
+            print(f"  pool model, column inputs, {oh} trips per draw: sequential walk {seq:.2f} trips per sample; a wave-wide pool of the stretches"
+                  f" between a-priori bends finishes a 1088-sample segment in {span:.1f} trips = {span / 17:.2f} per sample")
