@@ -378,6 +378,34 @@ int host_whole_fibre(const double *y, double lam, int len, int reflect, double *
     return bad;
 }
 
+// One call of the interior walk of a chunk (chunkcore.hpp: walk_interior -- the specification of the assembly loops in
+// walk_asm.hpp) on a plain array standing for the LDS window: state in `wk` (lo, hi, hlo, hhi) / `wi` (i, k0, klo, khi) and
+// `rc` (ends, types, mine, next, last, done), in and out.  tests/test_walk_asm_emulated.py interprets the assembly text lane
+// by lane and compares.  w (may be null): per-edge penalties.
+void host_walk_interior(const double *y, const double *w, int n, int lo, int lim, int cs, int ce, double lam, double *wk, int *wi,
+                        unsigned *rc) {
+    HostWin win;
+    win.lo = lo;
+    win.hi = n;
+    win.yy.assign(y + lo, y + n);
+    win.yy.push_back(1e300);
+    win.yy.push_back(1e300);
+    if (w) {
+        win.ww.assign((size_t)(n - lo) + 2, 0.0);
+        for (int k = lo; k < n - 1; k++) win.ww[(size_t)(k - lo)] = w[k];
+    }
+    Walker wa;
+    wa.lo = wk[0]; wa.hi = wk[1]; wa.hlo = wk[2]; wa.hhi = wk[3];
+    wa.i = wi[0]; wa.k0 = wi[1]; wa.klo = wi[2]; wa.khi = wi[3];
+    ChunkRec rec;
+    rec.ends = rc[0]; rec.types = rc[1]; rec.mine = rc[2]; rec.next = rc[3]; rec.last = rc[4]; rec.done = rc[5] != 0;
+    if (w) walk_interior<true>(wa, rec, win, lim, cs, ce, lam);
+    else   walk_interior<false>(wa, rec, win, lim, cs, ce, lam);
+    wk[0] = wa.lo; wk[1] = wa.hi; wk[2] = wa.hlo; wk[3] = wa.hhi;
+    wi[0] = wa.i; wi[1] = wa.k0; wi[2] = wa.klo; wi[3] = wa.khi;
+    rc[0] = rec.ends; rc[1] = rec.types; rc[2] = rec.mine; rc[3] = rec.next; rc[4] = rec.last; rc[5] = rec.done ? 1u : 0u;
+}
+
 // full sequential walk, what sweep_seq_kernel does per lane
 int host_walk(const double *y, const double *w, double lam, double *x, int n) {
     if (n <= 0) return 0;

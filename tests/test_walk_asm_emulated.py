@@ -1,0 +1,304 @@
+"""The hand-written gfx950 assembly walks (proxtv_amd/csrc/walk_asm.hpp) interpreted on the CPU, lane by lane under an exec
+mask, against their specification -- the C++ walk_interior of chunkcore.hpp, run by tests/host_harness.cpp.
+
+The interpreter reads the assembly TEXT out of the header (the string literals of the `asm volatile` statement and its operand
+lists) and implements the two dozen instructions the loops use: 64 lanes, VGPRs as 64-element arrays, SGPR pairs as 64-bit masks,
+VALU writes and LDS reads masked by exec, comparisons writing zeros for inactive lanes.  It knows nothing about wait states or
+counters -- hazards are the GPU suite's business -- but every mask, operand order, register reuse and address computation of a
+loop is executed exactly as written.  Geometry: the along-fibre kernel's (64 consecutive chunks of one fibre, one LDS window)."""
+import ctypes as C
+import os
+import re
+import struct
+import subprocess
+import tempfile
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+HEADER = os.path.join(os.path.dirname(HERE), "proxtv_amd", "csrc", "walk_asm.hpp")
+MASK64 = (1 << 64) - 1
+
+
+@pytest.fixture(scope="module")
+def harness():
+    out = os.path.join(tempfile.mkdtemp(prefix="ptv_asm_"), "libhost.so")
+    flags = ["-DPTV_TABLE_RECIP"] if os.environ.get("PTV_EMULATE_TABLE") else []
+    subprocess.run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-pthread", *flags, "-o", out,
+                    os.path.join(HERE, "host_harness.cpp")], check=True)
+    lib = C.CDLL(out)
+    lib.host_walk_interior.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double,
+                                       C.c_void_p, C.c_void_p, C.c_void_p]
+    return lib
+
+
+def asm_lines(function):
+    """instructions of the asm statement inside `function` of walk_asm.hpp, and its operand names by class"""
+    src = open(HEADER).read()
+    k = src.index(function + "(")
+    a = src.index("asm volatile(", k)
+    body = src[a:src.index(");", src.index('"memory"', a))]
+    text, ops = body.split("\n        :", 1)
+    lines = []
+    for piece in re.findall(r'"((?:[^"\\]|\\.)*)"', text):
+        for ln in piece.split("\\n"):
+            ln = ln.strip()
+            if ln:
+                lines.append(ln)
+    return lines, re.findall(r'\[(\w+)\]\s*"([^"]+)"\((\w+)\)', ops)
+
+
+class Machine:
+    """64 lanes.  V: name -> list of 64 python numbers ; S: name -> int (64-bit mask, or a scalar value)."""
+
+    def __init__(self, lds):
+        self.lds = lds          # list of doubles, byte address = 8 * index
+        self.V, self.S = {}, {}
+        self.exec = MASK64
+        self.vcc = 0
+        self.trips = 0
+
+    def active(self):
+        return [l for l in range(64) if (self.exec >> l) & 1]
+
+    def src(self, tok, lane, as_float):
+        neg = tok.startswith("-")
+        if neg:
+            tok = tok[1:]
+        m = re.fullmatch(r"%\[(\w+)\]", tok)
+        if m:
+            n = m.group(1)
+            v = self.V[n][lane] if n in self.V else self.S[n]
+        else:
+            v = float(tok) if as_float else int(tok, 0)
+        return -v if neg else v
+
+    def mask(self, tok):
+        if tok == "exec":
+            return self.exec
+        if tok == "vcc":
+            return self.vcc
+        m = re.fullmatch(r"%\[(\w+)\]", tok)
+        return self.S[m.group(1)] if m else int(tok, 0)
+
+    def set_mask(self, tok, v):
+        v &= MASK64
+        if tok == "exec":
+            self.exec = v
+        elif tok == "vcc":
+            self.vcc = v
+        else:
+            self.S[re.fullmatch(r"%\[(\w+)\]", tok).group(1)] = v
+
+    def wv(self, tok, lane, v):
+        self.V[re.fullmatch(r"%\[(\w+)\]", tok).group(1)][lane] = v
+
+    def run(self, lines, imm):
+        labels = {ln[:-1]: k for k, ln in enumerate(lines) if ln.endswith(":")}
+        pc = 0
+        while pc < len(lines):
+            ln = lines[pc]
+            pc += 1
+            if ln.endswith(":"):
+                self.trips += 1
+                assert self.trips < 100000, "runaway loop"
+                continue
+            op, _, rest = ln.partition(" ")
+            for k, v in imm.items():
+                rest = rest.replace(f"%[{k}]", str(v))
+            a = [t.strip() for t in rest.split(",")] if rest else []
+            u32 = lambda x: int(x) & 0xffffffff
+            i32 = lambda x: ((int(x) & 0xffffffff) ^ 0x80000000) - 0x80000000
+            if op in ("s_waitcnt", "s_nop"):
+                continue
+            if op == "s_cbranch_execnz":
+                if self.exec:
+                    pc = labels[a[0]]
+                continue
+            if op == "s_mov_b64":
+                self.set_mask(a[0], self.mask(a[1]))
+            elif op == "s_and_b64":
+                self.set_mask(a[0], self.mask(a[1]) & self.mask(a[2]))
+            elif op == "s_or_b64":
+                self.set_mask(a[0], self.mask(a[1]) | self.mask(a[2]))
+            elif op == "s_andn2_b64":
+                self.set_mask(a[0], self.mask(a[1]) & ~self.mask(a[2]))
+            elif op == "ds_read_b64":
+                off = 0
+                addr = a[1]
+                if " offset:" in addr:
+                    addr, o = addr.split(" offset:")
+                    off = int(o)
+                for l in self.active():
+                    byte = u32(self.src(addr.strip(), l, False)) + off
+                    assert byte % 8 == 0 and 0 <= byte // 8 < len(self.lds), (ln, l, byte)
+                    self.wv(a[0], l, self.lds[byte // 8])
+            elif op.startswith("v_cmp_"):
+                _, _, rel, ty = op.split("_")[:4]
+                f = {"lt": lambda x, y: x < y, "gt": lambda x, y: x > y, "ge": lambda x, y: x >= y, "le": lambda x, y: x <= y}[rel]
+                conv = {"f64": float, "i32": i32, "u32": u32}[ty]
+                bits = 0
+                for l in self.active():
+                    if f(conv(self.src(a[1], l, ty == "f64")), conv(self.src(a[2], l, ty == "f64"))):
+                        bits |= 1 << l
+                self.set_mask(a[0], bits)
+            else:
+                for l in self.active():
+                    s = lambda k, fl=False: self.src(a[k], l, fl)
+                    if op == "v_add_f64":
+                        r = np.float64(s(1, True)) + np.float64(s(2, True))
+                    elif op == "v_mul_f64":
+                        r = np.float64(s(1, True)) * np.float64(s(2, True))
+                    elif op == "v_fma_f64":   # one rounding
+                        r = fma(s(1, True), s(2, True), s(3, True))
+                    elif op == "v_min_f64":
+                        r = min(s(1, True), s(2, True))
+                    elif op == "v_max_f64":
+                        r = max(s(1, True), s(2, True))
+                    elif op == "v_rcp_f64":
+                        r = 1.0 / s(1, True)
+                    elif op == "v_cvt_f64_i32":
+                        r = float(i32(s(1)))
+                    elif op in ("v_mov_b64", "v_mov_b32"):
+                        r = s(1, op == "v_mov_b64")
+                    elif op == "v_add_u32":
+                        r = u32(s(1) + s(2))
+                    elif op == "v_sub_u32":
+                        r = u32(s(1) - s(2))
+                    elif op == "v_subrev_u32":
+                        r = u32(s(2) - s(1))
+                    elif op == "v_mad_u32_u24":
+                        r = u32((u32(s(1)) & 0xffffff) * (u32(s(2)) & 0xffffff) + s(3))
+                    elif op == "v_lshl_add_u32":
+                        r = u32((u32(s(1)) << (s(2) & 31)) + s(3))
+                    elif op == "v_lshl_or_b32":
+                        r = u32((u32(s(1)) << (s(2) & 31)) | u32(s(3)))
+                    elif op == "v_lshlrev_b32_e64":
+                        r = u32(u32(s(2)) << (u32(s(1)) & 31))
+                    elif op == "v_or_b32":
+                        r = u32(s(1)) | u32(s(2))
+                    elif op == "v_cndmask_b32_e64":
+                        r = s(2) if (self.mask(a[3]) >> l) & 1 else s(1)
+                    else:
+                        raise NotImplementedError(ln)
+                    self.wv(a[0], l, float(r) if isinstance(r, (float, np.floating)) else r)
+
+
+def fma(a, b, c):
+    """a * b + c with one rounding (exact rational arithmetic on the operands)"""
+    from fractions import Fraction
+    return float(Fraction(a) * Fraction(b) + Fraction(c))
+
+
+C17, H, T = 17, 16, 8
+
+
+def segment_case(rng, lam, weighted):
+    """one 64-chunk segment of a fibre, the along-fibre kernel's window: rows [lo, hi) with lo = seg_s - H"""
+    n = H + 64 * C17 + T + 40
+    kind = int(rng.integers(0, 3))
+    y = rng.standard_normal(n) if kind == 0 else (np.repeat(rng.standard_normal(n // 5 + 1), 5)[:n] + 0.1 * rng.standard_normal(n)
+                                                  if kind == 1 else np.round(rng.standard_normal(n) * 2))
+    w = rng.uniform(0.2 * lam, 1.8 * lam, n - 1) if weighted else None
+    return np.ascontiguousarray(y), w
+
+
+def spec_and_emulated(harness, function, y, w, lam, tab_entries=0):
+    n = y.size
+    seg_s = H
+    lo, hi = seg_s - H, seg_s + 64 * C17 + T
+    lim = min(n - 1, hi)
+    lines, operands = asm_lines(function)
+    # ---- initial state of every lane: a free-end start H samples before its chunk (walker_start)
+    st = []
+    for l in range(64):
+        cs = seg_s + l * C17
+        start = cs - H
+        r0 = w[start] if w is not None else lam
+        st.append(dict(cs=cs, ce=cs + C17, lo=-r0 + y[start], hi=r0 + y[start], hlo=0.0, hhi=0.0, i=start, k0=start - 1, klo=start, khi=start))
+    # ---- specification
+    want = []
+    for s in st:
+        wk = np.array([s["lo"], s["hi"], s["hlo"], s["hhi"]])
+        wi = np.array([s["i"], s["k0"], s["klo"], s["khi"]], dtype=np.int32)
+        rc = np.zeros(6, dtype=np.uint32)
+        harness.host_walk_interior(y.ctypes.data, None if w is None else w.ctypes.data, n, lo, lim, s["cs"], s["ce"], lam,
+                                   wk.ctypes.data, wi.ctypes.data, rc.ctypes.data)
+        want.append((wk, wi, rc))
+    # ---- the machine: LDS = [sample plane | penalty plane | reciprocal table]
+    rows = hi - lo + 2
+    lds = [float(v) for v in y[lo:hi]] + [1e300, 1e300]
+    wdelta = 8 * rows
+    lds += ([float(v) for v in w[lo:hi]] + [0.0, 0.0]) if w is not None else []
+    rtab = 8 * len(lds)
+    lds += [0.0] + [1.0 / k for k in range(1, max(tab_entries, 1))]
+    m = Machine(lds)
+    wlo = lo
+    for name in ("lo", "hi", "hlo", "hhi"):
+        m.V[name] = [s[name] for s in st]
+    for name in ("i", "k0", "klo", "khi"):
+        m.V[name] = [s[name] - wlo for s in st]
+    m.V["ai"] = [8 * (s["i"] - wlo) for s in st]
+    m.V["awi"] = [8 * (s["i"] - wlo) + wdelta for s in st]
+    m.V["yi"] = [float(y[s["i"]]) for s in st]
+    m.V["r"] = [float(w[s["i"]]) if w is not None else 0.0 for s in st]
+    m.V["sp"] = [s["i"] - s["k0"] for s in st]
+    m.V["abase"] = [0] * 64
+    for name in ("ends", "types", "mine", "next", "last", "doneflag"):
+        m.V[name] = [0] * 64
+    for name, constraint, _ in operands:
+        if "v" in constraint and name not in m.V:
+            m.V[name] = [0] * 64                  # temporaries ("=&v")
+    # cs / ce differ from lane to lane here (one chunk per lane); the kernel passes them in SGPRs because there a wave shares
+    # them -- the interpreter resolves %[csr] etc. per lane through V
+    m.V["csr"] = [s["cs"] - wlo for s in st]
+    m.V["cer"] = [s["ce"] - wlo for s in st]
+    m.V["cem1r"] = [s["ce"] - 1 - wlo for s in st]
+    m.S.update(lam=lam, nlam=-lam, lam2=2 * lam, nlam2=2 * (-lam), pbs=8, limr=lim - wlo, span=C17, wlo=wlo, wd=wdelta, rtab=rtab,
+               tsz=tab_entries)
+    for name in ("msave", "mlive", "mcv", "mfv", "mb", "mth", "mtl", "mdone", "m1", "m2", "m3"):
+        m.S[name] = 0
+    for name, constraint, _ in operands:          # every operand of the statement is bound
+        assert name in m.V or name in m.S or constraint == "n", name
+    m.run(lines, {"pb": 8, "pb2": 16})
+    got = []
+    for l in range(64):
+        wk = np.array([m.V[k][l] for k in ("lo", "hi", "hlo", "hhi")])
+        wi = np.array([m.V[k][l] + wlo for k in ("i", "k0", "klo", "khi")], dtype=np.int64)
+        rc = np.array([m.V["ends"][l], m.V["types"][l], m.V["mine"][l], m.V["next"][l], m.V["last"][l], m.V["doneflag"][l]], dtype=np.uint64)
+        got.append((wk, wi, rc))
+    return want, got, m.trips
+
+
+def compare(want, got, exact):
+    for l, ((wk, wi, rc), (gk, gi, gc)) in enumerate(zip(want, got)):
+        assert list(wi) == list(gi), (l, wi, gi)
+        assert [int(v) for v in rc] == [int(v) for v in gc], (l, rc, gc)
+        if exact:
+            assert [struct.pack("d", v) for v in wk] == [struct.pack("d", float(v)) for v in gk], (l, wk, gk)
+        else:
+            assert np.allclose(wk, gk, rtol=1e-13, atol=1e-13), (l, wk, gk)
+
+
+@pytest.mark.parametrize("lam", [0.1, 0.4, 1.0])
+def test_unweighted_assembly_walk_follows_its_specification(harness, lam):
+    """(the device divides by v_rcp_f64 + Newton + residual, the specification by `/`: decisions and codes must agree exactly,
+    heights and slopes to rounding)"""
+    rng = np.random.default_rng(int(lam * 100))
+    total = 0
+    for _ in range(6):
+        y, _w = segment_case(rng, lam, False)
+        want, got, trips = spec_and_emulated(harness, "void walk_interior_asm", y, None, lam)
+        compare(want, got, exact=False)
+        total += trips
+    assert total > 100
+
+
+@pytest.mark.parametrize("lam", [0.1, 0.5])
+def test_weighted_assembly_walk_follows_its_specification(harness, lam):
+    rng = np.random.default_rng(7 + int(lam * 100))
+    for _ in range(4):
+        y, w = segment_case(rng, lam, True)
+        want, got, trips = spec_and_emulated(harness, "void walk_interior_asm_w", y, w, 0.0)
+        compare(want, got, exact=False)
