@@ -356,3 +356,42 @@ def test_table_walk_leaves_the_loop_where_the_table_ends(harness_table):
         harness_table.host_walk_interior(y.ctypes.data, None, n, lo, lim, cs, cs + C17, 3.0, k2.ctypes.data, i2.ctypes.data, c2.ctypes.data)
         assert list(i2) == list(wi) and [int(v) for v in c2] == [int(v) for v in rc], (l, i2, wi)
     assert stopped > 0
+
+def test_assembly_walk_in_the_tile_geometry(harness):
+    """The 64-fibre tile: lane l walks ITS fibre's column of a window of pitch 64 (row r of lane l at byte 8 (64 r + l)), every
+    lane the same chunk -- the addressing the strided sweeps use (`abase` differs per lane, the row pitch is 512 bytes)."""
+    rng = np.random.default_rng(21)
+    lam, Hh, Cc, NWw, Tt = 0.3, 16, 16, 8, 8
+    rows = Hh + NWw * Cc + Tt
+    n = rows + 30
+    Y = np.ascontiguousarray(rng.standard_normal((64, n)))            # one fibre per lane
+    lines, operands = asm_lines("void walk_interior_asm")
+    for wave in (0, 3, 7):                                              # which chunk of the block the wave owns
+        lo, hi = 0, rows
+        cs = Hh + wave * Cc
+        ce, start, lim = cs + Cc, cs - Hh, min(n - 1, rows)
+        want = []
+        for l in range(64):
+            y = np.ascontiguousarray(Y[l])
+            wk = np.array([-lam + y[start], lam + y[start], 0.0, 0.0])
+            wi = np.array([start, start - 1, start, start], dtype=np.int32)
+            rc = np.zeros(6, dtype=np.uint32)
+            harness.host_walk_interior(y.ctypes.data, None, n, lo, lim, cs, ce, lam, wk.ctypes.data, wi.ctypes.data, rc.ctypes.data)
+            want.append((wk, wi, rc))
+        lds = [float(Y[l, r]) if r < rows else 1e300 for r in range(rows + 2) for l in range(64)]
+        m = Machine(lds)
+        m.V.update(lo=[-lam + Y[l, start] for l in range(64)], hi=[lam + Y[l, start] for l in range(64)], hlo=[0.0] * 64, hhi=[0.0] * 64,
+                   i=[start] * 64, k0=[start - 1] * 64, klo=[start] * 64, khi=[start] * 64, ai=[8 * (64 * start + l) for l in range(64)],
+                   yi=[float(Y[l, start]) for l in range(64)], abase=[8 * l for l in range(64)])
+        for name in ("ends", "types", "mine", "next", "last", "doneflag"):
+            m.V[name] = [0] * 64
+        for name, constraint, _ in operands:
+            if "v" in constraint and name not in m.V:
+                m.V[name] = [0] * 64
+        m.S.update(lam=lam, nlam=-lam, lam2=2 * lam, nlam2=2 * (-lam), pbs=512, limr=lim, csr=cs, cer=ce, cem1r=ce - 1, span=Cc, wlo=0)
+        for name in ("msave", "mlive", "mcv", "mfv", "mb", "mth", "mtl", "mdone", "m1", "m2", "m3"):
+            m.S[name] = 0
+        m.run(lines, {"pb": 512})
+        got = [(np.array([m.V[k][l] for k in ("lo", "hi", "hlo", "hhi")]), np.array([m.V[k][l] for k in ("i", "k0", "klo", "khi")]),
+                np.array([m.V[k][l] for k in ("ends", "types", "mine", "next", "last", "doneflag")], dtype=np.uint64)) for l in range(64)]
+        compare(want, got, exact=False)
