@@ -155,3 +155,18 @@ def test_force_float_helpers():
     assert ptv.force_float_matrix(a) is a                          # float64 passes through as the same object (Q3)
     assert ptv.force_float_matrix([1, 2]).dtype == np.float64
     assert ptv.force_float_matrix(np.arange(3)).dtype == np.float64
+
+
+def test_every_documented_knob_is_accepted():
+    """The keys listed in include/proxtv_amd.h's knob comment are the ones proxtv_set_option knows (options are plain host state:
+    no device needed) -- a knob that is documented but misspelt in the dispatch, or the other way round, shows here."""
+    from proxtv_amd import _lib
+    lib = _lib.load()
+    text = open(os.path.join(ROOT, "include", "proxtv_amd.h")).read()
+    block = text[text.index("/* Knobs"):text.index("int proxtv_set_option")]
+    keys = sorted(set(re.findall(r'"([a-z_0-9]+)"', block)))
+    assert {"chunk", "chunk_mode", "deterministic", "dr_form", "xlink", "verbose", "profile", "host_register"} <= set(keys), keys
+    for k in keys:
+        before = lib.proxtv_set_option(k.encode(), 12345)
+        assert lib.proxtv_set_option(k.encode(), before) == 12345, f"knob {k!r} is documented but not known to proxtv_set_option"
+    assert lib.proxtv_set_option(b"no_such_knob", 1) == -1

@@ -204,7 +204,7 @@ def segment_case(rng, lam, weighted):
     return np.ascontiguousarray(y), w
 
 
-def spec_and_emulated(harness, function, y, w, lam, tab_entries=0):
+def spec_and_emulated(harness, function, y, w, lam, tab_entries=0, entry_exec=MASK64):
     n = y.size
     seg_s = H
     lo, hi = seg_s - H, seg_s + 64 * C17 + T
@@ -261,7 +261,9 @@ def spec_and_emulated(harness, function, y, w, lam, tab_entries=0):
         m.S[name] = 0
     for name, constraint, _ in operands:          # every operand of the statement is bound
         assert name in m.V or name in m.S or constraint == "n", name
+    m.exec = entry_exec
     m.run(lines, {"pb": 8, "pb2": 16})
+    assert m.exec == entry_exec                   # the statement restores the mask it was entered with
     got = []
     for l in range(64):
         wk = np.array([m.V[k][l] for k in ("lo", "hi", "hlo", "hhi")])
@@ -395,3 +397,18 @@ def test_assembly_walk_in_the_tile_geometry(harness):
         got = [(np.array([m.V[k][l] for k in ("lo", "hi", "hlo", "hhi")]), np.array([m.V[k][l] for k in ("i", "k0", "klo", "khi")]),
                 np.array([m.V[k][l] for k in ("ends", "types", "mine", "next", "last", "doneflag")], dtype=np.uint64)) for l in range(64)]
         compare(want, got, exact=False)
+
+
+def test_assembly_walk_entered_with_some_lanes_off(harness):
+    """A wave enters the loop with the lanes that have no chunk switched off (the kernels call it inside `if (has_chunk)`): those
+    lanes' registers must come out untouched, the others as before."""
+    rng = np.random.default_rng(33)
+    y, _w = segment_case(rng, 0.3, False)
+    entry = int(rng.integers(1, 1 << 62)) | 1
+    want, got, _ = spec_and_emulated(harness, "void walk_interior_asm", y, None, 0.3, entry_exec=entry)
+    on = [l for l in range(64) if (entry >> l) & 1]
+    compare([want[l] for l in on], [got[l] for l in on], exact=False)
+    for l in range(64):
+        if not (entry >> l) & 1:
+            cs = H + l * C17
+            assert list(got[l][1]) == [cs - H, cs - H - 1, cs - H, cs - H] and not any(int(v) for v in got[l][2]), l
