@@ -170,7 +170,7 @@ void proxtv_release_scratch(void);
      "host_register"  1: page-lock large caller arrays around the transfers of the host-pointer entry points (default 0: no gain measured)
      "verbose"        1: log every decision of the geometry policy to stderr
      "profile"        1: hipEvent pair around every sweep launch (proxtv_last_kernel_ms / _launches)
-     "why", "trace", "ablate", "blocks_per_wg", "seed_noisy_e4", "seed_mid_e4", "warmup"   tuning / profiling aids (tools/) */
+     "why", "trace", "ablate", "blocks_per_wg", "seed_noisy_e4", "seed_mid_e4", "seed_row_along_e4", "warmup"   tuning / profiling aids (tools/) */
 int proxtv_set_option(const char *key, int value);
 
 /* Device-pointer solvers: every double* is an HBM pointer valid on the current device, `stream` is

@@ -512,6 +512,7 @@ int proxtv_set_option(const char *key, int value) {
     else if (!strcmp(key, "why")) slot = &o.why;
     else if (!strcmp(key, "seed_noisy_e4")) slot = &o.seed_noisy_e4;
     else if (!strcmp(key, "seed_mid_e4")) slot = &o.seed_mid_e4;
+    else if (!strcmp(key, "seed_row_along_e4")) slot = &o.seed_row_along_e4;
     if (!slot) return -1;
     const int old = *slot;
     *slot = value;

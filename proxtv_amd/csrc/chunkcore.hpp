@@ -214,9 +214,24 @@ struct NoFar {
 // Rows are replaced by F::fuse(y, v): the prox value itself, or directly the sweep's output when it depends on (y, x) only.
 // UNROLL: how many rows of the two passes are in flight together (1 where registers are scarce: the 64-fibre tile at two
 // workgroups per CU; more where the LDS latency of a row would otherwise be paid row by row).
-template <class F, bool WEIGHTED, int C, int UNROLL = 1, class Win>
+// TAB / rt: piece lengths are bounded by the window (plain geometries: zone + chunk + look-ahead rows), so the division by the
+// length is one product with rt[length] = the correctly rounded 1.0 / length (see walk_asm.hpp: walk_interior_asm_tab).
+// TSZ > 0: the table has TSZ entries and longer pieces are possible (robust instantiations): those divide.
+template <class F, bool WEIGHTED, int C, int UNROLL = 1, bool TAB = false, class RT = const double *, int TSZ = 0, class Win>
 __device__ __forceinline__ void rebuild_owned(Win &win, const ChunkRec &rec, int cs, int ce, int len, int start, bool link_ok,
-                                              int wlo, bool block_last, double lam) {
+                                              int wlo, bool block_last, double lam, RT rt = RT()) {
+    auto quotient = [&](double num, double count) {
+        if constexpr (TAB) {
+            if (TSZ > 0 && count >= (double)TSZ) {
+                const SpanDiv over(count);
+                return over(num);
+            }
+            return num * rt[(int)count];
+        } else {
+            const SpanDiv over(count);
+            return over(num);
+        }
+    };
     // An unproven lane keeps to its own rows -- but if its own walk bent exactly at the chunk start, the piece that
     // begins there must still come out right: a repair walk that arrives at that very bend hands over to this chunk.
     int a0 = cs;
@@ -242,10 +257,7 @@ __device__ __forceinline__ void rebuild_owned(Win &win, const ChunkRec &rec, int
         const double r = WEIGHTED ? ((cs + u < len - 1) ? win.r(cs + u) : 0.0) : lam;
         const double hk = (cs + u == len - 1) ? 0.0 : (((rec.types >> u) & 1u) ? r : -r);
         double v = 0.0;
-        if (divide) {
-            const SpanDiv over(cnt_);
-            v = over(s_ + (hk - hprev_));
-        }
+        if (divide) v = quotient(s_ + (hk - hprev_), cnt_);
         s_ = e ? 0.0 : s_;
         cnt_ = e ? 0.0 : cnt_;
         hprev_ = e ? hk : hprev_;
@@ -264,8 +276,7 @@ __device__ __forceinline__ void rebuild_owned(Win &win, const ChunkRec &rec, int
             }
             const double r = WEIGHTED ? win.r(brk) : lam;
             const double hk = (rec.last & 1u) ? r : -r;
-            const SpanDiv over(cnt_);
-            cur_ = over(s_ + (hk - hprev_));
+            cur_ = quotient(s_ + (hk - hprev_), cnt_);
         }
         return true;
     };

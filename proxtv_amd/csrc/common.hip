@@ -35,6 +35,7 @@ Options &options() {
         if (const char *e = getenv("PROXTV_XLINK")) v.xlink = atoi(e);
         if (const char *e = getenv("PROXTV_SEED_NOISY_E4")) v.seed_noisy_e4 = atoi(e);
         if (const char *e = getenv("PROXTV_SEED_MID_E4")) v.seed_mid_e4 = atoi(e);
+        if (const char *e = getenv("PROXTV_SEED_ROW_ALONG_E4")) v.seed_row_along_e4 = atoi(e);
         return v;
     }();
     return o;

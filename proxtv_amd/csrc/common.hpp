@@ -47,6 +47,7 @@ struct Options {
     int along_min_len = 160;  // ... for fibres at least this long (16, 32 or 64 lanes share a fibre segment of 17-sample chunks)
     int row_along = 1;        // strided sweeps through transposed copies + the along-fibre kernel: bit 0 = rung 2 (64-sample zones),
                               // bit 1 = rung 1 as well (0 = the 64-fibre tile for both)
+    int seed_row_along_e4 = 0;   // tuning aid: kSeedRowAlong (policy.hpp) in units of 1e-4 ; 0 = built in
     int seed_noisy_e4 = 0, seed_mid_e4 = 0;   // tuning aid: the policy seed's thresholds (policy.hpp) in units of 1e-4 ; 0 = built in
     int pin = 1;              // geometry rung 3: the pinning solver (pin.hip) where it applies; 0 = global-memory chunks
     int whole = 1;            // fibres of 16 .. chunk_min_len samples: 1 = by length and data (sequential up to 32 samples; one block of the

@@ -264,11 +264,13 @@ constexpr int kOverflow = 48;   // samples a walk of the robust instantiation ma
 
 // One chunk's walk from a given walker state: the branch-free interior loop (chunkcore.hpp), then walker_run for what
 // is left -- the fibre's last sample, the window's end (PAST: up to kOverflow samples beyond it from global memory).
-template <int OP, bool WEIGHTED, int PITCH, bool PAST>
+template <int OP, bool WEIGHTED, int PITCH, bool PAST, bool TAB = false>
 __device__ __forceinline__ void walk_chunk(Walker &w, ChunkRec &rec, const LdsWin<WEIGHTED, PITCH> &win, const FarFibre<OP> &far,
-                                           int hi, int cs, int ce, int len, double lam) {
+                                           int hi, int cs, int ce, int len, double lam, unsigned rtab = 0u) {
 #ifndef PTV_NO_ASM_WALK
-    if constexpr (!WEIGHTED) walk_interior_asm<PITCH>(w, rec, win, min(len - 1, hi), cs, ce, lam);
+    if constexpr (!WEIGHTED && TAB) walk_interior_asm_tab<PITCH, PAST>(w, rec, win, min(len - 1, hi), cs, ce, lam, rtab);   // (spans bounded: see walk_asm.hpp)
+    else if constexpr (WEIGHTED && TAB) walk_interior_asm_w_tab<PITCH, PAST>(w, rec, win, min(len - 1, hi), cs, ce, rtab);
+    else if constexpr (!WEIGHTED) walk_interior_asm<PITCH>(w, rec, win, min(len - 1, hi), cs, ce, lam);
     else                     walk_interior_asm_w<PITCH>(w, rec, win, min(len - 1, hi), cs, ce);
 #else
     walk_interior<WEIGHTED>(w, rec, win, min(len - 1, hi), cs, ce, lam);
@@ -324,6 +326,18 @@ __global__ __launch_bounds__(64 * NW, SHORT ? 16 / NW : ((WEIGHTED || H > 16 || 
     link_t *stash = reinterpret_cast<link_t *>(unproven + NW);
     constexpr link_t kNoCheck = 0xffffffffu;
     link_t began_reg = kNoCheck;
+    // the walk's reciprocal table (walk_asm.hpp: walk_interior_asm_tab), after the stash row: the strided short-zone tiles only
+    // (the pitch-65 tile has no LDS left for it at two workgroups per CU)
+#ifdef PTV_WALK_TABLE
+    constexpr bool TAB = (WEIGHTED || !TRANSPOSED) && !SHORT && H <= kWarm && NW <= 8 && (ROUNDS || H + C + T < kRecipTable);
+#else
+    constexpr bool TAB = false;
+#endif
+    constexpr int TS = ROUNDS ? kRecipTableRobust : kRecipTable;
+    double *rtab = reinterpret_cast<double *>(stash + 64);
+    if constexpr (TAB) {
+        if (threadIdx.x < TS) rtab[threadIdx.x] = threadIdx.x ? 1.0 / (double)threadIdx.x : 0.0;   // (visible after the staging barrier)
+    }
 
     if (p.gate && *p.gate == 0) return;   // uniform over the grid
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -454,7 +468,7 @@ __global__ __launch_bounds__(64 * NW, SHORT ? 16 / NW : ((WEIGHTED || H > 16 || 
             } else {
                 walker_start<WEIGHTED>(w, win, start, p.lam);
             }
-            walk_chunk<OP, WEIGHTED, PITCH, ROUNDS>(w, rec, win, far, hi, cs, ce, len, p.lam);
+            walk_chunk<OP, WEIGHTED, PITCH, ROUNDS, TAB>(w, rec, win, far, hi, cs, ce, len, p.lam, (unsigned)(unsigned long long)rtab);
         }
         // ---- prove the links between consecutive chunks ------------------------------------------------------------------
         codes[wave * 64 + lane] = rec.next;
@@ -487,7 +501,7 @@ __global__ __launch_bounds__(64 * NW, SHORT ? 16 / NW : ((WEIGHTED || H > 16 || 
                     walker_restart_with<WEIGHTED>(w, at, (int)(prev & 1u), len, p.lam, win.y(at), WEIGHTED ? win.r(at - 1) : 0.0,
                                                   (WEIGHTED && at < len - 1) ? win.r(at) : 0.0);
                     again.mine = again.next = again.last = prev;
-                    walk_chunk<OP, WEIGHTED, PITCH, ROUNDS>(w, again, win, far, hi, cs, ce, len, p.lam);
+                    walk_chunk<OP, WEIGHTED, PITCH, ROUNDS, TAB>(w, again, win, far, hi, cs, ce, len, p.lam, (unsigned)(unsigned long long)rtab);
                     if (!again.failed) {
                         rec = again;
                         certain = false;   // from now on the chunk hangs on its predecessor like any other
@@ -549,7 +563,8 @@ __global__ __launch_bounds__(64 * NW, SHORT ? 16 / NW : ((WEIGHTED || H > 16 || 
                 }
         }
         if (has_chunk && !(plan.ablate & 1))
-            rebuild_owned<Op<OP>, WEIGHTED, C, PTV_TILE_UNROLL>(win, rec, cs, ce, len, start, !bad, wlo, wave == NW - 1 || ce == len, p.lam);
+            rebuild_owned<Op<OP>, WEIGHTED, C, PTV_TILE_UNROLL, TAB, lds_double *, (ROUNDS ? TS : 0)>(win, rec, cs, ce, len, start, !bad, wlo,
+                                                                                                    wave == NW - 1 || ce == len, p.lam, (lds_double *)rtab);
         __syncthreads();
         if (kb == 0) trace_mark(plan, 4);
 
@@ -631,6 +646,16 @@ __global__ __launch_bounds__(64 * NW, SHORT ? 16 / NW : ((WEIGHTED || H > 16 || 
 // of a read hit 32 different bank pairs -- the floor for 8-byte accesses -- without any padding (with 16 they would
 // hit two).
 constexpr int kAlongC = 17;
+// The robust instantiation (rungs 1 / 2: pieces of a few samples) takes chunks of 31 samples where one LDS plane suffices:
+// the zone is walked once per 31 samples instead of once per 17, and -- what matters more -- a wave's walk lasts as long as
+// its slowest lane's, and the spread between lanes shrinks with the chunk: on the inputs of DR sweeps a wave walks
+// 2.70 -> 2.03 trips per sample at lambda = 0.5 and 4.24 -> 3.03 at 0.7 (host model: tools/study/links_study.py).  The
+// price is LDS: 16.9 KB per wave instead of 9.7, eight waves per CU instead of sixteen.  (31 is odd, see above, and a
+// chunk's piece ends fit the 32-bit masks of ChunkRec.)
+#ifndef PTV_ALONG_ROBUST_C
+#define PTV_ALONG_ROBUST_C 31
+#endif
+constexpr int along_chunk(bool robust, bool weighted) { return robust && !weighted ? PTV_ALONG_ROBUST_C : kAlongC; }
 #ifndef PTV_ALONG_WAVES
 #define PTV_ALONG_WAVES 4
 #endif
@@ -662,7 +687,7 @@ constexpr int along_zone_rows(int H, bool robust) { return robust && H < 64 ? 64
 template <int OP, bool WEIGHTED, int H, int G, bool ROBUST>
 __global__ __launch_bounds__(64 * kAlongWaves) void sweep_along_kernel(SweepArgs p, FibreGeom g, ChunkPlan plan, link_t *code_mine,
                                                                         link_t *code_next, int *failflags) {
-    constexpr int C = kAlongC, SEG = G * C, T = along_tail_rows(H, ROBUST), HZ = along_zone_rows(H, ROBUST), ROWS = HZ + SEG + T, NG = 64 / G;
+    constexpr int C = along_chunk(ROBUST, WEIGHTED), SEG = G * C, T = along_tail_rows(H, ROBUST), HZ = along_zone_rows(H, ROBUST), ROWS = HZ + SEG + T, NG = 64 / G;
     constexpr int NU = (ROWS + G - 1) / G;   // staged elements per lane
     constexpr int UL = 9;                    // epilogue operand fetches in flight per lane (C = 17 rows per lane: 9 + 8)
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -673,6 +698,19 @@ __global__ __launch_bounds__(64 * kAlongWaves) void sweep_along_kernel(SweepArgs
     double *Wp = Yp + (WEIGHTED ? ROWS + 2 : 0);   // per-edge penalties, same rows (weighted sweeps)
     // ROBUST: what a wave's last lane ends up with, for the first lane of the next wave: [kAlongWaves] codes, [kAlongWaves] "ready"
     unsigned *xwave = reinterpret_cast<unsigned *>(reinterpret_cast<double *>(smem) + (size_t)kAlongWaves * NG * (ROWS + 2) * (WEIGHTED ? 2 : 1));
+    // plain instantiation: the pull-backs of the walk divide by table (walk_asm.hpp: walk_interior_asm_tab); one table per workgroup
+#ifdef PTV_WALK_TABLE
+    constexpr bool TAB = H <= kWarm && (ROBUST || H + kAlongC + T < kRecipTable);
+#else
+    constexpr bool TAB = false;
+#endif
+    constexpr int TS = ROBUST ? kRecipTableRobust : kRecipTable;
+    double *rtab = reinterpret_cast<double *>(xwave + (ROBUST ? 16 : 0));
+    if constexpr (TAB) {
+        if (threadIdx.x < TS) rtab[threadIdx.x] = threadIdx.x ? 1.0 / (double)threadIdx.x : 0.0;
+        if (!ROBUST || G != 64) __syncthreads();   // (before anything else happens: every wave of the workgroup is here; the robust
+                                                   //  64-lane instantiation has its own barrier right below)
+    }
     if (ROBUST && G == 64) {
         if (lane == 0) xwave[kAlongWaves + wave] = 0u;
         __syncthreads();   // (the only workgroup barrier of the kernel: before anything else happens)
@@ -697,20 +735,26 @@ __global__ __launch_bounds__(64 * kAlongWaves) void sweep_along_kernel(SweepArgs
 
     // ---- stage: the segment as it lies in memory ---------------------------------------------------------------------------
     if (live && !(plan.ablate & 4)) {
-        double s0[NU], s1[NU], sw[WEIGHTED ? NU : 1];
+        // every load of a batch is issued before the first is waited for; NB rows per lane and batch (the 31-sample chunks stage
+        // 34 rows per lane: in one batch a two-operand op would hold 136 registers)
+        constexpr int NB = NU <= 20 ? NU : (NU + 1) / 2;
 #pragma unroll
-        for (int u = 0; u < NU; u++) {
-            const int r = lo + G * u + gl;
-            s0[u] = s1[u] = 0.0;
-            if (r >= 0 && r < hi) Op<OP>::fetch_in(p, fbase + r, s0[u], s1[u]);
-            if (WEIGHTED) sw[WEIGHTED ? u : 0] = (r >= 0 && r < hi && r < len - 1) ? p.w[wbase + r] : 0.0;
-        }
+        for (int b0 = 0; b0 < NU; b0 += NB) {
+            double s0[NB], s1[NB], sw[WEIGHTED ? NB : 1];
 #pragma unroll
-        for (int u = 0; u < NU; u++) {
-            const int r = lo + G * u + gl;
-            if (r >= 0 && r < hi) {
-                Yp[r - lo] = Op<OP>::y_of(p, s0[u], s1[u]);
-                if (WEIGHTED) Wp[r - lo] = sw[WEIGHTED ? u : 0];
+            for (int u = 0; u < NB; u++) {
+                const int r = lo + G * (b0 + u) + gl;
+                s0[u] = s1[u] = 0.0;
+                if (b0 + u < NU && r >= 0 && r < hi) Op<OP>::fetch_in(p, fbase + r, s0[u], s1[u]);
+                if (WEIGHTED) sw[WEIGHTED ? u : 0] = (b0 + u < NU && r >= 0 && r < hi && r < len - 1) ? p.w[wbase + r] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < NB; u++) {
+                const int r = lo + G * (b0 + u) + gl;
+                if (b0 + u < NU && r >= 0 && r < hi) {
+                    Yp[r - lo] = Op<OP>::y_of(p, s0[u], s1[u]);
+                    if (WEIGHTED) Wp[r - lo] = sw[WEIGHTED ? u : 0];
+                }
             }
         }
     }
@@ -741,7 +785,7 @@ __global__ __launch_bounds__(64 * kAlongWaves) void sweep_along_kernel(SweepArgs
         } else {
             walker_start<WEIGHTED>(w, win, start, p.lam);
         }
-        walk_chunk<OP, WEIGHTED, 1, ROBUST>(w, rec, win, far, hi, cs, ce, len, p.lam);
+        walk_chunk<OP, WEIGHTED, 1, ROBUST, TAB>(w, rec, win, far, hi, cs, ce, len, p.lam, (unsigned)(unsigned long long)rtab);
     }
     if (plan.trace && lane == 0) plan.trace[8 * (size_t)wid + 3] = wall_clock64();
 
@@ -763,7 +807,7 @@ __global__ __launch_bounds__(64 * kAlongWaves) void sweep_along_kernel(SweepArgs
         walker_restart_with<WEIGHTED>(w, at, (int)(from & 1u), len, p.lam, win.y(at), WEIGHTED ? win.r(at - 1) : 0.0,
                                       (WEIGHTED && at < len - 1) ? win.r(at) : 0.0);
         again.mine = again.next = again.last = from;
-        walk_chunk<OP, WEIGHTED, 1, ROBUST>(w, again, win, far, hi, cs, ce, len, p.lam);
+        walk_chunk<OP, WEIGHTED, 1, ROBUST, TAB>(w, again, win, far, hi, cs, ce, len, p.lam, (unsigned)(unsigned long long)rtab);
         if (!again.failed) {
             rec = again;
             certain = false;   // from now on the chunk hangs on its predecessor like any other
@@ -823,7 +867,8 @@ __global__ __launch_bounds__(64 * kAlongWaves) void sweep_along_kernel(SweepArgs
         if (below) wlo = seg_s + (63 - __clzll((long long)below)) * C;
     }
     if (has_chunk && !(plan.ablate & 1))
-        rebuild_owned<Op<OP>, WEIGHTED, C, PTV_ALONG_UNROLL>(win, rec, cs, ce, len, start, !bad, wlo, gl == G - 1 || ce == len, p.lam);
+        rebuild_owned<Op<OP>, WEIGHTED, C, PTV_ALONG_UNROLL, TAB, lds_double *, (ROBUST ? TS : 0)>(win, rec, cs, ce, len, start, !bad, wlo, gl == G - 1 || ce == len, p.lam,
+                                                                                (lds_double *)rtab);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     if (plan.trace && lane == 0) plan.trace[8 * (size_t)wid + 4] = wall_clock64();
@@ -1578,7 +1623,12 @@ void launch_chunk_h(const SweepArgs &args, const FibreGeom &g, hipStream_t strea
     const int WQ = (plan.Q + plan.qpw - 1) / plan.qpw;
     plan.dirty = chunk_state().next_dirty(stream);
     plan.xlink = chunk_state().xlink_for((size_t)WQ * (size_t)g.count, stream);
-    constexpr size_t lds = sizeof(double) * PITCH * (size_t)ROWS * (WEIGHTED ? 2 : 1) + sizeof(link_t) * ((NW + (TRANSPOSED ? 2 : 3)) * 64 + 4 + 2 * NW);
+#ifdef PTV_WALK_TABLE
+    constexpr size_t tab_bytes = ((WEIGHTED || !TRANSPOSED) && !SHORT && H <= kWarm && NW <= 8) ? sizeof(double) * (ROBUST ? kRecipTableRobust : kRecipTable) : 0;
+#else
+    constexpr size_t tab_bytes = 0;
+#endif
+    constexpr size_t lds = sizeof(double) * PITCH * (size_t)ROWS * (WEIGHTED ? 2 : 1) + sizeof(link_t) * ((NW + (TRANSPOSED ? 2 : 3)) * 64 + 4 + 2 * NW) + tab_bytes;
     static_assert(WEIGHTED || H > kWarm || NW > 8 || 2 * lds <= 160 * 1024, "the short-zone geometry is meant to run two workgroups per CU");
     if (SHORT && g.len > NW * C) {
         set_error("launch_chunk_h: a fibre of %d samples does not fit the single-block geometry (%d)", g.len, NW * C);
@@ -1624,7 +1674,7 @@ void launch_chunk_h(const SweepArgs &args, const FibreGeom &g, hipStream_t strea
 // the codes of 64 consecutive chunks of one fibre).
 template <int OP, bool WEIGHTED, int H, int G, bool ROBUST>
 void launch_along_g(const SweepArgs &args, const FibreGeom &g, hipStream_t stream, int fam, int rounds_wanted) {
-    constexpr int C = kAlongC, SEG = G * C, ROWS = along_zone_rows(H, ROBUST) + SEG + along_tail_rows(H, ROBUST), NG = 64 / G;
+    constexpr int C = along_chunk(ROBUST, WEIGHTED), SEG = G * C, ROWS = along_zone_rows(H, ROBUST) + SEG + along_tail_rows(H, ROBUST), NG = 64 / G;
     const int nseg = (g.len + SEG - 1) / SEG;
     const int NC = (g.len + C - 1) / C;
     const long units = g.count * nseg;
@@ -1636,7 +1686,7 @@ void launch_along_g(const SweepArgs &args, const FibreGeom &g, hipStream_t strea
     plan.trace = options().trace ? chunk_state().trace_buffer((size_t)waves) : nullptr;
     plan.dirty = chunk_state().next_dirty(stream);
     plan.xlink = chunk_state().xlink_for((size_t)g.count * (size_t)nseg, stream);
-    constexpr size_t lds = sizeof(double) * (size_t)(ROWS + 2) * NG * kAlongWaves * (WEIGHTED ? 2 : 1) + (ROBUST ? 64 : 0);
+    constexpr size_t lds = sizeof(double) * (size_t)(ROWS + 2) * NG * kAlongWaves * (WEIGHTED ? 2 : 1) + (ROBUST ? 64 + sizeof(double) * kRecipTableRobust : sizeof(double) * kRecipTable);
     static_assert(lds <= 160 * 1024, "along-fibre geometry does not fit the LDS of a CU");
     auto kern = sweep_along_kernel<OP, WEIGHTED, H, G, ROBUST>;
     if (lds > 64 * 1024) {   // above the default dynamic-LDS limit
@@ -1670,8 +1720,9 @@ void launch_along_g(const SweepArgs &args, const FibreGeom &g, hipStream_t strea
 // one when the fibre fits 32 or 16 chunks.
 template <int OP, bool WEIGHTED, int H, bool ROBUST>
 void launch_along(const SweepArgs &args, const FibreGeom &g, hipStream_t stream, int fam, int rounds) {
-    if (g.len <= 16 * kAlongC)      launch_along_g<OP, WEIGHTED, H, 16, ROBUST>(args, g, stream, fam, rounds);
-    else if (g.len <= 32 * kAlongC) launch_along_g<OP, WEIGHTED, H, 32, ROBUST>(args, g, stream, fam, rounds);
+    constexpr int C = along_chunk(ROBUST, WEIGHTED);
+    if (g.len <= 16 * C)      launch_along_g<OP, WEIGHTED, H, 16, ROBUST>(args, g, stream, fam, rounds);
+    else if (g.len <= 32 * C) launch_along_g<OP, WEIGHTED, H, 32, ROBUST>(args, g, stream, fam, rounds);
     else                            launch_along_g<OP, WEIGHTED, H, 64, ROBUST>(args, g, stream, fam, rounds);
 }
 
@@ -1697,6 +1748,9 @@ void launch_gchunk(const SweepArgs &args, const FibreGeom &g, int C, int H, hipS
 // contiguous; a tiled copy at HBM speed), the sweep runs as a dimension-0 sweep, and the outputs are transposed back.
 // Fibre numbering is unchanged: fibre j = slab * inc + off sits at j * len after the transposition of every
 // (inc x len) slab.
+// (tuning aid: option seed_row_along_e4 overrides policy.hpp's kSeedRowAlong)
+static inline double seed_row_along() { return options().seed_row_along_e4 > 0 ? options().seed_row_along_e4 * 1e-4 : kSeedRowAlong; }
+
 template <int OP, int H>
 void launch_row_along(const SweepArgs &args, const FibreGeom &g, hipStream_t stream, int fam, int rounds) {
     TransposedOperands tr(args, Op<OP>::IN_MASK, Op<OP>::OUT_MASK, g, stream);
@@ -1772,7 +1826,7 @@ void launch_chunk(const SweepArgs &args, const FibreGeom &g, hipStream_t stream,
         if constexpr (!WEIGHTED) launch_row_along<OP, kWarmLong>(args, g, stream, fam, rounds);
     }
     else if (!TRANSPOSED && !WEIGHTED && along_ok && mode == 1 &&
-             ((options().row_along & 2) || ((options().row_along & 1) && seed_f >= 0.0 && seed_f < kSeedRowAlong))) {
+             ((options().row_along & 2) || ((options().row_along & 1) && seed_f >= 0.0 && seed_f < seed_row_along()))) {
         // rung 1 near its upper end (pieces of ~4 samples): the 64-fibre tile leaves the links between its workgroups to the
         // repair kernel, and those start to fail; chunks along transposed copies settle nearly all links inside the kernel
         if constexpr (!WEIGHTED) launch_row_along<OP, kWarm>(args, g, stream, fam, rounds);
@@ -1902,7 +1956,7 @@ int strided_tile_rung(const FibreGeom &g, double lam, bool weighted, double *cer
     if (weighted || !(options().along && g.len >= options().along_min_len)) return 1;
     if (options().row_along & 2) return -1;
     const double f = st.certain_fraction(g, lam, weighted);
-    return ((options().row_along & 1) && f >= 0.0 && f < kSeedRowAlong) ? -1 : 1;
+    return ((options().row_along & 1) && f >= 0.0 && f < seed_row_along()) ? -1 : 1;
 }
 
 long chunk_stats_fixups(hipStream_t s) {

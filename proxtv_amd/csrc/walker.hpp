@@ -192,8 +192,13 @@ __device__ __forceinline__ bool walker_run(Walker &w, S &src, int n, double lam)
 struct SpanDiv {
     double s, inv;
 #ifdef PTV_HOST_TEST
+#ifdef PTV_TABLE_RECIP   // design study: the quotient as ONE product with the correctly rounded reciprocal (a table entry on the device)
+    explicit SpanDiv(double s_) : s(s_), inv(1.0 / s_) {}
+    double operator()(double a) const { return a * inv; }
+#else
     explicit SpanDiv(double s_) : s(s_), inv(0.0) {}
     double operator()(double a) const { return a / s; }
+#endif
 #else
     __device__ __forceinline__ explicit SpanDiv(double s_) : s(s_) {
         const double x = __builtin_amdgcn_rcp(s_);

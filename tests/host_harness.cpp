@@ -318,9 +318,14 @@ extern "C" {
 int host_chunk_fibre(const double *y, const double *w, double lam, int len, int H, int T, int NW, int past, int seed,
                      double *x, int *first_bad, int *write_errors) {
     const bool refl = seed & 1;   // both rebuild flavours: outputs that depend on the row's own sample, and that do not
-    if (!w && (NW == 64 || NW == 32 || NW == 16))   // the along-fibre kernel's geometries: 64 / 32 / 16 chunks of 17 samples per segment
+    if (!w && (NW == 64 || NW == 32 || NW == 16)) {   // the along-fibre kernel's geometries: 64 / 32 / 16 chunks per segment,
+        // of 17 samples, or of 31 in the robust instantiation (64 look-ahead rows)
+        if (T >= 64)
+            return refl ? chunk_fibre<false, false, Reflect, 31>(y, w, lam, len, H, T, NW, seed, x, first_bad, write_errors)
+                        : chunk_fibre<false, false, Identity, 31>(y, w, lam, len, H, T, NW, seed, x, first_bad, write_errors);
         return refl ? chunk_fibre<false, false, Reflect, 17>(y, w, lam, len, H, T, NW, seed, x, first_bad, write_errors)
                     : chunk_fibre<false, false, Identity, 17>(y, w, lam, len, H, T, NW, seed, x, first_bad, write_errors);
+    }
     if (w) {
         if (refl) return past ? chunk_fibre<true, true, Reflect>(y, w, lam, len, H, T, NW, seed, x, first_bad, write_errors)
                               : chunk_fibre<true, false, Reflect>(y, w, lam, len, H, T, NW, seed, x, first_bad, write_errors);

@@ -62,7 +62,8 @@ def test_chunked_walk_equals_oracle_unweighted(harness, oracle):
         y = families(rng, n)
         lam = float(rng.choice([0.0, 0.02, 0.1, 0.3, 1.0]) * abs(rng.standard_normal()))
         truth = oracle.tv1_linearized(y, lam)
-        for (H, T, NW, past) in ((16, 8, 8, 0), (16, 8, 8, 1), (64, 64, 8, 0), (16, 8, 3, 0), (16, 8, 64, 0), (64, 64, 64, 0), (16, 8, 32, 0), (64, 64, 16, 0)):
+        for (H, T, NW, past) in ((16, 8, 8, 0), (16, 8, 8, 1), (64, 64, 8, 0), (16, 8, 3, 0), (16, 8, 64, 0), (64, 64, 64, 0), (16, 8, 32, 0), (64, 64, 16, 0),
+                                    (16, 64, 64, 0), (16, 64, 32, 0)):   # (64 look-ahead rows: the robust along-fibre geometry, chunks of 31)
             x, fb, we = run(harness, y, lam, H=H, T=T, NW=NW, past=past, seed=t)
             covered += check(x, fb, we, truth, H, max(1.0, np.max(np.abs(y))))
             total += n

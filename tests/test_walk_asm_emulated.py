@@ -306,6 +306,59 @@ def test_weighted_assembly_walk_follows_its_specification(harness, lam):
         compare(want, got, exact=False)
 
 
+# ---- the staged table walks (walk_interior_asm_tab / _w_tab): against the specification built with -DPTV_TABLE_RECIP, whose
+# quotient is the same single product with the correctly rounded reciprocal -- so the bar is bit equality.
+@pytest.fixture(scope="module")
+def harness_table():
+    out = os.path.join(tempfile.mkdtemp(prefix="ptv_asmt_"), "libhost.so")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-pthread", "-DPTV_TABLE_RECIP", "-o", out,
+                    os.path.join(HERE, "host_harness.cpp")], check=True)
+    lib = C.CDLL(out)
+    lib.host_walk_interior.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double,
+                                       C.c_void_p, C.c_void_p, C.c_void_p]
+    return lib
+
+
+@pytest.mark.parametrize("lam", [0.1, 0.4, 1.0])
+def test_table_walk_follows_its_specification_bit_for_bit(harness_table, lam):
+    rng = np.random.default_rng(11 + int(lam * 100))
+    for _ in range(6):
+        y, _w = segment_case(rng, lam, False)
+        want, got, trips = spec_and_emulated(harness_table, "void walk_interior_asm_tab", y, None, lam, tab_entries=48)
+        compare(want, got, exact=True)
+
+
+@pytest.mark.parametrize("lam", [0.1, 0.5])
+def test_weighted_table_walk_follows_its_specification_bit_for_bit(harness_table, lam):
+    rng = np.random.default_rng(13 + int(lam * 100))
+    for _ in range(4):
+        y, w = segment_case(rng, lam, True)
+        want, got, trips = spec_and_emulated(harness_table, "void walk_interior_asm_w_tab", y, w, 0.0, tab_entries=48)
+        compare(want, got, exact=True)
+
+
+def test_table_walk_leaves_the_loop_where_the_table_ends(harness_table):
+    """Robust instantiations: a lane whose span reaches the table's end stops there (the slow tail takes over) -- with a short
+    table on long pieces every lane's state must still be a state of the specification's walk: continue the specification from
+    it and from the start, and arrive at the same place."""
+    rng = np.random.default_rng(5)
+    y, _w = segment_case(rng, 3.0, False)
+    want, got, trips = spec_and_emulated(harness_table, "void walk_interior_asm_tab", y, None, 3.0, tab_entries=12)
+    n = y.size
+    lo, hi = 0, H + 64 * C17 + T
+    lim = min(n - 1, hi)
+    stopped = 0
+    for l, ((wk, wi, rc), (gk, gi, gc)) in enumerate(zip(want, got)):
+        cs = H + l * C17
+        if list(wi) == list(gi):
+            continue
+        stopped += 1
+        assert gi[0] - gi[1] >= 12 or gc[5], (l, gi)          # it left the loop because of its span
+        k2, i2, c2 = np.array(gk, dtype=np.float64), np.array(gi, dtype=np.int32), np.array(gc, dtype=np.uint32)
+        harness_table.host_walk_interior(y.ctypes.data, None, n, lo, lim, cs, cs + C17, 3.0, k2.ctypes.data, i2.ctypes.data, c2.ctypes.data)
+        assert list(i2) == list(wi) and [int(v) for v in c2] == [int(v) for v in rc], (l, i2, wi)
+    assert stopped > 0
+
 def test_assembly_walk_in_the_tile_geometry(harness):
     """The 64-fibre tile: lane l walks ITS fibre's column of a window of pitch 64 (row r of lane l at byte 8 (64 r + l)), every
     lane the same chunk -- the addressing the strided sweeps use (`abase` differs per lane, the row pitch is 512 bytes)."""
