@@ -488,31 +488,7 @@ const char *proxtv_last_error(void) { return last_error(); }
 void proxtv_release_scratch(void) { release_scratch(); }
 
 int proxtv_set_option(const char *key, int value) {
-    Options &o = options();
-    int *slot = nullptr;
-    if (!strcmp(key, "chunk")) slot = &o.chunk;
-    else if (!strcmp(key, "warmup")) slot = &o.warmup;
-    else if (!strcmp(key, "verbose")) slot = &o.verbose;
-    else if (!strcmp(key, "profile")) slot = &o.profile;
-    else if (!strcmp(key, "ablate")) slot = &o.ablate;
-    else if (!strcmp(key, "blocks_per_wg")) slot = &o.blocks_per_wg;
-    else if (!strcmp(key, "trace")) slot = &o.trace;
-    else if (!strcmp(key, "along")) slot = &o.along;
-    else if (!strcmp(key, "whole")) slot = &o.whole;
-    else if (!strcmp(key, "row_along")) slot = &o.row_along;
-    else if (!strcmp(key, "pin")) slot = &o.pin;
-    else if (!strcmp(key, "along_min_len")) slot = &o.along_min_len;
-    else if (!strcmp(key, "chunk_min_len")) slot = &o.chunk_min_len;
-    else if (!strcmp(key, "rounds")) slot = &o.rounds;
-    else if (!strcmp(key, "chunk_mode")) slot = &o.chunk_mode;
-    else if (!strcmp(key, "deterministic")) slot = &o.deterministic;
-    else if (!strcmp(key, "host_register")) slot = &o.host_register;
-    else if (!strcmp(key, "dr_form")) slot = &o.dr_form;
-    else if (!strcmp(key, "xlink")) slot = &o.xlink;
-    else if (!strcmp(key, "why")) slot = &o.why;
-    else if (!strcmp(key, "seed_noisy_e4")) slot = &o.seed_noisy_e4;
-    else if (!strcmp(key, "seed_mid_e4")) slot = &o.seed_mid_e4;
-    else if (!strcmp(key, "seed_row_along_e4")) slot = &o.seed_row_along_e4;
+    int *slot = option_slot(key);   // (common.hip: the one table of knobs, shared with the PROXTV_<KEY> environment variables)
     if (!slot) return -1;
     const int old = *slot;
     *slot = value;

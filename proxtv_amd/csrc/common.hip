@@ -1,6 +1,9 @@
 // common.hip -- error capture, device selection, per-thread stream, HBM scratch pool, kernel-family timers.
 #include "common.hpp"
 
+#include <cctype>
+#include <cstring>
+
 namespace ptv {
 
 // ---- error capture ---------------------------------------------------------------------------------------------
@@ -14,28 +17,59 @@ void set_error(const char *fmt, ...) {
 }
 const char *last_error() { return g_err; }
 
+// One table for both ways of setting a knob: proxtv_set_option("key", v) and the environment variable PROXTV_KEY read at
+// load time (every knob has both: include/proxtv_amd.h).
+namespace {
+struct OptionEntry {
+    const char *key;
+    int Options::*field;
+};
+constexpr OptionEntry kOptionTable[] = {
+    {"chunk", &Options::chunk},
+    {"warmup", &Options::warmup},
+    {"chunk_mode", &Options::chunk_mode},
+    {"deterministic", &Options::deterministic},
+    {"blocks_per_wg", &Options::blocks_per_wg},
+    {"rounds", &Options::rounds},
+    {"along", &Options::along},
+    {"along_min_len", &Options::along_min_len},
+    {"row_along", &Options::row_along},
+    {"seed_row_along_e4", &Options::seed_row_along_e4},
+    {"seed_noisy_e4", &Options::seed_noisy_e4},
+    {"seed_mid_e4", &Options::seed_mid_e4},
+    {"pin", &Options::pin},
+    {"whole", &Options::whole},
+    {"chunk_min_len", &Options::chunk_min_len},
+    {"xlink", &Options::xlink},
+    {"dr_form", &Options::dr_form},
+    {"tile", &Options::tile},
+    {"host_register", &Options::host_register},
+    {"verbose", &Options::verbose},
+    {"profile", &Options::profile},
+    {"why", &Options::why},
+    {"trace", &Options::trace},
+    {"ablate", &Options::ablate},
+};
+}  // namespace
+
+int *option_slot(const char *key) {
+    if (!key) return nullptr;
+    Options &o = options();
+    for (const OptionEntry &e : kOptionTable)
+        if (!strcmp(key, e.key)) return &(o.*(e.field));
+    return nullptr;
+}
+
 Options &options() {
     static Options o = [] {
         Options v;
-        if (const char *e = getenv("PROXTV_CHUNK")) v.chunk = atoi(e);
-        if (const char *e = getenv("PROXTV_WARMUP")) v.warmup = atoi(e);
-        if (const char *e = getenv("PROXTV_VERBOSE")) v.verbose = atoi(e);
-        if (const char *e = getenv("PROXTV_ABLATE")) v.ablate = atoi(e);
-        if (const char *e = getenv("PROXTV_BLOCKS_PER_WG")) v.blocks_per_wg = atoi(e);
-        if (const char *e = getenv("PROXTV_CHUNK_MIN_LEN")) v.chunk_min_len = atoi(e);
-        if (const char *e = getenv("PROXTV_ROUNDS")) v.rounds = atoi(e);
-        if (const char *e = getenv("PROXTV_ALONG")) v.along = atoi(e);
-        if (const char *e = getenv("PROXTV_WHOLE")) v.whole = atoi(e);
-        if (const char *e = getenv("PROXTV_ROW_ALONG")) v.row_along = atoi(e);
-        if (const char *e = getenv("PROXTV_DR_FORM")) v.dr_form = atoi(e);
-        if (const char *e = getenv("PROXTV_PIN")) v.pin = atoi(e);
-        if (const char *e = getenv("PROXTV_ALONG_MIN_LEN")) v.along_min_len = atoi(e);
-        if (const char *e = getenv("PROXTV_CHUNK_MODE")) v.chunk_mode = atoi(e);
-        if (const char *e = getenv("PROXTV_DETERMINISTIC")) v.deterministic = atoi(e);
-        if (const char *e = getenv("PROXTV_XLINK")) v.xlink = atoi(e);
-        if (const char *e = getenv("PROXTV_SEED_NOISY_E4")) v.seed_noisy_e4 = atoi(e);
-        if (const char *e = getenv("PROXTV_SEED_MID_E4")) v.seed_mid_e4 = atoi(e);
-        if (const char *e = getenv("PROXTV_SEED_ROW_ALONG_E4")) v.seed_row_along_e4 = atoi(e);
+        for (const OptionEntry &e : kOptionTable) {
+            char name[64] = "PROXTV_";
+            size_t n = strlen(name);
+            for (const char *c = e.key; *c && n + 1 < sizeof(name); c++) name[n++] = (char)toupper((unsigned char)*c);
+            name[n] = 0;
+            if (const char *val = getenv(name)) v.*(e.field) = atoi(val);
+        }
         return v;
     }();
     return o;
@@ -85,6 +119,7 @@ static void probe_device(int dev) {
         warm_tv2();
     } catch (const HipFailure &) {
         (void)hipGetLastError();   // not fatal: the first launch will load (or report) what this could not
+        set_error("%s", "");        // ... and PTV_HIP recorded a message before it threw: a solve that then succeeds must not report it
     }
 }
 

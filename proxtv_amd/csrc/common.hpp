@@ -58,6 +58,8 @@ struct Options {
     int dr_form = 1;          // DR2 / DR2L1W: 1 = the column sweep leaves the row sweep's input and epilogue operand (OP_DR_COL_V / OP_DR_ROW_V)
                               // when the row sweep runs on the robust 64-fibre tile (rung 1); 2 = on rung 0 too; 0 = always the
                               // reference's split (OP_DR_COL / OP_DR_ROW)
+    int tile = 1;             // strided sweeps on rung 0 (unweighted and weighted): 1 = tiles of 32 fibres x 8 chunks in 4 waves (four
+                              // workgroups per CU), 0 = the 64-fibre x 8-wave tile (two)
     int host_register = 0;    // host-pointer entry points: page-lock large caller arrays around their transfers (see cabi.hip)
     int verbose = 0;
     int profile = 0;    // per-kernel-family hipEvent timing
@@ -66,6 +68,7 @@ struct Options {
     int ablate = 0;     // profiling aid, see ChunkPlan::ablate (results are WRONG when non-zero)
 };
 Options &options();
+int *option_slot(const char *key);   // null for an unknown key
 
 // ---- device / stream -------------------------------------------------------------------------------------------
 // Throws HipFailure (with last_error set) when the current device is not a usable gfx950.  All library state is kept per
@@ -111,6 +114,20 @@ struct FibreGeom {
     int len;     // samples per fibre
     long count;  // number of fibres
 };
+
+// q = a / b, r = a % b for non-negative a and positive b.  Fibre numbers and strides fit 32 bits in every array that fits
+// HBM's address space many times over, and a 64-bit division costs a GPU lane ~170 instructions against ~25: the narrow form
+// runs whenever both operands allow it (the wide one stays for exactness' sake).
+__host__ __device__ __forceinline__ void divmod_nonneg(long a, long b, long &q, long &r) {
+    if ((((unsigned long)a | (unsigned long)b) >> 32) == 0) {
+        const unsigned qa = (unsigned)a / (unsigned)b;
+        q = (long)qa;
+        r = (long)((unsigned)a - qa * (unsigned)b);
+    } else {
+        q = a / b;
+        r = a % b;
+    }
+}
 
 inline FibreGeom fibres_along(const int *ns, int nds, int d) {
     long n = 1, inc = 1;

@@ -57,6 +57,16 @@ struct NoKeep {
 
 template <int ID> struct Op;
 
+// Streams a sweep touches exactly once (U and the old t of a DR row sweep, the new t it writes) can be marked non-temporal
+// (-DPTV_NT_STREAMS: an experiment switch) so that the one array the row sweep reads twice, s', has the XCD's L2 to itself.
+#ifdef PTV_NT_STREAMS
+__device__ __forceinline__ double ld_once(const double *p) { return __builtin_nontemporal_load(p); }
+__device__ __forceinline__ void st_once(double *p, double v) { __builtin_nontemporal_store(v, p); }
+#else
+__device__ __forceinline__ double ld_once(const double *p) { return *p; }
+__device__ __forceinline__ void st_once(double *p, double v) { *p = v; }
+#endif
+
 // ---- one-operand inputs: y = a ---------------------------------------------------------------------------------------
 struct InA : NoKeep {
     static constexpr int NIN = 1;
@@ -67,7 +77,7 @@ struct InA : NoKeep {
 // ---- y = b - a  (DR rows: unary - s') ----------------------------------------------------------------------------------
 struct InBminusA : NoKeep {
     static constexpr int NIN = 2;
-    __device__ static __forceinline__ void fetch_in(const SweepArgs &p, long idx, double &i0, double &i1) { i0 = p.b[idx]; i1 = p.a[idx]; }
+    __device__ static __forceinline__ void fetch_in(const SweepArgs &p, long idx, double &i0, double &i1) { i0 = ld_once(p.b + idx); i1 = p.a[idx]; }
     __device__ static __forceinline__ double y_of(const SweepArgs &, double i0, double i1) { return i0 - i1; }
     __device__ static __forceinline__ double load_y(const SweepArgs &p, long idx) { return p.b[idx] - p.a[idx]; }
 };
@@ -146,11 +156,11 @@ template <> struct Op<OP_DR_ROW> : InBminusA, NotFused {
 #ifdef PTV_EXP_NOREFETCH   // experiment only (wrong results): what would the sweep cost without the second read of s'?
     __device__ static __forceinline__ Ext fetch(const SweepArgs &p, long idx) { return Ext{0.0, p.c[idx]}; }
 #else
-    __device__ static __forceinline__ Ext fetch(const SweepArgs &p, long idx) { return Ext{p.a[idx], p.c[idx]}; }
+    __device__ static __forceinline__ Ext fetch(const SweepArgs &p, long idx) { return Ext{p.a[idx], ld_once(p.c + idx)}; }
 #endif
     __device__ static __forceinline__ void finish(const SweepArgs &p, long idx, const Ext &e, double x) {
         const double tb = e.e0 + 2 * x;
-        p.o0[idx] = 0.5 * (e.e1 + tb);
+        st_once(p.o0 + idx, 0.5 * (e.e1 + tb));
     }
 };
 // The same iteration with the work split the other way round (round 3; dr2 in solvers.hip picks it when the row sweep runs

@@ -185,7 +185,8 @@ struct SeqSource {
 // walker's mispredictions cost more than its batching saves).
 template <int OP, bool WEIGHTED, bool PIPELINED>
 __device__ __forceinline__ void solve_fibre_seq(const SweepArgs &p, const FibreGeom &g, long j) {
-    const long blk = j / g.inc, off = j % g.inc;
+    long blk, off;
+    divmod_nonneg(j, g.inc, blk, off);
     SeqSource<OP, WEIGHTED> src{p, blk * g.inc * g.len + off, g.inc, blk * g.inc * (g.len - 1) + off, {}};
     if (WEIGHTED && g.len == 1) {  // no edge at all: prox is the identity (the reference reads lambda[0] out of bounds here)
         const double y0 = src.y(0);
@@ -294,26 +295,33 @@ __device__ __forceinline__ void walk_chunk(Walker &w, ChunkRec &rec, const LdsWi
 // the fibre itself -- no zone rows before it, no look-ahead rows after it are allocated (HA = TA = 0: chunks still start
 // their walks H samples early, inside the block) -- so a workgroup of NW = 4 waves holds 32 KB of LDS and four or five of
 // them share a CU; there are no links between workgroups, and the HBM traffic is exactly the algorithmic one.
-template <int OP, bool WEIGHTED, bool TRANSPOSED, int C, int NW, int H, bool ROUNDS, int T = tail_rows(H), bool SHORT = false>
-__global__ __launch_bounds__(64 * NW, SHORT ? 16 / NW : ((WEIGHTED || H > 16 || NW > 8) ? NW / 4 : NW / 2)) void sweep_chunk_kernel(SweepArgs p, FibreGeom g, ChunkPlan plan,
+// FW (fibres per tile, 64 or 32): with FW = 32 a wave carries TWO consecutive chunks of the same 32 fibres (lanes 0-31 the
+// first, 32-63 the second), so a workgroup of NW = 4 waves covers the same 8-chunk block over half the fibres: half the LDS,
+// FOUR independent workgroups per CU instead of two -- the stage / stream-out phases of one (memory latency) overlap the walks
+// of three others -- and rows of 256 bytes towards HBM (two full 128-byte lines).  Strided plain tiles only.
+template <int OP, bool WEIGHTED, bool TRANSPOSED, int C, int NW, int H, bool ROUNDS, int T = tail_rows(H), bool SHORT = false, int FW = 64>
+__global__ __launch_bounds__(64 * NW, SHORT ? 16 / NW : (FW < 64 ? ((WEIGHTED ? 8 : 16) / NW) : ((WEIGHTED || H > 16 || NW > 8) ? NW / 4 : NW / 2))) void sweep_chunk_kernel(SweepArgs p, FibreGeom g, ChunkPlan plan,
                                                                                    link_t *code_mine, link_t *code_next,
                                                                                    int *failflags) {
-    constexpr int PITCH = TRANSPOSED ? 65 : 64;
+    static_assert(FW == 64 || (FW == 32 && !TRANSPOSED && !ROUNDS && !SHORT && H <= C), "the 32-fibre tile is a plain strided tile");
+    constexpr int CPW = 64 / FW;            // chunks per wave
+    constexpr int NCH = NW * CPW;           // chunks per block
+    constexpr int PITCH = TRANSPOSED ? 65 : FW;
     constexpr int HA = SHORT ? 0 : H, TA = SHORT ? 0 : T;   // zone / look-ahead rows the window really has
-    constexpr int ROWS = HA + NW * C + TA;
-    static_assert(!(!TRANSPOSED && Op<OP>::KEEP) || (HA % NW == 0 && TA % NW == 0), "Op::KEEP relies on whole staging shares");
+    constexpr int ROWS = HA + NCH * C + TA;
+    static_assert(!(!TRANSPOSED && Op<OP>::KEEP) || (HA % NCH == 0 && TA % NCH == 0), "Op::KEEP relies on whole staging shares");
     constexpr int RB = (ROWS + 63) / 64;                                      // transposed: 64-row blocks per fibre
     constexpr int FPW = (64 + NW - 1) / NW;                                   // transposed: fibres per wave (the last wave's share may be short)
-    constexpr int NST = TRANSPOSED ? FPW * RB : (ROWS + NW - 1) / NW;         // staged window elements per thread (the last may fall past the window)
+    constexpr int NST = TRANSPOSED ? FPW * RB : (ROWS + NCH - 1) / NCH;       // staged window elements per thread (the last may fall past the window)
     constexpr int UL = 8;                                                     // epilogue rows in flight per lane
     constexpr bool KEEP = !TRANSPOSED && Op<OP>::KEEP;                        // a staged operand is reused by the epilogue
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double *Yp = reinterpret_cast<double *>(smem);
     double *Wp = Yp + (WEIGHTED ? (size_t)ROWS * PITCH : 0);
     // (the walk's look-ahead read of row `hi` lands in whatever follows the Y window -- allocated LDS, value never used)
-    link_t *codes = reinterpret_cast<link_t *>(Wp + (size_t)ROWS * PITCH);   // [NW + 2][64]; slots NW, NW + 1 carry over blocks
+    link_t *codes = reinterpret_cast<link_t *>(Wp + (size_t)ROWS * PITCH);   // [NCH + 2][FW]; slots NCH, NCH + 1 carry over blocks
     // (bit 31 of a slot -- never part of a code: restart indices are below 2^30 -- says "this lane's link is proven")
-    int *anybad = reinterpret_cast<int *>(codes + (NW + 2) * 64);            // [2], by round parity: some lane of the block has an unproven link
+    int *anybad = reinterpret_cast<int *>(codes + (NCH + 2) * FW);           // [2], by round parity: some lane of the block has an unproven link
     // A lane rewrites the rows of a piece that ends in its chunk even where they lie in earlier chunks; its walk reaches
     // back H rows (second-chance walks: anywhere in the block).  With H <= C that is the chunk before at most, and if
     // that chunk's lane is unproven its rows are rewritten by the repair kernel anyway.  Further back there may be
@@ -341,6 +349,8 @@ __global__ __launch_bounds__(64 * NW, SHORT ? 16 / NW : ((WEIGHTED || H > 16 || 
 
     if (p.gate && *p.gate == 0) return;   // uniform over the grid
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // fl: this lane's fibre within the tile ; ch: its chunk within the block (FW = 64: the lane and the wave)
+    const int fl = FW == 64 ? lane : (lane & (FW - 1)), ch = FW == 64 ? wave : wave * CPW + lane / FW;
     if (plan.trace && tid == 0) {
         unsigned hwid, xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
@@ -349,12 +359,13 @@ __global__ __launch_bounds__(64 * NW, SHORT ? 16 / NW : ((WEIGHTED || H > 16 || 
     }
     trace_mark(plan, 1);
     const int len = g.len;
-    const long j0 = (long)blockIdx.x * 64;
-    const long j = j0 + lane;
+    const long j0 = (long)blockIdx.x * FW;
+    const long j = j0 + fl;
     const bool active = j < g.count;
     long base = 0, wbase = 0;
     if (active) {
-        const long blk = j / g.inc, off = j % g.inc;
+        long blk, off;
+        divmod_nonneg(j, g.inc, blk, off);
         base = blk * g.inc * len + off;
         wbase = blk * g.inc * (len - 1) + off;
     }
@@ -373,8 +384,8 @@ __global__ __launch_bounds__(64 * NW, SHORT ? 16 / NW : ((WEIGHTED || H > 16 || 
     constexpr int NB = TRANSPOSED ? (Op<OP>::NIN > 1 ? (NST + 2) / 3 : (NST + 1) / 2) : (Op<OP>::NIN > 1 ? (NST + 1) / 2 : NST);
     double kept[KEEP ? C : 1];
     auto stage = [&](int q) {
-        const int cs_wg = q * NW * C;
-        const int lo = cs_wg - HA, hi = min(len, cs_wg + NW * C + TA);
+        const int cs_wg = q * NCH * C;
+        const int lo = cs_wg - HA, hi = min(len, cs_wg + NCH * C + TA);
 #pragma unroll
         for (int u0 = 0; u0 < NST; u0 += NB) {
             double s0[NB], s1[NB], sw[NB];
@@ -385,7 +396,7 @@ __global__ __launch_bounds__(64 * NW, SHORT ? 16 / NW : ((WEIGHTED || H > 16 || 
                 long idx, widx;
                 bool ok;
                 if (!TRANSPOSED) {
-                    r = lo + wave + NW * u;
+                    r = lo + ch + NCH * u;
                     ok = active && r >= 0 && r < hi && r - lo < ROWS;
                     idx = base + (long)r * g.inc;
                     widx = wbase + (long)r * g.inc;
@@ -407,8 +418,8 @@ __global__ __launch_bounds__(64 * NW, SHORT ? 16 / NW : ((WEIGHTED || H > 16 || 
                 int r, col;
                 bool ok;
                 if (!TRANSPOSED) {
-                    r = lo + wave + NW * u;
-                    col = lane;
+                    r = lo + ch + NCH * u;
+                    col = fl;
                     ok = active && r >= 0 && r < hi && r - lo < ROWS;
                 } else {
                     col = wave + NW * (u / RB);
@@ -419,7 +430,7 @@ __global__ __launch_bounds__(64 * NW, SHORT ? 16 / NW : ((WEIGHTED || H > 16 || 
                     Yp[(r - lo) * PITCH + col] = Op<OP>::y_of(p, s0[v], s1[v]);
                     if (WEIGHTED) Wp[(r - lo) * PITCH + col] = sw[v];
                 }
-                if (KEEP && u >= HA / NW && u < HA / NW + C) kept[KEEP ? u - HA / NW : 0] = s1[v];
+                if (KEEP && u >= HA / NCH && u < HA / NCH + C) kept[KEEP ? u - HA / NCH : 0] = s1[v];
             }
         }
     };
@@ -438,16 +449,16 @@ __global__ __launch_bounds__(64 * NW, SHORT ? 16 / NW : ((WEIGHTED || H > 16 || 
         __syncthreads();
         if (kb == 0) trace_mark(plan, 2);
 
-        const int cs_wg = q * NW * C;
+        const int cs_wg = q * NCH * C;
         const int lo = cs_wg - HA;
-        const int hi = min(len, cs_wg + NW * C + TA);
+        const int hi = min(len, cs_wg + NCH * C + TA);
 
-        // ---- speculative walk of this wave's chunk --------------------------------------------------------------------
-        const int cs = cs_wg + wave * C;
+        // ---- speculative walk of this wave's chunk(s) -----------------------------------------------------------------
+        const int cs = cs_wg + ch * C;
         const int ce = min(cs + C, len);
         const bool has_chunk = active && cs < len;
         const int start = max(0, cs - H);
-        const LdsWin<WEIGHTED, PITCH> win{(lds_double *)Yp + lane, (lds_double *)Wp + lane, lo};
+        const LdsWin<WEIGHTED, PITCH> win{(lds_double *)Yp + fl, (lds_double *)Wp + fl, lo};
         ChunkRec rec;
         bool certain = false;
         if (has_chunk && !(plan.ablate & 1)) {
@@ -471,11 +482,11 @@ __global__ __launch_bounds__(64 * NW, SHORT ? 16 / NW : ((WEIGHTED || H > 16 || 
             walk_chunk<OP, WEIGHTED, PITCH, ROUNDS, TAB>(w, rec, win, far, hi, cs, ce, len, p.lam, (unsigned)(unsigned long long)rtab);
         }
         // ---- prove the links between consecutive chunks ------------------------------------------------------------------
-        codes[wave * 64 + lane] = rec.next;
+        codes[ch * FW + fl] = rec.next;
         if (ROUNDS && tid == 0) anybad[0] = anybad[1] = 0;
         __syncthreads();   // all walks done: link codes visible, window rows no longer read as walk input
         if (kb == 0) trace_mark(plan, 3);
-        const int prev_slot = (wave > 0) ? (wave - 1) * 64 + lane : (NW + ((kb + 1) & 1)) * 64 + lane;
+        const int prev_slot = (ch > 0) ? (ch - 1) * FW + fl : (NCH + ((kb + 1) & 1)) * FW + fl;
         bool bad = false;
         // Second chances inside the block (plan.rounds > 0; data whose walks need more than the zone to meet): a lane
         // whose link fails, while its predecessor's holds, walks its chunk again from the predecessor's last bend -- a
@@ -483,15 +494,15 @@ __global__ __launch_bounds__(64 * NW, SHORT ? 16 / NW : ((WEIGHTED || H > 16 || 
         // chunk on; links are re-examined after every round (a predecessor that walked again may have changed its
         // code), and what is still unproven after the last round goes to the repair kernel as usual.
         for (int round = 0; ; round++) {
-            const bool linked = has_chunk && !(start == 0 || certain) && (wave > 0 || kb > 0);   // hangs on its predecessor
+            const bool linked = has_chunk && !(start == 0 || certain) && (ch > 0 || kb > 0);   // hangs on its predecessor
             bad = has_chunk && (rec.failed || (linked && (rec.mine == 0 || rec.mine != (codes[prev_slot] & ~kLinkCertain))));
             if (!ROUNDS || round >= plan.rounds) break;
-            if (has_chunk) codes[wave * 64 + lane] = bad ? rec.next : (rec.next | kLinkCertain);   // same code, plus the flag
+            if (has_chunk) codes[ch * FW + fl] = bad ? rec.next : (rec.next | kLinkCertain);   // same code, plus the flag
             if (bad) anybad[round & 1] = 1;
             __syncthreads();
             if (!anybad[round & 1]) break;               // uniform
             if (tid == 0) anybad[(round + 1) & 1] = 0;   // set again only after the barrier below
-            if (bad && (wave > 0 || kb > 0)) {
+            if (bad && (ch > 0 || kb > 0)) {
                 const link_t praw = codes[prev_slot];
                 const link_t prev = praw & ~kLinkCertain;
                 const int at = (int)(prev >> 1);
@@ -505,7 +516,7 @@ __global__ __launch_bounds__(64 * NW, SHORT ? 16 / NW : ((WEIGHTED || H > 16 || 
                     if (!again.failed) {
                         rec = again;
                         certain = false;   // from now on the chunk hangs on its predecessor like any other
-                        codes[wave * 64 + lane] = rec.next;
+                        codes[ch * FW + fl] = rec.next;
                     }
                 }
             }
@@ -516,27 +527,27 @@ __global__ __launch_bounds__(64 * NW, SHORT ? 16 / NW : ((WEIGHTED || H > 16 || 
                 rec.mine = kLinkBad;
                 rec.next = 0;
             }
-            if (bad) flag_chunk(failflags, j, q * NW + wave, (len + C - 1) / C, plan.dirty, rec.failed);
+            if (bad) flag_chunk(failflags, j, q * NCH + ch, (len + C - 1) / C, plan.dirty, rec.failed);
             // Every chunk publishes its two codes: sweep_repair_kernel proves the links between workgroups with them
             // and, for a fibre with an unproven link, finds where a repair walk may stop.
-            const long slot = (long)(q * NW + wave) * g.count + j;
+            const long slot = (long)(q * NCH + ch) * g.count + j;
             code_mine[slot] = (certain && rec.mine != kLinkBad) ? (rec.mine | kLinkCertain) : rec.mine;
             code_next[slot] = rec.next;
             // ... and the workgroup's last chunk, right now, what the next workgroup's first chunk must have begun with
-            if (plan.xlink && kb == nblk - 1 && wave == NW - 1)
+            if (plan.xlink && kb == nblk - 1 && ch == NCH - 1)
                 xlink_publish(plan.xlink + (size_t)blockIdx.y * g.count + j, plan.dirty.epoch, rec.next);
         }
         // (the link INTO this workgroup is checked at the very end, when the workgroup before has surely published)
-        if (kb == 0 && wave == 0) {
+        if (kb == 0 && ch == 0) {
             const link_t began = (has_chunk && !certain) ? rec.mine : kNoCheck;
             if (TRANSPOSED) began_reg = began;
-            else stash[lane] = began;
+            else stash[fl] = began;
         }
         // carried to the next block's first chunk; two slots in turn, so that no barrier is needed before the write
-        if (wave == NW - 1) codes[(NW + (kb & 1)) * 64 + lane] = (bad || !has_chunk) ? rec.next : (rec.next | kLinkCertain);
+        if (ch == NCH - 1) codes[(NCH + (kb & 1)) * FW + fl] = (bad || !has_chunk) ? rec.next : (rec.next | kLinkCertain);
         // Non-fused ops: the operand fetches of the epilogue's first batch of rows go out now and fly while the rebuild
         // runs (the walk's registers are free by now); the second batch is fetched while the first is stored.
-        const int ce_wg = min(len, cs_wg + NW * C);
+        const int ce_wg = min(len, cs_wg + NCH * C);
 #ifdef PTV_PREFETCH_EPILOGUE   // measured: the 32 VGPRs it holds across the rebuild spill at two workgroups per CU, 14 % slower
         constexpr bool PREFETCH = !TRANSPOSED && !Op<OP>::FUSED && !KEEP;
 #else
@@ -547,12 +558,13 @@ __global__ __launch_bounds__(64 * NW, SHORT ? 16 / NW : ((WEIGHTED || H > 16 || 
         if (PREFETCH && active && !(plan.ablate & 2)) {
 #pragma unroll
             for (int m = 0; m < NPRE; m++) {
-                const int k = min(cs_wg + wave + NW * m, ce_wg - 1);
+                const int k = min(cs_wg + ch + NCH * m, ce_wg - 1);
                 pre[PREFETCH ? m : 0] = Op<OP>::fetch(p, base + (long)k * g.inc);
             }
         }
         int wlo = cs_wg;   // first row this lane may write
         if (GUARD) {
+            static_assert(!GUARD || FW == 64, "the write guard keeps one lane mask per chunk = wave");
             const unsigned long long mask = __ballot(bad);
             if (lane == 0) unproven[wave] = mask;
             __syncthreads();
@@ -564,7 +576,7 @@ __global__ __launch_bounds__(64 * NW, SHORT ? 16 / NW : ((WEIGHTED || H > 16 || 
         }
         if (has_chunk && !(plan.ablate & 1))
             rebuild_owned<Op<OP>, WEIGHTED, C, PTV_TILE_UNROLL, TAB, lds_double *, (ROUNDS ? TS : 0)>(win, rec, cs, ce, len, start, !bad, wlo,
-                                                                                                    wave == NW - 1 || ce == len, p.lam, (lds_double *)rtab);
+                                                                                                    ch == NCH - 1 || ce == len, p.lam, (lds_double *)rtab);
         __syncthreads();
         if (kb == 0) trace_mark(plan, 4);
 
@@ -572,22 +584,22 @@ __global__ __launch_bounds__(64 * NW, SHORT ? 16 / NW : ((WEIGHTED || H > 16 || 
         if (!(plan.ablate & 2)) {
             if (!TRANSPOSED) {
                 if (active) {
-                    // the thread that staged rows cs_wg + wave + NW*m streams them out (Op::KEEP: with the staged operand)
+                    // the thread that staged rows cs_wg + ch + NCH*m streams them out (Op::KEEP: with the staged operand)
 #pragma unroll
                     for (int m0 = 0; m0 < C; m0 += UL) {
                         Ext ex[UL];
 #pragma unroll
                         for (int u = 0; u < UL; u++) {
-                            const int k = min(cs_wg + wave + NW * (m0 + u), ce_wg - 1);
+                            const int k = min(cs_wg + ch + NCH * (m0 + u), ce_wg - 1);
                             if (KEEP) ex[u] = Op<OP>::fetch_rest(p, base + (long)k * g.inc, kept[KEEP ? m0 + u : 0]);
                             else if (PREFETCH && m0 == 0) ex[u] = pre[PREFETCH ? u : 0];
                             else if (!Op<OP>::FUSED) ex[u] = Op<OP>::fetch(p, base + (long)k * g.inc);
                         }
 #pragma unroll
                         for (int u = 0; u < UL; u++) {
-                            const int k = cs_wg + wave + NW * (m0 + u);
+                            const int k = cs_wg + ch + NCH * (m0 + u);
                             if (k < ce_wg) {
-                                const double v = Yp[(k - lo) * PITCH + lane];
+                                const double v = Yp[(k - lo) * PITCH + fl];
                                 if (Op<OP>::FUSED) Op<OP>::store_fused(p, base + (long)k * g.inc, v);
                                 else               Op<OP>::finish(p, base + (long)k * g.inc, ex[u], v);
                             }
@@ -624,8 +636,8 @@ __global__ __launch_bounds__(64 * NW, SHORT ? 16 / NW : ((WEIGHTED || H > 16 || 
         }
         if (kb + 1 < nblk) __syncthreads();   // every wave is done reading this block's window
     }
-    if (plan.xlink && blockIdx.y > 0 && wave == 0 && active) {
-        const link_t began = TRANSPOSED ? began_reg : stash[lane];   // (written by this very thread)
+    if (plan.xlink && blockIdx.y > 0 && ch == 0 && active) {
+        const link_t began = TRANSPOSED ? began_reg : stash[fl];   // (written by this very thread)
         if (began != kNoCheck) {
             const int why = xlink_check(plan.xlink + (size_t)(blockIdx.y - 1) * g.count + j, plan.dirty.epoch, began);
             if (why) plan.dirty.set(why);
@@ -653,7 +665,7 @@ constexpr int kAlongC = 17;
 // price is LDS: 16.9 KB per wave instead of 9.7, eight waves per CU instead of sixteen.  (31 is odd, see above, and a
 // chunk's piece ends fit the 32-bit masks of ChunkRec.)
 #ifndef PTV_ALONG_ROBUST_C
-#define PTV_ALONG_ROBUST_C 31
+#define PTV_ALONG_ROBUST_C 17
 #endif
 constexpr int along_chunk(bool robust, bool weighted) { return robust && !weighted ? PTV_ALONG_ROBUST_C : kAlongC; }
 #ifndef PTV_ALONG_WAVES
@@ -719,8 +731,9 @@ __global__ __launch_bounds__(64 * kAlongWaves) void sweep_along_kernel(SweepArgs
     const int nseg = (len + SEG - 1) / SEG, NC = (len + C - 1) / C;
     const long wid = (long)blockIdx.x * kAlongWaves + wave;
     const long unit = wid * NG + gi;         // one group of G lanes = one segment of one fibre
-    const long j = unit / nseg;
-    const int sg = (int)(unit % nseg);
+    long j, sg_l;
+    divmod_nonneg(unit, (long)nseg, j, sg_l);
+    const int sg = (int)sg_l;
     const bool live = j < g.count;           // (nothing in this kernel synchronises across waves; a group past the end idles)
     if (plan.trace && lane == 0) {
         unsigned hwid, xcc;
@@ -927,7 +940,8 @@ __global__ __launch_bounds__(64) void sweep_whole_kernel(SweepArgs p, FibreGeom 
     const bool active = j < g.count;
     long base = 0;
     if (active) {
-        const long blk = j / g.inc, off = j % g.inc;
+        long blk, off;
+        divmod_nonneg(j, g.inc, blk, off);
         base = blk * g.inc * len + off;
     }
     // ---- stage ---------------------------------------------------------------------------------------------------------------
@@ -1078,7 +1092,8 @@ __global__ __launch_bounds__(64) void sweep_gchunk_kernel(SweepArgs p, FibreGeom
     if (j >= g.count || cs >= len) return;
     if (p.gate && *p.gate == 0) return;
     const int ce = min(cs + C, len);
-    const long blk = j / g.inc, off = j % g.inc;
+    long blk, off;
+    divmod_nonneg(j, g.inc, blk, off);
     GlobalChunkSource<OP, WEIGHTED> src{p, blk * g.inc * len + off, g.inc, blk * g.inc * (len - 1) + off, cs, ce,
                                         min(len, ce + H), 0u, 0u, false, false, {}};
     Walker w;
@@ -1286,7 +1301,8 @@ __global__ __launch_bounds__(64) void sweep_repair_kernel(SweepArgs p, FibreGeom
     atomicAdd(failcount, 1);       // fibres that needed a repair
     int walks = 0;
 
-    const long blk = j / g.inc, off = j % g.inc;
+    long blk, off;
+    divmod_nonneg(j, g.inc, blk, off);
     const long base = blk * g.inc * len + off, wbase = blk * g.inc * (len - 1) + off;
     const RepairBook book{code_mine, cstride, fstride, j, C, len};
     const bool windowed = H <= kWarmLong;
@@ -1598,14 +1614,15 @@ static ChunkScratch &chunk_state() { return g_chunks[current_device()]; }
 // than the reads past the window did.  What makes these sweeps slow is the walk itself -- at lambda = 0.5 the linearized
 // taut string re-walks every piece about once: 2.6 x the trips of the headline.)
 template <int OP, bool WEIGHTED, bool TRANSPOSED, int H, bool ROBUST = false, int C = 16, int NW = 8,
-          int T = tail_rows(H), bool SHORT = false>
+          int T = tail_rows(H), bool SHORT = false, int FW = 64>
 void launch_chunk_h(const SweepArgs &args, const FibreGeom &g, hipStream_t stream, int fam, int rounds_wanted) {
-    constexpr int PITCH = TRANSPOSED ? 65 : 64;
-    constexpr int ROWS = SHORT ? NW * C : H + NW * C + T;
+    constexpr int PITCH = TRANSPOSED ? 65 : FW;
+    constexpr int NCH = NW * (64 / FW);   // chunks per block
+    constexpr int ROWS = SHORT ? NCH * C : H + NCH * C + T;
     ChunkPlan plan;
-    plan.Q = (g.len + NW * C - 1) / (NW * C);
+    plan.Q = (g.len + NCH * C - 1) / (NCH * C);
     // blocks per workgroup: enough workgroups to fill the chip a few times over
-    const long groups = (g.count + 63) / 64;
+    const long groups = (g.count + FW - 1) / FW;
     int qpw = options().blocks_per_wg;
     if (qpw <= 0) {
         qpw = 8;
@@ -1613,7 +1630,7 @@ void launch_chunk_h(const SweepArgs &args, const FibreGeom &g, hipStream_t strea
         // every CU one; 14.5 -> 14.05 ms on the 4096^2 weighted solve.  Keeping the next block's window share in registers
         // while the current one is processed -- the waves own 256 VGPRs there -- was tried and hid the staging phase, but the
         // sweep did not get faster: at 8 waves per CU it is the walk's dependent-instruction latency that bounds it)
-        const long want = (WEIGHTED && !TRANSPOSED && !SHORT) ? 256 : 2048;
+        const long want = (WEIGHTED && !TRANSPOSED && !SHORT) ? (FW < 64 ? 512 : 256) : (FW < 64 ? 4096 : 2048);
         while (qpw > 1 && groups * ((plan.Q + qpw - 1) / qpw) < want) qpw >>= 1;
     }
     plan.qpw = qpw < plan.Q ? qpw : plan.Q;
@@ -1628,10 +1645,11 @@ void launch_chunk_h(const SweepArgs &args, const FibreGeom &g, hipStream_t strea
 #else
     constexpr size_t tab_bytes = 0;
 #endif
-    constexpr size_t lds = sizeof(double) * PITCH * (size_t)ROWS * (WEIGHTED ? 2 : 1) + sizeof(link_t) * ((NW + (TRANSPOSED ? 2 : 3)) * 64 + 4 + 2 * NW) + tab_bytes;
+    constexpr size_t lds = sizeof(double) * PITCH * (size_t)ROWS * (WEIGHTED ? 2 : 1) + sizeof(link_t) * ((NCH + 2) * FW + (TRANSPOSED ? 0 : 64) + 4 + 2 * NW) + tab_bytes;
     static_assert(WEIGHTED || H > kWarm || NW > 8 || 2 * lds <= 160 * 1024, "the short-zone geometry is meant to run two workgroups per CU");
-    if (SHORT && g.len > NW * C) {
-        set_error("launch_chunk_h: a fibre of %d samples does not fit the single-block geometry (%d)", g.len, NW * C);
+    static_assert(FW == 64 || (WEIGHTED ? 2 : 4) * lds <= 160 * 1024, "the 32-fibre tile is meant to run four workgroups per CU (weighted: two)");
+    if (SHORT && g.len > NCH * C) {
+        set_error("launch_chunk_h: a fibre of %d samples does not fit the single-block geometry (%d)", g.len, NCH * C);
         throw HipFailure{hipErrorInvalidValue};
     }
     static_assert(lds <= 160 * 1024, "chunk geometry does not fit the LDS of a CU");
@@ -1641,13 +1659,19 @@ void launch_chunk_h(const SweepArgs &args, const FibreGeom &g, hipStream_t strea
     // does not have (it sits at the 128-VGPR budget of two workgroups per CU)
     static_assert(!ROBUST || H <= kWarm, "second chances exist for the short-zone geometry");
     if (!ROBUST) plan.rounds = 0;
-    auto kern = sweep_chunk_kernel<OP, WEIGHTED, TRANSPOSED, C, NW, H, ROBUST, T, SHORT>;
+    auto kern = sweep_chunk_kernel<OP, WEIGHTED, TRANSPOSED, C, NW, H, ROBUST, T, SHORT, FW>;
     static thread_local bool attr_done[kMaxDevices] = {};   // function attributes are per device
     bool &attr_set = attr_done[current_device()];
     if (!attr_set) {
         PTV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     160 * 1024));
         attr_set = true;
+        if (options().verbose) {
+            int per_cu = 0;
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(kern), 64 * NW, lds);
+            fprintf(stderr, "[proxtv_amd] tile kernel op %d%s%s: %d fibres x %d chunks of %d in %d waves, %zu B of LDS -> %d workgroups per CU\n", OP,
+                    WEIGHTED ? " weighted" : "", ROBUST ? " robust" : "", FW, NCH, C, NW, lds, per_cu);
+        }
     }
     const dim3 grid((unsigned)groups, (unsigned)WQ);
     hipLaunchKernelGGL(kern, grid, dim3(64 * NW), lds, stream, args, g, plan, chunk_state().code_mine,
@@ -1662,7 +1686,7 @@ void launch_chunk_h(const SweepArgs &args, const FibreGeom &g, hipStream_t strea
                                         (int)rlds));
             rattr_set = true;
         }
-        hipLaunchKernelGGL(rkern, dim3((unsigned)groups), dim3(64), rlds, stream, args, g, C, H, plan.qpw * NW,
+        hipLaunchKernelGGL(rkern, dim3((unsigned)((g.count + 63) / 64)), dim3(64), rlds, stream, args, g, C, H, plan.qpw * NCH,
                            chunk_state().code_mine, chunk_state().code_next, chunk_state().failflags, chunk_state().failcount + 2 * fam, (long)g.count, 1L,
                            plan.dirty);
     }
@@ -1834,9 +1858,11 @@ void launch_chunk(const SweepArgs &args, const FibreGeom &g, hipStream_t stream,
     else if constexpr (!WEIGHTED) {
         if (mode == 2)      launch_chunk_h<OP, false, TRANSPOSED, kWarmLong>(args, g, stream, fam, 0);
         else if (mode == 1) launch_chunk_h<OP, false, TRANSPOSED, kWarm, true>(args, g, stream, fam, rounds);
+        else if (!TRANSPOSED && options().tile == 1) launch_chunk_h<OP, false, false, kWarm, false, 16, 4, kTail, false, 32>(args, g, stream, fam, 0);
         else                launch_chunk_h<OP, false, TRANSPOSED, kWarm>(args, g, stream, fam, 0);
     } else {
         if (mode == 1) launch_chunk_h<OP, true, TRANSPOSED, kWarm, true>(args, g, stream, fam, rounds);
+        else if (!TRANSPOSED && options().tile == 1) launch_chunk_h<OP, true, false, kWarm, false, 16, 4, kTail, false, 32>(args, g, stream, fam, 0);
         else           launch_chunk_h<OP, true, TRANSPOSED, kWarm>(args, g, stream, fam, 0);
     }
     pl.sweeps++;

@@ -112,7 +112,8 @@ __device__ __forceinline__ double tri_solve(const Tv2Args &p, long base, long in
 __global__ __launch_bounds__(64) void tv2_fibres_kernel(Tv2Args p, FibreGeom g) {
     const long j = (long)blockIdx.x * 64 + threadIdx.x;
     if (j >= g.count || g.len <= 0) return;
-    const long blk = j / g.inc, off = j % g.inc;
+    long blk, off;
+    divmod_nonneg(j, g.inc, blk, off);
     const long base = blk * g.inc * g.len + off, inc = g.inc;
     const int n = g.len, nn = n - 1;
     if (nn == 0 || !(p.lam > 0.0)) {

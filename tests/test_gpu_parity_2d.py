@@ -330,3 +330,33 @@ def test_anisotropic_image_mixes_rungs_and_forms(ptv, clib, oracle):
     finally:
         for k, v in zip((b"chunk_mode", b"deterministic", b"dr_form"), before):
             clib.proxtv_set_option(k, v)
+
+
+@pytest.mark.parametrize("tile", [1, 0])
+def test_both_tile_geometries_of_strided_sweeps(ptv, clib, oracle, tile):
+    """Strided sweeps on rung 0 run on tiles of 32 fibres x 8 chunks in 4 waves (option tile = 1, the default: four workgroups per
+    CU) or on the 64-fibre x 8-wave tile (tile = 0).  Every op that reaches them -- both forms of the DR iteration, weighted DR,
+    PD2, Yang, plain sweeps of a 3-D array -- on both, pinned to rung 0, against the oracle; fibre counts that leave the last
+    tile ragged (not a multiple of 32 / 64), fibres of one block, of several blocks and with a short last block."""
+    rng = np.random.default_rng(211 + tile)
+    before = (clib.proxtv_set_option(b"tile", tile), clib.proxtv_set_option(b"chunk_mode", 0), clib.proxtv_set_option(b"dr_form", 0))
+    try:
+        for M, N, lam in [(130, 97, 0.1), (333, 260, 0.1), (96, 1100, 0.08), (1000, 417, 0.12)]:
+            X = rng.standard_normal((M, N))
+            for form in (0, 2):
+                clib.proxtv_set_option(b"dr_form", form)
+                assert_close(ptv.tv1_2d(X, lam), oracle.dr2(X, lam)[0], tol=1e-9, what=f"dr2 form {form} {M}x{N} tile {tile}")
+            W1, W2 = rng.uniform(0.2 * lam, 2 * lam, (M - 1, N)), rng.uniform(0.2 * lam, 2 * lam, (M, N - 1))
+            for form in (0, 2):
+                clib.proxtv_set_option(b"dr_form", form)
+                assert_close(ptv.tv1w_2d(X, W1, W2), oracle.dr2w(X, W1, W2)[0], tol=1e-9, what=f"dr2w form {form} {M}x{N} tile {tile}")
+            assert_close(ptv.tv1_2d(X, lam, method="pd"), oracle.pd2(X, [lam, lam], [1, 2])[0], tol=1e-9, what=f"pd2 {M}x{N} tile {tile}")
+            assert_close(ptv.tv1_2d(X, lam, method="yang", max_iters=12), oracle.yang2(X, lam, 12)[0], tol=1e-9, what=f"yang2 {M}x{N} tile {tile}")
+        V = rng.standard_normal((70, 200, 150))
+        lams = [0.1, 0.1, 0.08]
+        assert_close(ptv.tvgen(V, lams, [1, 2, 3], [1, 1, 1], max_iters=6), oracle.pd(V, lams, [1, 2, 3], max_iters=6)[0], tol=1e-9,
+                     what=f"pd 3-D tile {tile}")
+    finally:
+        clib.proxtv_set_option(b"tile", before[0])
+        clib.proxtv_set_option(b"chunk_mode", before[1])
+        clib.proxtv_set_option(b"dr_form", before[2])

@@ -131,6 +131,91 @@ int study_fibre(const double *y, int len, double lam, int C, int H, int look, in
     return done;
 }
 
+// Temporal seeding (round 4): inside a splitting loop the input of a sweep changes little from one iteration to the next, so a
+// lane that finds no bend known a priori may start its walk AT the last bend the PREVIOUS iteration's solution had at or before
+// its chunk start (restart state, like a bend known a priori -- but a guess: the link must still be proven) instead of a free
+// end H samples back.  y_prev / y_cur: the same fibre at two consecutive iterations.  back: how far before the chunk start a seed
+// may lie (rows the window keeps before the chunk).
+// out: 8 ints per chunk:  [0] valid  [1] trips today  [2] trips seeded  [3] link proven today  [4] link proven seeded
+//   [5] started at a bend known a priori (both schemes alike)  [6] trips of the true walk inside the chunk  [7] a seed was available
+int study_seeded(const double *y_prev, const double *y, int len, double lam, int C, int H, int look, int back, int *out) {
+    const int nchunks = len / C;
+    for (int c = 0; c < nchunks; c++) out[8 * c] = -1;
+    BendLog prev{y_prev, {}}, log{y, {}};
+    {
+        Walker w;
+        walker_start<false>(w, prev, 0, lam);
+        walker_run<false>(w, prev, len, lam);
+        walker_start<false>(w, log, 0, lam);
+        walker_run<false>(w, log, len, lam);
+    }
+    std::vector<long> trips_at((size_t)nchunks + 1, 0);
+    {
+        CountWin win{y};
+        Walker w;
+        walker_start<false>(w, win, 0, lam);
+        ChunkRec rec;
+        long total = 0;
+        for (int c = 1; c <= nchunks && c * C < len - 1; c++) {
+            const long before = win.reads;
+            const bool ran = w.i < c * C;
+            walk_interior<false>(w, rec, win, c * C, 0, len + 64, lam);
+            if (ran) total += trips_of(win, before, 1);
+            trips_at[(size_t)c] = total;
+        }
+    }
+    auto code_at_or_before = [](const std::vector<unsigned> &codes, int pos) {
+        unsigned best = 0;
+        for (unsigned code : codes) {
+            if ((int)(code >> 1) <= pos) best = code; else break;
+        }
+        return best;
+    };
+    int done = 0;
+    for (int c = 1; c < nchunks; c++) {
+        const int cs = c * C, ce = cs + C;
+        if (cs - 80 < 1 || ce + 200 >= len - 1) continue;
+        CountWin win{y};
+        int cat = -1, ctype = 0;
+        if (look == 8) cat = certain_bend_before<false, 8>(win, cs, len, lam, ctype);
+        else if (look == 14) cat = certain_bend_before<false, 14>(win, cs, len, lam, ctype);
+        const unsigned truth = code_at_or_before(log.codes, cs);
+        const unsigned seed = code_at_or_before(prev.codes, cs);
+        const bool have_seed = seed != 0 && cs - (int)(seed >> 1) <= back;
+        long trips[2];
+        bool link[2];
+        for (int scheme = 0; scheme < 2; scheme++) {
+            Walker w;
+            ChunkRec rec;
+            if (cat >= 0) {
+                walker_restart_with<false>(w, cat, ctype, len, lam, y[cat], 0.0, 0.0);
+                rec.mine = rec.next = rec.last = ((unsigned)cat << 1) | (unsigned)ctype;
+            } else if (scheme == 1 && have_seed) {
+                const int at = (int)(seed >> 1);
+                walker_restart_with<false>(w, at, (int)(seed & 1u), len, lam, y[at], 0.0, 0.0);
+                rec.mine = rec.next = rec.last = seed;
+            } else {
+                walker_start<false>(w, win, cs - H, lam);
+            }
+            const long before = win.reads;
+            walk_interior<false>(w, rec, win, len - 1, cs, ce, lam);
+            trips[scheme] = trips_of(win, before, 1);
+            link[scheme] = cat >= 0 || (rec.mine != 0 && rec.mine == truth);
+        }
+        int *o = out + 8 * c;
+        o[0] = 1;
+        o[1] = (int)trips[0];
+        o[2] = (int)trips[1];
+        o[3] = link[0];
+        o[4] = link[1];
+        o[5] = cat >= 0;
+        o[6] = (int)(trips_at[(size_t)c + 1] - trips_at[(size_t)c]);
+        o[7] = have_seed;
+        done++;
+    }
+    return done;
+}
+
 // The true walk's trip counter at every bend: out_at[k] = restart sample, out_trip[k] = trips walked when that bend was made
 // (the walk restarts there in closed form).  Returns the number of bends (at most cap are stored).
 int study_bends(const double *y, int len, double lam, int *out_at, long *out_trip, int cap) {
