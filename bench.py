@@ -22,7 +22,9 @@ Extra objects on that line:
   c5           -- BASELINE config #5 per rank: 64 independent 2048x2048 images through proxtv_DR2_TV_batch_dev, solver
                   time and (N > 1) the RCCL gather to rank 0 timed separately.
   cpu_baseline -- the compiled reference (oracle/_ref, kind "reference") or, if it did not travel, this repo's
-                  C restatement (kind "port"), timed on the host cores on a bounded sample (rank 0, N = 1 only).
+                  C restatement (kind "port"), timed on the host cores on a bounded sample (rank 0, N = 1 only): the headline
+                  size at the best thread count of a probe, plus the 1024^2 probe at one thread and at all logical cores.
+  end_to_end   -- the same solve through the drop-in host-pointer DR2_TV (transfers included); never `value`.
 """
 import argparse
 import json
@@ -66,9 +68,19 @@ def cpu_baseline():
     t0 = time.perf_counter()
     _, info, _ = lib.dr2(X, LAM, n_threads=best_thr)
     dt = time.perf_counter() - t0
+    # the same path at ONE thread and at ALL logical cores, on the bounded 1024^2 sample (a 4096^2 solve at one thread
+    # alone takes ~40 s); Mpixel/s of that sample, so the three figures are comparable only through the stated sizes
+    def sample_rate(thr):
+        t0 = time.perf_counter()
+        lib.dr2(probe, LAM, n_threads=thr)
+        return 1024 * 1024 / (time.perf_counter() - t0) / 1e6
+    one, everything = sample_rate(1), sample_rate(cores)
     return {"value": side * side / dt / 1e6, "unit": "Mpixel/s", "cores": best_thr, "kind": kind,
             "sample": f"one DR2_TV solve, {side}x{side} f64, lambda={LAM}, {int(info[0])} iterations, {dt:.2f} s with "
-                      f"{best_thr} OpenMP threads (best of {cands} probed on 1024x1024; host has {cores} logical cores)"}
+                      f"{best_thr} OpenMP threads (best of {cands} probed on 1024x1024; host has {cores} logical cores)",
+            "threads_1": {"value": one, "unit": "Mpixel/s", "cores": 1, "sample": "one DR2_TV solve, 1024x1024 f64, same lambda / iterations"},
+            "threads_all": {"value": everything, "unit": "Mpixel/s", "cores": cores, "sample": "one DR2_TV solve, 1024x1024 f64, same lambda / iterations"},
+            "best_on_sample": {"value": 1024 * 1024 / best_t / 1e6, "unit": "Mpixel/s", "cores": best_thr, "sample": "one DR2_TV solve, 1024x1024 f64"}}
 
 
 def main():
@@ -129,6 +141,19 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     assert int(info[0]) == ITERS, info
+
+    # ---- end to end through the drop-in host-pointer entry point (what an unmodified caller of the reference gets): H2D + solve +
+    # D2H from / to the caller's pageable numpy arrays.  Reported beside the device-resident rate, never as `value`.
+    x_f = np.asfortranarray(x_host)
+    y_f = np.zeros_like(x_f, order="F")
+    info_h = np.zeros(3)
+    e2e = []
+    for k in range(4):
+        ts = time.perf_counter()
+        lib.DR2_TV(M, N, x_f.ctypes.data, LAM, LAM, 1.0, 1.0, y_f.ctypes.data, 1, 0, info_h.ctypes.data)
+        if k: e2e.append(time.perf_counter() - ts)
+    end_to_end_ms = float(np.median(e2e)) * 1e3
+    del x_f, y_f
 
     # ---- the same K solves again with a hipEvent pair around every sweep (library option "profile") -------------------
     # The events go on the library's own stream; each record drains the queue, which costs ~6 us per event = ~0.8 ms per
@@ -270,6 +295,9 @@ def main():
                          "solve_frac": (solve_bytes / (ms_per_step * 1e-3) / 1e9) / HBM_PEAK_GBS,
                          "solve_algorithmic_bytes": solve_bytes},
             "step_ms": {"min": min(step_t) * 1e3, "median": float(np.median(step_t)) * 1e3, "max": max(step_t) * 1e3},
+            "end_to_end_ms": end_to_end_ms,
+            "end_to_end": {"ms": end_to_end_ms, "value": M * N / end_to_end_ms / 1e3, "unit": "Mpixel/s",
+                           "what": "DR2_TV through the host-pointer C-ABI: pageable numpy in, numpy out (2 x 134 MB over the link + the solve)"},
         }
         if c5 is not None:
             line["c5"] = c5

@@ -20,9 +20,10 @@ thread count); results agree with the reference within the reference's own guara
 Out of scope (raise ``NotImplementedError``): general p (``tvp_1d`` / ``tvp_2d`` / ``tvgen`` with p not in {1, 2}).
 ``tv1_1d``'s alternative method names are served by the one exact HIP solver.
 
-Reproducibility: results are exact minimisers whatever kernel geometry the adaptive policy picks, but geometries differ
-in the last ulps (refined-reciprocal division, closed-form piece values); pin one with ``PROXTV_CHUNK_MODE`` (or
-``proxtv_set_option("chunk_mode", m)``) when bit-identical reruns matter.
+Reproducibility: by default the same call returns the same bits whatever ran before -- which kernel geometry a sweep takes is a
+function of sampled statistics of its input and of lambda alone (``deterministic = 1``).  Every geometry is
+exact, but they round differently in the last ulps, so results may differ by ~1e-13 between calls only with
+``proxtv_set_option("deterministic", 0)`` (the hill climb on measured sweep times).
 """
 import numpy as np
 

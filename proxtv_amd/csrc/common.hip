@@ -38,6 +38,7 @@ constexpr OptionEntry kOptionTable[] = {
     {"seed_noisy_e4", &Options::seed_noisy_e4},
     {"seed_mid_e4", &Options::seed_mid_e4},
     {"pin", &Options::pin},
+    {"pin_seed", &Options::pin_seed},
     {"whole", &Options::whole},
     {"chunk_min_len", &Options::chunk_min_len},
     {"xlink", &Options::xlink},

@@ -33,7 +33,7 @@ namespace {
 using namespace pin;
 
 template <int OP, bool WEIGHTED, int P, int G>
-__global__ __launch_bounds__(kPinThreads) void sweep_pin_kernel(SweepArgs p, FibreGeom g, int *pieces, int *gaveup) {
+__global__ __launch_bounds__(kPinThreads) void sweep_pin_kernel(SweepArgs p, FibreGeom g, int *pieces, int *gaveup, int seeded) {
     using Geo = PinGeom<P, G, WEIGHTED>;
     using Sh = PinShared<P, G, WEIGHTED>;
     constexpr int SLOTS = Geo::SLOTS;
@@ -78,6 +78,32 @@ __global__ __launch_bounds__(kPinThreads) void sweep_pin_kernel(SweepArgs p, Fib
     double *own = Sp + Geo::lane_base(t);   // own[k]: sample t P + k, then the sum at knot t P + k + 1
     const int cnt = n - t * P < 0 ? 0 : (n - t * P < P ? n - t * P : P);
     double *red = reinterpret_cast<double *>(mx);
+    // ---- knots known a priori (PinLane::seed), while the plane still holds the samples: own knot k = 1 + t P + k lies between the
+    // samples own[k] and the one after it (the lane's last knot looks at its neighbour's first sample: the barriers of the sums
+    // below come before anybody overwrites a sample)
+    typename PinLane<P>::Mask seedU = 0, seedL = 0;
+    if (seeded) {
+        double prev = cnt > 0 ? own[0] : 0.0;
+#pragma unroll
+        for (int k = 0; k < P; k++) {
+            const int j = 1 + t * P + k;
+            if (j < n) {
+                const double cur = Sp[Geo::sa(j + 1)];
+                const double d = cur - prev;
+                double thr = 4.0000001 * p.lam;
+                bool ok = p.lam > 0.0;
+                if (WEIGHTED) {   // r_{j+1} + 2 r_j + r_{j-1} ; the fibre ends have no wall (half-width 0)
+                    const double rm = j > 1 ? Wp[Geo::sa(j - 1)] : 0.0, r0 = Wp[Geo::sa(j)], rp = j + 1 < n ? Wp[Geo::sa(j + 1)] : 0.0;
+                    thr = 1.0000001 * (rp + 2.0 * r0 + rm);
+                    ok = (rm >= 0.0) & (r0 > 0.0) & (rp >= 0.0);
+                }
+                const bool hit = ok & (fabs(d) > thr);
+                if (hit && d > 0) seedU |= (typename PinLane<P>::Mask)1 << k;
+                if (hit && !(d > 0)) seedL |= (typename PinLane<P>::Mask)1 << k;
+                prev = cur;
+            }
+        }
+    }
     double mean;
     {
         double ls = 0.0;
@@ -93,6 +119,31 @@ __global__ __launch_bounds__(kPinThreads) void sweep_pin_kernel(SweepArgs p, Fib
             acc += own[k] - mean;
             own[k] = acc;
         }
+    }
+    // the nearest seeded knot on either side of the lane's range, and the string's height there (read before any lane settles:
+    // settle() turns the sum of a pinned knot into that height in place)
+    int s_la = 0, s_rb = n;
+    double s_hl = 0.0, s_hr = 0.0;
+    if (seeded) {
+        group_sync<G>();   // the sums are in place; `red` is free again
+        using Mask = typename PinLane<P>::Mask;
+        const Mask both = seedU | seedL;
+        const int j0 = 1 + t * P;
+        int last = 0, first = 0x7fffffff;
+        if (both) {
+            const int kl = (int)(8 * sizeof(Mask)) - 1 - (sizeof(Mask) == 4 ? __builtin_clz((unsigned)both) : __builtin_clzll((unsigned long long)both));
+            const int kf = PinLane<P>::ctz(both);
+            last = ((j0 + kl) << 1) | (int)((seedL >> kl) & 1);
+            first = ((j0 + kf) << 1) | (int)((seedL >> kf) & 1);
+        }
+        int before, after;
+        group_neighbour_seeds<G>(last, first, t, reinterpret_cast<int *>(red), before, after);
+        if (before) s_la = before >> 1;
+        if (after != 0x7fffffff) s_rb = after >> 1;
+        const double wl = (s_la > 0) ? (WEIGHTED ? Wp[Geo::sa(s_la)] : p.lam) : 0.0, wr = (s_rb < n) ? (WEIGHTED ? Wp[Geo::sa(s_rb)] : p.lam) : 0.0;
+        s_hl = Sp[Geo::sa(s_la)] + ((before & 1) ? -wl : wl);
+        s_hr = Sp[Geo::sa(s_rb)] + ((after != 0x7fffffff && (after & 1)) ? -wr : wr);
+        group_sync<G>();
     }
     // reduction slots: empty (from here on the lanes clear what they own as the levels go: pincore.hpp)
     for (int wall = 0; wall < 2; wall++) {
@@ -113,6 +164,7 @@ __global__ __launch_bounds__(kPinThreads) void sweep_pin_kernel(SweepArgs p, Fib
         for (int k = 0; k < (Sh::kCached ? P : 1); k++) sh.cached[k] = own[k];
     }
     ln.init(n, t, sh);
+    if (seeded && t * P < n) ln.seed(seedU, seedL, s_la, s_hl, s_rb, s_hr);
     bool capped = false;
 #pragma unroll 1
     for (int level = 0;; level++) {
@@ -189,7 +241,7 @@ void launch_geom(const SweepArgs &args, const FibreGeom &g, hipStream_t stream, 
     }
     const long wgs = (g.count + Geo::NG - 1) / Geo::NG;
     int *gaveup = g_gaveup[current_device()].get(g.count, stream);
-    hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(kPinThreads), Geo::lds, stream, args, g, pieces, gaveup);
+    hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(kPinThreads), Geo::lds, stream, args, g, pieces, gaveup, options().pin_seed);
     PTV_HIP(hipGetLastError());
     // fibres that hit the level cap (none on anything but periodic data: the kernel returns at once)
     launch_seq_gated((OpId)OP, WEIGHTED, args, g, stream, gaveup);

@@ -113,5 +113,39 @@ __device__ __forceinline__ double group_scan(double v, int t, double *red, doubl
     }
 }
 
+// Nearest seeded knot on either side of every lane's range (PinLane::seed).  last / first: the lane's own last / first seeded
+// knot as (knot << 1 | wall), 0 / INT_MAX when it has none.  Returns through `before` the largest `last` of the lanes below t
+// (0: none -- the fibre start) and through `after` the smallest `first` of the lanes above (INT_MAX: none -- the fibre end).
+// red: 2 * (G / 64) ints of LDS scratch.
+template <int G>
+__device__ __forceinline__ void group_neighbour_seeds(int last, int first, int t, int *red, int &before, int &after) {
+    const int lane = t & 63;
+    int up = last, dn = first;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int a = __shfl_up(up, d), b = __shfl_down(dn, d);
+        if (lane >= d) up = max(up, a);
+        if (lane + d < 64) dn = min(dn, b);
+    }
+    // exclusive: what the lanes strictly below / above hold
+    int ex_up = __shfl_up(up, 1), ex_dn = __shfl_down(dn, 1);
+    if (lane == 0) ex_up = 0;
+    if (lane == 63) ex_dn = 0x7fffffff;
+    if constexpr (G > 64) {
+        const int wave = t >> 6;
+        if (lane == 63) red[wave] = up;                  // the wave's largest
+        if (lane == 0) red[G / 64 + wave] = dn;          // the wave's smallest
+        __syncthreads();
+#pragma unroll
+        for (int w = 0; w < G / 64; w++) {
+            if (w < wave) ex_up = max(ex_up, red[w]);
+            if (w > wave) ex_dn = min(ex_dn, red[G / 64 + w]);
+        }
+        __syncthreads();
+    }
+    before = ex_up;
+    after = ex_dn;
+}
+
 }  // namespace pin
 }  // namespace ptv

@@ -138,6 +138,21 @@ struct PinLane {
                                  // but no knot (the fibre's last) follows its neighbours' pins
     }
 
+    // Knots known before the first level.  Where |y_j - y_{j-1}| > r_{j+1} + 2 r_j + r_{j-1} (4 lambda) the prox keeps the sign of
+    // that jump whatever the rest of the fibre looks like (chunkcore.hpp: bends known a priori), i.e. the string bends at knot j:
+    // upwards -- a convex bend, on the UPPER wall -- for an up-jump, on the lower wall for a down-jump.  Pinning them at once
+    // spares the levels that would find them: on the inputs of DR sweeps at lambda = 0.8 x noise 13 levels become 6-10
+    // (tools/study/pin_study.py).  up / lo: the lane's own such knots; (la_, hl_) / (rb_, hr_): the nearest one on either side of
+    // the lane's range (or the fibre end) and the string's height there.  Call after init(), before the first scan().
+    PTV_PIN_FN void seed(Mask up, Mask lo, int la_, double hl_, int rb_, double hr_) {
+        pinU = pendU = up;
+        pinL = pendL = lo;
+        la = la_;
+        hl = hl_;
+        rb = rb_;
+        hr = hr_;
+    }
+
     template <class Sh>
     PTV_PIN_FN double height(const Sh &sh, int j, bool lower) const {
         return lower ? sh.S(j) - sh.r(j) : sh.S(j) + sh.r(j);

@@ -70,47 +70,66 @@ __global__ __launch_bounds__(kThreads) void scale_kernel(const double *y, double
     for (long i = (long)blockIdx.x * kThreads + threadIdx.x; i < n; i += (long)gridDim.x * kThreads) x[i] = y[i] / divisor;
 }
 
+// Two adjacent elements of a stream as one 16-byte access where the array allows it.  Caller arrays (the *_dev entry points) are
+// only guaranteed 8-byte alignment -- a tensor view that starts at an odd element -- so the host side checks every operand and
+// picks WIDE = false (two 8-byte accesses, same element -> lane map, same results) when any of them is not 16-byte aligned.
+template <bool WIDE>
+__device__ __forceinline__ double2 load_pair(const double *a, long k) {
+    if (WIDE) return reinterpret_cast<const double2 *>(a)[k];
+    return double2{a[2 * k], a[2 * k + 1]};
+}
+template <bool WIDE>
+__device__ __forceinline__ void store_pair(double *a, long k, double2 v) {
+    if (WIDE) {
+        reinterpret_cast<double2 *>(a)[k] = v;
+    } else {
+        a[2 * k] = v.x;
+        a[2 * k + 1] = v.y;
+    }
+}
+static bool aligned16(const void *ptr) { return (reinterpret_cast<uintptr_t>(ptr) & 15u) == 0; }
+
 // The combine kernels stream 2 P + 1 arrays in and P + 1 out (P = 3: eleven streams).  Two adjacent elements per lane (16-byte
 // accesses: half as many, twice as large memory requests per stream) and the term count as a template parameter (pointers in
 // scalar registers, every load of an iteration issued before the first use); PT = 0 is the run-time-P form for P > 4.
 // Arithmetic and its order per element are the reference's (src/TVNDopt.cpp:212-227); the partial sums of the stopping value
 // keep a fixed layout (kReduceBlocks blocks, a fixed element -> lane map): run-to-run deterministic.
-template <int PT>
+template <int PT, bool WIDE>
 __global__ __launch_bounds__(kThreads) void pd_combine_kernel(PtrPack p, PtrPack z, const double *x, double *xo, int Prt,
                                                                 long n, double *partials) {
     const int P = PT > 0 ? PT : Prt;
     double acc = 0;
     const long pairs = n / 2;
     for (long k = (long)blockIdx.x * kThreads + threadIdx.x; k < pairs; k += (long)gridDim.x * kThreads) {
-        const double2 xold = reinterpret_cast<const double2 *>(x)[k];
+        const double2 xold = load_pair<WIDE>(x, k);
         double2 pv[PT > 0 ? PT : 1], zv[PT > 0 ? PT : 1];
         double2 xn{0, 0};
         if (PT > 0) {
 #pragma unroll
-            for (int i = 0; i < PT; i++) pv[i] = reinterpret_cast<const double2 *>(p.v[i])[k];
+            for (int i = 0; i < PT; i++) pv[i] = load_pair<WIDE>(p.v[i], k);
 #pragma unroll
-            for (int i = 0; i < PT; i++) zv[i] = reinterpret_cast<const double2 *>(z.v[i])[k];
+            for (int i = 0; i < PT; i++) zv[i] = load_pair<WIDE>(z.v[i], k);
 #pragma unroll
             for (int i = 0; i < PT; i++) { xn.x += pv[i].x / P; xn.y += pv[i].y / P; }
 #pragma unroll
             for (int i = 0; i < PT; i++) {
                 zv[i].x += xn.x - pv[i].x;
                 zv[i].y += xn.y - pv[i].y;
-                reinterpret_cast<double2 *>(z.v[i])[k] = zv[i];
+                store_pair<WIDE>(z.v[i], k, zv[i]);
             }
         } else {
             for (int i = 0; i < P; i++) {
-                const double2 q = reinterpret_cast<const double2 *>(p.v[i])[k];
+                const double2 q = load_pair<WIDE>(p.v[i], k);
                 xn.x += q.x / P; xn.y += q.y / P;
             }
             for (int i = 0; i < P; i++) {
-                const double2 q = reinterpret_cast<const double2 *>(p.v[i])[k];
-                double2 w = reinterpret_cast<const double2 *>(z.v[i])[k];
+                const double2 q = load_pair<WIDE>(p.v[i], k);
+                double2 w = load_pair<WIDE>(z.v[i], k);
                 w.x += xn.x - q.x; w.y += xn.y - q.y;
-                reinterpret_cast<double2 *>(z.v[i])[k] = w;
+                store_pair<WIDE>(z.v[i], k, w);
             }
         }
-        reinterpret_cast<double2 *>(xo)[k] = xn;
+        store_pair<WIDE>(xo, k, xn);
         acc += fabs(xn.x - xold.x);
         acc += fabs(xn.y - xold.y);
     }
@@ -145,23 +164,23 @@ __global__ __launch_bounds__(kThreads) void pdr_combine_kernel(PtrPack p, PtrPac
     if (threadIdx.x == 0) partials[blockIdx.x] = acc;
 }
 
-template <int D>
+template <int D, bool WIDE>
 __global__ __launch_bounds__(kThreads) void yang_x_kernel(const double *Y, PtrPack U, PtrPack Z, double *X, double rho,
                                                             long n) {
     const long pairs = n / 2;   // two adjacent elements per lane (see pd_combine_kernel)
     for (long i = (long)blockIdx.x * kThreads + threadIdx.x; i < pairs; i += (long)gridDim.x * kThreads) {
-        const double2 y = reinterpret_cast<const double2 *>(Y)[i];
+        const double2 y = load_pair<WIDE>(Y, i);
         double2 u[D], zz[D];
 #pragma unroll
-        for (int k = 0; k < D; k++) u[k] = reinterpret_cast<const double2 *>(U.v[k])[i];
+        for (int k = 0; k < D; k++) u[k] = load_pair<WIDE>(U.v[k], i);
 #pragma unroll
-        for (int k = 0; k < D; k++) zz[k] = reinterpret_cast<const double2 *>(Z.v[k])[i];
+        for (int k = 0; k < D; k++) zz[k] = load_pair<WIDE>(Z.v[k], i);
         double2 su = y, sz = zz[0];
 #pragma unroll
         for (int k = 0; k < D; k++) { su.x += u[k].x; su.y += u[k].y; }
 #pragma unroll
         for (int k = 1; k < D; k++) { sz.x += zz[k].x; sz.y += zz[k].y; }
-        reinterpret_cast<double2 *>(X)[i] = double2{(su.x + rho * sz.x) / (1 + D * rho), (su.y + rho * sz.y) / (1 + D * rho)};
+        store_pair<WIDE>(X, i, double2{(su.x + rho * sz.x) / (1 + D * rho), (su.y + rho * sz.y) / (1 + D * rho)});
     }
     if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
         const long i = n - 1;
@@ -292,13 +311,19 @@ void absdiff_to(const double *a, const double *b, long n, double *partials, doub
 void pd_combine(const PtrPack &p, const PtrPack &z, const double *x, double *xo, int P, long n, double *partials,
                 double *out, hipStream_t s) {
     const dim3 grid(kReduceBlocks), block(kThreads);
+    bool wide = aligned16(x) && aligned16(xo);
+    for (int i = 0; i < P; i++) wide = wide && aligned16(p.v[i]) && aligned16(z.v[i]);
+#define PTV_COMBINE(PT)                                                                                                    \
+    if (wide) hipLaunchKernelGGL((pd_combine_kernel<PT, true>), grid, block, 0, s, p, z, x, xo, P, n, partials);           \
+    else      hipLaunchKernelGGL((pd_combine_kernel<PT, false>), grid, block, 0, s, p, z, x, xo, P, n, partials);
     switch (P) {
-        case 1: hipLaunchKernelGGL(pd_combine_kernel<1>, grid, block, 0, s, p, z, x, xo, P, n, partials); break;
-        case 2: hipLaunchKernelGGL(pd_combine_kernel<2>, grid, block, 0, s, p, z, x, xo, P, n, partials); break;
-        case 3: hipLaunchKernelGGL(pd_combine_kernel<3>, grid, block, 0, s, p, z, x, xo, P, n, partials); break;
-        case 4: hipLaunchKernelGGL(pd_combine_kernel<4>, grid, block, 0, s, p, z, x, xo, P, n, partials); break;
-        default: hipLaunchKernelGGL(pd_combine_kernel<0>, grid, block, 0, s, p, z, x, xo, P, n, partials); break;
+        case 1: PTV_COMBINE(1) break;
+        case 2: PTV_COMBINE(2) break;
+        case 3: PTV_COMBINE(3) break;
+        case 4: PTV_COMBINE(4) break;
+        default: PTV_COMBINE(0) break;
     }
+#undef PTV_COMBINE
     hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(kThreads), 0, s, partials, kReduceBlocks, out);
     PTV_HIP(hipGetLastError());
 }
@@ -343,8 +368,12 @@ void scale_to(const double *y, double *x, double divisor, long n, hipStream_t s)
 
 void yang_x(const double *Y, const PtrPack &U, const PtrPack &Z, double *X, int D, double rho, long n, hipStream_t s) {
     const dim3 grid(grid_for(n, 4096)), block(kThreads);
-    if (D == 2)      hipLaunchKernelGGL(yang_x_kernel<2>, grid, block, 0, s, Y, U, Z, X, rho, n);
-    else if (D == 3) hipLaunchKernelGGL(yang_x_kernel<3>, grid, block, 0, s, Y, U, Z, X, rho, n);
+    bool wide = aligned16(Y) && aligned16(X);
+    for (int k = 0; k < D && k < 3; k++) wide = wide && aligned16(U.v[k]) && aligned16(Z.v[k]);
+    if (D == 2 && wide)      hipLaunchKernelGGL((yang_x_kernel<2, true>), grid, block, 0, s, Y, U, Z, X, rho, n);
+    else if (D == 2)         hipLaunchKernelGGL((yang_x_kernel<2, false>), grid, block, 0, s, Y, U, Z, X, rho, n);
+    else if (D == 3 && wide) hipLaunchKernelGGL((yang_x_kernel<3, true>), grid, block, 0, s, Y, U, Z, X, rho, n);
+    else if (D == 3)         hipLaunchKernelGGL((yang_x_kernel<3, false>), grid, block, 0, s, Y, U, Z, X, rho, n);
     else { set_error("yang_x: D must be 2 or 3"); throw HipFailure{hipErrorInvalidValue}; }
     PTV_HIP(hipGetLastError());
 }

@@ -156,6 +156,11 @@ SolveInfo dr2_norms(size_t M, size_t N, const double *unary, double W1, double W
     const size_t bytes = sizeof(double) * (size_t)n;
     Scratch t(bytes), x(bytes), sp(bytes), v(bytes);
     Scratch partials(sizeof(double) * kReduceBlocks), sums(sizeof(double));
+    {   // seed of the geometry policy: the image's edge statistics, like dr2 -- probes are matched by geometry, and the first array a
+        // TV-L1 sweep of this loop sees is the constant t0 (every edge 0: it would pin the whole solve to the long-piece rung)
+        const int both[2] = {0, 1};
+        policy_probe(unary, nullptr, ns, 2, both, 2, s);
+    }
     sum_to(unary, n, 1, partials.d(), sums.d(), s);
     dr_fill(t.d(), n, 1, sums.d(), 1.0, s);
     auto cols = [&](const double *tin, double *sout, double c_s, double c_t) {   // sout = c_s (t - prox_c(t)) + c_t t

@@ -1950,6 +1950,7 @@ void policy_probe(const double *y, const double *const *weights, const int *ns, 
         const FibreGeom g = fibres_along(ns, nds, dims[k]);
         const double *w = weights ? weights[k] : nullptr;
         if (g.len < 16 || g.count < 1 || (long)g.len * g.count < kProbeMinElements) continue;   // (below 16 samples: the sequential kernel, always)
+        if (g.len < options().chunk_min_len && options().whole != 1) continue;   // (short fibres with the kernel forced: nothing to decide)
         if (st.find_probe(g, w != nullptr)) continue;
         if (!st.probe_dev) st.probe_dev.reset(new Scratch(sizeof(unsigned) * kWords * ChunkScratch::kMaxProbes));
         unsigned *dev = st.probe_dev->as<unsigned>() + kWords * (size_t)st.nprobes;

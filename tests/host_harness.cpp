@@ -188,7 +188,7 @@ struct PinHostShared {
 };
 
 template <int P, bool W, class Key = unsigned>
-static int pin_fibre(const double *y, const double *w, double lam, double *x, int n) {
+static int pin_fibre(const double *y, const double *w, double lam, double *x, int n, bool seeded = false) {
     PinHostShared<P, W, Key> sh;
     const int lanes = (n + P - 1) / P;
     double mean = 0;
@@ -201,6 +201,36 @@ static int pin_fibre(const double *y, const double *w, double lam, double *x, in
     std::vector<PinLane<P, Key>> lane((size_t)lanes);
     (void)W;
     for (int t = 0; t < lanes; t++) lane[(size_t)t].init(n, t, sh);
+    if (seeded) {   // knots known a priori (PinLane::seed; the device kernel's criterion: pin.hip)
+        std::vector<int> wall((size_t)n + 1, -1);
+        for (int j = 1; j < n; j++) {
+            const double d = y[j] - y[j - 1];
+            double thr = 4.0000001 * lam;
+            bool ok = lam > 0.0;
+            if (w) {
+                const double rm = j > 1 ? w[j - 2] : 0.0, r0 = w[j - 1], rp = j + 1 < n ? w[j] : 0.0;
+                thr = 1.0000001 * (rp + 2.0 * r0 + rm);
+                ok = rm >= 0.0 && r0 > 0.0 && rp >= 0.0;
+            }
+            if (ok && std::fabs(d) > thr) wall[(size_t)j] = d > 0 ? 0 : 1;
+        }
+        for (int t = 0; t < lanes; t++) {
+            PinLane<P, Key> &L = lane[(size_t)t];
+            if (t * P >= n) continue;
+            typename PinLane<P, Key>::Mask up = 0, lo = 0;
+            for (int j = L.j0; j < L.j1; j++) {
+                if (wall[(size_t)j] == 0) up |= (typename PinLane<P, Key>::Mask)1 << (j - L.j0);
+                if (wall[(size_t)j] == 1) lo |= (typename PinLane<P, Key>::Mask)1 << (j - L.j0);
+            }
+            int la = 0, rb = n;
+            double hl = sh.S(0), hr = sh.S(n);
+            for (int j = L.j0 - 1; j >= 1; j--)
+                if (wall[(size_t)j] >= 0) { la = j; hl = L.height(sh, j, wall[(size_t)j] != 0); break; }
+            for (int j = L.j1; j < n; j++)
+                if (wall[(size_t)j] >= 0) { rb = j; hr = L.height(sh, j, wall[(size_t)j] != 0); break; }
+            L.seed(up, lo, la, hl, rb, hr);
+        }
+    }
     int levels = 0;
     for (int wall = 0; wall < 2; wall++) {   // one buffer of slots for all levels: the lanes clear what they own (pincore.hpp)
         sh.mx[wall].assign((size_t)lanes + 1, 0.0);
@@ -493,6 +523,15 @@ int host_pin_fibre_threads(const double *y, const double *w, double lam, double 
 // exactly like the lanes of a workgroup: the protocol is the same, its barriers span the grid)
 int host_pin_fibre_long(const double *y, const double *w, double lam, double *x, int n) {
     return w ? pin_fibre<16, true, unsigned long long>(y, w, lam, x, n) : pin_fibre<16, false, unsigned long long>(y, w, lam, x, n);
+}
+
+// the same, starting from the knots known a priori
+int host_pin_fibre_seeded(const double *y, const double *w, double lam, double *x, int n, int P) {
+    if (P == 16) return w ? pin_fibre<16, true>(y, w, lam, x, n, true) : pin_fibre<16, false>(y, w, lam, x, n, true);
+    if (P == 32) return w ? pin_fibre<32, true>(y, w, lam, x, n, true) : pin_fibre<32, false>(y, w, lam, x, n, true);
+    if (P == 64) return w ? pin_fibre<64, true>(y, w, lam, x, n, true) : pin_fibre<64, false>(y, w, lam, x, n, true);
+    if (P == 4) return w ? pin_fibre<4, true>(y, w, lam, x, n, true) : pin_fibre<4, false>(y, w, lam, x, n, true);
+    return -1;
 }
 
 int host_pin_fibre(const double *y, const double *w, double lam, double *x, int n, int P) {

@@ -177,7 +177,7 @@ def test_level_cap_hands_periodic_fibres_to_the_walker(ptv, oracle, rung3):
                 got = ptv.tv1_1d(x, lam)
                 dt = time.perf_counter() - t0
                 assert_close(got, oracle.tv1_hybrid(x, lam), tol=1e-11, what=f"{name} n={n} lam={lam}")
-                assert dt < 2.0, (name, n, lam, dt)
+                assert dt < 15.0, (name, n, lam, dt)   # (uncapped, these data took minutes; the bound is loose: shared / cold devices)
 
 
 def test_level_cap_batched_and_strided(oracle, rung3):
@@ -207,4 +207,4 @@ def test_level_cap_long_fibre_takes_the_next_rung(ptv, oracle, rung3):
         got = ptv.tv1_1d(x, 0.4)
         dt = time.perf_counter() - t0
         assert_close(got, oracle.tv1_hybrid(x, 0.4), tol=1e-11, what=f"{name} n={n}")
-        assert dt < 2.0, (name, dt)
+        assert dt < 15.0, (name, dt)

@@ -20,6 +20,8 @@ def harness():
     lib = C.CDLL(out)
     lib.host_pin_fibre.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_int, C.c_int]
     lib.host_pin_fibre.restype = C.c_int
+    lib.host_pin_fibre_seeded.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_int, C.c_int]
+    lib.host_pin_fibre_seeded.restype = C.c_int
     lib.host_pin_fibre_long.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_int]
     lib.host_pin_fibre_long.restype = C.c_int
     lib.host_pin_fibre_threads.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_int, C.c_int]
@@ -31,6 +33,14 @@ def pin(lib, y, lam, w=None, P=16):
     y = np.ascontiguousarray(y, dtype=np.float64)
     x = np.full(y.size, np.nan)
     levels = lib.host_pin_fibre(y.ctypes.data, None if w is None else w.ctypes.data, lam, x.ctypes.data, y.size, P)
+    assert levels >= 1
+    return x, levels
+
+
+def pin_seeded(lib, y, lam, w=None, P=16):
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    x = np.full(y.size, np.nan)
+    levels = lib.host_pin_fibre_seeded(y.ctypes.data, None if w is None else w.ctypes.data, lam, x.ctypes.data, y.size, P)
     assert levels >= 1
     return x, levels
 
@@ -153,3 +163,32 @@ def test_protocol_under_real_concurrency(harness):
         lb = harness.host_pin_fibre_threads(y.ctypes.data, None if w is None else w.ctypes.data, lam, b.ctypes.data, n, 8)
         assert la == lb, (name, n, lam, la, lb)
         np.testing.assert_array_equal(a, b)
+
+
+def test_seeded_pinning_equals_oracle_and_saves_levels(harness, oracle):
+    """Starting from the knots known a priori (|dy| > 4 lambda, weighted: r_{j+1} + 2 r_j + r_{j-1}; PinLane::seed) the solver returns
+    the same string -- those knots ARE on it -- in fewer levels wherever there are any."""
+    rng = np.random.default_rng(11)
+    saved = total = 0
+    for trial in range(300):
+        name = list(FAMILIES)[trial % len(FAMILIES)]
+        n = int(rng.choice([2, 3, 17, 33, 64, 257, 1000, 1025, 4096, 5000]))
+        y = FAMILIES[name](rng, n)
+        lam = float(10 ** rng.uniform(-2, 0.5))
+        weighted = trial % 3 == 0
+        if weighted:
+            w = lam * rng.uniform(0.2, 1.8, n - 1)
+            if trial % 6 == 0:
+                w[rng.integers(0, n - 1, max(1, n // 10))] = 0.0
+            want = oracle.tv1_weighted(y.copy(), w)
+        else:
+            w = None
+            want = oracle.tv1_linearized(y.copy(), lam)
+        for P in (16, 32) if trial % 2 else (4, 64):
+            x, levels = pin_seeded(harness, y, lam, w=w, P=P)
+            _, plain = pin(harness, y, lam, w=w, P=P)
+            assert np.abs(x - want).max() <= tol(y), (name, n, lam, P, weighted, np.abs(x - want).max())
+            assert levels <= plain + 1, (name, n, lam, P, levels, plain)
+            saved += plain - levels
+            total += plain
+    assert saved > 0.1 * total, (saved, total)
