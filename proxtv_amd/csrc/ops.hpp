@@ -57,14 +57,24 @@ struct NoKeep {
 
 template <int ID> struct Op;
 
-// Streams a sweep touches exactly once (U and the old t of a DR row sweep, the new t it writes) can be marked non-temporal
-// (-DPTV_NT_STREAMS: an experiment switch) so that the one array the row sweep reads twice, s', has the XCD's L2 to itself.
-#ifdef PTV_NT_STREAMS
+// Streams a sweep touches exactly once -- an operand only its epilogue reads, every output -- are marked non-temporal, so that
+// what the sweep reads twice (a window operand the epilogue fetches again, the halo rows two workgroups share) has the XCD's L2
+// to itself.  Measured on the DR row sweep (R s', R U | R s', R t, W t: U, t and the new t non-temporal): 126.3 -> 118.5 us per
+// 4096^2 launch on the 32-fibre tile, 7.67 -> 7.36 ms per solve (profiles/r04_s1_ab_matrix.txt).  -DPTV_NO_NT_STREAMS: plain.
+#ifndef PTV_NO_NT_STREAMS
 __device__ __forceinline__ double ld_once(const double *p) { return __builtin_nontemporal_load(p); }
 __device__ __forceinline__ void st_once(double *p, double v) { __builtin_nontemporal_store(v, p); }
 #else
 __device__ __forceinline__ double ld_once(const double *p) { return *p; }
 __device__ __forceinline__ void st_once(double *p, double v) { *p = v; }
+#endif
+// (the same for the other ops' outputs and epilogue-only operands: -DPTV_NT_ALL, an experiment switch until measured)
+#ifdef PTV_NT_ALL
+__device__ __forceinline__ double ld_once2(const double *p) { return __builtin_nontemporal_load(p); }
+__device__ __forceinline__ void st_once2(double *p, double v) { __builtin_nontemporal_store(v, p); }
+#else
+__device__ __forceinline__ double ld_once2(const double *p) { return *p; }
+__device__ __forceinline__ void st_once2(double *p, double v) { *p = v; }
 #endif
 
 // ---- one-operand inputs: y = a ---------------------------------------------------------------------------------------
@@ -106,9 +116,9 @@ template <> struct Op<OP_PROX> : InA {
     static constexpr bool FUSED = true;
     static constexpr bool USES_Y = false;
     __device__ static __forceinline__ double fuse(double, double x) { return x; }
-    __device__ static __forceinline__ void store_fused(const SweepArgs &p, long idx, double v) { p.o0[idx] = v; }
+    __device__ static __forceinline__ void store_fused(const SweepArgs &p, long idx, double v) { st_once2(p.o0 + idx, v); }
     __device__ static __forceinline__ Ext fetch(const SweepArgs &, long) { return Ext{0, 0}; }
-    __device__ static __forceinline__ void finish(const SweepArgs &p, long idx, const Ext &, double x) { p.o0[idx] = x; }
+    __device__ static __forceinline__ void finish(const SweepArgs &p, long idx, const Ext &, double x) { st_once2(p.o0 + idx, x); }
 };
 
 // DR, columns (a = t): s = t - prox(t) ; s' = 2 s - t          (src/TV2Dopt.cpp:408-411, 539-547)
@@ -120,10 +130,10 @@ template <> struct Op<OP_DR_COL> : InA {
         const double s = y - x;
         return 2 * s - y;
     }
-    __device__ static __forceinline__ void store_fused(const SweepArgs &p, long idx, double v) { p.o0[idx] = v; }
+    __device__ static __forceinline__ void store_fused(const SweepArgs &p, long idx, double v) { st_once2(p.o0 + idx, v); }
     __device__ static __forceinline__ Ext fetch(const SweepArgs &p, long idx) { return Ext{p.a[idx], 0}; }
     __device__ static __forceinline__ void finish(const SweepArgs &p, long idx, const Ext &e, double x) {
-        p.o0[idx] = fuse(e.e0, x);
+        st_once2(p.o0 + idx, fuse(e.e0, x));
     }
 };
 // final projection: s = t - prox(t)                              (src/TV2Dopt.cpp:427)
@@ -132,9 +142,9 @@ template <> struct Op<OP_DR_COL_FINAL> : InA {
     static constexpr bool FUSED = true;
     static constexpr bool USES_Y = true;
     __device__ static __forceinline__ double fuse(double y, double x) { return y - x; }
-    __device__ static __forceinline__ void store_fused(const SweepArgs &p, long idx, double v) { p.o0[idx] = v; }
+    __device__ static __forceinline__ void store_fused(const SweepArgs &p, long idx, double v) { st_once2(p.o0 + idx, v); }
     __device__ static __forceinline__ Ext fetch(const SweepArgs &p, long idx) { return Ext{p.a[idx], 0}; }
-    __device__ static __forceinline__ void finish(const SweepArgs &p, long idx, const Ext &e, double x) { p.o0[idx] = e.e0 - x; }
+    __device__ static __forceinline__ void finish(const SweepArgs &p, long idx, const Ext &e, double x) { st_once2(p.o0 + idx, e.e0 - x); }
 };
 
 // DR, rows (a = s', b = unary, c = t_old, o0 = t_new).  Reference (src/TV2Dopt.cpp:417-422, 514-520):
@@ -172,18 +182,18 @@ template <> struct Op<OP_DR_ROW> : InBminusA, NotFused {
 // 2 R + 2 W, row 2 R + 1 W (7, against 6 + the second read of s' above), and the row sweep's halo is read for ONE array.
 template <> struct Op<OP_DR_COL_V> : InA, NotFused {
     static constexpr unsigned IN_MASK = 3, OUT_MASK = 3;
-    __device__ static __forceinline__ Ext fetch(const SweepArgs &p, long idx) { return Ext{p.a[idx], p.b[idx]}; }
+    __device__ static __forceinline__ Ext fetch(const SweepArgs &p, long idx) { return Ext{p.a[idx], ld_once2(p.b + idx)}; }
     __device__ static __forceinline__ void finish(const SweepArgs &p, long idx, const Ext &e, double x) {
         const double s = e.e0 - x;
         const double sp = 2 * s - e.e0;
-        p.o0[idx] = e.e1 - sp;
-        p.o1[idx] = s;
+        st_once2(p.o0 + idx, e.e1 - sp);
+        st_once2(p.o1 + idx, s);
     }
 };
 template <> struct Op<OP_DR_ROW_V> : InA, NotFused {
     static constexpr unsigned IN_MASK = 3, OUT_MASK = 1;
-    __device__ static __forceinline__ Ext fetch(const SweepArgs &p, long idx) { return Ext{p.b[idx], 0}; }
-    __device__ static __forceinline__ void finish(const SweepArgs &p, long idx, const Ext &e, double x) { p.o0[idx] = e.e0 + x; }
+    __device__ static __forceinline__ Ext fetch(const SweepArgs &p, long idx) { return Ext{ld_once2(p.b + idx), 0}; }
+    __device__ static __forceinline__ void finish(const SweepArgs &p, long idx, const Ext &e, double x) { st_once2(p.o0 + idx, e.e0 + x); }
 };
 // recovery (a = s, b = unary): out = (U - (v - prox(v))) - s                         (src/TV2Dopt.cpp:429-430)
 template <> struct Op<OP_DR_ROW_FINAL> : InBminusA, NotFused {
@@ -192,7 +202,7 @@ template <> struct Op<OP_DR_ROW_FINAL> : InBminusA, NotFused {
     __device__ static __forceinline__ void finish(const SweepArgs &p, long idx, const Ext &e, double x) {
         const double y = e.e0 - e.e1;
         const double tb = e.e0 - (y - x);
-        p.o0[idx] = tb - e.e1;
+        st_once2(p.o0 + idx, tb - e.e1);
     }
 };
 // weighted recovery: tbw = (v - prox(v)) - U ; out = -s - tbw                          (src/TV2DWopt.cpp:124-126, 218)
@@ -202,7 +212,7 @@ template <> struct Op<OP_DRW_ROW_FINAL> : InBminusA, NotFused {
     __device__ static __forceinline__ void finish(const SweepArgs &p, long idx, const Ext &e, double x) {
         const double y = e.e0 - e.e1;
         const double tb = (y - x) - e.e0;
-        p.o0[idx] = -e.e1 - tb;
+        st_once2(p.o0 + idx, -e.e1 - tb);
     }
 };
 
@@ -211,8 +221,8 @@ template <> struct Op<OP_PD2_A> : InAplusB, NotFused {
     static constexpr unsigned IN_MASK = 3, OUT_MASK = 3;
     __device__ static __forceinline__ Ext fetch(const SweepArgs &p, long idx) { return Ext{p.a[idx], p.b[idx]}; }
     __device__ static __forceinline__ void finish(const SweepArgs &p, long idx, const Ext &e, double x) {
-        p.o0[idx] = x;
-        p.o1[idx] = e.e1 + (e.e0 - x);
+        st_once2(p.o0 + idx, x);
+        st_once2(p.o1 + idx, e.e1 + (e.e0 - x));
     }
 };
 // Dykstra term 2 (a = z, b = q_in, o0 = x, o1 = q_out): x = prox(z + q) ; q += z - x    (src/TV2Dopt.cpp:234-263)
@@ -220,8 +230,8 @@ template <> struct Op<OP_PD2_B> : InAplusB, NotFused {
     static constexpr unsigned IN_MASK = 3, OUT_MASK = 3;
     __device__ static __forceinline__ Ext fetch(const SweepArgs &p, long idx) { return Ext{p.a[idx], p.b[idx]}; }
     __device__ static __forceinline__ void finish(const SweepArgs &p, long idx, const Ext &e, double x) {
-        p.o0[idx] = x;
-        p.o1[idx] = e.e1 + (e.e0 - x);
+        st_once2(p.o0 + idx, x);
+        st_once2(p.o1 + idx, e.e1 + (e.e0 - x));
     }
 };
 
@@ -235,8 +245,8 @@ template <> struct Op<OP_YANG> : NotFused, NoKeep {
     __device__ static __forceinline__ double load_y(const SweepArgs &p, long idx) { return -1. / p.s0 * p.b[idx] + p.a[idx]; }
     __device__ static __forceinline__ Ext fetch(const SweepArgs &p, long idx) { return Ext{p.a[idx], p.b[idx]}; }
     __device__ static __forceinline__ void finish(const SweepArgs &p, long idx, const Ext &e, double x) {
-        p.o0[idx] = x;
-        p.o1[idx] = e.e1 + p.s0 * (x - e.e0);
+        st_once2(p.o0 + idx, x);
+        st_once2(p.o1 + idx, e.e1 + p.s0 * (x - e.e0));
     }
 };
 

@@ -303,7 +303,7 @@ template <int OP, bool WEIGHTED, bool TRANSPOSED, int C, int NW, int H, bool ROU
 __global__ __launch_bounds__(64 * NW, SHORT ? 16 / NW : (FW < 64 ? ((WEIGHTED ? 8 : 16) / NW) : ((WEIGHTED || H > 16 || NW > 8) ? NW / 4 : NW / 2))) void sweep_chunk_kernel(SweepArgs p, FibreGeom g, ChunkPlan plan,
                                                                                    link_t *code_mine, link_t *code_next,
                                                                                    int *failflags) {
-    static_assert(FW == 64 || (FW == 32 && !TRANSPOSED && !ROUNDS && !SHORT && H <= C), "the 32-fibre tile is a plain strided tile");
+    static_assert(FW == 64 || (FW == 32 && !TRANSPOSED && !SHORT && H <= C), "the 32-fibre tile is a strided short-zone tile");
     constexpr int CPW = 64 / FW;            // chunks per wave
     constexpr int NCH = NW * CPW;           // chunks per block
     constexpr int PITCH = TRANSPOSED ? 65 : FW;
@@ -336,13 +336,13 @@ __global__ __launch_bounds__(64 * NW, SHORT ? 16 / NW : (FW < 64 ? ((WEIGHTED ? 
     link_t began_reg = kNoCheck;
     // the walk's reciprocal table (walk_asm.hpp: walk_interior_asm_tab), after the stash row: the strided short-zone tiles only
     // (the pitch-65 tile has no LDS left for it at two workgroups per CU)
-#ifdef PTV_WALK_TABLE
+#ifndef PTV_NO_WALK_TABLE   // (the switch stays for A/B builds: the walk then divides with v_rcp_f64 + Newton + residual)
     constexpr bool TAB = (WEIGHTED || !TRANSPOSED) && !SHORT && H <= kWarm && NW <= 8 && (ROUNDS || H + C + T < kRecipTable);
 #else
     constexpr bool TAB = false;
 #endif
     constexpr int TS = ROUNDS ? kRecipTableRobust : kRecipTable;
-    double *rtab = reinterpret_cast<double *>(stash + 64);
+    double *rtab = reinterpret_cast<double *>(stash + FW);
     if constexpr (TAB) {
         if (threadIdx.x < TS) rtab[threadIdx.x] = threadIdx.x ? 1.0 / (double)threadIdx.x : 0.0;   // (visible after the staging barrier)
     }
@@ -382,7 +382,12 @@ __global__ __launch_bounds__(64 * NW, SHORT ? 16 / NW : (FW < 64 ? ((WEIGHTED ? 
     // share of the thread) unless that would not fit the register budget: transposed sweeps stage in two batches (three
     // for two-operand inputs: 48 live doubles spill otherwise), two-operand strided sweeps in two.
     constexpr int NB = TRANSPOSED ? (Op<OP>::NIN > 1 ? (NST + 2) / 3 : (NST + 1) / 2) : (Op<OP>::NIN > 1 ? (NST + 1) / 2 : NST);
-    double kept[KEEP ? C : 1];
+    // (PTV_KEEP_N: how many of a thread's C own rows keep the operand -- the rest is fetched again; an experiment knob: all C spill)
+#ifndef PTV_KEEP_N
+#define PTV_KEEP_N 16
+#endif
+    constexpr int KN = KEEP ? (PTV_KEEP_N < C ? PTV_KEEP_N : C) : 0;
+    double kept[KEEP ? KN : 1];
     auto stage = [&](int q) {
         const int cs_wg = q * NCH * C;
         const int lo = cs_wg - HA, hi = min(len, cs_wg + NCH * C + TA);
@@ -430,7 +435,7 @@ __global__ __launch_bounds__(64 * NW, SHORT ? 16 / NW : (FW < 64 ? ((WEIGHTED ? 
                     Yp[(r - lo) * PITCH + col] = Op<OP>::y_of(p, s0[v], s1[v]);
                     if (WEIGHTED) Wp[(r - lo) * PITCH + col] = sw[v];
                 }
-                if (KEEP && u >= HA / NCH && u < HA / NCH + C) kept[KEEP ? u - HA / NCH : 0] = s1[v];
+                if (KEEP && u >= HA / NCH && u < HA / NCH + KN) kept[(KEEP && u >= HA / NCH && u < HA / NCH + KN) ? u - HA / NCH : 0] = s1[v];
             }
         }
     };
@@ -564,12 +569,12 @@ __global__ __launch_bounds__(64 * NW, SHORT ? 16 / NW : (FW < 64 ? ((WEIGHTED ? 
         }
         int wlo = cs_wg;   // first row this lane may write
         if (GUARD) {
-            static_assert(!GUARD || FW == 64, "the write guard keeps one lane mask per chunk = wave");
+            // one lane mask per wave: FW = 64 -> the wave's chunk ; FW = 32 -> its two chunks, the later one in the high half
             const unsigned long long mask = __ballot(bad);
             if (lane == 0) unproven[wave] = mask;
             __syncthreads();
-            for (int k = wave - 1; k >= 0; k--)
-                if ((unproven[k] >> lane) & 1ull) {
+            for (int k = ch - 1; k >= 0; k--)
+                if ((unproven[k / CPW] >> ((k % CPW) * FW + fl)) & 1ull) {
                     wlo = cs_wg + k * C;
                     break;
                 }
@@ -591,7 +596,7 @@ __global__ __launch_bounds__(64 * NW, SHORT ? 16 / NW : (FW < 64 ? ((WEIGHTED ? 
 #pragma unroll
                         for (int u = 0; u < UL; u++) {
                             const int k = min(cs_wg + ch + NCH * (m0 + u), ce_wg - 1);
-                            if (KEEP) ex[u] = Op<OP>::fetch_rest(p, base + (long)k * g.inc, kept[KEEP ? m0 + u : 0]);
+                            if (KEEP && m0 + u < KN) ex[u] = Op<OP>::fetch_rest(p, base + (long)k * g.inc, kept[(KEEP && m0 + u < KN) ? m0 + u : 0]);
                             else if (PREFETCH && m0 == 0) ex[u] = pre[PREFETCH ? u : 0];
                             else if (!Op<OP>::FUSED) ex[u] = Op<OP>::fetch(p, base + (long)k * g.inc);
                         }
@@ -711,7 +716,7 @@ __global__ __launch_bounds__(64 * kAlongWaves) void sweep_along_kernel(SweepArgs
     // ROBUST: what a wave's last lane ends up with, for the first lane of the next wave: [kAlongWaves] codes, [kAlongWaves] "ready"
     unsigned *xwave = reinterpret_cast<unsigned *>(reinterpret_cast<double *>(smem) + (size_t)kAlongWaves * NG * (ROWS + 2) * (WEIGHTED ? 2 : 1));
     // plain instantiation: the pull-backs of the walk divide by table (walk_asm.hpp: walk_interior_asm_tab); one table per workgroup
-#ifdef PTV_WALK_TABLE
+#ifndef PTV_NO_WALK_TABLE   // (the switch stays for A/B builds: the walk then divides with v_rcp_f64 + Newton + residual)
     constexpr bool TAB = H <= kWarm && (ROBUST || H + kAlongC + T < kRecipTable);
 #else
     constexpr bool TAB = false;
@@ -1640,12 +1645,12 @@ void launch_chunk_h(const SweepArgs &args, const FibreGeom &g, hipStream_t strea
     const int WQ = (plan.Q + plan.qpw - 1) / plan.qpw;
     plan.dirty = chunk_state().next_dirty(stream);
     plan.xlink = chunk_state().xlink_for((size_t)WQ * (size_t)g.count, stream);
-#ifdef PTV_WALK_TABLE
+#ifndef PTV_NO_WALK_TABLE   // (the switch stays for A/B builds: the walk then divides with v_rcp_f64 + Newton + residual)
     constexpr size_t tab_bytes = ((WEIGHTED || !TRANSPOSED) && !SHORT && H <= kWarm && NW <= 8) ? sizeof(double) * (ROBUST ? kRecipTableRobust : kRecipTable) : 0;
 #else
     constexpr size_t tab_bytes = 0;
 #endif
-    constexpr size_t lds = sizeof(double) * PITCH * (size_t)ROWS * (WEIGHTED ? 2 : 1) + sizeof(link_t) * ((NCH + 2) * FW + (TRANSPOSED ? 0 : 64) + 4 + 2 * NW) + tab_bytes;
+    constexpr size_t lds = sizeof(double) * PITCH * (size_t)ROWS * (WEIGHTED ? 2 : 1) + sizeof(link_t) * ((NCH + 2) * FW + (TRANSPOSED ? 0 : FW) + 4 + 2 * NW) + tab_bytes;
     static_assert(WEIGHTED || H > kWarm || NW > 8 || 2 * lds <= 160 * 1024, "the short-zone geometry is meant to run two workgroups per CU");
     static_assert(FW == 64 || (WEIGHTED ? 2 : 4) * lds <= 160 * 1024, "the 32-fibre tile is meant to run four workgroups per CU (weighted: two)");
     if (SHORT && g.len > NCH * C) {
@@ -1857,11 +1862,13 @@ void launch_chunk(const SweepArgs &args, const FibreGeom &g, hipStream_t stream,
     }
     else if constexpr (!WEIGHTED) {
         if (mode == 2)      launch_chunk_h<OP, false, TRANSPOSED, kWarmLong>(args, g, stream, fam, 0);
+        else if (mode == 1 && !TRANSPOSED && options().tile == 1) launch_chunk_h<OP, false, false, kWarm, true, 16, 4, kTail, false, 32>(args, g, stream, fam, rounds);
         else if (mode == 1) launch_chunk_h<OP, false, TRANSPOSED, kWarm, true>(args, g, stream, fam, rounds);
         else if (!TRANSPOSED && options().tile == 1) launch_chunk_h<OP, false, false, kWarm, false, 16, 4, kTail, false, 32>(args, g, stream, fam, 0);
         else                launch_chunk_h<OP, false, TRANSPOSED, kWarm>(args, g, stream, fam, 0);
     } else {
-        if (mode == 1) launch_chunk_h<OP, true, TRANSPOSED, kWarm, true>(args, g, stream, fam, rounds);
+        if (mode == 1 && !TRANSPOSED && options().tile == 1) launch_chunk_h<OP, true, false, kWarm, true, 16, 4, kTail, false, 32>(args, g, stream, fam, rounds);
+        else if (mode == 1) launch_chunk_h<OP, true, TRANSPOSED, kWarm, true>(args, g, stream, fam, rounds);
         else if (!TRANSPOSED && options().tile == 1) launch_chunk_h<OP, true, false, kWarm, false, 16, 4, kTail, false, 32>(args, g, stream, fam, 0);
         else           launch_chunk_h<OP, true, TRANSPOSED, kWarm>(args, g, stream, fam, 0);
     }

@@ -165,7 +165,8 @@ __device__ __forceinline__ void walk_interior_asm(Walker &w, ChunkRec &rec, cons
 // (walker_run through TailSource, which divides), exactly as a lane that reaches the window's end does.
 // The read is issued first in the trip and used last: the corrections moved behind the bend's bookkeeping (different lanes:
 // a lane either bends or is pulled back), so one wait covers all four LDS reads of a trip.
-// STAGED FOR THE NEXT ROUND -- assembles, not yet run on a GPU.
+// Round 4, measured (same box, alternating processes; profiles/r04_s1_ab_matrix.txt): DR column sweep 88.3 -> 83.3 us, plain
+// sweeps 91.5 -> 86.2 (columns) / 93.4 -> 87.6 us (rows), 4096^2 DR solve 7.67 -> 7.49 ms at lambda = 0.1, 12.9 -> 12.45 ms at 0.5.
 constexpr int kRecipTable = 48;        // plain geometries: zone 16 + chunk 17 + look-ahead 8 = 41 rows at most
 constexpr int kRecipTableRobust = 64;
 
@@ -466,7 +467,6 @@ __device__ __forceinline__ void walk_interior_asm_w(Walker &w, ChunkRec &rec, co
 }
 
 // The weighted walk with the table (see walk_interior_asm_tab): same reordering, same exit where the table ends.
-// STAGED FOR THE NEXT ROUND -- assembles, not yet run on a GPU.
 template <int PITCH, bool SPAN_EXIT, class Win>
 __device__ __forceinline__ void walk_interior_asm_w_tab(Walker &w, ChunkRec &rec, const Win &win, int lim, int cs, int ce, unsigned rtab) {
     if (w.i >= lim || rec.done) return;

@@ -20,5 +20,13 @@ s1)   # the 32-fibre tile, the table walk, non-temporal streams: parity first, t
   PROXTV_TILE=0 python tools/wg_trace.py 0.1 > $OUT/wg_trace_tile64.txt 2>&1
   grep "^##\|^# mean" $OUT/wg_trace_tile32.txt $OUT/wg_trace_tile64.txt
   ;;
+s2)   # new defaults (32-fibre tiles on rungs 0 and 1, table walk, non-temporal streams, a-priori pins): the whole suite, then A/B
+  timeout 900 python -m pytest tests -m gpu -x -q > $OUT/pytest_default.log 2>&1; tail -3 $OUT/pytest_default.log
+  ab --reps 7 --rounds 2 --cases c2,c2@0.3,c2@0.5,c3,pd2,c4,c4y base t0,tile=0 > $OUT/ab_tiles.txt 2>&1; cat $OUT/ab_tiles.txt
+  ab --reps 5 --rounds 2 --cases c2@0.7,c2@0.8,c2@1.0,c2@3.0 base noseed,pin_seed=0 > $OUT/ab_pins.txt 2>&1; cat $OUT/ab_pins.txt
+  ab --reps 7 --rounds 2 --cases c2,c2@0.5,c3 base ntall=$W/lib_ntall.so nont=$W/lib_nont.so > $OUT/ab_nt.txt 2>&1; cat $OUT/ab_nt.txt
+  ab --reps 7 --rounds 2 --cases c2 base keep4=$W/lib_keep4.so keep8=$W/lib_keep8.so keep16=$W/lib_keep.so > $OUT/ab_keep.txt 2>&1; cat $OUT/ab_keep.txt
+  QUICK=1 bash tools/collect_profiles.sh r04q > $OUT/profiles_quick.log 2>&1; tail -4 $OUT/profiles_quick.log
+  ;;
 *) echo "unknown session $S"; exit 2;;
 esac
