@@ -39,6 +39,7 @@ constexpr OptionEntry kOptionTable[] = {
     {"seed_mid_e4", &Options::seed_mid_e4},
     {"pin", &Options::pin},
     {"pin_seed", &Options::pin_seed},
+    {"pin_overlap", &Options::pin_overlap},
     {"whole", &Options::whole},
     {"chunk_min_len", &Options::chunk_min_len},
     {"xlink", &Options::xlink},
@@ -142,6 +143,8 @@ void ensure_device() {
 
 struct ThreadState {
     hipStream_t stream = nullptr;
+    hipStream_t helper = nullptr;            // second stream of this thread (StreamFork)
+    hipEvent_t fork = nullptr, join = nullptr;
     std::multimap<size_t, void *> free_blocks;
     size_t cached = 0;   // bytes in free_blocks
 };
@@ -171,6 +174,24 @@ hipStream_t thread_stream() {
     ThreadState &t = g_ts.dev[current_device()];
     if (!t.stream) PTV_HIP(hipStreamCreateWithFlags(&t.stream, hipStreamNonBlocking));
     return t.stream;
+}
+
+// A helper stream ordered after everything enqueued on `main` so far; join() orders `main` after everything enqueued on the helper.
+StreamFork::StreamFork(hipStream_t main) : main_(main) {
+    ThreadState &t = g_ts.dev[current_device()];
+    if (!t.helper) {
+        PTV_HIP(hipStreamCreateWithFlags(&t.helper, hipStreamNonBlocking));
+        PTV_HIP(hipEventCreateWithFlags(&t.fork, hipEventDisableTiming));
+        PTV_HIP(hipEventCreateWithFlags(&t.join, hipEventDisableTiming));
+    }
+    helper_ = t.helper;
+    PTV_HIP(hipEventRecord(t.fork, main_));
+    PTV_HIP(hipStreamWaitEvent(helper_, t.fork, 0));
+}
+void StreamFork::join() {
+    ThreadState &t = g_ts.dev[current_device()];
+    PTV_HIP(hipEventRecord(t.join, helper_));
+    PTV_HIP(hipStreamWaitEvent(main_, t.join, 0));
 }
 
 // ---- scratch pool --------------------------------------------------------------------------------------------------

@@ -50,6 +50,8 @@ struct Options {
     int seed_row_along_e4 = 0;   // tuning aid: kSeedRowAlong (policy.hpp) in units of 1e-4 ; 0 = built in
     int seed_noisy_e4 = 0, seed_mid_e4 = 0;   // tuning aid: the policy seed's thresholds (policy.hpp) in units of 1e-4 ; 0 = built in
     int pin = 1;              // geometry rung 3: the pinning solver (pin.hip) where it applies; 0 = global-memory chunks
+    int pin_overlap = 1;      // strided sweeps of the pinning solver: the transpositions of one range of fibres run on a second stream
+                              // under the levels of another (0: one after the other on one stream)
     int pin_seed = 1;         // the pinning solver starts from the knots known a priori (|dy| > 4 lambda) instead of the fibre ends alone
     int whole = 1;            // fibres of 16 .. chunk_min_len samples: 1 = by length and data (sequential up to 32 samples; one block of the
                               // chunk kernel on noisy data, else whole fibres in LDS), 2 = the whole-fibre-in-LDS kernel, 0 = the sequential kernel
@@ -86,6 +88,17 @@ void warm_pinlong();
 void warm_pointwise();
 void warm_tv2();
 hipStream_t thread_stream();
+// Two-stream sections (a memory-bound pass of one range of fibres under the compute-bound pass of another): a per-thread helper
+// stream, ordered after what `main` holds at construction; join() makes `main` wait for what the helper holds then.
+class StreamFork {
+  public:
+    explicit StreamFork(hipStream_t main);
+    hipStream_t helper() const { return helper_; }
+    void join();
+
+  private:
+    hipStream_t main_, helper_ = nullptr;
+};
 
 // ---- HBM scratch pool ------------------------------------------------------------------------------------------
 // Per-thread, per-device cache of device allocations: solvers ask for a handful of image-sized arrays per call and

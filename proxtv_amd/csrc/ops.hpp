@@ -68,14 +68,17 @@ __device__ __forceinline__ void st_once(double *p, double v) { __builtin_nontemp
 __device__ __forceinline__ double ld_once(const double *p) { return *p; }
 __device__ __forceinline__ void st_once(double *p, double v) { *p = v; }
 #endif
-// (the same for the other ops' outputs and epilogue-only operands: -DPTV_NT_ALL, an experiment switch until measured)
-#ifdef PTV_NT_ALL
-__device__ __forceinline__ double ld_once2(const double *p) { return __builtin_nontemporal_load(p); }
-__device__ __forceinline__ void st_once2(double *p, double v) { __builtin_nontemporal_store(v, p); }
+// The other ops' outputs and epilogue-only operands likewise (measured apart: 7.10 -> 7.01 ms at lambda = 0.1, 11.91 -> 11.68 at 0.5,
+// weighted unchanged).  -DPTV_NO_NT_ALL: plain.
+#ifndef PTV_NO_NT_ALL
+__device__ __forceinline__ double ld_once2(const double *p) { return ld_once(p); }
+__device__ __forceinline__ void st_once2(double *p, double v) { st_once(p, v); }
 #else
 __device__ __forceinline__ double ld_once2(const double *p) { return *p; }
 __device__ __forceinline__ void st_once2(double *p, double v) { *p = v; }
 #endif
+
+template <int ID> struct Op;
 
 // ---- one-operand inputs: y = a ---------------------------------------------------------------------------------------
 struct InA : NoKeep {

@@ -49,7 +49,9 @@ inline bool pin_supports(OpId op, bool weighted, const FibreGeom &g, double lam)
 // Returns true when the sweep is done (fibres that hit the level cap included: launch_seq_gated finishes them on the
 // stream), false when NOTHING was written and the caller has to run another rung: the grid-wide variant found that its
 // instantiation does not fit the device after all, or hit the level cap.
-bool launch_pin(OpId op, bool weighted, const SweepArgs &args, const FibreGeom &g, hipStream_t stream, int *pieces = nullptr);
+// seeds: start the levels from the knots known a priori (pincore.hpp: PinLane::seed) -- finding them costs about a third of a level,
+// so the caller says no where the input has none (the one-workgroup kernels only; the grid-wide variant starts from the fibre ends)
+bool launch_pin(OpId op, bool weighted, const SweepArgs &args, const FibreGeom &g, hipStream_t stream, int *pieces = nullptr, bool seeds = true);
 // (the grid-wide variant behind it, for fibres beyond kPinMaxLen: pinlong.hip)
 bool launch_pin_long(OpId op, bool weighted, const SweepArgs &args, const FibreGeom &g, hipStream_t stream, int *pieces);
 

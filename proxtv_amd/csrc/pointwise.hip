@@ -405,19 +405,22 @@ void ccp_step(const CcpArgs &a, bool first, hipStream_t s) {
 }
 
 namespace {
-__global__ __launch_bounds__(256) void slab_transpose_kernel(const double *in, double *out, long rows, long cols) {
+// element (r, c) of a rows x cols block at in[r + ld_in c] -> out[c + ld_out r]; slab z of the grid is slab_in / slab_out elements on
+__global__ __launch_bounds__(256) void slab_transpose_kernel(const double *in, double *out, long rows, long cols, long ld_in, long ld_out,
+                                                             long slab_in, long slab_out) {
     __shared__ double tile[32][33];
-    const long slab = (long)blockIdx.z * rows * cols;
+    in += (long)blockIdx.z * slab_in;
+    out += (long)blockIdx.z * slab_out;
     const long r0 = (long)blockIdx.x * 32, c0 = (long)blockIdx.y * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
     for (int k = ty; k < 32; k += 8) {
         const long r = r0 + tx, c = c0 + k;
-        if (r < rows && c < cols) tile[k][tx] = in[slab + r + rows * c];
+        if (r < rows && c < cols) tile[k][tx] = in[r + ld_in * c];
     }
     __syncthreads();
     for (int k = ty; k < 32; k += 8) {
         const long c = c0 + tx, r = r0 + k;
-        if (r < rows && c < cols) out[slab + c + cols * r] = tile[tx][k];
+        if (r < rows && c < cols) out[c + ld_out * r] = tile[tx][k];
     }
 }
 }  // namespace
@@ -425,7 +428,15 @@ __global__ __launch_bounds__(256) void slab_transpose_kernel(const double *in, d
 void slab_transpose(const double *in, double *out, long rows, long cols, long slabs, hipStream_t s) {
     if (rows <= 0 || cols <= 0 || slabs <= 0) return;
     const dim3 grid((unsigned)((rows + 31) / 32), (unsigned)((cols + 31) / 32), (unsigned)slabs);
-    hipLaunchKernelGGL(slab_transpose_kernel, grid, dim3(256), 0, s, in, out, rows, cols);
+    hipLaunchKernelGGL(slab_transpose_kernel, grid, dim3(256), 0, s, in, out, rows, cols, rows, cols, rows * cols, rows * cols);
+    PTV_HIP(hipGetLastError());
+}
+
+// a rows x cols block of a larger column-major array (leading dimension ld_in) into a block of another (ld_out)
+void block_transpose(const double *in, double *out, long rows, long cols, long ld_in, long ld_out, hipStream_t s) {
+    if (rows <= 0 || cols <= 0) return;
+    const dim3 grid((unsigned)((rows + 31) / 32), (unsigned)((cols + 31) / 32), 1u);
+    hipLaunchKernelGGL(slab_transpose_kernel, grid, dim3(256), 0, s, in, out, rows, cols, ld_in, ld_out, 0L, 0L);
     PTV_HIP(hipGetLastError());
 }
 
@@ -591,9 +602,10 @@ void TransposeCache::forget(const double *p) {
         if (entries[k].src == p) entries.erase(entries.begin() + (long)k);
 }
 
-TransposedOperands::TransposedOperands(const SweepArgs &args, unsigned in_mask, unsigned out_mask, const FibreGeom &g, hipStream_t s)
+TransposedOperands::TransposedOperands(const SweepArgs &args, unsigned in_mask, unsigned out_mask, const FibreGeom &g, hipStream_t s,
+                                       bool by_parts)
     : orig_(args), t_(args), g_(g), s_(s), out_mask_(out_mask), slabs_(g.count / g.inc),
-      bytes_(sizeof(double) * (size_t)g.count * (size_t)g.len) {
+      bytes_(sizeof(double) * (size_t)g.count * (size_t)g.len), by_parts_(by_parts) {
     if (in_mask & 1u) t_.a = input(args.a, ia_, g.len);
     if (in_mask & 2u) t_.b = input(args.b, ib_, g.len);
     if (in_mask & 4u) t_.c = input(args.c, ic_, g.len);
@@ -607,21 +619,33 @@ const double *TransposedOperands::input(const double *src, std::unique_ptr<Scrat
     if (cache.active)
         if (Scratch *c = cache.find(src, shape(len))) return c->d();
     std::unique_ptr<Scratch> copy(new Scratch(sizeof(double) * (size_t)g_.count * (size_t)len));
-    slab_transpose(src, copy->d(), g_.inc, len, slabs_, s_);
+    if (by_parts_) pending_.push_back(Pending{src, copy->d(), len});   // transposed range by range: stage_part()
+    else slab_transpose(src, copy->d(), g_.inc, len, slabs_, s_);
     const double *p = copy->d();
     if (cache.active) cache.remember(src, shape(len), std::move(copy));
     else own = std::move(copy);
     return p;
 }
 
+// by_parts (one slab): fibres [j0, j1) of every input that was not at hand in transposed form, on stream q
+void TransposedOperands::stage_part(long j0, long j1, hipStream_t q) {
+    for (const Pending &p : pending_) block_transpose(p.src + j0, p.dst + j0 * p.len, j1 - j0, p.len, g_.inc, p.len, q);
+}
+
+// ... and the outputs of those fibres back to where the caller wants them
+void TransposedOperands::finish_part(long j0, long j1, hipStream_t q) {
+    if (out_mask_ & 1u) block_transpose(o0_->d() + j0 * g_.len, orig_.o0 + j0, g_.len, j1 - j0, g_.len, g_.inc, q);
+    if (out_mask_ & 2u) block_transpose(o1_->d() + j0 * g_.len, orig_.o1 + j0, g_.len, j1 - j0, g_.len, g_.inc, q);
+}
+
 void TransposedOperands::finish() {
     TransposeCache &cache = transpose_cache();
     if (out_mask_ & 1u) {
-        slab_transpose(o0_->d(), orig_.o0, g_.len, g_.inc, slabs_, s_);
+        if (!by_parts_) slab_transpose(o0_->d(), orig_.o0, g_.len, g_.inc, slabs_, s_);
         if (cache.active) cache.remember(orig_.o0, shape(g_.len), std::move(o0_));   // (what was just written, in the form the next strided sweep wants)
     }
     if (out_mask_ & 2u) {
-        slab_transpose(o1_->d(), orig_.o1, g_.len, g_.inc, slabs_, s_);
+        if (!by_parts_) slab_transpose(o1_->d(), orig_.o1, g_.len, g_.inc, slabs_, s_);
         if (cache.active) cache.remember(orig_.o1, shape(g_.len), std::move(o1_));
     }
 }

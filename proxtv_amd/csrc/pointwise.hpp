@@ -36,6 +36,7 @@ void lincomb(double *out, const double *a, double ca, const double *b, double cb
 // Sweeps along a strided dimension use it to run as dimension-0 sweeps on transposed copies: fibre j = slab * inc + off
 // sits at j * len after the transposition of every (inc x len) slab.
 void slab_transpose(const double *in, double *out, long rows, long cols, long slabs, hipStream_t s);
+void block_transpose(const double *in, double *out, long rows, long cols, long ld_in, long ld_out, hipStream_t s);
 // Edge statistics of an array along one dimension -- what the geometry policy (sweep.hip) is seeded with: a histogram of
 // |y[e + inc] - y[e]| (weighted: divided by the edge's penalty) over a fixed sample of edges, kProbeBins bins of an eighth
 // of an octave each (bin = biased exponent and three mantissa bits of the value, clamped to the window that starts at 2^-60),

@@ -58,6 +58,8 @@ constexpr int kQuietSolves = 16;    // one-sweep solves between explorations
 // to the last bit; without it the hill climb below starts from the seed instead of exploring from scratch.
 constexpr double kSeedNoisy = 0.45;   // f at or above: rung 0
 constexpr double kSeedMid = 0.03;     // f at or above: rung 1 ; below: rung 3  (as sampled -- edges in the threshold's own eighth-octave bin do not count -- lambda = 0.7 on unit noise gives 0.034, 0.75-0.8 gives 0.022; at 0.8: 35.0 ms on rung 1, 34.0 on rung 3)
+constexpr double kSeedPins = 0.001;    // rung 3: the pinning solver searches for knots known a priori when f is at least this (lambda = 1 on unit noise: 0.005,
+                                       // 29.4 against 30.0 ms per 4096^2 DR solve; 0.8: 25.3 against 31.8; 3: none to find, 18.3 against 19.1 with the search)
 constexpr double kSeedFlat = 0.02;     // more than this fraction of the sampled 16-edge stretches (all but) flat at lambda: rung 3
 constexpr double kSeedRowAlong = 0.06; // rung 1, strided sweeps, f below (lambda >= 0.65 on unit noise): through transposed copies and the along-fibre kernel
 // DR2L1W: the second form of the iteration (ops.hpp, OP_DR_COL_V) pays below this certain fraction only -- the weighted column

@@ -1836,7 +1836,10 @@ void launch_chunk(const SweepArgs &args, const FibreGeom &g, hipStream_t stream,
         }
         // false: the grid-wide variant wrote nothing (its instantiation does not fit this device at once after all, or it
         // hit the level cap on periodic data) -- the global-memory chunks below take the sweep
-        pinned_done = launch_pin((OpId)OP, WEIGHTED, args, g, stream, pieces);
+        // (knots known a priori: none to be had where the sampled input shows no edge above 4 lambda -- lambda = 3 on unit noise: the
+        // search costs 3-6 % of such a sweep; unsampled inputs search)
+        const bool seeds = options().pin_seed && (seed_f < 0.0 || seed_f >= kSeedPins);
+        pinned_done = launch_pin((OpId)OP, WEIGHTED, args, g, stream, pieces, seeds);
         if (pinned_done && measure) pl.chunks_done += (long)g.len * g.count;
     }
     if (pinned_done) {}

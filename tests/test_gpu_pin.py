@@ -208,3 +208,28 @@ def test_level_cap_long_fibre_takes_the_next_rung(ptv, oracle, rung3):
         dt = time.perf_counter() - t0
         assert_close(got, oracle.tv1_hybrid(x, 0.4), tol=1e-11, what=f"{name} n={n}")
         assert dt < 15.0, (name, dt)
+
+
+@pytest.mark.parametrize("seed,overlap", [(1, 1), (0, 1), (1, 0), (0, 0)])
+def test_a_priori_pins_and_overlapped_transpositions(ptv, clib, oracle, rung3, seed, overlap):
+    """Two switches of the pinning rung, all four combinations against the oracle: pin_seed (the levels start from the knots known a
+    priori -- |dy| > 4 lambda, weighted r_{j+1} + 2 r_j + r_{j-1} -- instead of the fibre ends alone) and pin_overlap (a strided sweep
+    moves its transposed copies range by range on a second stream).  Tall images so that the strided sweep has the 4096 fibres the
+    overlap asks for; lambdas with many, few and no seeds; weighted, both forms of the DR iteration, PD2."""
+    rng = np.random.default_rng(300 + 2 * seed + overlap)
+    before = (clib.proxtv_set_option(b"pin_seed", seed), clib.proxtv_set_option(b"pin_overlap", overlap))
+    try:
+        for (M, N), lam in (((4100, 300), 0.6), ((4200, 130), 0.15), ((4128, 97), 2.5)):
+            X = rng.standard_normal((M, N))
+            assert_close(ptv.tv1_2d(X, lam, max_iters=5), oracle.dr2(X, lam, max_iters=5)[0], tol=1e-9, what=f"dr2 {M}x{N} lam {lam}")
+            W1, W2 = rng.uniform(0.3 * lam, 1.7 * lam, (M - 1, N)), rng.uniform(0.3 * lam, 1.7 * lam, (M, N - 1))
+            assert_close(ptv.tv1w_2d(X, W1, W2, max_iters=4), oracle.dr2w(X, W1, W2, max_iters=4)[0], tol=1e-9, what=f"dr2w {M}x{N} lam {lam}")
+            assert_close(ptv.tv1_2d(X, lam, method="pd", max_iters=3), oracle.pd2(X, [lam, lam], [1, 2], max_iters=3)[0], tol=1e-9,
+                         what=f"pd2 {M}x{N} lam {lam}")
+        for n in (96, 1025, 4097, 9000):       # single fibres of every group geometry, seeds on
+            for name, x in _families(rng, n):
+                for lam in (0.05, 0.4):
+                    assert_close(ptv.tv1_1d(x, lam), oracle.tv1_hybrid(x, lam), tol=1e-11, what=f"{name} n={n} lam={lam}")
+    finally:
+        clib.proxtv_set_option(b"pin_seed", before[0])
+        clib.proxtv_set_option(b"pin_overlap", before[1])
