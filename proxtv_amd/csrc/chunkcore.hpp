@@ -249,20 +249,6 @@ __device__ __forceinline__ void rebuild_owned(Win &win, const ChunkRec &rec, int
         s += win.y(k);
         cnt += 1.0;
     }
-    // One forward step of the piece recurrence at own row u: returns the value of the piece if it ends there.
-    auto step = [&](int u, double yu, double &s_, double &cnt_, double &hprev_, bool divide) {
-        s_ += yu;
-        cnt_ += 1.0;
-        const bool e = (rec.ends >> u) & 1u;
-        const double r = WEIGHTED ? ((cs + u < len - 1) ? win.r(cs + u) : 0.0) : lam;
-        const double hk = (cs + u == len - 1) ? 0.0 : (((rec.types >> u) & 1u) ? r : -r);
-        double v = 0.0;
-        if (divide) v = quotient(s_ + (hk - hprev_), cnt_);
-        s_ = e ? 0.0 : s_;
-        cnt_ = e ? 0.0 : cnt_;
-        hprev_ = e ? hk : hprev_;
-        return v;
-    };
     // the piece that covers ce - 1 and ends beyond it: the block's last lane writes its rows inside the block
     auto tail_value = [&](double s_, double cnt_, double hprev_, double &cur_) {
         if (!(block_last && rec.done && !((rec.ends >> (ce - 1 - cs)) & 1u))) return false;
@@ -280,16 +266,40 @@ __device__ __forceinline__ void rebuild_owned(Win &win, const ChunkRec &rec, int
         }
         return true;
     };
+    // height of the string above the tube centre at the knot after own row u, where a piece ends: 0 at the fibre end, else the
+    // tube's half-width with the sign of the bend type (unweighted, device: lambda with its sign bit flipped -- a shift and a xor)
+    const int uend = len - 1 - cs;   // own row of the fibre's last sample, if it lies in this chunk
+    auto knot_height = [&](int u) {
+        if (u == uend) return 0.0;
+        if constexpr (WEIGHTED) {
+            const double r = win.r(cs + u);
+            return ((rec.types >> u) & 1u) ? r : -r;
+        } else {
+#ifdef PTV_HOST_TEST
+            return ((rec.types >> u) & 1u) ? lam : -lam;
+#else
+            return __hiloint2double(__double2hiint(lam) ^ (int)((~(rec.types >> u) & 1u) << 31), __double2loint(lam));
+#endif
+        }
+    };
     double cur = 0.0;
     bool have = false;
     if (!F::USES_Y) {
         // The output does not depend on the row's own sample: the value of a piece is parked in the row where the piece
         // ends (forward pass), then every other row takes the value of the next piece end after it (backward pass).
+        // (A row that ends no piece costs an add and a count: height, quotient, store and resets sit under the piece-end branch.)
 #pragma unroll UNROLL
         for (int u = 0; u < C; u++) {
             const bool in = cs + u < ce;
-            const double v = step(u, in ? win.y(cs + u) : 0.0, s, cnt, hprev, true);
-            if (in && ((rec.ends >> u) & 1u)) win.put(cs + u, F::fuse(0.0, v));
+            s += in ? win.y(cs + u) : 0.0;
+            cnt += 1.0;
+            if (in && ((rec.ends >> u) & 1u)) {
+                const double hk = knot_height(u);
+                win.put(cs + u, F::fuse(0.0, quotient(s + (hk - hprev), cnt)));
+                s = 0.0;
+                cnt = 0.0;
+                hprev = hk;
+            }
         }
         have = tail_value(s, cnt, hprev, cur);
         if (have) cur = F::fuse(0.0, cur);
@@ -306,16 +316,23 @@ __device__ __forceinline__ void rebuild_owned(Win &win, const ChunkRec &rec, int
         // The output needs the row's own sample too: when a piece ends its rows are replaced there and then, last row
         // first (it is in a register), the earlier ones -- none for a one-sample piece -- in a short loop.  No second pass,
         // nothing waits in registers (sixteen parked values spill at the 128-VGPR budget of two workgroups per CU).
+        // Same recurrence, same branch form: everything but the running sum and the count happens where a piece ends.
         int first = a0 > wlo ? a0 : wlo;
 #pragma unroll UNROLL
         for (int u = 0; u < C; u++) {
             const bool in = cs + u < ce;
             const double yu = in ? win.y(cs + u) : 0.0;
-            const double v = step(u, yu, s, cnt, hprev, true);
+            s += yu;
+            cnt += 1.0;
             if (in && ((rec.ends >> u) & 1u)) {
+                const double hk = knot_height(u);
+                const double v = quotient(s + (hk - hprev), cnt);
                 win.put(cs + u, F::fuse(yu, v));
                 for (int k = cs + u - 1; k >= first; k--) win.put(k, F::fuse(win.y(k), v));
                 first = cs + u + 1;
+                s = 0.0;
+                cnt = 0.0;
+                hprev = hk;
             }
         }
         if (tail_value(s, cnt, hprev, cur))

@@ -701,10 +701,13 @@ constexpr int along_zone_rows(int H, bool robust) { return robust && H < 64 ? 64
 //     and gets its second chance from it.
 // What is still unproven goes to the repair kernel as before, which also re-checks every link between segments from the
 // codes the waves finally publish -- so none of the above is load-bearing for exactness.
-template <int OP, bool WEIGHTED, int H, int G, bool ROBUST>
+// ONESEG: fibres of at most one segment (G chunks) -- there is no row before the segment and none after it, so the robust
+// instantiation's 64 + 64 rows of look-back / look-ahead are not allocated: a third of its LDS for 512-sample fibres, and with it
+// twelve waves per CU become sixteen.
+template <int OP, bool WEIGHTED, int H, int G, bool ROBUST, bool ONESEG = false>
 __global__ __launch_bounds__(64 * kAlongWaves) void sweep_along_kernel(SweepArgs p, FibreGeom g, ChunkPlan plan, link_t *code_mine,
                                                                         link_t *code_next, int *failflags) {
-    constexpr int C = along_chunk(ROBUST, WEIGHTED), SEG = G * C, T = along_tail_rows(H, ROBUST), HZ = along_zone_rows(H, ROBUST), ROWS = HZ + SEG + T, NG = 64 / G;
+    constexpr int C = along_chunk(ROBUST, WEIGHTED), SEG = G * C, T = ONESEG ? 0 : along_tail_rows(H, ROBUST), HZ = ONESEG ? 0 : along_zone_rows(H, ROBUST), ROWS = HZ + SEG + T, NG = 64 / G;
     constexpr int NU = (ROWS + G - 1) / G;   // staged elements per lane
     constexpr int UL = 9;                    // epilogue operand fetches in flight per lane (C = 17 rows per lane: 9 + 8)
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1701,10 +1704,14 @@ void launch_chunk_h(const SweepArgs &args, const FibreGeom &g, hipStream_t strea
 
 // Chunks along the fibre (kernel 2a): dimension-0 sweeps, unweighted.  Codes are laid out [fibre][chunk] (a wave writes
 // the codes of 64 consecutive chunks of one fibre).
-template <int OP, bool WEIGHTED, int H, int G, bool ROBUST>
+template <int OP, bool WEIGHTED, int H, int G, bool ROBUST, bool ONESEG = false>
 void launch_along_g(const SweepArgs &args, const FibreGeom &g, hipStream_t stream, int fam, int rounds_wanted) {
-    constexpr int C = along_chunk(ROBUST, WEIGHTED), SEG = G * C, ROWS = along_zone_rows(H, ROBUST) + SEG + along_tail_rows(H, ROBUST), NG = 64 / G;
+    constexpr int C = along_chunk(ROBUST, WEIGHTED), SEG = G * C, ROWS = ONESEG ? SEG : along_zone_rows(H, ROBUST) + SEG + along_tail_rows(H, ROBUST), NG = 64 / G;
     const int nseg = (g.len + SEG - 1) / SEG;
+    if (ONESEG && nseg != 1) {
+        set_error("launch_along_g: a fibre of %d samples is more than one segment (%d)", g.len, SEG);
+        throw HipFailure{hipErrorInvalidValue};
+    }
     const int NC = (g.len + C - 1) / C;
     const long units = g.count * nseg;
     const long waves = (units + NG - 1) / NG;
@@ -1717,7 +1724,7 @@ void launch_along_g(const SweepArgs &args, const FibreGeom &g, hipStream_t strea
     plan.xlink = chunk_state().xlink_for((size_t)g.count * (size_t)nseg, stream);
     constexpr size_t lds = sizeof(double) * (size_t)(ROWS + 2) * NG * kAlongWaves * (WEIGHTED ? 2 : 1) + (ROBUST ? 64 + sizeof(double) * kRecipTableRobust : sizeof(double) * kRecipTable);
     static_assert(lds <= 160 * 1024, "along-fibre geometry does not fit the LDS of a CU");
-    auto kern = sweep_along_kernel<OP, WEIGHTED, H, G, ROBUST>;
+    auto kern = sweep_along_kernel<OP, WEIGHTED, H, G, ROBUST, ONESEG>;
     if (lds > 64 * 1024) {   // above the default dynamic-LDS limit
         static thread_local bool attr_done[kMaxDevices] = {};
         bool &attr_set = attr_done[current_device()];
@@ -1750,8 +1757,10 @@ void launch_along_g(const SweepArgs &args, const FibreGeom &g, hipStream_t strea
 template <int OP, bool WEIGHTED, int H, bool ROBUST>
 void launch_along(const SweepArgs &args, const FibreGeom &g, hipStream_t stream, int fam, int rounds) {
     constexpr int C = along_chunk(ROBUST, WEIGHTED);
-    if (g.len <= 16 * C)      launch_along_g<OP, WEIGHTED, H, 16, ROBUST>(args, g, stream, fam, rounds);
-    else if (g.len <= 32 * C) launch_along_g<OP, WEIGHTED, H, 32, ROBUST>(args, g, stream, fam, rounds);
+    // (fibres of one segment: the robust instantiation without its look-back / look-ahead rows)
+    if (g.len <= 16 * C)      launch_along_g<OP, WEIGHTED, H, 16, ROBUST, true>(args, g, stream, fam, rounds);
+    else if (g.len <= 32 * C) launch_along_g<OP, WEIGHTED, H, 32, ROBUST, true>(args, g, stream, fam, rounds);
+    else if (ROBUST && H <= kWarm && g.len <= 64 * C) launch_along_g<OP, WEIGHTED, H, 64, ROBUST, ROBUST && H <= kWarm>(args, g, stream, fam, rounds);
     else                            launch_along_g<OP, WEIGHTED, H, 64, ROBUST>(args, g, stream, fam, rounds);
 }
 

@@ -28,5 +28,12 @@ s2)   # new defaults (32-fibre tiles on rungs 0 and 1, table walk, non-temporal 
   ab --reps 7 --rounds 2 --cases c2 base keep4=$W/lib_keep4.so keep8=$W/lib_keep8.so keep16=$W/lib_keep.so > $OUT/ab_keep.txt 2>&1; cat $OUT/ab_keep.txt
   QUICK=1 bash tools/collect_profiles.sh r04q > $OUT/profiles_quick.log 2>&1; tail -4 $OUT/profiles_quick.log
   ;;
+s3)   # rebuild in branch form, one-segment along-fibre instantiations, overlapped transpositions, seeds gated: suite, then A/B by knobs
+  timeout 900 python -m pytest tests -m gpu -x -q > $OUT/pytest_default.log 2>&1; tail -3 $OUT/pytest_default.log
+  ab --reps 7 --rounds 2 --cases c2,c2@0.3,c2@0.5,c3,pd2,c4,c4y,s1024,s512,prox0,prox1 base > $OUT/ab_base.txt 2>&1; cat $OUT/ab_base.txt
+  ab --reps 5 --rounds 2 --cases c2@0.8,c2@1.0,c2@3.0 base nooverlap,pin_overlap=0 noseed,pin_seed=0 > $OUT/ab_pins.txt 2>&1; cat $OUT/ab_pins.txt
+  ab --reps 5 --rounds 1 --cases c2@0.5,c2@0.6,c2@0.7 base rung3,chunk_mode=3 > $OUT/ab_rung3.txt 2>&1; cat $OUT/ab_rung3.txt
+  ab --reps 5 --rounds 1 --cases c2@0.2,c2@0.3,c4 base rung0,chunk_mode=0 > $OUT/ab_rung0.txt 2>&1; cat $OUT/ab_rung0.txt
+  ;;
 *) echo "unknown session $S"; exit 2;;
 esac
