@@ -168,8 +168,8 @@ void proxtv_release_scratch(void);
                       from the same sampled statistics as the rung) ; 2: on the plain tile too ; 0: never (the reference's split).
                       Same iterates either way, to a few ulps
      "pin_seed"       1 (default): the pinning solver (rung 3) starts from the knots known a priori, 0: from the fibre ends alone
-     "pin_overlap"    1 (default): a strided sweep of the pinning solver moves its transposed copies range by range on a second stream,
-                      under the levels of the other ranges ; 0: one stream
+     "pin_overlap"    1: a strided sweep of the pinning solver moves its transposed copies range by range on a second stream, under
+                      the levels of the other ranges ; 0 (default: measured slower): one stream
      "tile"           strided sweeps on rung 0: 1 (default) tiles of 32 fibres x 8 chunks in 4 waves, four workgroups per CU ;
                       0: the 64-fibre x 8-wave tile, two per CU
      "host_register"  1: page-lock large caller arrays around the transfers of the host-pointer entry points (default 0: no gain measured)

@@ -50,8 +50,9 @@ struct Options {
     int seed_row_along_e4 = 0;   // tuning aid: kSeedRowAlong (policy.hpp) in units of 1e-4 ; 0 = built in
     int seed_noisy_e4 = 0, seed_mid_e4 = 0;   // tuning aid: the policy seed's thresholds (policy.hpp) in units of 1e-4 ; 0 = built in
     int pin = 1;              // geometry rung 3: the pinning solver (pin.hip) where it applies; 0 = global-memory chunks
-    int pin_overlap = 1;      // strided sweeps of the pinning solver: the transpositions of one range of fibres run on a second stream
-                              // under the levels of another (0: one after the other on one stream)
+    int pin_overlap = 0;      // strided sweeps of the pinning solver: 1 = the transpositions of one range of fibres run on a second stream
+                              // under the levels of another.  Measured and NOT kept (4096^2 DR, lambda 0.8 / 1 / 3: 25.1 -> 27.1, 29.3 -> 30.9,
+                              // 18.2 -> 21.0 ms): four quarter-size launches per sweep lose more than the hidden copies win
     int pin_seed = 1;         // the pinning solver starts from the knots known a priori (|dy| > 4 lambda) instead of the fibre ends alone
     int whole = 1;            // fibres of 16 .. chunk_min_len samples: 1 = by length and data (sequential up to 32 samples; one block of the
                               // chunk kernel on noisy data, else whole fibres in LDS), 2 = the whole-fibre-in-LDS kernel, 0 = the sequential kernel

@@ -280,9 +280,10 @@ void launch_op(const SweepArgs &args, const FibreGeom &g, hipStream_t stream, in
         return;
     }
     // strided: the same sweep along dimension 0 of transposed copies (transposed.hpp)
-    // The transpositions are memory-bound (2 x 47 us per 4096^2 DR row sweep, of 390-480), the levels LDS- and instruction-bound:
-    // cut the fibres into ranges, alternate the ranges between the caller's stream and a helper, and the copies of one range move
-    // while the other range's levels run.  (One slab only: a range of fibres is then a block of rows of one column-major array.)
+    // Option pin_overlap (off: measured slower, see common.hpp).  The transpositions are memory-bound (2 x 47 us per 4096^2 DR row
+    // sweep, of 390-480), the levels LDS- and instruction-bound: cut the fibres into ranges, alternate the ranges between the
+    // caller's stream and a helper, and the copies of one range move while the other range's levels run.  (One slab only: a range
+    // of fibres is then a block of rows of one column-major array.)
     constexpr int kParts = 4;
     if (options().pin_overlap && g.count == g.inc && g.count >= 1024 * kParts) {
         TransposedOperands tr(args, Op<OP>::IN_MASK, Op<OP>::OUT_MASK, g, stream, true);
