@@ -70,7 +70,6 @@ __device__ __forceinline__ int certain_bend_before(const Win &win, int cs, int l
         for (int u = 0; u <= LOOK + 1; u++) rv[u] = (cs - u < len - 1) ? win.r(cs - u) : 0.0;
     }
     int cat = -1;
-    type = 0;
 #pragma unroll
     for (int u = LOOK - 1; u >= 0; u--) {   // edge (k - 1, k), k = cs - u
         const double d = yv[u] - yv[u + 1];
@@ -80,10 +79,11 @@ __device__ __forceinline__ int certain_bend_before(const Win &win, int cs, int l
             thr = 1.0000001 * (rv[u] + 2.0 * rv[u + 1] + rv[u + 2]);
             ok = (rv[u] >= 0.0) & (rv[u + 1] > 0.0) & (rv[u + 2] >= 0.0);
         }
-        const bool hit = ok & (fabs(d) > thr);
-        cat = hit ? cs - u : cat;
-        type = hit ? (d > 0 ? BEND_FLOOR : BEND_CEIL) : type;
+        cat = (ok & (fabs(d) > thr)) ? cs - u : cat;
     }
+    // (the bend's type from the chosen edge alone -- two more window reads -- instead of a compare and a select per edge looked at)
+    type = 0;
+    if (cat >= 0) type = (win.y(cat) - win.y(cat - 1) > 0) ? BEND_FLOOR : BEND_CEIL;
     return cat;
 }
 

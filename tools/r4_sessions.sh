@@ -35,5 +35,9 @@ s3)   # rebuild in branch form, one-segment along-fibre instantiations, overlapp
   ab --reps 5 --rounds 1 --cases c2@0.5,c2@0.6,c2@0.7 base rung3,chunk_mode=3 > $OUT/ab_rung3.txt 2>&1; cat $OUT/ab_rung3.txt
   ab --reps 5 --rounds 1 --cases c2@0.2,c2@0.3,c4 base rung0,chunk_mode=0 > $OUT/ab_rung0.txt 2>&1; cat $OUT/ab_rung0.txt
   ;;
+s4)   # occupancy / unroll variants of the two hot kernels; rung-1 rows on the robust 32-fibre tile instead of transposed copies
+  ab --reps 7 --rounds 2 --cases c2,prox0,prox1 base aw3=$W/lib_aw3.so au2=$W/lib_au2.so au8=$W/lib_au8.so tu2=$W/lib_tu2.so tu4=$W/lib_tu4.so > $OUT/ab_variants.txt 2>&1; cat $OUT/ab_variants.txt
+  ab --reps 5 --rounds 2 --cases c2@0.6,c2@0.65,c2@0.7,c2@0.75 base tilerows,seed_row_along_e4=1 > $OUT/ab_tilerows.txt 2>&1; cat $OUT/ab_tilerows.txt
+  ;;
 *) echo "unknown session $S"; exit 2;;
 esac
