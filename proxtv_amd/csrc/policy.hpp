@@ -61,7 +61,9 @@ constexpr double kSeedMid = 0.03;     // f at or above: rung 1 ; below: rung 3  
 constexpr double kSeedPins = 0.001;    // rung 3: the pinning solver searches for knots known a priori when f is at least this (lambda = 1 on unit noise: 0.005,
                                        // 29.4 against 30.0 ms per 4096^2 DR solve; 0.8: 25.3 against 31.8; 3: none to find, 18.3 against 19.1 with the search)
 constexpr double kSeedFlat = 0.02;     // more than this fraction of the sampled 16-edge stretches (all but) flat at lambda: rung 3
-constexpr double kSeedRowAlong = 0.06; // rung 1, strided sweeps, f below (lambda >= 0.65 on unit noise): through transposed copies and the along-fibre kernel
+constexpr double kSeedRowAlong = 0.0;  // rung 1, strided sweeps, f below: through transposed copies and the along-fibre kernel.  Round 3: 0.06 (lambda >= 0.65
+                                       // on unit noise: the 64-fibre tile left too many links to the repair kernel); with the robust 32-fibre tile of round 4
+                                       // the tile wins there too (4096^2 DR at lambda = 0.65 / 0.7: 19.4 -> 18.4, 22.5 -> 22.2 ms), so: never
 // DR2L1W: the second form of the iteration (ops.hpp, OP_DR_COL_V) pays below this certain fraction only -- the weighted column
 // sweep is the heavier one to begin with (4096^2, weights U(0.5, 1.5) lambda: lambda = 0.4: 17.4 -> 18.1 ms, 0.6: 25.3 -> 24.0)
 constexpr double kSeedDrFormWeighted = 0.2;

@@ -39,5 +39,21 @@ s4)   # occupancy / unroll variants of the two hot kernels; rung-1 rows on the r
   ab --reps 7 --rounds 2 --cases c2,prox0,prox1 base aw3=$W/lib_aw3.so au2=$W/lib_au2.so au8=$W/lib_au8.so tu2=$W/lib_tu2.so tu4=$W/lib_tu4.so > $OUT/ab_variants.txt 2>&1; cat $OUT/ab_variants.txt
   ab --reps 5 --rounds 2 --cases c2@0.6,c2@0.65,c2@0.7,c2@0.75 base tilerows,seed_row_along_e4=1 > $OUT/ab_tilerows.txt 2>&1; cat $OUT/ab_tilerows.txt
   ;;
+s5)   # tile unroll 4, rows of rung 1 on the tile, the long-fibre TV-L2 solver: suite, then the survey of cases and the lambda sweep
+  timeout 900 python -m pytest tests -m gpu -x -q > $OUT/pytest_default.log 2>&1; tail -3 $OUT/pytest_default.log
+  timeout 300 python tools/time_cases.py > $OUT/time_cases.txt 2>&1; cat $OUT/time_cases.txt
+  timeout 300 python tools/lambda_probe.py --modes -1 --lams 0.1,0.2,0.3,0.4,0.5,0.6,0.65,0.7,0.75,0.8,1.0,3.0,10.0,30.0 > $OUT/lambda_sweep.txt 2>&1; cat $OUT/lambda_sweep.txt
+  python - > $OUT/tv2_long.txt 2>&1 <<'PY'
+import time, numpy as np, proxtv_amd
+rng = np.random.default_rng(0)
+for n in (100_000, 1_000_000, 4_000_000):
+    y = np.cumsum(rng.standard_normal(n)) * 0.05 + rng.standard_normal(n)
+    for lam in (1.0, 30.0):
+        proxtv_amd.tv2_1d(y, lam)
+        t0 = time.perf_counter(); proxtv_amd.tv2_1d(y, lam); dt = time.perf_counter() - t0
+        print(f"tv2_1d n={n} lambda={lam}: {dt*1e3:.2f} ms (host arrays in and out)")
+PY
+  cat $OUT/tv2_long.txt
+  ;;
 *) echo "unknown session $S"; exit 2;;
 esac
