@@ -105,7 +105,14 @@ def test_long_signal_solves_in_parallel_inside_the_fibre(ptv, oracle):
             got = ptv.tv2_1d(y, lam)
             dt = time.perf_counter() - t0
             want, _ = oracle.tv(y, lam, 2)
-            assert np.max(np.abs(got - want)) <= 1e-9 * max(1.0, np.max(np.abs(y))), (n, lam, np.max(np.abs(got - want)))
+            scale = max(1.0, np.max(np.abs(y)))
+            if lam >= 1e8:
+                # the dual lies inside the ball: the prox is the mean of y, and T u = Dy at mu = 0 is conditioned like n^2 -- the
+                # oracle's sequential sweeps drift by ~3e-8 along 2 x 10^5 samples; the exact answer is known, so compare with it
+                assert np.max(np.abs(got - y.mean())) <= 1e-9 * scale, (n, lam, np.max(np.abs(got - y.mean())))
+                assert np.max(np.abs(got - want)) <= 1e-6 * scale, (n, lam)
+            else:
+                assert np.max(np.abs(got - want)) <= 1e-9 * scale, (n, lam, np.max(np.abs(got - want)))
             gap, infeas = kkt_gap(got, y, lam)
             assert infeas <= 1e-10 * max(lam, 1.0), (n, lam, infeas)
             if n >= 200_000:
