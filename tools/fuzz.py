@@ -2,7 +2,7 @@
 """Randomised differential test of the HIP path against the CPU oracle: shapes, data families, penalties over five
 decades, every geometry mode pinned or adaptive, weighted / unweighted, every 2-D solver and both sweep directions.
 
-    python tools/fuzz.py [seconds] [seed]
+    python tools/fuzz.py [seconds] [seed] [nd | long]
 """
 import os, sys, time
 import numpy as np
@@ -47,6 +47,9 @@ def run(budget=60.0, seed=0, tol=1e-9, sizes=(2, 3, 17, 95, 96, 97, 130, 257, 40
             lib.proxtv_set_option(b"deterministic", int(rng.integers(0, 2)))   # (mode -1: seeded-deterministic or hill-climbing policy)
             form = int(rng.integers(0, 3))
             lib.proxtv_set_option(b"dr_form", form)                            # (which of the two forms of the DR iteration: never / rung 1 / rungs 0, 1)
+            tile, seeds = int(rng.integers(0, 2)), int(rng.integers(0, 2))
+            lib.proxtv_set_option(b"tile", tile)                               # (32-fibre x 4-wave or 64-fibre x 8-wave tiles)
+            lib.proxtv_set_option(b"pin_seed", seeds)                          # (the pinning solver with / without the knots known a priori)
             what = int(rng.integers(0, 6))
             if what == 0:
                 got, want, name = ptv.tv1_2d(X, lam), orc.dr2(X, lam)[0], "dr2"
@@ -66,7 +69,7 @@ def run(budget=60.0, seed=0, tol=1e-9, sizes=(2, 3, 17, 95, 96, 97, 130, 257, 40
                 want = np.apply_along_axis(lambda f: orc.tv1_hybrid(np.ascontiguousarray(f), lam), d - 1, X)
                 name = f"prox dim {d}"
             e = rel(got, want, np.max(np.abs(X)))
-            desc = f"{name} {M}x{N} lam={lam:.4g} mode={mode} dr_form={form}"
+            desc = f"{name} {M}x{N} lam={lam:.4g} mode={mode} dr_form={form} tile={tile} pin_seed={seeds}"
             if e > worst:
                 worst, worst_case = e, desc
             cases += 1
@@ -75,6 +78,8 @@ def run(budget=60.0, seed=0, tol=1e-9, sizes=(2, 3, 17, 95, 96, 97, 130, 257, 40
         lib.proxtv_set_option(b"chunk_mode", before)
         lib.proxtv_set_option(b"deterministic", 1)
         lib.proxtv_set_option(b"dr_form", 1)
+        lib.proxtv_set_option(b"tile", 1)
+        lib.proxtv_set_option(b"pin_seed", 1)
     return cases, worst, worst_case
 
 
@@ -136,6 +141,10 @@ if __name__ == "__main__":
     if len(sys.argv) > 3 and sys.argv[3] == "nd":
         n, w, where = run_nd(float(sys.argv[1]), int(sys.argv[2]))
         print(f"fuzz nd: {n} cases, worst relative error {w:.2e} ({where})")
+        sys.exit(0)
+    if len(sys.argv) > 3 and sys.argv[3] == "long":   # fibres of 2-4 segments / 9-34 blocks: the machinery across workgroups
+        n, w, where = run(float(sys.argv[1]), int(sys.argv[2]), sizes=(96, 130, 1089, 2177, 3300, 4353))
+        print(f"fuzz long fibres: {n} cases, worst relative error {w:.2e} ({where})")
         sys.exit(0)
     n, w, where = run(float(sys.argv[1]) if len(sys.argv) > 1 else 60.0, int(sys.argv[2]) if len(sys.argv) > 2 else 0)
     print(f"fuzz: {n} cases, worst relative error {w:.2e} ({where})")

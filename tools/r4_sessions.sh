@@ -55,5 +55,13 @@ for n in (100_000, 1_000_000, 4_000_000):
 PY
   cat $OUT/tv2_long.txt
   ;;
+s6)   # rung 1 near its upper end: blocks per workgroup of the robust tile (fewer links across workgroups), second-chance rounds
+  timeout 300 python -m pytest tests/test_gpu_p2.py -m gpu -x -q > $OUT/pytest_p2.log 2>&1; tail -2 $OUT/pytest_p2.log
+  ab --reps 5 --rounds 2 --cases c2@0.5,c2@0.6,c2@0.65,c2@0.7 base bpw2,blocks_per_wg=2 bpw4,blocks_per_wg=4 rounds8,rounds=8 rounds2,rounds=2 > $OUT/ab_rung1.txt 2>&1; cat $OUT/ab_rung1.txt
+  ;;
+s7)   # soak: the randomised differential test on the round-4 build (tiles, a-priori pins and the form of the DR iteration drawn at random)
+  { echo "# python tools/fuzz.py <seconds> <seed> [nd|long] on one MI355X box; assertion: relative error <= 1e-9"
+    python tools/fuzz.py 150 31; python tools/fuzz.py 60 32 nd; python tools/fuzz.py 90 33 long; } > $OUT/fuzz_soak.txt 2>&1; cat $OUT/fuzz_soak.txt
+  ;;
 *) echo "unknown session $S"; exit 2;;
 esac
