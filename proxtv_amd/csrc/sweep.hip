@@ -343,7 +343,7 @@ __global__ __launch_bounds__(64 * NW, SHORT ? 16 / NW : (FW < 64 ? ((WEIGHTED ? 
     constexpr bool TAB = false;
 #endif
     constexpr int TS = ROUNDS ? kRecipTableRobust : kRecipTable;
-    double *rtab = reinterpret_cast<double *>(stash + FW);
+    double *rtab = reinterpret_cast<double *>(stash + (TRANSPOSED ? 0 : FW));   // (the pitch-65 tile has no stash row: launch_chunk_h's LDS size)
     if constexpr (TAB) {
         if (threadIdx.x < TS) rtab[threadIdx.x] = threadIdx.x ? 1.0 / (double)threadIdx.x : 0.0;   // (visible after the staging barrier)
     }

@@ -360,3 +360,20 @@ def test_both_tile_geometries_of_strided_sweeps(ptv, clib, oracle, tile):
         clib.proxtv_set_option(b"tile", before[0])
         clib.proxtv_set_option(b"chunk_mode", before[1])
         clib.proxtv_set_option(b"dr_form", before[2])
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_weighted_columns_of_96_to_159_samples(ptv, clib, oracle, mode):
+    """Weighted dimension-0 fibres of 96 ... 159 samples are the one workload of the pitch-65 (transposed) tile with two LDS planes:
+    long enough for the chunk kernels, too short for the along-fibre kernel.  (Round 4's soak found its reciprocal table outside the
+    workgroup's LDS -- reads of zeros, every pull-back a no-op: relative error 1.7e-2 -- which no other test reached.)"""
+    rng = np.random.default_rng(401 + mode)
+    before = clib.proxtv_set_option(b"chunk_mode", mode)
+    try:
+        for M, N, lam in [(96, 3, 9.5), (96, 70, 0.1), (120, 200, 0.3), (159, 65, 0.1), (130, 64, 2.0)]:
+            X = rng.standard_normal((M, N))
+            W1, W2 = rng.uniform(0.2 * lam, 2 * lam, (M - 1, N)), rng.uniform(0.2 * lam, 2 * lam, (M, N - 1))
+            assert_close(ptv.tv1w_2d(X, W1, W2), oracle.dr2w(X, W1, W2)[0], tol=1e-9, what=f"dr2w {M}x{N} lam {lam} mode {mode}")
+            assert_close(ptv.tv1_2d(X, lam), oracle.dr2(X, lam)[0], tol=1e-9, what=f"dr2 {M}x{N} lam {lam} mode {mode}")
+    finally:
+        clib.proxtv_set_option(b"chunk_mode", before)

@@ -63,5 +63,10 @@ s7)   # soak: the randomised differential test on the round-4 build (tiles, a-pr
   { echo "# python tools/fuzz.py <seconds> <seed> [nd|long] on one MI355X box; assertion: relative error <= 1e-9"
     python tools/fuzz.py 150 31; python tools/fuzz.py 60 32 nd; python tools/fuzz.py 90 33 long; } > $OUT/fuzz_soak.txt 2>&1; cat $OUT/fuzz_soak.txt
   ;;
+s8)   # after the fix of the weighted pitch-65 tile's table: the new test, the soak again (same seeds, then fresh ones)
+  timeout 600 python -m pytest tests/test_gpu_parity_2d.py tests/test_gpu_fuzz.py -m gpu -x -q > $OUT/pytest_2d.log 2>&1; tail -2 $OUT/pytest_2d.log
+  { echo "# python tools/fuzz.py <seconds> <seed> [nd|long] on one MI355X box; assertion: relative error <= 1e-9"
+    python tools/fuzz.py 150 31; python tools/fuzz.py 100 41; python tools/fuzz.py 45 42 nd; python tools/fuzz.py 60 43 long; } > $OUT/fuzz_soak.txt 2>&1; cat $OUT/fuzz_soak.txt
+  ;;
 *) echo "unknown session $S"; exit 2;;
 esac
