@@ -80,6 +80,15 @@ __device__ __forceinline__ void st_once2(double *p, double v) { *p = v; }
 
 template <int ID> struct Op;
 
+// Ops whose epilogue fetches BOTH staged operands again (PD2_A / PD2_B / YANG: iterate + correction): the strided tiles can keep the
+// second one -- the correction -- in registers for PTV_KEEP_N of a thread's 16 rows (sweep.hip), half a pass of six.
+// -DPTV_KEEP_OPS: an experiment switch until measured.
+#ifdef PTV_KEEP_OPS
+constexpr bool kKeepCorrection = true;
+#else
+constexpr bool kKeepCorrection = false;
+#endif
+
 // ---- one-operand inputs: y = a ---------------------------------------------------------------------------------------
 struct InA : NoKeep {
     static constexpr int NIN = 1;
@@ -222,6 +231,8 @@ template <> struct Op<OP_DRW_ROW_FINAL> : InBminusA, NotFused {
 // Dykstra term 1 (a = x, b = p_in, o0 = z, o1 = p_out): z = prox(x + p) ; p += x - z   (src/TV2Dopt.cpp:187-213)
 template <> struct Op<OP_PD2_A> : InAplusB, NotFused {
     static constexpr unsigned IN_MASK = 3, OUT_MASK = 3;
+    static constexpr bool KEEP = kKeepCorrection;   // (the correction staged for the walk waits in registers for part of the thread's rows)
+    __device__ static __forceinline__ Ext fetch_rest(const SweepArgs &p, long idx, double kept) { return Ext{p.a[idx], kept}; }
     __device__ static __forceinline__ Ext fetch(const SweepArgs &p, long idx) { return Ext{p.a[idx], p.b[idx]}; }
     __device__ static __forceinline__ void finish(const SweepArgs &p, long idx, const Ext &e, double x) {
         st_once2(p.o0 + idx, x);
@@ -231,6 +242,8 @@ template <> struct Op<OP_PD2_A> : InAplusB, NotFused {
 // Dykstra term 2 (a = z, b = q_in, o0 = x, o1 = q_out): x = prox(z + q) ; q += z - x    (src/TV2Dopt.cpp:234-263)
 template <> struct Op<OP_PD2_B> : InAplusB, NotFused {
     static constexpr unsigned IN_MASK = 3, OUT_MASK = 3;
+    static constexpr bool KEEP = kKeepCorrection;   // (the correction staged for the walk waits in registers for part of the thread's rows)
+    __device__ static __forceinline__ Ext fetch_rest(const SweepArgs &p, long idx, double kept) { return Ext{p.a[idx], kept}; }
     __device__ static __forceinline__ Ext fetch(const SweepArgs &p, long idx) { return Ext{p.a[idx], p.b[idx]}; }
     __device__ static __forceinline__ void finish(const SweepArgs &p, long idx, const Ext &e, double x) {
         st_once2(p.o0 + idx, x);
@@ -243,6 +256,8 @@ template <> struct Op<OP_PD2_B> : InAplusB, NotFused {
 template <> struct Op<OP_YANG> : NotFused, NoKeep {
     static constexpr unsigned IN_MASK = 3, OUT_MASK = 3;
     static constexpr int NIN = 2;
+    static constexpr bool KEEP = kKeepCorrection;
+    __device__ static __forceinline__ Ext fetch_rest(const SweepArgs &p, long idx, double kept) { return Ext{p.a[idx], kept}; }
     __device__ static __forceinline__ void fetch_in(const SweepArgs &p, long idx, double &i0, double &i1) { i0 = p.a[idx]; i1 = p.b[idx]; }
     __device__ static __forceinline__ double y_of(const SweepArgs &p, double i0, double i1) { return -1. / p.s0 * i1 + i0; }
     __device__ static __forceinline__ double load_y(const SweepArgs &p, long idx) { return -1. / p.s0 * p.b[idx] + p.a[idx]; }

@@ -473,7 +473,12 @@ __global__ __launch_bounds__(64 * NW, SHORT ? 16 / NW : (FW < 64 ? ((WEIGHTED ? 
             // walk AT it -- exact by construction, no warm-up zone to walk, no link to prove.  On noisy data with small
             // lambda (the headline: 78 % of all edges qualify) every lane of a wave does; otherwise the lane falls back to
             // the speculative start.
-            constexpr int kLook = 8;
+            // (robust instantiation: the whole zone is searched -- a lane that starts at a bend known a priori has no link that could
+            // fail, and failed links across workgroups are what the repair kernel is left with at the upper end of rung 1)
+#ifndef PTV_TILE_ROBUST_LOOK
+#define PTV_TILE_ROBUST_LOOK 8
+#endif
+            constexpr int kLook = ROUNDS ? PTV_TILE_ROBUST_LOOK : 8;
             static_assert(H >= kLook + 2, "the certain-bend search reads rows of the warm-up zone");
             int cat = -1, ctype = 0;
             if (start > 0 && H <= kWarm && p.lam > 0.0) cat = certain_bend_before<WEIGHTED, kLook>(win, cs, len, p.lam, ctype);

@@ -170,3 +170,23 @@ def test_every_documented_knob_is_accepted():
         before = lib.proxtv_set_option(k.encode(), 12345)
         assert lib.proxtv_set_option(k.encode(), before) == 12345, f"knob {k!r} is documented but not known to proxtv_set_option"
     assert lib.proxtv_set_option(b"no_such_knob", 1) == -1
+
+
+def test_every_knob_has_its_environment_variable():
+    """include/proxtv_amd.h: "each also has an environment variable PROXTV_<KEY> read at load time" -- one table in common.hip serves
+    both ways of setting a knob.  A fresh process per check (the variables are read once)."""
+    import subprocess
+    import sys
+    text = open(os.path.join(ROOT, "include", "proxtv_amd.h")).read()
+    block = text[text.index("/* Knobs"):text.index("int proxtv_set_option")]
+    keys = sorted(set(re.findall(r'"([a-z_0-9]+)"', block)))
+    assert {"tile", "pin_seed", "why", "host_register", "trace", "profile"} <= set(keys), keys
+    code = ("import sys, json; sys.path.insert(0, %r); from proxtv_amd import _lib; lib = _lib.load(); "
+            "print(json.dumps({k: lib.proxtv_set_option(k.encode(), 0) for k in %r}))" % (ROOT, keys))
+    env = dict(os.environ)
+    for i, k in enumerate(keys):
+        env["PROXTV_" + k.upper()] = str(700 + i)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True).stdout
+    import json
+    got = json.loads(out.strip().splitlines()[-1])
+    assert got == {k: 700 + i for i, k in enumerate(keys)}, got

@@ -68,5 +68,9 @@ s8)   # after the fix of the weighted pitch-65 tile's table: the new test, the s
   { echo "# python tools/fuzz.py <seconds> <seed> [nd|long] on one MI355X box; assertion: relative error <= 1e-9"
     python tools/fuzz.py 150 31; python tools/fuzz.py 100 41; python tools/fuzz.py 45 42 nd; python tools/fuzz.py 60 43 long; } > $OUT/fuzz_soak.txt 2>&1; cat $OUT/fuzz_soak.txt
   ;;
+s9)   # the correction of PD2 / Yang sweeps kept in registers for half a thread's rows; the robust tile searching its whole zone for known bends
+  ab --reps 7 --rounds 2 --cases pd2,c4y,yang2 base keepops=$W/lib_keepops.so > $OUT/ab_keepops.txt 2>&1; cat $OUT/ab_keepops.txt
+  ab --reps 5 --rounds 2 --cases c2@0.4,c2@0.5,c2@0.6,c2@0.65,c2@0.7 base look14=$W/lib_look14.so > $OUT/ab_look14.txt 2>&1; cat $OUT/ab_look14.txt
+  ;;
 *) echo "unknown session $S"; exit 2;;
 esac
