@@ -80,10 +80,11 @@ __device__ __forceinline__ void st_once2(double *p, double v) { *p = v; }
 
 template <int ID> struct Op;
 
-// Ops whose epilogue fetches BOTH staged operands again (PD2_A / PD2_B / YANG: iterate + correction): the strided tiles can keep the
-// second one -- the correction -- in registers for PTV_KEEP_N of a thread's 16 rows (sweep.hip), half a pass of six.
-// -DPTV_KEEP_OPS: an experiment switch until measured.
-#ifdef PTV_KEEP_OPS
+// Ops whose epilogue fetches BOTH staged operands again (PD2_A / PD2_B / YANG: iterate + correction): the strided tiles keep the
+// second one -- the correction -- in registers for PTV_KEEP_N = 8 of a thread's 16 rows (sweep.hip: one to three spilled registers;
+// all 16 spill dozens), a twelfth of those sweeps' traffic: PD2 4096^2 4.40 -> 4.33 ms, Yang3 512 x 512 x 64 22.05 -> 21.47 ms
+// (profiles/r04_s9_ab.txt).  -DPTV_NO_KEEP_OPS: fetch everything again.
+#ifndef PTV_NO_KEEP_OPS
 constexpr bool kKeepCorrection = true;
 #else
 constexpr bool kKeepCorrection = false;

@@ -383,9 +383,10 @@ __global__ __launch_bounds__(64 * NW, SHORT ? 16 / NW : (FW < 64 ? ((WEIGHTED ? 
     // share of the thread) unless that would not fit the register budget: transposed sweeps stage in two batches (three
     // for two-operand inputs: 48 live doubles spill otherwise), two-operand strided sweeps in two.
     constexpr int NB = TRANSPOSED ? (Op<OP>::NIN > 1 ? (NST + 2) / 3 : (NST + 1) / 2) : (Op<OP>::NIN > 1 ? (NST + 1) / 2 : NST);
-    // (PTV_KEEP_N: how many of a thread's C own rows keep the operand -- the rest is fetched again; an experiment knob: all C spill)
+    // (PTV_KEEP_N: how many of a thread's C own rows keep the operand -- the rest is fetched again; all 16 spill dozens of registers:
+    // DR row sweep with -DPTV_KEEP_STAGED 116.7 -> 115.1 / 114.5 / 144 us at 4 / 8 / 16)
 #ifndef PTV_KEEP_N
-#define PTV_KEEP_N 16
+#define PTV_KEEP_N 8
 #endif
     constexpr int KN = KEEP ? (PTV_KEEP_N < C ? PTV_KEEP_N : C) : 0;
     double kept[KEEP ? KN : 1];
@@ -476,7 +477,7 @@ __global__ __launch_bounds__(64 * NW, SHORT ? 16 / NW : (FW < 64 ? ((WEIGHTED ? 
             // (robust instantiation: the whole zone is searched -- a lane that starts at a bend known a priori has no link that could
             // fail, and failed links across workgroups are what the repair kernel is left with at the upper end of rung 1)
 #ifndef PTV_TILE_ROBUST_LOOK
-#define PTV_TILE_ROBUST_LOOK 8
+#define PTV_TILE_ROBUST_LOOK 14   // (against 8: 4096^2 DR at lambda = 0.4 / 0.5: 10.01 -> 9.89, 11.47 -> 11.33 ms; nothing from 0.6 on)
 #endif
             constexpr int kLook = ROUNDS ? PTV_TILE_ROBUST_LOOK : 8;
             static_assert(H >= kLook + 2, "the certain-bend search reads rows of the warm-up zone");

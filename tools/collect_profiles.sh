@@ -26,7 +26,7 @@ done
 {
 echo "# rocprofv3 --kernel-trace --pmc <set> -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-c5   (three passes, one counter set each)"
 echo "# averages per dispatch of the two hot kernels: sweep_along_kernel<1,...> = DR column sweep, sweep_chunk_kernel<3,...> = DR row sweep"
-for k in 1 2 3; do python $R/tools/pmc_summary.py $(find $O/sq$k -name "p_results.db" | head -1) "sweep_along_kernel<1, false, 16, 64, false>" "sweep_chunk_kernel<3, false, false, 16,"; done
+for k in 1 2 3; do python $R/tools/pmc_summary.py $(find $O/sq$k -name "p_results.db" | head -1) "sweep_along_kernel<1, false, 16, 64, false," "sweep_chunk_kernel<3, false, false, 16,"; done
 } > $O/${TAG}_final_sq_counters.txt 2>&1
 cd $R
 timeout 60 python tools/wg_trace.py > $O/${TAG}_wg_trace.txt 2>&1

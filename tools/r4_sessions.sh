@@ -72,5 +72,13 @@ s9)   # the correction of PD2 / Yang sweeps kept in registers for half a thread'
   ab --reps 7 --rounds 2 --cases pd2,c4y,yang2 base keepops=$W/lib_keepops.so > $OUT/ab_keepops.txt 2>&1; cat $OUT/ab_keepops.txt
   ab --reps 5 --rounds 2 --cases c2@0.4,c2@0.5,c2@0.6,c2@0.65,c2@0.7 base look14=$W/lib_look14.so > $OUT/ab_look14.txt 2>&1; cat $OUT/ab_look14.txt
   ;;
+s10)  # the last defaults (correction kept for PD2 / Yang, whole-zone search in the robust tile): suite default + rung 1, then profiles of the final build
+  timeout 900 python -m pytest tests -m gpu -q > $OUT/pytest_default.log 2>&1; echo "default: $(tail -1 $OUT/pytest_default.log)" | tee $OUT/summary.txt
+  FILES="tests/test_gpu_chunk_repair.py tests/test_gpu_parity_2d.py tests/test_gpu_parity_1d.py tests/test_gpu_parity_nd.py tests/test_gpu_fuzz.py tests/test_gpu_pin.py tests/test_gpu_boundary.py"
+  PROXTV_CHUNK_MODE=1 timeout 900 python -m pytest $FILES -m gpu -q > $OUT/pytest_mode1.log 2>&1; echo "pinned to rung 1: $(tail -1 $OUT/pytest_mode1.log)" | tee -a $OUT/summary.txt
+  python tools/fuzz.py 60 51 > $OUT/fuzz.txt 2>&1; python tools/fuzz.py 30 52 nd >> $OUT/fuzz.txt 2>&1; grep "^fuzz\|MISMATCH" $OUT/fuzz.txt | tee -a $OUT/summary.txt
+  python -c "import sys; sys.path.insert(0,'.'); from proxtv_amd import build; print('build id', build.build_id())" | tee -a $OUT/summary.txt
+  bash tools/collect_profiles.sh r04 > $OUT/profiles.log 2>&1; tail -3 $OUT/profiles.log
+  ;;
 *) echo "unknown session $S"; exit 2;;
 esac
