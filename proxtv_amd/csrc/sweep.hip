@@ -1290,6 +1290,13 @@ __global__ __launch_bounds__(64) void sweep_repair_kernel(SweepArgs p, FibreGeom
         if (f0 > 0) first = NC - f0;
         if (f1 > 0) lastbad = f1 - 1;
     }
+    // Which chunks may fail the scan below at all: those inside the range the chunk kernel flagged [ff, fl] (links inside a workgroup,
+    // walks that ran off their window) and the first chunk of a workgroup whose link IN failed (xbad: one bit per boundary).  Every
+    // other chunk was proven by the chunk kernel to continue its predecessor's walk -- mine == the predecessor's non-zero next code, or
+    // a start at a bend known a priori -- so the scan accepts it whenever its predecessor is true: the scan may jump over them.
+    const int ff = first, fl = lastbad;
+    unsigned long long xbad = 0ull;
+    const bool jump = (NC + chunks_per_wg - 1) / chunks_per_wg <= 64;
     // links between workgroups (inside a workgroup they were checked through LDS): 16 boundaries = 32 independent
     // loads in flight per lane -- the cost of the common case is the latency of these reads
     constexpr int UB = 16;
@@ -1308,6 +1315,7 @@ __global__ __launch_bounds__(64) void sweep_repair_kernel(SweepArgs p, FibreGeom
             if (c < NC && c * C - H > 0 && !certain && (in[u] == 0 || in[u] != out[u])) {
                 first = min(first, c);
                 lastbad = max(lastbad, c);
+                if (jump) xbad |= 1ull << (c / chunks_per_wg);
             }
         }
     }
@@ -1324,14 +1332,25 @@ __global__ __launch_bounds__(64) void sweep_repair_kernel(SweepArgs p, FibreGeom
     RepairSource<OP, WEIGHTED> gsrc(book, p, base, g.inc, wbase);
     WindowRepairSource<OP, WEIGHTED> wsrc(book, p, base, g.inc, wbase, repair_lds, (int)threadIdx.x);
     // every chunk before `first` is proven: the true walk's last bend there is the last non-zero `next` code before it
-    link_t cur = kFromStart;
-    for (int b = first - 1; b >= 0; b--) {
-        const link_t nx = code_next[(long)b * cstride + j * fstride];
-        if (nx != 0) {
-            cur = nx;
-            break;
+    auto last_bend_before = [&](int chunk) {
+        for (int b = chunk - 1; b >= 0; b--) {
+            const link_t nx = code_next[(long)b * cstride + j * fstride];
+            if (nx != 0) return nx;
         }
-    }
+        return kFromStart;
+    };
+    // the first chunk at or after `chunk` that the scan could reject (NC: none)
+    auto next_suspect = [&](int chunk) {
+        if (!jump || (chunk >= ff && chunk <= fl)) return chunk;
+        int best = chunk < ff ? ff : NC;
+        const int b0 = (chunk + chunks_per_wg - 1) / chunks_per_wg;
+        if (b0 < 64) {
+            const unsigned long long m = xbad >> b0;
+            if (m) best = min(best, (b0 + (int)__builtin_ctzll(m)) * chunks_per_wg);
+        }
+        return best;
+    };
+    link_t cur = last_bend_before(first);
     int c = first;
     // Two-phase loop so that the lanes of a wave repair TOGETHER: first every lane scans ahead to its next unproven
     // chunk, then all lanes that found one walk at the same time (a walk nested inside the scan would serialise the
@@ -1341,6 +1360,14 @@ __global__ __launch_bounds__(64) void sweep_repair_kernel(SweepArgs p, FibreGeom
         // one memory round trip per UB chunks instead of two per chunk
         bool rejected = false;
         while (c < NC && c <= lastbad && !rejected) {   // (everything after the last flagged chunk is proven)
+            // jump over the chunks that cannot be rejected (after a repair walk: from the chunk that took its walk over, whose codes
+            // and everything after it are true) -- one memory round trip per failure instead of one per UB chunks in between
+            const int suspect = next_suspect(c);
+            if (suspect > c) {
+                c = suspect;
+                if (c >= NC || c > lastbad) break;
+                cur = last_bend_before(c);
+            }
             link_t mm[UB], nn[UB];
 #pragma unroll
             for (int u = 0; u < UB; u++) {
