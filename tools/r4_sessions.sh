@@ -80,5 +80,12 @@ s10)  # the last defaults (correction kept for PD2 / Yang, whole-zone search in 
   python -c "import sys; sys.path.insert(0,'.'); from proxtv_amd import build; print('build id', build.build_id())" | tee -a $OUT/summary.txt
   bash tools/collect_profiles.sh r04 > $OUT/profiles.log 2>&1; tail -3 $OUT/profiles.log
   ;;
+s11)  # the repair kernel jumping from failure to failure: parity where it works hardest (rungs 0 / 1 / 2 / 4 pinned, fuzz), then the upper end of rung 1
+  FILES="tests/test_gpu_chunk_repair.py tests/test_gpu_parity_2d.py tests/test_gpu_parity_1d.py tests/test_gpu_parity_nd.py tests/test_gpu_fuzz.py"
+  timeout 600 python -m pytest $FILES -m gpu -q > $OUT/pytest_default.log 2>&1; echo "default: $(tail -1 $OUT/pytest_default.log)" | tee $OUT/summary.txt
+  for m in 0 1 2 4; do PROXTV_CHUNK_MODE=$m timeout 600 python -m pytest $FILES -m gpu -q > $OUT/pytest_mode$m.log 2>&1; echo "pinned to rung $m: $(tail -1 $OUT/pytest_mode$m.log)" | tee -a $OUT/summary.txt; done
+  python tools/fuzz.py 90 61 > $OUT/fuzz.txt 2>&1; python tools/fuzz.py 60 62 long >> $OUT/fuzz.txt 2>&1; grep "^fuzz\|MISMATCH" $OUT/fuzz.txt | tee -a $OUT/summary.txt
+  ab --reps 5 --rounds 2 --cases c2,c2@0.4,c2@0.5,c2@0.6,c2@0.65,c2@0.7 base > $OUT/ab_repair.txt 2>&1; cat $OUT/ab_repair.txt
+  ;;
 *) echo "unknown session $S"; exit 2;;
 esac
