@@ -670,12 +670,12 @@ __global__ __launch_bounds__(64 * NW, SHORT ? 16 / NW : (FW < 64 ? ((WEIGHTED ? 
 // of a read hit 32 different bank pairs -- the floor for 8-byte accesses -- without any padding (with 16 they would
 // hit two).
 constexpr int kAlongC = 17;
-// The robust instantiation (rungs 1 / 2: pieces of a few samples) takes chunks of 31 samples where one LDS plane suffices:
-// the zone is walked once per 31 samples instead of once per 17, and -- what matters more -- a wave's walk lasts as long as
-// its slowest lane's, and the spread between lanes shrinks with the chunk: on the inputs of DR sweeps a wave walks
-// 2.70 -> 2.03 trips per sample at lambda = 0.5 and 4.24 -> 3.03 at 0.7 (host model: tools/study/links_study.py).  The
-// price is LDS: 16.9 KB per wave instead of 9.7, eight waves per CU instead of sixteen.  (31 is odd, see above, and a
-// chunk's piece ends fit the 32-bit masks of ChunkRec.)
+// Chunk length of the robust instantiation (rungs 1 / 2: pieces of a few samples).  Longer chunks walk the zone less often and --
+// what matters more -- shrink the spread between the lanes of a wave, whose walk lasts as long as its slowest lane's: with 31
+// samples a wave walks 2.70 -> 2.03 trips per sample at lambda = 0.5 and 4.24 -> 3.03 at 0.7 on the inputs of DR sweeps (host model:
+// tools/study/links_study.py).  The price is LDS: 16.9 KB per wave instead of 9.7, eight waves per CU instead of sixteen -- and
+// measured (end of round 3) that price is too high: 4096^2 DR at lambda = 0.5 / 0.7 12.7 -> 16.1, 23.7 -> 33.3 ms with 31, 13.7 / 25.0
+// with 23.  So: 17, like the plain instantiation.  (An odd number, see above; a chunk's piece ends fit the 32-bit masks of ChunkRec.)
 #ifndef PTV_ALONG_ROBUST_C
 #define PTV_ALONG_ROBUST_C 17
 #endif
@@ -1132,6 +1132,11 @@ __global__ __launch_bounds__(64) void sweep_gchunk_kernel(SweepArgs p, FibreGeom
 // chunk recorded there continues ITS walk (same last bend): if so the recorded outputs beyond are exact and the walk
 // stops; the scan resumes there.  Cost: the unproven stretches only (plus the overhang of their last piece), not
 // the fibre.  Data with pieces much longer than a chunk fail everywhere and degrade to one sequential walk per fibre.
+// The scan does not visit the chunks in between two failures (round 4): the chunk kernels PROVED every link they did not flag, so
+// only the flagged range and the first chunks of workgroups whose link in failed can be rejected, and the scan jumps from one of
+// those to the next (one bit per boundary, found by the check of the links across workgroups anyway).  At the upper end of rung 1
+// (lambda = 0.65 - 0.7 on unit noise: ~600 failed links across tile workgroups per row sweep) the lanes of a wave scan in lockstep
+// between their walks, and the scan was a third of the kernel: 4096^2 DR 18.3 -> 17.7, 22.1 -> 21.4 ms.
 constexpr link_t kFromStart = 1;   // "no bend yet: the true walk is still in its first piece" (real codes are >= 2)
 
 // what a repair walk keeps track of, whatever it reads its samples from

@@ -87,5 +87,10 @@ s11)  # the repair kernel jumping from failure to failure: parity where it works
   python tools/fuzz.py 90 61 > $OUT/fuzz.txt 2>&1; python tools/fuzz.py 60 62 long >> $OUT/fuzz.txt 2>&1; grep "^fuzz\|MISMATCH" $OUT/fuzz.txt | tee -a $OUT/summary.txt
   ab --reps 5 --rounds 2 --cases c2,c2@0.4,c2@0.5,c2@0.6,c2@0.65,c2@0.7 base > $OUT/ab_repair.txt 2>&1; cat $OUT/ab_repair.txt
   ;;
+s12)  # the final build (repair kernel that jumps): the suite once more, then the whole profile collection keyed to this build
+  timeout 900 python -m pytest tests -m gpu -q > $OUT/pytest_default.log 2>&1; echo "default: $(tail -1 $OUT/pytest_default.log)" | tee $OUT/summary.txt
+  python -c "import sys; sys.path.insert(0,'.'); from proxtv_amd import build; print('build id', build.build_id())" | tee -a $OUT/summary.txt
+  bash tools/collect_profiles.sh r04 > $OUT/profiles.log 2>&1; tail -3 $OUT/profiles.log
+  ;;
 *) echo "unknown session $S"; exit 2;;
 esac
