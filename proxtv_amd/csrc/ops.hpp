@@ -167,15 +167,17 @@ template <> struct Op<OP_DR_COL_FINAL> : InA {
 // in that form, which needs s' and t but not U at the epilogue -- a few ulps of |U| away from the reference's order.
 template <> struct Op<OP_DR_ROW> : InBminusA, NotFused {
     static constexpr unsigned IN_MASK = 7, OUT_MASK = 1;
-    // s' is staged for the walk (y = U - s') and needed again here.  Keeping it (4 array passes instead of 5) costs the
-    // kernel 32 VGPRs it does not have at two workgroups per CU -- measured 4 % slower than fetching it again, and
-    // the second read is served by the memory-side cache; the switch stays for builds with a roomier register budget.
-#ifdef PTV_KEEP_STAGED
+    // s' is staged for the walk (y = U - s') and needed again here: the strided tiles keep it in registers for PTV_KEEP_N = 8 of a
+    // thread's 16 rows (sweep.hip) and fetch the rest again.  All 16 cost the kernel 32 VGPRs it does not have at four workgroups
+    // per CU (28 spilled: 116.7 -> 144 us per launch); 8 cost three spilled registers and take a tenth off the sweep's HBM traffic
+    // (116.7 -> 114.5 us; the second read is mostly served by the L2 since U, t and the new t are non-temporal).  -DPTV_NO_KEEP_STAGED:
+    // fetch every row again.
+#ifndef PTV_NO_KEEP_STAGED
     static constexpr bool KEEP = true;
 #else
     static constexpr bool KEEP = false;
 #endif
-    __device__ static __forceinline__ Ext fetch_rest(const SweepArgs &p, long idx, double sp) { return Ext{sp, p.c[idx]}; }
+    __device__ static __forceinline__ Ext fetch_rest(const SweepArgs &p, long idx, double sp) { return Ext{sp, ld_once(p.c + idx)}; }
 #ifdef PTV_EXP_NOREFETCH   // experiment only (wrong results): what would the sweep cost without the second read of s'?
     __device__ static __forceinline__ Ext fetch(const SweepArgs &p, long idx) { return Ext{0.0, p.c[idx]}; }
 #else

@@ -92,5 +92,14 @@ s12)  # the final build (repair kernel that jumps): the suite once more, then th
   python -c "import sys; sys.path.insert(0,'.'); from proxtv_amd import build; print('build id', build.build_id())" | tee -a $OUT/summary.txt
   bash tools/collect_profiles.sh r04 > $OUT/profiles.log 2>&1; tail -3 $OUT/profiles.log
   ;;
+s13)  # s' kept in registers for half the rows of a DR row sweep: suite (default + rung 1 + the 64-fibre tile), the seed check, profiles of this build
+  timeout 900 python -m pytest tests -m gpu -q > $OUT/pytest_default.log 2>&1; echo "default: $(tail -1 $OUT/pytest_default.log)" | tee $OUT/summary.txt
+  FILES="tests/test_gpu_parity_2d.py tests/test_gpu_fuzz.py tests/test_gpu_boundary.py"
+  PROXTV_CHUNK_MODE=1 timeout 600 python -m pytest $FILES -m gpu -q > $OUT/pytest_mode1.log 2>&1; echo "pinned to rung 1 ($FILES): $(tail -1 $OUT/pytest_mode1.log)" | tee -a $OUT/summary.txt
+  PROXTV_TILE=0 timeout 600 python -m pytest $FILES -m gpu -q > $OUT/pytest_tile0.log 2>&1; echo "tile=0 ($FILES): $(tail -1 $OUT/pytest_tile0.log)" | tee -a $OUT/summary.txt
+  python -c "import sys; sys.path.insert(0,'.'); from proxtv_amd import build; print('build id', build.build_id())" | tee -a $OUT/summary.txt
+  QUICK=1 bash tools/collect_profiles.sh r04k > $OUT/profiles.log 2>&1; tail -3 $OUT/profiles.log
+  timeout 300 python tools/seed_check.py > $OUT/seed_check.txt 2>&1; tail -40 $OUT/seed_check.txt
+  ;;
 *) echo "unknown session $S"; exit 2;;
 esac
