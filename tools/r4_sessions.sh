@@ -101,5 +101,9 @@ s13)  # s' kept in registers for half the rows of a DR row sweep: suite (default
   QUICK=1 bash tools/collect_profiles.sh r04k > $OUT/profiles.log 2>&1; tail -3 $OUT/profiles.log
   timeout 300 python tools/seed_check.py > $OUT/seed_check.txt 2>&1; tail -40 $OUT/seed_check.txt
   ;;
+s14)  # soak of the last build
+  { echo "# python tools/fuzz.py <seconds> <seed> [nd|long] on one MI355X box, build $(python -c "import sys; sys.path.insert(0,'.'); from proxtv_amd import build; print(build.build_id())"); assertion: relative error <= 1e-9"
+    python tools/fuzz.py 150 71; python tools/fuzz.py 70 72 long; python tools/fuzz.py 40 73 nd; } > $OUT/fuzz_soak.txt 2>&1; grep -v amdgpu $OUT/fuzz_soak.txt
+  ;;
 *) echo "unknown session $S"; exit 2;;
 esac
