@@ -93,6 +93,39 @@ def test_global_chunks_long_pieces(ptv, clib, oracle, modes):
             assert_close(device.tv1_fibres(bd, lam, 1).cpu().numpy(), want.T, tol=1e-11, what=f"dim1 lam={lam} mode={m}")
 
 
+def test_lively_stretches_followed_by_flat_ones(clib, oracle, modes):
+    """Fibres whose lively stretches (unit noise) alternate with flat ones longer than a workgroup's span, through the
+    speculative rungs pinned, against the oracle fibre by fibre.  In a flat stretch every link across workgroups is in
+    doubt (no bend in the warm-up zone to start from), and the repair kernel jumps from the chunk that took a repair walk
+    over straight to the next such link: the bend its next walk starts from must come from the chunks it jumped over or
+    stay the one in hand -- the records before them may be a speculative walk's that a repair replaced."""
+    torch = pytest.importorskip("torch")
+    from proxtv_amd import device
+    rng = np.random.default_rng(4242)
+    m, n = 2048, 192
+    A = np.empty((m, n))
+    for j in range(n):
+        k, lively = 0, bool(rng.integers(0, 2))
+        while k < m:
+            span = int(rng.integers(30, 330)) if lively else int(rng.integers(100, 700))
+            A[k:k + span, j] = rng.normal() * 2 + (rng.standard_normal(min(span, m - k)) if lively else 0.0)
+            k += span
+            lively = not lively
+    ad = device.to_colmajor(torch.from_numpy(A).cuda())
+    bd = device.to_colmajor(torch.from_numpy(np.ascontiguousarray(A.T)).cuda())
+    before = clib.proxtv_set_option(b"tile", 1)
+    try:
+        for lam in (0.3, 0.7, 1.0, 1.6):
+            want = np.apply_along_axis(lambda f: oracle.tv1_hybrid(f, lam), 0, A)
+            for m_, tile in ((0, 1), (1, 1), (1, 0), (2, 1)):
+                modes(m_)
+                clib.proxtv_set_option(b"tile", tile)
+                assert_close(device.tv1_fibres(ad, lam, 0).cpu().numpy(), want, tol=1e-10, what=f"dim0 lam={lam} rung {m_}")
+                assert_close(device.tv1_fibres(bd, lam, 1).cpu().numpy(), want.T, tol=1e-10, what=f"dim1 lam={lam} rung {m_} tile {tile}")
+    finally:
+        clib.proxtv_set_option(b"tile", before)
+
+
 @pytest.mark.parametrize("deterministic", [1, 0])
 def test_policy_escalates_and_recovers(ptv, clib, oracle, modes, deterministic):
     """The policy, seeded from the input's statistics (deterministic = 1: the default) or hill-climbing on measured times
