@@ -1,0 +1,357 @@
+// repair_model.cpp -- HOST-ONLY model (never part of the library) of the stage behind the chunk kernels: speculative chunk walks leave
+// link codes and outputs; a repair pass finds the links that do not hold and re-walks from the last true bend.  Compiles the device
+// walker (walker.hpp) with g++ like tests/host_harness.cpp.  Every chunk is its own "workgroup" here (all links are links across
+// workgroups: the case the repair kernel's jump and the jobs repair are about).
+//
+// Four repairs of the same speculative state, each compared with the true prox of the fibre:
+//   SEQ_OLD   the sequential scan that JUMPS to the next link in doubt and looks the starting bend up with an unbounded scan back
+//             through the recorded codes (round 4 until its last commit)
+//   SEQ_NEW   the same with the scan bounded by the chunk the jump started from (the bend in hand stays if nothing in between bent)
+//   JOBS      one walk per failing link, all from the RECORDED codes, validity decided afterwards in order (sweep_repair_jobs_kernel);
+//             what it declines goes to SEQ_NEW
+//   JOBS_G    JOBS with the guard: a valid job must have started from a record at or behind the chunk that took the previous valid
+//             walk over
+#define PTV_HOST_TEST 1
+#define __device__
+#define __forceinline__ inline
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "../../proxtv_amd/csrc/walker.hpp"
+#include "../../proxtv_amd/csrc/chunkcore.hpp"
+
+using namespace ptv;
+
+namespace {
+typedef unsigned link_t;
+constexpr link_t kBad = 0xfffffffeu, kCertain = 0x80000000u, kFromStart = 1u;
+
+struct Fibre {
+    const double *y;
+    int len, C, H, NC;
+    double lam;
+    std::vector<link_t> mine, next;   // as the chunk kernels publish them
+    std::vector<double> spec;         // the speculative outputs
+    std::vector<char> doubt;          // link INTO chunk c in doubt
+};
+
+// one chunk's speculative walk: from a bend known a priori, else from a free end H samples before the chunk; it owns the pieces that
+// END inside the chunk -- their rows before the chunk too if its link is proven, else only its own rows (the rows between the last
+// true bend and an unproven chunk belong to the repair walk) -- and stops when the piece over its last sample is closed
+struct SpecSource {
+    const Fibre &f;
+    double *x;       // nullptr: codes only
+    int cs, ce;
+    bool proven;
+    link_t mine = 0, next = 0;
+    bool done = false;
+    double y(int i) const { return f.y[i]; }
+    double r(int) const { return 0.0; }
+    void piece(int from, int to, double v) {
+        if (x && to >= cs && to < ce) for (int k = proven ? from : std::max(from, cs); k <= to; k++) x[k] = v;
+        if (to >= ce - 1) done = true;
+    }
+    void bend(int at, int type) {
+        const link_t code = ((link_t)at << 1) | (link_t)type;
+        if (at <= cs) mine = code;
+        if (at <= ce) next = code;
+    }
+    bool keep_going(int) const { return !done; }
+};
+
+struct CertainWin {
+    const double *p;
+    double y(int i) const { return p[i]; }
+    double r(int) const { return 0.0; }
+};
+
+void speculate(Fibre &f) {
+    f.mine.assign(f.NC, 0);
+    f.next.assign(f.NC, 0);
+    f.doubt.assign(f.NC, 0);
+    f.spec.assign(f.len, 0.0);
+    for (int pass = 0; pass < 2; pass++) {
+    for (int c = 0; c < f.NC; c++) {
+        const int cs = c * f.C, ce = std::min(cs + f.C, f.len);
+        SpecSource s{f, pass ? f.spec.data() : nullptr, cs, ce, pass ? !f.doubt[c] : false};
+        Walker w;
+        bool certain = false;
+        if (cs - f.H <= 0) {
+            walker_start<false>(w, s, 0, f.lam);
+        } else {
+            int type = 0;
+            CertainWin win{f.y};
+            const int cat = certain_bend_before<false, 14>(win, cs, f.len, f.lam, type);
+            if (cat >= 0) {
+                walker_restart<false>(w, s, cat, type, f.len, f.lam);
+                s.mine = s.next = ((link_t)cat << 1) | (link_t)type;
+                certain = true;
+            } else {
+                walker_start<false>(w, s, cs - f.H, f.lam);
+            }
+        }
+        walker_run<false>(w, s, f.len, f.lam);
+        if (pass) continue;
+        f.mine[c] = certain ? (s.mine | kCertain) : s.mine;
+        f.next[c] = s.next;
+    }
+    if (pass) break;
+    for (int c = 1; c < f.NC; c++) {
+        const link_t in = f.mine[c], out = f.next[c - 1];
+        const bool certain = (in & kCertain) && in != kBad;
+        f.doubt[c] = (c * f.C - f.H > 0 && !certain && (in == 0 || in != out));
+    }
+    }
+}
+
+// the walk of a repair: from `cur`, writing from that bend on, until a chunk's recorded start agrees with it at a boundary
+struct RepairSrc {
+    const Fibre &f;
+    double *x;
+    int wfrom = 0, boundary = 0;
+    link_t last = 0;
+    bool stop = false;
+    int resume_chunk = 0;
+    link_t resume_code = 0;
+    int lo = 0, hi = 1 << 30;    // (jobs: the window; a walk that needs more aborts)
+    bool abort = false;
+    std::vector<std::pair<int, double>> parked;   // (jobs: outputs wait for the verdict)
+    bool park = false;
+    double y(int i) { if (i < lo || i >= hi) { abort = true; return 0.0; } return f.y[i]; }
+    double r(int) const { return 0.0; }
+    void begin(int chunk, link_t cur) {
+        wfrom = cur ? (int)(cur >> 1) : 0;
+        boundary = (chunk + 1) * f.C;
+        last = cur;
+        stop = false;
+    }
+    void piece(int from, int to, double v) {
+        from = std::max(from, wfrom);
+        if (from > to) return;
+        if (to >= hi) { abort = true; return; }
+        for (int k = from; k <= to; k++) {
+            if (park) parked.emplace_back(k, v); else x[k] = v;
+        }
+    }
+    void bend(int at, int type) {
+        const link_t code = ((link_t)at << 1) | (link_t)type;
+        while (!stop && boundary < f.len && at >= boundary) {
+            const link_t here = (at == boundary) ? code : last;
+            const int c = boundary / f.C;
+            link_t m = f.mine[c];
+            if (m != kBad) m &= ~kCertain;
+            if (m != 0 && m == here) {
+                stop = true;
+                resume_chunk = c;
+                resume_code = here;
+            } else {
+                boundary += f.C;
+            }
+        }
+        last = code;
+    }
+    bool keep_going(int) const { return !stop && !abort; }
+};
+
+link_t last_bend_before(const Fibre &f, int chunk, int floor_chunk, int *from_chunk = nullptr) {
+    for (int b = chunk - 1; b >= floor_chunk; b--)
+        if (f.next[b] != 0) {
+            if (from_chunk) *from_chunk = b;
+            return f.next[b];
+        }
+    if (from_chunk) *from_chunk = -1;
+    return 0;   // (none in range)
+}
+
+void run_walk(const Fibre &f, RepairSrc &s, int chunk, link_t cur) {
+    const link_t from = (cur == kFromStart) ? 0u : cur;
+    s.begin(chunk, from);
+    Walker w;
+    if (cur == kFromStart) walker_start<false>(w, s, 0, f.lam);
+    else walker_restart<false>(w, s, (int)(cur >> 1), (int)(cur & 1u), f.len, f.lam);
+    walker_run<false>(w, s, f.len, f.lam);
+}
+
+// the sequential repair with the jump; `bounded`: the scan behind a jump stops at the chunk the jump started from.
+// `skip`: fibres' chunks a jobs pass has dealt with are not in doubt any more (pass nullptr otherwise)
+int repair_seq(const Fibre &f, double *x, bool bounded, long *stale_reads) {
+    int first = f.NC, lastbad = -1;
+    for (int c = 1; c < f.NC; c++)
+        if (f.doubt[c]) { first = std::min(first, c); lastbad = c; }
+    if (lastbad < 0) return 0;
+    auto next_suspect = [&](int c) {
+        for (int b = c; b < f.NC; b++) if (f.doubt[b]) return b;
+        return f.NC;
+    };
+    link_t cur = last_bend_before(f, first, 0);
+    if (cur == 0) cur = kFromStart;
+    int c = first, walks = 0;
+    int rewritten_from = f.NC, rewritten_to = -1;   // chunks whose records a repair walk has made stale: [from, to)
+    while (true) {
+        bool rejected = false;
+        while (c < f.NC && c <= lastbad && !rejected) {
+            const int suspect = next_suspect(c);
+            if (suspect > c) {
+                if (suspect >= f.NC || suspect > lastbad) { c = suspect; break; }
+                if (bounded) {
+                    const link_t found = last_bend_before(f, suspect, c);
+                    if (found) cur = found;
+                } else {
+                    int from_chunk = -1;
+                    link_t found = last_bend_before(f, suspect, 0, &from_chunk);
+                    if (found == 0) found = kFromStart;
+                    if (from_chunk >= rewritten_from && from_chunk < rewritten_to && found != cur && stale_reads) ++*stale_reads;
+                    cur = found;
+                }
+                c = suspect;
+            }
+            const link_t mraw = f.mine[c];
+            const bool certain = (mraw & kCertain) && mraw != kBad;
+            const link_t m = certain ? (mraw & ~kCertain) : mraw;
+            const bool accept = (c * f.C - f.H <= 0 || certain) ? (m != kBad) : (m != 0 && m == cur);
+            if (accept) {
+                if (f.next[c] != 0) cur = f.next[c];
+                c++;
+            } else {
+                rejected = true;
+            }
+        }
+        if (c >= f.NC || !rejected) break;
+        RepairSrc s{f, x};
+        run_walk(f, s, c, cur);
+        walks++;
+        if (!s.stop) break;
+        rewritten_from = std::min(rewritten_from, c);
+        rewritten_to = std::max(rewritten_to, s.resume_chunk);
+        c = s.resume_chunk;
+        cur = s.resume_code;
+    }
+    return walks;
+}
+
+// the jobs repair: returns false if it declines the fibre (nothing written then)
+bool repair_jobs(const Fibre &f, double *x, bool guard, int window, int max_jobs) {
+    std::vector<int> X;
+    for (int c = 1; c < f.NC; c++) if (f.doubt[c]) X.push_back(c);
+    if (X.empty()) return true;
+    if ((int)X.size() > max_jobs) return false;
+    struct Job { int X, r, from_chunk; bool abort; std::vector<std::pair<int, double>> out; };
+    std::vector<Job> jobs;
+    for (int Xk : X) {
+        Job j{Xk, f.NC, -1, false, {}};
+        link_t cur = last_bend_before(f, Xk, 0, &j.from_chunk);
+        if (cur == 0) cur = kFromStart;
+        const link_t mine = f.mine[Xk];
+        if (mine != 0 && mine != kBad && mine == cur) {
+            j.r = Xk;
+        } else {
+            RepairSrc s{f, nullptr};
+            s.park = true;
+            const int at = (cur == kFromStart) ? 0 : (int)(cur >> 1);
+            s.lo = std::max(0, at - 1);
+            s.hi = std::min(f.len, s.lo + window);
+            run_walk(f, s, Xk, cur);
+            j.abort = s.abort;
+            j.r = s.stop ? s.resume_chunk : f.NC;
+            j.out.swap(s.parked);
+        }
+        jobs.push_back(std::move(j));
+    }
+    int lastr = -1;
+    std::vector<char> valid(jobs.size(), 0);
+    for (size_t k = 0; k < jobs.size(); k++) {
+        if (jobs[k].abort) return false;
+        const bool vk = lastr < 0 || lastr <= jobs[k].X - 1;
+        if (vk && guard && lastr >= 0 && jobs[k].from_chunk < lastr) return false;
+        if (vk) lastr = jobs[k].r;
+        valid[k] = vk;
+    }
+    for (size_t k = 0; k < jobs.size(); k++)
+        if (valid[k]) for (auto &kv : jobs[k].out) x[kv.first] = kv.second;
+    return true;
+}
+
+double worst_diff(const std::vector<double> &a, const std::vector<double> &b) {
+    double w = 0.0;
+    for (size_t k = 0; k < a.size(); k++) w = std::max(w, std::fabs(a[k] - b[k]));
+    return w;
+}
+}  // namespace
+
+extern "C" {
+// out[0..11]: fibres with a link in doubt ; links in doubt ; walks of SEQ_NEW ; fibres where SEQ_OLD / SEQ_NEW / JOBS / JOBS_G end wrong (4) ;
+//             fibres JOBS / JOBS_G declined (2) ; stale records read by SEQ_OLD ; fibres where the speculation alone is already exact ; spare
+// worst[0..3]: largest absolute error of the four repairs.  Returns the index of the first fibre SEQ_OLD gets wrong (-1: none).
+int model_fibres(const double *Y, int count, int len, double lam, int C, int H, int window, int max_jobs, long *out, double *worst) {
+    int first_bad = -1;
+    for (int j = 0; j < count; j++) {
+        Fibre f{Y + (size_t)j * len, len, C, H, (len + C - 1) / C, lam, {}, {}, {}, {}};
+        speculate(f);
+        std::vector<double> truth(len);
+        {
+            struct Src {
+                const double *yy; double *x;
+                double y(int i) const { return yy[i]; }
+                double r(int) const { return 0.0; }
+                void piece(int a, int b, double v) { for (int k = a; k <= b; k++) x[k] = v; }
+                void bend(int, int) {}
+                bool keep_going(int) const { return true; }
+            } s{f.y, truth.data()};
+            Walker w;
+            walker_start<false>(w, s, 0, lam);
+            walker_run<false>(w, s, len, lam);
+        }
+        int doubts = 0;
+        for (int c = 1; c < f.NC; c++) doubts += f.doubt[c];
+        if (doubts == 0) {
+            out[10] += worst_diff(f.spec, truth) <= 1e-9;
+            continue;
+        }
+        out[0]++;
+        out[1] += doubts;
+        const double tol = 1e-9;
+        {
+            std::vector<double> x = f.spec;
+            repair_seq(f, x.data(), false, &out[9]);
+            const double e = worst_diff(x, truth);
+            worst[0] = std::max(worst[0], e);
+            if (e > tol) { out[3]++; if (first_bad < 0) first_bad = j; }
+        }
+        {
+            std::vector<double> x = f.spec;
+            out[2] += repair_seq(f, x.data(), true, nullptr);
+            const double e = worst_diff(x, truth);
+            worst[1] = std::max(worst[1], e);
+            if (e > tol) out[4]++;
+        }
+        for (int g = 0; g < 2; g++) {
+            std::vector<double> x = f.spec;
+            if (!repair_jobs(f, x.data(), g == 1, window, max_jobs)) {
+                out[7 + g]++;
+                repair_seq(f, x.data(), true, nullptr);
+            }
+            const double e = worst_diff(x, truth);
+            worst[2 + g] = std::max(worst[2 + g], e);
+            if (e > tol) out[5 + g]++;
+        }
+    }
+    return first_bad;
+}
+
+// one fibre laid open: the speculative outputs and codes, and the result of one repair (which: 0 SEQ_OLD, 1 SEQ_NEW, 2 JOBS, 3 JOBS_G)
+void model_debug(const double *y, int len, double lam, int C, int H, int which, double *spec, double *repaired, unsigned *mine, unsigned *next,
+                 char *doubt) {
+    Fibre f{y, len, C, H, (len + C - 1) / C, lam, {}, {}, {}, {}};
+    speculate(f);
+    std::copy(f.spec.begin(), f.spec.end(), spec);
+    std::copy(f.mine.begin(), f.mine.end(), mine);
+    std::copy(f.next.begin(), f.next.end(), next);
+    std::copy(f.doubt.begin(), f.doubt.end(), doubt);
+    std::vector<double> x = f.spec;
+    if (which < 2) repair_seq(f, x.data(), which == 1, nullptr);
+    else if (!repair_jobs(f, x.data(), which == 3, 128, 4)) repair_seq(f, x.data(), true, nullptr);
+    std::copy(x.begin(), x.end(), repaired);
+}
+}
