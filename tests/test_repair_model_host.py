@@ -1,0 +1,59 @@
+"""The stage behind the chunk kernels as a HOST model (tools/study/repair_model.cpp: the device walker compiled with g++, speculative
+chunk walks with the device's ownership rule, then the repairs): the sequential repair that jumps from link in doubt to link in doubt
+-- with the scan behind a jump unbounded, as in round 4, and bounded -- and the repair with one walk per failing link whose validity
+is decided afterwards (staged: tools/staged/), each against the sequential walk of the whole fibre.  Exact by construction, every one
+of them, on every fibre: what DESIGN 5 argues, checked here on a sample small enough for the CPU suite."""
+import ctypes as C
+import os
+import subprocess
+import tempfile
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def model():
+    out = os.path.join(tempfile.mkdtemp(prefix="ptv_repair_"), "librepair_model.so")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", out, os.path.join(ROOT, "tools", "study", "repair_model.cpp")], check=True)
+    lib = C.CDLL(out)
+    lib.model_fibres.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    lib.model_fibres.restype = C.c_int
+    return lib
+
+
+def lively_flat(rng, n, m):
+    X = np.empty((n, m))
+    for f in X:
+        k, on = 0, bool(rng.integers(0, 2))
+        while k < m:
+            span = int(rng.integers(20, 200)) if on else int(rng.integers(40, 400))
+            f[k:k + span] = rng.normal() * 2 + (rng.standard_normal(min(span, m - k)) if on else 0.0)
+            k += span
+            on = not on
+    return X
+
+
+@pytest.mark.parametrize("max_jobs", [4, 1 << 20])
+def test_every_repair_is_exact(model, max_jobs):
+    rng = np.random.default_rng(31)
+    n, m = 60, 1024
+    families = {
+        "noise": rng.standard_normal((n, m)),
+        "lively / flat": lively_flat(rng, n, m),
+        "random walk": np.cumsum(rng.standard_normal((n, m)), axis=1) * 0.3,
+        "blocks": np.repeat(rng.standard_normal((n, m // 16)), 16, axis=1) + 0.2 * rng.standard_normal((n, m)),
+    }
+    doubts = handled = 0
+    for name, X in families.items():
+        X = np.ascontiguousarray(X)
+        for lam in (0.7, 1.2, 3.0):
+            out, worst = np.zeros(12, dtype=np.int64), np.zeros(4)
+            first = model.model_fibres(X.ctypes.data, n, m, lam, 16, 16, 128, max_jobs, out.ctypes.data, worst.ctypes.data)
+            assert first == -1 and not out[3:7].any(), f"{name} lambda {lam}: fibres wrong after seq old / seq new / jobs / jobs+guard {out[3:7]}, worst {worst}"
+            doubts += int(out[1])
+            handled += int(out[0] - out[8])
+    assert doubts > 1000          # the sample has links in doubt by the thousand ...
+    assert handled > 50           # ... and fibres the jobs repair took on itself
