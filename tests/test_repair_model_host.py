@@ -19,7 +19,7 @@ def model():
     out = os.path.join(tempfile.mkdtemp(prefix="ptv_repair_"), "librepair_model.so")
     subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", out, os.path.join(ROOT, "tools", "study", "repair_model.cpp")], check=True)
     lib = C.CDLL(out)
-    lib.model_fibres.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    lib.model_fibres.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     lib.model_fibres.restype = C.c_int
     return lib
 
@@ -36,8 +36,9 @@ def lively_flat(rng, n, m):
     return X
 
 
+@pytest.mark.parametrize("weighted", [False, True])
 @pytest.mark.parametrize("max_jobs", [4, 1 << 20])
-def test_every_repair_is_exact(model, max_jobs):
+def test_every_repair_is_exact(model, max_jobs, weighted):
     rng = np.random.default_rng(31)
     n, m = 60, 1024
     families = {
@@ -51,7 +52,8 @@ def test_every_repair_is_exact(model, max_jobs):
         X = np.ascontiguousarray(X)
         for lam in (0.7, 1.2, 3.0):
             out, worst = np.zeros(12, dtype=np.int64), np.zeros(4)
-            first = model.model_fibres(X.ctypes.data, n, m, lam, 16, 16, 128, max_jobs, out.ctypes.data, worst.ctypes.data)
+            Wt = np.ascontiguousarray(rng.uniform(0.3 * lam, 1.7 * lam, (n, m))) if weighted else None
+            first = model.model_fibres(X.ctypes.data, Wt.ctypes.data if weighted else None, n, m, lam, 16, 16, 128, max_jobs, out.ctypes.data, worst.ctypes.data)
             assert first == -1 and not out[3:7].any(), f"{name} lambda {lam}: fibres wrong after seq old / seq new / jobs / jobs+guard {out[3:7]}, worst {worst}"
             doubts += int(out[1])
             handled += int(out[0] - out[8])

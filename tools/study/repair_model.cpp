@@ -30,6 +30,7 @@ constexpr link_t kBad = 0xfffffffeu, kCertain = 0x80000000u, kFromStart = 1u;
 
 struct Fibre {
     const double *y;
+    const double *w;   // per-edge penalties (len - 1), or nullptr: lam on every edge
     int len, C, H, NC;
     double lam;
     std::vector<link_t> mine, next;   // as the chunk kernels publish them
@@ -48,7 +49,7 @@ struct SpecSource {
     link_t mine = 0, next = 0;
     bool done = false;
     double y(int i) const { return f.y[i]; }
-    double r(int) const { return 0.0; }
+    double r(int i) const { return f.w[i]; }
     void piece(int from, int to, double v) {
         if (x && to >= cs && to < ce) for (int k = proven ? from : std::max(from, cs); k <= to; k++) x[k] = v;
         if (to >= ce - 1) done = true;
@@ -62,11 +63,12 @@ struct SpecSource {
 };
 
 struct CertainWin {
-    const double *p;
+    const double *p, *w;
     double y(int i) const { return p[i]; }
-    double r(int) const { return 0.0; }
+    double r(int i) const { return w[i]; }
 };
 
+template <bool W>
 void speculate(Fibre &f) {
     f.mine.assign(f.NC, 0);
     f.next.assign(f.NC, 0);
@@ -79,20 +81,20 @@ void speculate(Fibre &f) {
         Walker w;
         bool certain = false;
         if (cs - f.H <= 0) {
-            walker_start<false>(w, s, 0, f.lam);
+            walker_start<W>(w, s, 0, f.lam);
         } else {
             int type = 0;
-            CertainWin win{f.y};
-            const int cat = certain_bend_before<false, 14>(win, cs, f.len, f.lam, type);
+            CertainWin win{f.y, f.w};
+            const int cat = certain_bend_before<W, 14>(win, cs, f.len, f.lam, type);
             if (cat >= 0) {
-                walker_restart<false>(w, s, cat, type, f.len, f.lam);
+                walker_restart<W>(w, s, cat, type, f.len, f.lam);
                 s.mine = s.next = ((link_t)cat << 1) | (link_t)type;
                 certain = true;
             } else {
-                walker_start<false>(w, s, cs - f.H, f.lam);
+                walker_start<W>(w, s, cs - f.H, f.lam);
             }
         }
-        walker_run<false>(w, s, f.len, f.lam);
+        walker_run<W>(w, s, f.len, f.lam);
         if (pass) continue;
         f.mine[c] = certain ? (s.mine | kCertain) : s.mine;
         f.next[c] = s.next;
@@ -120,7 +122,7 @@ struct RepairSrc {
     std::vector<std::pair<int, double>> parked;   // (jobs: outputs wait for the verdict)
     bool park = false;
     double y(int i) { if (i < lo || i >= hi) { abort = true; return 0.0; } return f.y[i]; }
-    double r(int) const { return 0.0; }
+    double r(int i) { if (i < lo || i >= hi) { abort = true; return 0.0; } return f.w[i]; }
     void begin(int chunk, link_t cur) {
         wfrom = cur ? (int)(cur >> 1) : 0;
         boundary = (chunk + 1) * f.C;
@@ -165,17 +167,19 @@ link_t last_bend_before(const Fibre &f, int chunk, int floor_chunk, int *from_ch
     return 0;   // (none in range)
 }
 
+template <bool W>
 void run_walk(const Fibre &f, RepairSrc &s, int chunk, link_t cur) {
     const link_t from = (cur == kFromStart) ? 0u : cur;
     s.begin(chunk, from);
     Walker w;
-    if (cur == kFromStart) walker_start<false>(w, s, 0, f.lam);
-    else walker_restart<false>(w, s, (int)(cur >> 1), (int)(cur & 1u), f.len, f.lam);
-    walker_run<false>(w, s, f.len, f.lam);
+    if (cur == kFromStart) walker_start<W>(w, s, 0, f.lam);
+    else walker_restart<W>(w, s, (int)(cur >> 1), (int)(cur & 1u), f.len, f.lam);
+    walker_run<W>(w, s, f.len, f.lam);
 }
 
 // the sequential repair with the jump; `bounded`: the scan behind a jump stops at the chunk the jump started from.
 // `skip`: fibres' chunks a jobs pass has dealt with are not in doubt any more (pass nullptr otherwise)
+template <bool W>
 int repair_seq(const Fibre &f, double *x, bool bounded, long *stale_reads) {
     int first = f.NC, lastbad = -1;
     for (int c = 1; c < f.NC; c++)
@@ -220,7 +224,7 @@ int repair_seq(const Fibre &f, double *x, bool bounded, long *stale_reads) {
         }
         if (c >= f.NC || !rejected) break;
         RepairSrc s{f, x};
-        run_walk(f, s, c, cur);
+        run_walk<W>(f, s, c, cur);
         walks++;
         if (!s.stop) break;
         rewritten_from = std::min(rewritten_from, c);
@@ -232,6 +236,7 @@ int repair_seq(const Fibre &f, double *x, bool bounded, long *stale_reads) {
 }
 
 // the jobs repair: returns false if it declines the fibre (nothing written then)
+template <bool W>
 bool repair_jobs(const Fibre &f, double *x, bool guard, int window, int max_jobs) {
     std::vector<int> X;
     for (int c = 1; c < f.NC; c++) if (f.doubt[c]) X.push_back(c);
@@ -252,7 +257,7 @@ bool repair_jobs(const Fibre &f, double *x, bool guard, int window, int max_jobs
             const int at = (cur == kFromStart) ? 0 : (int)(cur >> 1);
             s.lo = std::max(0, at - 1);
             s.hi = std::min(f.len, s.lo + window);
-            run_walk(f, s, Xk, cur);
+            run_walk<W>(f, s, Xk, cur);
             j.abort = s.abort;
             j.r = s.stop ? s.resume_chunk : f.NC;
             j.out.swap(s.parked);
@@ -278,30 +283,26 @@ double worst_diff(const std::vector<double> &a, const std::vector<double> &b) {
     for (size_t k = 0; k < a.size(); k++) w = std::max(w, std::fabs(a[k] - b[k]));
     return w;
 }
-}  // namespace
 
-extern "C" {
-// out[0..11]: fibres with a link in doubt ; links in doubt ; walks of SEQ_NEW ; fibres where SEQ_OLD / SEQ_NEW / JOBS / JOBS_G end wrong (4) ;
-//             fibres JOBS / JOBS_G declined (2) ; stale records read by SEQ_OLD ; fibres where the speculation alone is already exact ; spare
-// worst[0..3]: largest absolute error of the four repairs.  Returns the index of the first fibre SEQ_OLD gets wrong (-1: none).
-int model_fibres(const double *Y, int count, int len, double lam, int C, int H, int window, int max_jobs, long *out, double *worst) {
+template <bool W>
+int model_run(const double *Y, const double *Wt, int count, int len, double lam, int C, int H, int window, int max_jobs, long *out, double *worst) {
     int first_bad = -1;
     for (int j = 0; j < count; j++) {
-        Fibre f{Y + (size_t)j * len, len, C, H, (len + C - 1) / C, lam, {}, {}, {}, {}};
-        speculate(f);
+        Fibre f{Y + (size_t)j * len, W ? Wt + (size_t)j * len : nullptr, len, C, H, (len + C - 1) / C, lam, {}, {}, {}, {}};
+        speculate<W>(f);
         std::vector<double> truth(len);
         {
             struct Src {
-                const double *yy; double *x;
+                const double *yy, *ww; double *x;
                 double y(int i) const { return yy[i]; }
-                double r(int) const { return 0.0; }
+                double r(int i) const { return ww[i]; }
                 void piece(int a, int b, double v) { for (int k = a; k <= b; k++) x[k] = v; }
                 void bend(int, int) {}
                 bool keep_going(int) const { return true; }
-            } s{f.y, truth.data()};
+            } s{f.y, f.w, truth.data()};
             Walker w;
-            walker_start<false>(w, s, 0, lam);
-            walker_run<false>(w, s, len, lam);
+            walker_start<W>(w, s, 0, lam);
+            walker_run<W>(w, s, len, lam);
         }
         int doubts = 0;
         for (int c = 1; c < f.NC; c++) doubts += f.doubt[c];
@@ -314,23 +315,23 @@ int model_fibres(const double *Y, int count, int len, double lam, int C, int H, 
         const double tol = 1e-9;
         {
             std::vector<double> x = f.spec;
-            repair_seq(f, x.data(), false, &out[9]);
+            repair_seq<W>(f, x.data(), false, &out[9]);
             const double e = worst_diff(x, truth);
             worst[0] = std::max(worst[0], e);
             if (e > tol) { out[3]++; if (first_bad < 0) first_bad = j; }
         }
         {
             std::vector<double> x = f.spec;
-            out[2] += repair_seq(f, x.data(), true, nullptr);
+            out[2] += repair_seq<W>(f, x.data(), true, nullptr);
             const double e = worst_diff(x, truth);
             worst[1] = std::max(worst[1], e);
             if (e > tol) out[4]++;
         }
         for (int g = 0; g < 2; g++) {
             std::vector<double> x = f.spec;
-            if (!repair_jobs(f, x.data(), g == 1, window, max_jobs)) {
+            if (!repair_jobs<W>(f, x.data(), g == 1, window, max_jobs)) {
                 out[7 + g]++;
-                repair_seq(f, x.data(), true, nullptr);
+                repair_seq<W>(f, x.data(), true, nullptr);
             }
             const double e = worst_diff(x, truth);
             worst[2 + g] = std::max(worst[2 + g], e);
@@ -339,19 +340,15 @@ int model_fibres(const double *Y, int count, int len, double lam, int C, int H, 
     }
     return first_bad;
 }
+}  // namespace
 
-// one fibre laid open: the speculative outputs and codes, and the result of one repair (which: 0 SEQ_OLD, 1 SEQ_NEW, 2 JOBS, 3 JOBS_G)
-void model_debug(const double *y, int len, double lam, int C, int H, int which, double *spec, double *repaired, unsigned *mine, unsigned *next,
-                 char *doubt) {
-    Fibre f{y, len, C, H, (len + C - 1) / C, lam, {}, {}, {}, {}};
-    speculate(f);
-    std::copy(f.spec.begin(), f.spec.end(), spec);
-    std::copy(f.mine.begin(), f.mine.end(), mine);
-    std::copy(f.next.begin(), f.next.end(), next);
-    std::copy(f.doubt.begin(), f.doubt.end(), doubt);
-    std::vector<double> x = f.spec;
-    if (which < 2) repair_seq(f, x.data(), which == 1, nullptr);
-    else if (!repair_jobs(f, x.data(), which == 3, 128, 4)) repair_seq(f, x.data(), true, nullptr);
-    std::copy(x.begin(), x.end(), repaired);
+extern "C" {
+// Y: count fibres of len samples.  Wt: per-edge penalties, count x len (the last of a fibre unused), or nullptr: lam on every edge.
+// out[0..11]: fibres with a link in doubt ; links in doubt ; walks of SEQ_NEW ; fibres where SEQ_OLD / SEQ_NEW / JOBS / JOBS_G end wrong (4) ;
+//             fibres JOBS / JOBS_G declined (2) ; stale records read by SEQ_OLD ; fibres where the speculation alone is already exact ; spare
+// worst[0..3]: largest absolute error of the four repairs.  Returns the index of the first fibre SEQ_OLD gets wrong (-1: none).
+int model_fibres(const double *Y, const double *Wt, int count, int len, double lam, int C, int H, int window, int max_jobs, long *out, double *worst) {
+    return Wt ? model_run<true>(Y, Wt, count, len, lam, C, H, window, max_jobs, out, worst)
+              : model_run<false>(Y, nullptr, count, len, lam, C, H, window, max_jobs, out, worst);
 }
 }
