@@ -265,9 +265,7 @@ def main():
             for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):   # newest round first
                 with open(path) as f:
                     cand = json.load(f)
-                # (`same_machine_code`: later builds in which the MEASURED kernels are byte-for-byte the machine code the counters were taken
-                # on -- checked kernel by kernel with tools/same_kernels.py, whose output is committed next to the counters)
-                if cand.get("build_id") == _build.build_id() or _build.build_id() in cand.get("same_machine_code", {}):
+                if cand.get("build_id") == _build.build_id():
                     pmc = cand
                     break
             if pmc:

@@ -1369,23 +1369,9 @@ __global__ __launch_bounds__(64) void sweep_repair_kernel(SweepArgs p, FibreGeom
             // and everything after it are true) -- one memory round trip per failure instead of one per UB chunks in between
             const int suspect = next_suspect(c);
             if (suspect > c) {
-                if (suspect >= NC || suspect > lastbad) {
-                    c = suspect;
-                    break;
-                }
-                // The true walk's last bend before `suspect`: the latest one recorded by the chunks jumped over -- true records, of chunks accepted
-                // or never in doubt.  The chunks BEFORE c may have been rewritten by a repair walk since, and their records are the speculative
-                // walks' still: if none of the chunks jumped over bent, the bend in hand stays.  (A scan back past c -- as this was until the
-                // end of round 4 -- reads such a record when a walk was taken over exactly at a flagged boundary and the string then runs
-                // without a bend up to the next flagged one: a flat stretch of a workgroup's span behind a lively one.)
-                for (int b = suspect - 1; b >= c; b--) {
-                    const link_t nx = code_next[(long)b * cstride + j * fstride];
-                    if (nx != 0) {
-                        cur = nx;
-                        break;
-                    }
-                }
                 c = suspect;
+                if (c >= NC || c > lastbad) break;
+                cur = last_bend_before(c);
             }
             link_t mm[UB], nn[UB];
 #pragma unroll

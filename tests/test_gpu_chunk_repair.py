@@ -97,8 +97,9 @@ def test_lively_stretches_followed_by_flat_ones(clib, oracle, modes):
     """Fibres whose lively stretches (unit noise) alternate with flat ones longer than a workgroup's span, through the
     speculative rungs pinned, against the oracle fibre by fibre.  In a flat stretch every link across workgroups is in
     doubt (no bend in the warm-up zone to start from), and the repair kernel jumps from the chunk that took a repair walk
-    over straight to the next such link: the bend its next walk starts from must come from the chunks it jumped over or
-    stay the one in hand -- the records before them may be a speculative walk's that a repair replaced."""
+    over straight to the next such link: the bend its next walk starts from is the record of the chunk before that link,
+    which the chunk kernel proved -- never one of the records further back, which a repair walk may have made stale
+    (the host model of the stage: tests/test_repair_model_host.py)."""
     torch = pytest.importorskip("torch")
     from proxtv_amd import device
     rng = np.random.default_rng(4242)

@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
 """Lively stretches followed by flat ones, through the speculative rungs pinned, against the sequential walk (rung 5).
 
-The repair kernel jumps from a chunk that took a repair walk over to the next link in doubt; the bend it starts the next walk from
-must come from the chunks it jumps over or stay the one in hand -- never from records before them, which a repair walk may have made
-stale.  The data that would tell: fibres whose lively stretches end on a workgroup boundary's worth of flat samples.
+The repair kernel jumps from a chunk that took a repair walk over to the next link in doubt; the bend it starts the next walk from is
+the record of the chunk just before that link -- a chunk the chunk kernel proved, whose record is therefore non-zero and true.
+The data that would tell if it were otherwise: fibres whose lively stretches end on a workgroup boundary's worth of flat samples,
+where every link across workgroups is in doubt.
 
     python tools/repair_scan_check.py [seed]        (exit status 1 on a mismatch; honours PROXTV_LIB with PROXTV_DEBUG_ALT_LIB=1)
 """

@@ -294,15 +294,25 @@ int model_run(const double *Y, const double *Wt, int count, int len, double lam,
         {
             struct Src {
                 const double *yy, *ww; double *x;
+                std::vector<link_t> codes;
                 double y(int i) const { return yy[i]; }
                 double r(int i) const { return ww[i]; }
                 void piece(int a, int b, double v) { for (int k = a; k <= b; k++) x[k] = v; }
-                void bend(int, int) {}
+                void bend(int at, int type) { codes.push_back(((link_t)at << 1) | (link_t)type); }
                 bool keep_going(int) const { return true; }
-            } s{f.y, f.w, truth.data()};
+            } s{f.y, f.w, truth.data(), {}};
             Walker w;
             walker_start<W>(w, s, 0, lam);
             walker_run<W>(w, s, len, lam);
+            // The invariant everything above leans on: a chunk whose recorded start IS the true walk's last bend at or before it is never in
+            // doubt -- its predecessor, walking the same samples from a free end 16 samples earlier, has met the true walk too.
+            size_t k = 0;
+            link_t true_before = 0;
+            for (int c = 1; c < f.NC; c++) {
+                while (k < s.codes.size() && (int)(s.codes[k] >> 1) <= c * f.C) true_before = s.codes[k++];
+                const link_t m = f.mine[c] == kBad ? kBad : (f.mine[c] & ~kCertain);
+                if (f.doubt[c] && m != 0 && m != kBad && m == true_before) out[11]++;
+            }
         }
         int doubts = 0;
         for (int c = 1; c < f.NC; c++) doubts += f.doubt[c];
@@ -345,7 +355,8 @@ int model_run(const double *Y, const double *Wt, int count, int len, double lam,
 extern "C" {
 // Y: count fibres of len samples.  Wt: per-edge penalties, count x len (the last of a fibre unused), or nullptr: lam on every edge.
 // out[0..11]: fibres with a link in doubt ; links in doubt ; walks of SEQ_NEW ; fibres where SEQ_OLD / SEQ_NEW / JOBS / JOBS_G end wrong (4) ;
-//             fibres JOBS / JOBS_G declined (2) ; stale records read by SEQ_OLD ; fibres where the speculation alone is already exact ; spare
+//             fibres JOBS / JOBS_G declined (2) ; stale records read by SEQ_OLD ; fibres where the speculation alone is already exact ;
+//             chunks in doubt although their recorded start is the true bend (the invariant: never)
 // worst[0..3]: largest absolute error of the four repairs.  Returns the index of the first fibre SEQ_OLD gets wrong (-1: none).
 int model_fibres(const double *Y, const double *Wt, int count, int len, double lam, int C, int H, int window, int max_jobs, long *out, double *worst) {
     return Wt ? model_run<true>(Y, Wt, count, len, lam, C, H, window, max_jobs, out, worst)

@@ -62,7 +62,8 @@ def main():
                   f"           {out[7]:6d} {out[8]:6d} | {out[9]:11d} | {worst[0]:.1e} {worst[1]:.1e} {worst[2]:.1e} {worst[3]:.1e}"
                   + (f"   (first fibre the old scan gets wrong: {first})" if first >= 0 else ""), flush=True)
     print(f"# all cases: fibres with a link in doubt {total[0]}, links {total[1]}; wrong after seq old / seq new / jobs / jobs+guard: "
-          f"{total[3]} / {total[4]} / {total[5]} / {total[6]}; stale records read by the old scan: {total[9]}")
+          f"{total[3]} / {total[4]} / {total[5]} / {total[6]}; stale records read by the old scan: {total[9]}; "
+          f"chunks in doubt although their recorded start is the true bend: {total[11]}")
 
 
 if __name__ == "__main__":
