@@ -304,8 +304,9 @@ int model_run(const double *Y, const double *Wt, int count, int len, double lam,
             Walker w;
             walker_start<W>(w, s, 0, lam);
             walker_run<W>(w, s, len, lam);
-            // The invariant everything above leans on: a chunk whose recorded start IS the true walk's last bend at or before it is never in
-            // doubt -- its predecessor, walking the same samples from a free end 16 samples earlier, has met the true walk too.
+            // A first guess at why the repairs are sound -- "a chunk whose recorded start IS the true walk's last bend at or before it is never
+            // in doubt" -- counted: it is FALSE (a predecessor's walk can still be off at its end where the successor's warm-up has already
+            // met the true walk).  The reason that holds is about the codes: a proven chunk's `next` is never zero.
             size_t k = 0;
             link_t true_before = 0;
             for (int c = 1; c < f.NC; c++) {
@@ -356,7 +357,7 @@ extern "C" {
 // Y: count fibres of len samples.  Wt: per-edge penalties, count x len (the last of a fibre unused), or nullptr: lam on every edge.
 // out[0..11]: fibres with a link in doubt ; links in doubt ; walks of SEQ_NEW ; fibres where SEQ_OLD / SEQ_NEW / JOBS / JOBS_G end wrong (4) ;
 //             fibres JOBS / JOBS_G declined (2) ; stale records read by SEQ_OLD ; fibres where the speculation alone is already exact ;
-//             chunks in doubt although their recorded start is the true bend (the invariant: never)
+//             chunks in doubt although their recorded start is the true bend (it happens)
 // worst[0..3]: largest absolute error of the four repairs.  Returns the index of the first fibre SEQ_OLD gets wrong (-1: none).
 int model_fibres(const double *Y, const double *Wt, int count, int len, double lam, int C, int H, int window, int max_jobs, long *out, double *worst) {
     return Wt ? model_run<true>(Y, Wt, count, len, lam, C, H, window, max_jobs, out, worst)
