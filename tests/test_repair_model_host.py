@@ -59,3 +59,12 @@ def test_every_repair_is_exact(model, max_jobs, weighted):
             handled += int(out[0] - out[8])
     assert doubts > 1000          # the sample has links in doubt by the thousand ...
     assert handled > 50           # ... and fibres the jobs repair took on itself
+
+
+def test_staged_patch_still_applies():
+    """tools/staged/r5_repair_jobs.patch (the jobs repair, measured on a branch) is a diff against THIS tree's kernel sources."""
+    patch = os.path.join(ROOT, "tools", "staged", "r5_repair_jobs.patch")
+    if not os.path.isdir(os.path.join(ROOT, ".git")):
+        pytest.skip("no git metadata here (a snapshot of the tree)")
+    r = subprocess.run(["git", "apply", "--check", patch], cwd=ROOT, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
