@@ -170,7 +170,10 @@ void proxtv_release_scratch(void);
      "pin_seed"       1 (default): the pinning solver (rung 3) starts from the knots known a priori, 0: from the fibre ends alone
      "pin_overlap"    1: a strided sweep of the pinning solver moves its transposed copies range by range on a second stream, under
                       the levels of the other ranges ; 0 (default: measured slower): one stream
-     "tile"           strided sweeps on rung 0: 1 (default) tiles of 32 fibres x 8 chunks in 4 waves, four workgroups per CU ;
+     "repair_jobs"    failed links across the workgroups of a chunked sweep are first repaired one lane per failure, four to a
+                      fibre; what that leaves goes to the sequential repair: 1 (default) where the sampled statistic of the sweep's
+                      input says such links fail in numbers, 2 always ; 0: the sequential repair alone (same results, bit for bit)
+     "tile"           strided sweeps on rungs 0 and 1 (the robust instantiation follows the same knob): 1 (default) tiles of 32 fibres x 8 chunks in 4 waves, four workgroups per CU ;
                       0: the 64-fibre x 8-wave tile, two per CU
      "host_register"  1: page-lock large caller arrays around the transfers of the host-pointer entry points (default 0: no gain measured)
      "verbose"        1: log every decision of the geometry policy to stderr
@@ -249,6 +252,11 @@ long   proxtv_debug_trace(unsigned long long *dst, long max_wgs);
    their window, [1] links inside a workgroup / wave that stayed unproven, [2] links across workgroups / segments whose codes
    differ, [3] ... that were not published in time.  Returns 8, or <= 0. */
 int    proxtv_debug_why(unsigned *dst);
+/* What ran (process-wide, cumulative since load; tests and tools take differences): "sweep_launches" (fibre-sweep kernels),
+   "repair_launches" (sweep_repair_kernel behind them), "repair_jobs_launches" (option repair_jobs), "pin_sweeps" (sweeps the
+   pinning solver took), "pin_cap_next_rung" (sweeps its grid-wide variant handed on after the level cap), "tv2_long_fibres"
+   (TV-L2 fibres solved parallel inside the fibre).  -1 for an unknown name. */
+long   proxtv_debug_counter(const char *name);
 /* Geometry policy the adaptive chunk kernel currently uses on this thread (the highest over the sweep families):
    0 = 16-sample warm-up zones (noisy data, small lambda), 1 = the same, robust instantiation (walks may run past
    the window, second-chance rounds inside a block: pieces of ~5 samples), 2 = 64-sample zones (pieces of ~10 samples),

@@ -83,6 +83,7 @@ SIGNATURES = {
     "proxtv_chunk_mode": (C.c_int, []),
     "proxtv_debug_trace": (C.c_long, [C.c_void_p, C.c_long]),
     "proxtv_debug_why": (C.c_int, [C.c_void_p]),
+    "proxtv_debug_counter": (C.c_long, [C.c_char_p]),
     "proxtv_calib_copy_dev": (C.c_int, [_dp, _dp, C.c_long, C.c_void_p]),
     "proxtv_last_kernel_ms": (C.c_double, [C.c_int]),
     "proxtv_last_kernel_launches": (C.c_long, [C.c_int]),

@@ -506,6 +506,7 @@ long proxtv_debug_trace(unsigned long long *dst, long max_wgs) {
     try { return chunk_trace_fetch(dst, max_wgs, thread_stream()); } catch (...) { return -1; }
 }
 long proxtv_last_kernel_launches(int which) { return timing_launches(which); }
+long proxtv_debug_counter(const char *name) { return counter_value(name); }
 int proxtv_debug_why(unsigned *dst) {
     try { return chunk_why_fetch(dst, thread_stream()); } catch (...) { return -1; }
 }

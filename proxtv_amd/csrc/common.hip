@@ -1,6 +1,8 @@
 // common.hip -- error capture, device selection, per-thread stream, HBM scratch pool, kernel-family timers.
 #include "common.hpp"
 
+#include <atomic>
+
 #include <cctype>
 #include <cstring>
 
@@ -40,6 +42,7 @@ constexpr OptionEntry kOptionTable[] = {
     {"pin", &Options::pin},
     {"pin_seed", &Options::pin_seed},
     {"pin_overlap", &Options::pin_overlap},
+    {"repair_jobs", &Options::repair_jobs},
     {"whole", &Options::whole},
     {"chunk_min_len", &Options::chunk_min_len},
     {"xlink", &Options::xlink},
@@ -72,9 +75,25 @@ Options &options() {
             name[n] = 0;
             if (const char *val = getenv(name)) v.*(e.field) = atoi(val);
         }
+        // the one knob that makes results WRONG (a profiling aid) must not arrive through the environment unnoticed
+        if (v.ablate != 0) fprintf(stderr, "[proxtv_amd] WARNING: PROXTV_ABLATE=%d set in the environment: sweeps skip work and results are WRONG\n", v.ablate);
         return v;
     }();
     return o;
+}
+
+// ---- event counters (proxtv_debug_counter) -----------------------------------------------------------------------------
+namespace {
+std::atomic<long> g_counters[CNT_COUNT];
+constexpr const char *kCounterNames[CNT_COUNT] = {"sweep_launches", "repair_launches", "repair_jobs_launches", "pin_sweeps",
+                                                  "pin_cap_next_rung", "tv2_long_fibres"};
+}  // namespace
+void count_event(Counter c, long n) { g_counters[c].fetch_add(n, std::memory_order_relaxed); }
+long counter_value(const char *name) {
+    if (!name) return -1;
+    for (int c = 0; c < CNT_COUNT; c++)
+        if (!strcmp(name, kCounterNames[c])) return g_counters[c].load(std::memory_order_relaxed);
+    return -1;
 }
 
 // ---- device ------------------------------------------------------------------------------------------------------
@@ -113,6 +132,7 @@ static void probe_device(int dev) {
     }
     g_dev_ok[dev] = true;
     // load the code objects now (the device is current: probe_device runs under ensure_device on the calling thread)
+    const std::string before = last_error();
     try {
         warm_sweep();
         warm_pin();
@@ -121,7 +141,8 @@ static void probe_device(int dev) {
         warm_tv2();
     } catch (const HipFailure &) {
         (void)hipGetLastError();   // not fatal: the first launch will load (or report) what this could not
-        set_error("%s", "");        // ... and PTV_HIP recorded a message before it threw: a solve that then succeeds must not report it
+        set_error("%s", before.c_str());   // ... and PTV_HIP recorded a message before it threw: a solve that then succeeds must not report it
+                                           // (what was there before the warm-up -- say, a failed call on another device -- stays)
     }
 }
 

@@ -50,6 +50,9 @@ struct Options {
     int seed_row_along_e4 = 0;   // tuning aid: kSeedRowAlong (policy.hpp) in units of 1e-4 ; 0 = built in
     int seed_noisy_e4 = 0, seed_mid_e4 = 0;   // tuning aid: the policy seed's thresholds (policy.hpp) in units of 1e-4 ; 0 = built in
     int pin = 1;              // geometry rung 3: the pinning solver (pin.hip) where it applies; 0 = global-memory chunks
+    int repair_jobs = 1;      // chunked sweeps: failed links across workgroups are repaired one lane per failure first (sweep_repair_jobs_kernel), what that
+                              // leaves by the sequential repair kernel: 1 = where the sampled certain fraction says such links fail in numbers
+                              // (policy.hpp: kSeedJobs), 2 = always, 0 = the sequential repair alone
     int pin_overlap = 0;      // strided sweeps of the pinning solver: 1 = the transpositions of one range of fibres run on a second stream
                               // under the levels of another.  Measured and NOT kept (4096^2 DR, lambda 0.8 / 1 / 3: 25.1 -> 27.1, 29.3 -> 30.9,
                               // 18.2 -> 21.0 ms): four quarter-size launches per sweep lose more than the hidden copies win
@@ -62,7 +65,7 @@ struct Options {
     int dr_form = 1;          // DR2 / DR2L1W: 1 = the column sweep leaves the row sweep's input and epilogue operand (OP_DR_COL_V / OP_DR_ROW_V)
                               // when the row sweep runs on the robust 64-fibre tile (rung 1); 2 = on rung 0 too; 0 = always the
                               // reference's split (OP_DR_COL / OP_DR_ROW)
-    int tile = 1;             // strided sweeps on rung 0 (unweighted and weighted): 1 = tiles of 32 fibres x 8 chunks in 4 waves (four
+    int tile = 1;             // strided sweeps on rungs 0 and 1 (unweighted and weighted): 1 = tiles of 32 fibres x 8 chunks in 4 waves (four
                               // workgroups per CU), 0 = the 64-fibre x 8-wave tile (two)
     int host_register = 0;    // host-pointer entry points: page-lock large caller arrays around their transfers (see cabi.hip)
     int verbose = 0;
@@ -73,6 +76,19 @@ struct Options {
 };
 Options &options();
 int *option_slot(const char *key);   // null for an unknown key
+
+// ---- event counters: what ran, for tests and tools (process-wide, cumulative; proxtv_debug_counter) ------------------------------
+enum Counter {
+    CNT_SWEEP_LAUNCHES = 0,    // kernels launched to sweep fibres (chunk / along-fibre / sequential / pinning ... kernels)
+    CNT_REPAIR_LAUNCHES,       // sweep_repair_kernel launches behind them
+    CNT_REPAIR_JOBS_LAUNCHES,  // sweep_repair_jobs_kernel launches (option repair_jobs; gated by the sampled certain fraction)
+    CNT_PIN_SWEEPS,            // sweeps the pinning solver took
+    CNT_PIN_CAP_NEXT_RUNG,     // ... of which the grid-wide variant hit its level cap and handed the sweep to the next rung
+    CNT_TV2_LONG_FIBRES,       // TV-L2 fibres solved parallel inside the fibre (tv2.hip: tv2_long_fibre)
+    CNT_COUNT
+};
+void count_event(Counter c, long n = 1);
+long counter_value(const char *name);   // -1 for an unknown name
 
 // ---- device / stream -------------------------------------------------------------------------------------------
 // Throws HipFailure (with last_error set) when the current device is not a usable gfx950.  All library state is kept per

@@ -405,13 +405,18 @@ void tv2_fibres(const double *in, double *out, const int *ns, int nds, int dim, 
     for (int i = 0; i < nds; i++) n *= ns[i];
     if (n <= 0) return;
     const size_t bytes = sizeof(double) * (size_t)n;
-    Scratch d(bytes), z(bytes), u(bytes);
     FibreGeom g = fibres_along(ns, nds, dim);
-    // a handful of long contiguous fibres (a single signal through tv2_1d / TV(p = 2)): the solves run parallel inside the fibre
-    if (g.inc == 1 && g.count < 64 && g.len >= kLongMinLen && (g.len - 1 + kLongBlock - 1) / kLongBlock <= kLongMaxBlocks && lam > 0.0) {
+    // A handful of long contiguous fibres (a single signal through tv2_1d / TV(p = 2)): the solves run parallel inside the fibre,
+    // one fibre after the other -- ~14 launches and two host round trips per Newton iteration, about a millisecond per fibre --
+    // so only where that beats one lane per fibre, whose time grows with the fibre LENGTH (~1 us per sample: 0.2 s at 2 x 10^5)
+    // whatever the count: count <= len / 2048 (8 fibres of 16 384 samples, 14 of 30 000; 48 of 16 384 stay lane-per-fibre), at most 32.
+    const long long_max = g.len / 2048 < 32 ? g.len / 2048 : 32;
+    if (g.inc == 1 && g.count <= long_max && g.len >= kLongMinLen && (g.len - 1 + kLongBlock - 1) / kLongBlock <= kLongMaxBlocks && lam > 0.0) {
         for (long j = 0; j < g.count; j++) tv2_long_fibre(in + j * g.len, out + j * g.len, g.len, lam, s);
+        count_event(CNT_TV2_LONG_FIBRES, g.count);
         return;
     }
+    Scratch d(bytes), z(bytes), u(bytes);   // (the long path above brings its own, fibre-sized)
     if (g.inc == 1 && g.count > 1) {
         // dimension 0: fibres are contiguous, so lanes would stride by the fibre length -- transpose (len x count ->
         // count x len), solve along dimension 1 of the transposed array, transpose back

@@ -19,6 +19,8 @@
 #ifndef PTV_HOST_TEST   // tests/host_harness.cpp compiles this header with g++ to check the logic without a GPU
 #include <hip/hip_runtime.h>
 #endif
+#include <type_traits>
+#include <utility>
 
 namespace ptv {
 
@@ -38,6 +40,17 @@ struct Walker {
 //   void   piece(int from, int to, double v)   samples from..to (inclusive) of the prox equal v
 //   void   bend(int restart, int type)         a bend happened; the walk restarts at sample `restart`
 //   bool   keep_going(int i)   polled once per trip (chunked kernels stop early; sequential returns true)
+
+// A source may bring its own quotient by the span of a piece (a small positive integer): `double over_span(double a, int span)`.
+template <class S, class = void>
+struct SourceDivides : std::false_type {};
+template <class S>
+struct SourceDivides<S, std::void_t<decltype(std::declval<S &>().over_span(0.0, 0))>> : std::true_type {};
+template <class S>
+__device__ __forceinline__ double over_span(S &src, double a, int span) {
+    if constexpr (SourceDivides<S>::value) return src.over_span(a, span);
+    else return a / span;
+}
 
 // Start a walk at sample `at` as if the fibre began there (free left end: string height 0).
 template <bool WEIGHTED, class S>
@@ -164,17 +177,17 @@ __device__ __forceinline__ bool walker_run(Walker &w, S &src, int n, double lam)
                 // pull the pieces back inside the tube where they left it
                 const int span = i - w.k0;
                 if (w.hhi >= r) {
-                    w.hi += (r - w.hhi) / span;
+                    w.hi += over_span(src, r - w.hhi, span);
                     w.hhi = r;
                     w.khi = i;
                 }
                 if (w.hlo <= -r) {
-                    w.lo += (-r - w.hlo) / span;
+                    w.lo += over_span(src, -r - w.hlo, span);
                     w.hlo = -r;
                     w.klo = i;
                 }
             } else {
-                if (w.hlo <= 0) w.lo += (-w.hlo) / (i - w.k0);
+                if (w.hlo <= 0) w.lo += over_span(src, -w.hlo, i - w.k0);
             }
             w.i = i + 1;
         }

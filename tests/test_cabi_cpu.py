@@ -190,3 +190,16 @@ def test_every_knob_has_its_environment_variable():
     import json
     got = json.loads(out.strip().splitlines()[-1])
     assert got == {k: 700 + i for i, k in enumerate(keys)}, got
+
+
+def test_build_units_match_the_header():
+    """proxtv_amd/build.py compiles csrc/sweep_unit.hip once per (op, weighted) pair; the pairs are listed twice -- there and in
+    PTV_SWEEP_UNITS of csrc/sweep_kernels.hpp (what sweep.hip dispatches to) -- and a pair missing on either side is a link error
+    or a dead object."""
+    import re
+    from proxtv_amd import build
+    hdr = open(os.path.join(os.path.dirname(build.__file__), "csrc", "sweep_kernels.hpp")).read()
+    block = hdr[hdr.index("#define PTV_SWEEP_UNITS(X)"):hdr.index("#define PTV_DECLARE_UNIT")]
+    pairs = [(op, w == "true") for op, w in re.findall(r"X\((OP_\w+), (true|false)\)", block)]
+    assert pairs == build.SWEEP_UNITS
+    assert len(set(pairs)) == len(pairs) == 17

@@ -187,3 +187,73 @@ def test_fibre_lengths_around_chunk_and_block_edges(ptv, clib, oracle, modes):
             bd = device.to_colmajor(torch.from_numpy(np.ascontiguousarray(A.T)).cuda())
             got = device.tv1_fibres(bd, lam, 1).cpu().numpy()                       # strided fibres of length n
             assert_close(got, want.T, tol=1e-11, what=f"dim1 n={n} lam={lam} mode={m}")
+
+
+def test_jobs_repair_equals_the_sequential_repair(clib, oracle, modes):
+    """Option repair_jobs: failed links across workgroups repaired one lane per failure (sweep_repair_jobs_kernel) before the
+    sequential repair kernel takes what is left.  Rung 1 at lambda 0.65-0.9 on unit noise is where such links fail in numbers.
+    Every case is solved with the option off (0), gated by the sampled statistic (1: the default) and always on (2): the three
+    results must be the same to the last bit -- a job parks exactly the values the sequential walk would write -- and exact."""
+    import torch
+    from proxtv_amd import device
+    rng = np.random.default_rng(5)
+    dev = lambda a: device.to_colmajor(torch.from_numpy(np.ascontiguousarray(a)).cuda())
+    before = clib.proxtv_set_option(b"repair_jobs", 1)
+    tile_before = clib.proxtv_set_option(b"tile", 1)
+    launched = 0
+    try:
+        modes(1)
+        cases = []
+        for n, m in ((1024, 1024), (777, 1500)):
+            X = rng.standard_normal((n, m))
+            Xd = dev(X)
+            for lam in (0.4, 0.7, 0.9):
+                cases.append((f"DR {n}x{m} lam {lam}", lambda Xd=Xd, lam=lam: device.tv1_2d(Xd, lam)[0], (X, lam)))
+            for d in (0, 1):
+                cases.append((f"one sweep dim {d} {n}x{m}", lambda Xd=Xd, d=d: device.tv1_fibres(Xd, 0.7, d), None))
+        X = rng.standard_normal((1536, 640))
+        Xd = dev(X)
+        W1, W2 = dev(rng.uniform(0.35, 1.05, (1535, 640))), dev(rng.uniform(0.35, 1.05, (1536, 639)))
+        for tile in (0, 1):
+            cases.append((f"DR 1536x640 lam 0.7 tile={tile}", lambda tile=tile: (clib.proxtv_set_option(b"tile", tile), device.tv1_2d(Xd, 0.7)[0])[1], None))
+            cases.append((f"weighted DR tile={tile}", lambda tile=tile: (clib.proxtv_set_option(b"tile", tile), device.tv1w_2d(Xd, W1, W2)[0])[1], None))
+        V = dev(rng.standard_normal((256, 320, 24)))
+        cases.append(("tvgen PD 3-D lam 0.7", lambda: (clib.proxtv_set_option(b"tile", 1), device.tvgen(V, [0.7, 0.7, 0.7], [1, 2, 3])[0])[1], None))
+        Xpd = dev(rng.standard_normal((1024, 1024)))
+        cases.append(("PD2 1024^2 lam 0.7", lambda: device.tv1_2d(Xpd, 0.7, method="pd")[0], None))
+        for label, run, ref in cases:
+            outs, fixes = [], []
+            for jobs in (0, 1, 2):
+                clib.proxtv_set_option(b"repair_jobs", jobs)
+                c0 = clib.proxtv_debug_counter(b"repair_jobs_launches")
+                outs.append(run().clone())
+                fixes.append(clib.proxtv_last_fixups())
+                n_launched = clib.proxtv_debug_counter(b"repair_jobs_launches") - c0
+                if jobs == 0:
+                    assert n_launched == 0, label
+                if jobs == 2:
+                    launched += n_launched
+            assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), (label, fixes)
+            assert fixes[0] == fixes[2], (label, fixes)   # the same fibres were repaired, whoever repaired them
+            if ref is not None:
+                assert_close(outs[2].cpu().numpy(), oracle.dr2(ref[0], ref[1])[0], tol=1e-11, what=label)
+    finally:
+        clib.proxtv_set_option(b"repair_jobs", before)
+        clib.proxtv_set_option(b"tile", tile_before)
+    assert launched > 0   # (a run in which the jobs kernel never had a launch cannot pass for a green one)
+
+
+def test_jobs_repair_is_gated_by_the_sampled_statistic(clib):
+    """Default policy (repair_jobs = 1): the jobs kernel is launched only where the sampled certain fraction says links across
+    workgroups fail in numbers (lambda >= 0.65 on unit noise); the headline regime never pays for it."""
+    import torch
+    from proxtv_amd import device
+    X = device.to_colmajor(torch.from_numpy(np.random.default_rng(7).standard_normal((2048, 2048))).cuda())
+    assert clib.proxtv_set_option(b"repair_jobs", 1) in (0, 1, 2)
+    if clib.proxtv_set_option(b"chunk_mode", -1) != -1:
+        pytest.skip("a pinned rung (PROXTV_CHUNK_MODE) overrides the seeded policy")
+    c0 = clib.proxtv_debug_counter(b"repair_jobs_launches")
+    device.tv1_2d(X, 0.1)
+    assert clib.proxtv_debug_counter(b"repair_jobs_launches") == c0
+    device.tv1_2d(X, 0.7)
+    assert clib.proxtv_debug_counter(b"repair_jobs_launches") > c0

@@ -166,18 +166,18 @@ def _periodic_families(n):
     yield "stripes", np.repeat(np.where(np.arange(n // 4 + 1) % 2 == 0, 3.0, -3.0), 4)[:n]
 
 
-def test_level_cap_hands_periodic_fibres_to_the_walker(ptv, oracle, rung3):
+def test_level_cap_hands_periodic_fibres_to_the_walker(ptv, clib, oracle, rung3):
     """Data with exact periodic ties peel one knot per segment end and level; the kernels give such a fibre up after
     kPinMaxLevels = 64 levels and a gated sequential sweep finishes it (pin.hpp).  Exact either way, and bounded."""
-    import time
     for n in (1000, 4096, 16384):
         for name, x in _periodic_families(n):
             for lam in (0.1, 0.6):
-                t0 = time.perf_counter()
+                before = clib.proxtv_debug_counter(b"pin_sweeps")
                 got = ptv.tv1_1d(x, lam)
-                dt = time.perf_counter() - t0
                 assert_close(got, oracle.tv1_hybrid(x, lam), tol=1e-11, what=f"{name} n={n} lam={lam}")
-                assert dt < 15.0, (name, n, lam, dt)   # (uncapped, these data took minutes; the bound is loose: shared / cold devices)
+                # the pinning rung took the sweep (and gave the fibre up after kPinMaxLevels levels, whatever the data: the bound on
+                # its cost is structural -- uncapped, these data took minutes -- so no wall clock is asserted here)
+                assert clib.proxtv_debug_counter(b"pin_sweeps") - before == 1, (name, n, lam)
 
 
 def test_level_cap_batched_and_strided(oracle, rung3):
@@ -198,16 +198,18 @@ def test_level_cap_batched_and_strided(oracle, rung3):
     assert_close(proxtv_amd.tv1_2d(S, 0.2), oracle.dr2(S, 0.2)[0], tol=1e-9, what="DR on a checkerboard, rung 3")
 
 
-def test_level_cap_long_fibre_takes_the_next_rung(ptv, oracle, rung3):
+def test_level_cap_long_fibre_takes_the_next_rung(ptv, clib, oracle, rung3):
     """Beyond one workgroup (pinlong.hip) a capped sweep writes nothing and the global-memory chunk kernels take it."""
-    import time
     n = 70000
+    handed_on = 0
     for name, x in _periodic_families(n):
-        t0 = time.perf_counter()
+        before = clib.proxtv_debug_counter(b"pin_cap_next_rung")
         got = ptv.tv1_1d(x, 0.4)
-        dt = time.perf_counter() - t0
         assert_close(got, oracle.tv1_hybrid(x, 0.4), tol=1e-11, what=f"{name} n={n}")
-        assert dt < 15.0, (name, dt)
+        handed_on += clib.proxtv_debug_counter(b"pin_cap_next_rung") - before
+    # (which families exhaust the 64 levels is the data's business; the zigzag -- every sample a bend -- surely does.  What bounds the
+    # cost is that the capped sweep is handed on at all, not a wall clock: a shared or cold device must not turn this suite red.)
+    assert handed_on >= 1
 
 
 @pytest.mark.parametrize("seed,overlap", [(1, 1), (0, 1), (1, 0), (0, 0)])

@@ -1,7 +1,7 @@
 """The stage behind the chunk kernels as a HOST model (tools/study/repair_model.cpp: the device walker compiled with g++, speculative
 chunk walks with the device's ownership rule, then the repairs): the sequential repair that jumps from link in doubt to link in doubt
 -- with the scan behind a jump unbounded, as in round 4, and bounded -- and the repair with one walk per failing link whose validity
-is decided afterwards (staged: tools/staged/), each against the sequential walk of the whole fibre.  Exact by construction, every one
+is decided afterwards (sweep_repair_jobs_kernel, option repair_jobs), each against the sequential walk of the whole fibre.  Exact by construction, every one
 of them, on every fibre: what DESIGN 5 argues, checked here on a sample small enough for the CPU suite."""
 import ctypes as C
 import os
@@ -59,12 +59,3 @@ def test_every_repair_is_exact(model, max_jobs, weighted):
             handled += int(out[0] - out[8])
     assert doubts > 1000          # the sample has links in doubt by the thousand ...
     assert handled > 50           # ... and fibres the jobs repair took on itself
-
-
-def test_staged_patch_still_applies():
-    """tools/staged/r5_repair_jobs.patch (the jobs repair, measured on a branch) is a diff against THIS tree's kernel sources."""
-    patch = os.path.join(ROOT, "tools", "staged", "r5_repair_jobs.patch")
-    if not os.path.isdir(os.path.join(ROOT, ".git")):
-        pytest.skip("no git metadata here (a snapshot of the tree)")
-    r = subprocess.run(["git", "apply", "--check", patch], cwd=ROOT, capture_output=True, text=True)
-    assert r.returncode == 0, r.stderr
