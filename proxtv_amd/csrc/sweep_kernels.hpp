@@ -2209,6 +2209,18 @@ void launch_row_along(const SweepArgs &args, const FibreGeom &g, hipStream_t str
 
 template <int OP, bool WEIGHTED, bool TRANSPOSED>
 void launch_chunk(const SweepArgs &args, const FibreGeom &g, hipStream_t stream, int fam) {
+    // The aliasing contract of sweep.hpp, enforced: a chunked sweep stages windows of its input operand(s) while other workgroups
+    // write outputs, and an op with KEEP finishes rows with the operand value it captured at staging time -- an output array that
+    // IS a staged operand would be read half-written / finished with stale values.  (Epilogue-only operands may alias an output
+    // element for element: the thread that writes the element is the one that read it.)  The solvers ping-pong; this is the check.
+    {
+        const void *staged[2] = {args.a, Op<OP>::NIN > 1 ? args.b : nullptr};
+        for (const void *in : staged)
+            if (in && (in == args.o0 || in == args.o1)) {
+                set_error("launch_sweep: op %d writes an array its chunked sweep stages as fibre samples (outputs must not alias window operands)", OP);
+                throw HipFailure{hipErrorInvalidValue};
+            }
+    }
     ChunkScratch &st = chunk_state();
     ChunkScratch::Policy &pl = st.pol[fam];
     const bool pinned = options().chunk_mode >= 0;

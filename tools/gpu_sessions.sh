@@ -1,0 +1,30 @@
+#!/bin/bash
+# GPU sessions of the current round (one gpurun call each; everything lands under gpurun_out/r5/<session>/):
+#     gpurun --timeout N -- 'bash tools/gpu_sessions.sh <session>'
+# Variant builds (python -m proxtv_amd.build --variant NAME -- flags) must exist in proxtv_amd/build/ before the call: they travel
+# with the snapshot.
+S=$1
+OUT=gpurun_out/r5/$S
+mkdir -p $OUT
+export TMPDIR=/tmp
+W=proxtv_amd/build
+ab() { python tools/ab_run.py "$@"; }
+alt() { PROXTV_DEBUG_ALT_LIB=1 PROXTV_LIB=$PWD/$W/lib_$1.so "${@:2}"; }
+case $S in
+s1)   # the jobs repair merged as the default, the build split into units: the whole suite, the suite with the jobs kernel always on,
+      # a short soak, the A/B of the option, then counters for EVERY hot kernel (weighted, pinning, N-D combiners included)
+  timeout 900 python -m pytest tests -m gpu -x -q > $OUT/pytest_default.log 2>&1; echo "default: $(tail -1 $OUT/pytest_default.log)" | tee $OUT/summary.txt
+  FILES="tests/test_gpu_chunk_repair.py tests/test_gpu_parity_2d.py tests/test_gpu_parity_nd.py tests/test_gpu_fuzz.py tests/test_gpu_boundary.py"
+  PROXTV_REPAIR_JOBS=2 timeout 600 python -m pytest $FILES -m gpu -x -q > $OUT/pytest_jobs2.log 2>&1; echo "repair_jobs=2: $(tail -1 $OUT/pytest_jobs2.log)" | tee -a $OUT/summary.txt
+  PROXTV_REPAIR_JOBS=2 PROXTV_CHUNK_MODE=1 timeout 600 python -m pytest $FILES -m gpu -x -q > $OUT/pytest_jobs2_mode1.log 2>&1; echo "repair_jobs=2, rung 1: $(tail -1 $OUT/pytest_jobs2_mode1.log)" | tee -a $OUT/summary.txt
+  { python tools/fuzz.py 60 61; python tools/fuzz.py 25 62 nd; } > $OUT/fuzz.txt 2>&1; grep "^fuzz\|MISMATCH" $OUT/fuzz.txt | tee -a $OUT/summary.txt
+  ab --reps 5 --rounds 2 --cases c2,c2@0.6,c2@0.65,c2@0.7,c2@0.75,c3 base nojobs,repair_jobs=0 jobs2,repair_jobs=2 > $OUT/ab_jobs.txt 2>&1; cat $OUT/ab_jobs.txt
+  cd /tmp; R=$GRAFT_REPO_ROOT
+  timeout 900 python $R/tools/kernel_counters.py collect $R/$OUT/kc > $R/$OUT/kc_collect.log 2>&1
+  cd $R
+  python tools/kernel_counters.py report $OUT/kc > $OUT/kernel_counters.txt 2>&1; cat $OUT/kernel_counters.txt
+  python tools/kernel_counters.py traffic $OUT/kc > $OUT/pmc_traffic.json 2>&1
+  find $OUT/kc -name "*.db" -delete   # (the databases are tens of MB each; the table and the json are what is kept)
+  python -c "import sys; sys.path.insert(0,'.'); from proxtv_amd import build; print('build id', build.build_id())" | tee -a $OUT/summary.txt
+  ;;
+esac
