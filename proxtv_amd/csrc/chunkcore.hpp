@@ -217,7 +217,13 @@ struct NoFar {
 // TAB / rt: piece lengths are bounded by the window (plain geometries: zone + chunk + look-ahead rows), so the division by the
 // length is one product with rt[length] = the correctly rounded 1.0 / length (see walk_asm.hpp: walk_interior_asm_tab).
 // TSZ > 0: the table has TSZ entries and longer pieces are possible (robust instantiations): those divide.
-template <class F, bool WEIGHTED, int C, int UNROLL = 1, bool TAB = false, class RT = const double *, int TSZ = 0, class Win>
+// FULL >= 1: the caller vouches that every lane of the wave holds a whole chunk (ce - cs == C) and that the fibre's last sample lies
+// beyond the chunk -- the interior of a fibre, i.e. nearly everything: no row is tested for being in range, no knot for being the
+// fibre's end.  FULL == 2 (unweighted; the along-fibre kernel, which has the registers): the chunk's C samples also stay in registers
+// between the two passes, so the forward pass costs a row one LDS read, the backward pass none, and ops whose output needs the row's
+// own sample (DR_COL) take the same array-free passes as the others instead of a dynamic back-fill loop per piece.  Same arithmetic
+// in the same order as the general form: bit-identical (tests/host_harness.cpp runs all three).
+template <class F, bool WEIGHTED, int C, int UNROLL = 1, bool TAB = false, class RT = const double *, int TSZ = 0, int FULL = 0, class Win>
 __device__ __forceinline__ void rebuild_owned(Win &win, const ChunkRec &rec, int cs, int ce, int len, int start, bool link_ok,
                                               int wlo, bool block_last, double lam, RT rt = RT()) {
     auto quotient = [&](double num, double count) {
@@ -270,7 +276,7 @@ __device__ __forceinline__ void rebuild_owned(Win &win, const ChunkRec &rec, int
     // tube's half-width with the sign of the bend type (unweighted, device: lambda with its sign bit flipped -- a shift and a xor)
     const int uend = len - 1 - cs;   // own row of the fibre's last sample, if it lies in this chunk
     auto knot_height = [&](int u) {
-        if (u == uend) return 0.0;
+        if (FULL == 0 && u == uend) return 0.0;
         if constexpr (WEIGHTED) {
             const double r = win.r(cs + u);
             return ((rec.types >> u) & 1u) ? r : -r;
@@ -284,13 +290,48 @@ __device__ __forceinline__ void rebuild_owned(Win &win, const ChunkRec &rec, int
     };
     double cur = 0.0;
     bool have = false;
+    if constexpr (FULL == 2 && !WEIGHTED) {
+        double slot[C];   // row u: its sample, or -- once a piece has ended there -- that piece's value
+        // (unweighted, no fibre end in the chunk: the knot's height is lambda with the sign of the bend type)
+        auto height = [&](int u) {
+#ifdef PTV_HOST_TEST
+            return ((rec.types >> u) & 1u) ? lam : -lam;
+#else
+            return __hiloint2double(__double2hiint(lam) ^ (int)((~(rec.types >> u) & 1u) << 31), __double2loint(lam));
+#endif
+        };
+#pragma unroll
+        for (int u = 0; u < C; u++) {
+            const double yu = win.y(cs + u);
+            slot[u] = yu;
+            s += yu;
+            cnt += 1.0;
+            if ((rec.ends >> u) & 1u) {
+                const double hk = height(u);
+                const double v = quotient(s + (hk - hprev), cnt);
+                win.put(cs + u, F::fuse(yu, v));
+                slot[u] = v;
+                s = 0.0;
+                cnt = 0.0;
+                hprev = hk;
+            }
+        }
+        have = tail_value(s, cnt, hprev, cur);
+#pragma unroll
+        for (int u = C - 1; u >= 0; u--) {
+            const bool e = (rec.ends >> u) & 1u;
+            if (have && !e) win.put(cs + u, F::fuse(slot[u], cur));
+            cur = e ? slot[u] : cur;
+            have = have || e;
+        }
+    } else
     if (!F::USES_Y) {
         // The output does not depend on the row's own sample: the value of a piece is parked in the row where the piece
         // ends (forward pass), then every other row takes the value of the next piece end after it (backward pass).
         // (A row that ends no piece costs an add and a count: height, quotient, store and resets sit under the piece-end branch.)
 #pragma unroll UNROLL
         for (int u = 0; u < C; u++) {
-            const bool in = cs + u < ce;
+            const bool in = FULL != 0 || cs + u < ce;
             s += in ? win.y(cs + u) : 0.0;
             cnt += 1.0;
             if (in && ((rec.ends >> u) & 1u)) {
@@ -306,7 +347,7 @@ __device__ __forceinline__ void rebuild_owned(Win &win, const ChunkRec &rec, int
 #pragma unroll UNROLL
         for (int u = C - 1; u >= 0; u--) {
             const bool e = (rec.ends >> u) & 1u;
-            const bool in = cs + u < ce;
+            const bool in = FULL != 0 || cs + u < ce;
             const double here = in ? win.y(cs + u) : 0.0;
             cur = e ? here : cur;
             if (have && !e && in) win.put(cs + u, cur);
@@ -320,7 +361,7 @@ __device__ __forceinline__ void rebuild_owned(Win &win, const ChunkRec &rec, int
         int first = a0 > wlo ? a0 : wlo;
 #pragma unroll UNROLL
         for (int u = 0; u < C; u++) {
-            const bool in = cs + u < ce;
+            const bool in = FULL != 0 || cs + u < ce;
             const double yu = in ? win.y(cs + u) : 0.0;
             s += yu;
             cnt += 1.0;

@@ -249,6 +249,9 @@ __device__ __forceinline__ void walk_chunk(Walker &w, ChunkRec &rec, const LdsWi
 #else
     walk_interior<WEIGHTED>(w, rec, win, min(len - 1, hi), cs, ce, lam);
 #endif
+    // (every walking lane of the wave closed the piece that covers its chunk's last sample inside the window -- the common case:
+    //  walker_run would turn each of them away at its first test, after some eighty instructions of entry and exit)
+    if (__builtin_amdgcn_ballot_w64(!rec.done) == 0ull) return;
     TailSource<WEIGHTED, PAST, kOverflow, LdsWin<WEIGHTED, PITCH>, FarFibre<OP>> tail{win, far, rec, cs, ce, hi, len};
     walker_run<WEIGHTED>(w, tail, len, lam);
     if (rec.failed) rec.next = 0;   // ran off the window: nothing this lane recorded may be trusted
@@ -321,7 +324,7 @@ __global__ __launch_bounds__(64 * NW, SHORT ? 16 / NW : (FW < 64 ? ((WEIGHTED ? 
     }
 
     if (p.gate && *p.gate == 0) return;   // uniform over the grid
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (uniform over the wave: scalar)
     // fl: this lane's fibre within the tile ; ch: its chunk within the block (FW = 64: the lane and the wave)
     const int fl = FW == 64 ? lane : (lane & (FW - 1)), ch = FW == 64 ? wave : wave * CPW + lane / FW;
     if (plan.trace && tid == 0) {
@@ -362,7 +365,15 @@ __global__ __launch_bounds__(64 * NW, SHORT ? 16 / NW : (FW < 64 ? ((WEIGHTED ? 
 #endif
     constexpr int KN = KEEP ? (PTV_KEEP_N < C ? PTV_KEEP_N : C) : 0;
     double kept[KEEP ? KN : 1];
-    auto stage = [&](int q) {
+    // `inner` blocks (strided tiles): all FW fibres of the tile exist, the whole window lies inside the fibre (but, first block, the
+    // zone before sample 0) and the fibre's last sample beyond it -- nearly every block of a large image.  Uniform over the workgroup,
+    // so nothing is tested per element there: the window loads run down the fibre from one address (the zone rows before sample 0,
+    // which nothing ever reads, take copies of sample 0: a clamped row instead of a mask), the rebuild takes its FULL form, the
+    // stream-out its rows as they come.
+    const bool tile_whole = !TRANSPOSED && !SHORT && (long)blockIdx.x * FW + FW <= g.count;
+    auto inner_block = [&](int q) { return tile_whole && q * NCH * C + NCH * C + TA <= len - 1; };
+    auto stage_as = [&](int q, auto inner_tag) {
+        constexpr bool inner = decltype(inner_tag)::value;
         const int cs_wg = q * NCH * C;
         const int lo = cs_wg - HA, hi = min(len, cs_wg + NCH * C + TA);
 #pragma unroll
@@ -377,6 +388,10 @@ __global__ __launch_bounds__(64 * NW, SHORT ? 16 / NW : (FW < 64 ? ((WEIGHTED ? 
                 if (!TRANSPOSED) {
                     r = lo + ch + NCH * u;
                     ok = active && r >= 0 && r < hi && r - lo < ROWS;
+                    if constexpr (inner) {
+                        ok = NCH * u + NCH <= ROWS || r - lo < ROWS;          // (compile time for all but a ragged last share)
+                        if (NCH * u < HA) r = max(r, 0);                        // (compile time: the shares that hold zone rows)
+                    }
                     idx = base + (long)r * g.inc;
                     widx = wbase + (long)r * g.inc;
                 } else {
@@ -389,7 +404,7 @@ __global__ __launch_bounds__(64 * NW, SHORT ? 16 / NW : (FW < 64 ? ((WEIGHTED ? 
                 ok = ok && u < NST;
                 s0[v] = s1[v] = 0.0;
                 if (ok) Op<OP>::fetch_in(p, idx, s0[v], s1[v]);
-                if (WEIGHTED) sw[v] = (ok && r < len - 1) ? p.w[widx] : 0.0;
+                if (WEIGHTED) sw[v] = (ok && (inner || r < len - 1)) ? p.w[widx] : 0.0;
             }
 #pragma unroll
             for (int v = 0; v < NB; v++) {
@@ -400,6 +415,7 @@ __global__ __launch_bounds__(64 * NW, SHORT ? 16 / NW : (FW < 64 ? ((WEIGHTED ? 
                     r = lo + ch + NCH * u;
                     col = fl;
                     ok = active && r >= 0 && r < hi && r - lo < ROWS;
+                    if constexpr (inner) ok = NCH * u + NCH <= ROWS || r - lo < ROWS;
                 } else {
                     col = wave + NW * (u / RB);
                     r = lo + (u % RB) * 64 + lane;
@@ -412,6 +428,10 @@ __global__ __launch_bounds__(64 * NW, SHORT ? 16 / NW : (FW < 64 ? ((WEIGHTED ? 
                 if (KEEP && u >= HA / NCH && u < HA / NCH + KN) kept[(KEEP && u >= HA / NCH && u < HA / NCH + KN) ? u - HA / NCH : 0] = s1[v];
             }
         }
+    };
+    auto stage = [&](int q) {
+        if (inner_block(q)) stage_as(q, std::true_type{});
+        else                stage_as(q, std::false_type{});
     };
 
     const int q_first = blockIdx.y * plan.qpw;
@@ -558,7 +578,11 @@ __global__ __launch_bounds__(64 * NW, SHORT ? 16 / NW : (FW < 64 ? ((WEIGHTED ? 
                     break;
                 }
         }
-        if (has_chunk && !(plan.ablate & 1))
+        const bool inner = inner_block(q);   // (uniform over the workgroup)
+        if (inner && !(plan.ablate & 1))
+            rebuild_owned<Op<OP>, WEIGHTED, C, PTV_TILE_UNROLL, TAB, lds_double *, (ROUNDS ? TS : 0), 1>(win, rec, cs, ce, len, start, !bad, wlo,
+                                                                                                       ch == NCH - 1, p.lam, (lds_double *)rtab);
+        else if (has_chunk && !(plan.ablate & 1))
             rebuild_owned<Op<OP>, WEIGHTED, C, PTV_TILE_UNROLL, TAB, lds_double *, (ROUNDS ? TS : 0)>(win, rec, cs, ce, len, start, !bad, wlo,
                                                                                                     ch == NCH - 1 || ce == len, p.lam, (lds_double *)rtab);
         __syncthreads();
@@ -566,7 +590,26 @@ __global__ __launch_bounds__(64 * NW, SHORT ? 16 / NW : (FW < 64 ? ((WEIGHTED ? 
 
         // ---- stream the block's NW*C rows out: coalesced 512-byte rows, UL operand fetches in flight per lane ------------------
         if (!(plan.ablate & 2)) {
-            if (!TRANSPOSED) {
+            if (!TRANSPOSED && inner) {
+                // every row of the block exists for every fibre of the tile: nothing is tested
+#pragma unroll
+                for (int m0 = 0; m0 < C; m0 += UL) {
+                    Ext ex[UL];
+#pragma unroll
+                    for (int u = 0; u < UL; u++) {
+                        const long idx = base + (long)(cs_wg + ch + NCH * (m0 + u)) * g.inc;
+                        if (KEEP && m0 + u < KN) ex[u] = Op<OP>::fetch_rest(p, idx, kept[(KEEP && m0 + u < KN) ? m0 + u : 0]);
+                        else if (!Op<OP>::FUSED) ex[u] = Op<OP>::fetch(p, idx);
+                    }
+#pragma unroll
+                    for (int u = 0; u < UL; u++) {
+                        const int k = cs_wg + ch + NCH * (m0 + u);
+                        const double v = Yp[(k - lo) * PITCH + fl];
+                        if (Op<OP>::FUSED) Op<OP>::store_fused(p, base + (long)k * g.inc, v);
+                        else               Op<OP>::finish(p, base + (long)k * g.inc, ex[u], v);
+                    }
+                }
+            } else if (!TRANSPOSED) {
                 if (active) {
                     // the thread that staged rows cs_wg + ch + NCH*m streams them out (Op::KEEP: with the staged operand)
 #pragma unroll
@@ -693,7 +736,9 @@ __global__ __launch_bounds__(64 * kAlongWaves) void sweep_along_kernel(SweepArgs
     constexpr int UL = 9;                    // epilogue operand fetches in flight per lane (C = 17 rows per lane: 9 + 8)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (p.gate && *p.gate == 0) return;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // (the wave number is the same in every lane: said so, everything derived from it -- fibre, segment, base addresses, window
+    //  bounds -- lives in scalar registers and the address arithmetic of the memory phases runs on the scalar unit)
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int gi = lane / G, gl = lane % G;
     double *Yp = reinterpret_cast<double *>(smem) + (size_t)(wave * NG + gi) * (ROWS + 2) * (WEIGHTED ? 2 : 1);
     double *Wp = Yp + (WEIGHTED ? ROWS + 2 : 0);   // per-edge penalties, same rows (weighted sweeps)
@@ -736,6 +781,48 @@ __global__ __launch_bounds__(64 * kAlongWaves) void sweep_along_kernel(SweepArgs
     const int lo = seg_s - HZ, hi = min(len, seg_s + SEG + T);
 
     // ---- stage: the segment as it lies in memory ---------------------------------------------------------------------------
+    // `interior`: every row of the window but (first segment) the zone before sample 0 exists -- three segments out of four of a
+    // 4096-sample fibre.  Then nothing is tested per element: the loads are scalar base + lane + immediate, the LDS stores lane base +
+    // immediate (the first segment's zone rows, which nothing ever reads, take copies of sample 0: a clamped address instead of a mask).
+    // Uniform over the wave for whole-wave segments (G = 64: fibre and segment are scalar values there).
+    const bool interior = G == 64 && !ONESEG && live && seg_s + SEG + T <= len - 1;
+    const unsigned ul = (unsigned)gl;
+    if (interior && !(plan.ablate & 4)) {
+        constexpr int NB = NU <= 20 ? NU : (NU + 1) / 2;
+        const long row0 = fbase + lo, wrow0 = wbase + lo;   // (scalar; the first segment: lo = -HZ, element 0 is clamped below)
+#pragma unroll
+        for (int b0 = 0; b0 < NU; b0 += NB) {
+            double s0[NB], s1[NB], sw[WEIGHTED ? NB : 1];
+#pragma unroll
+            for (int u = 0; u < NB; u++) {
+                const int rel = G * (b0 + u);
+                s0[u] = s1[u] = 0.0;
+                if (b0 + u >= NU) continue;
+                long idx = (row0 + rel) + (long)ul, widx = (wrow0 + rel) + (long)ul;
+                if (rel < HZ) {   // (compile time: the element that holds the zone rows)
+                    const int r = max(lo + rel + gl, 0);
+                    idx = fbase + r;
+                    widx = wbase + r;
+                }
+                if (rel + G <= ROWS) {
+                    Op<OP>::fetch_in(p, idx, s0[u], s1[u]);
+                    if (WEIGHTED) sw[WEIGHTED ? u : 0] = p.w[widx];
+                } else if (rel + gl < ROWS) {   // (the window's last, partial group of rows)
+                    Op<OP>::fetch_in(p, idx, s0[u], s1[u]);
+                    if (WEIGHTED) sw[WEIGHTED ? u : 0] = p.w[widx];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < NB; u++) {
+                const int rel = G * (b0 + u);
+                if (b0 + u >= NU) continue;
+                if (rel + G <= ROWS || rel + gl < ROWS) {
+                    Yp[rel + ul] = Op<OP>::y_of(p, s0[u], s1[u]);
+                    if (WEIGHTED) Wp[rel + ul] = sw[WEIGHTED ? u : 0];
+                }
+            }
+        }
+    } else
     if (live && !(plan.ablate & 4)) {
         // every load of a batch is issued before the first is waited for; NB rows per lane and batch (the 31-sample chunks stage
         // 34 rows per lane: in one batch a two-operand op would hold 136 registers)
@@ -868,7 +955,10 @@ __global__ __launch_bounds__(64 * kAlongWaves) void sweep_along_kernel(SweepArgs
         const unsigned long long below = grp & ((1ull << gl) - 1ull);
         if (below) wlo = seg_s + (63 - __clzll((long long)below)) * C;
     }
-    if (has_chunk && !(plan.ablate & 1))
+    if (!WEIGHTED && interior && !(plan.ablate & 1))   // (every lane of the wave holds a whole chunk: the form that keeps it in registers)
+        rebuild_owned<Op<OP>, WEIGHTED, C, PTV_ALONG_UNROLL, TAB, lds_double *, (ROBUST ? TS : 0), 2>(win, rec, cs, ce, len, start, !bad, wlo, gl == G - 1, p.lam,
+                                                                                      (lds_double *)rtab);
+    else if (has_chunk && !(plan.ablate & 1))
         rebuild_owned<Op<OP>, WEIGHTED, C, PTV_ALONG_UNROLL, TAB, lds_double *, (ROBUST ? TS : 0)>(win, rec, cs, ce, len, start, !bad, wlo, gl == G - 1 || ce == len, p.lam,
                                                                                 (lds_double *)rtab);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -876,6 +966,24 @@ __global__ __launch_bounds__(64 * kAlongWaves) void sweep_along_kernel(SweepArgs
     if (plan.trace && lane == 0) plan.trace[8 * (size_t)wid + 4] = wall_clock64();
 
     // ---- stream the segment out: rows seg_s + G t + gl, t < C ----------------------------------------------------------------------
+    if (interior && !(plan.ablate & 2)) {   // (the whole segment exists: scalar base + lane + immediate, nothing tested)
+        const long out0 = fbase + seg_s;
+#pragma unroll
+        for (int t0 = 0; t0 < C; t0 += UL) {
+            Ext ex[UL];
+#pragma unroll
+            for (int u = 0; u < UL; u++)
+                ex[u] = (t0 + u < C && !Op<OP>::FUSED) ? Op<OP>::fetch(p, (out0 + G * (t0 + u)) + (long)ul) : Ext{0, 0};
+#pragma unroll
+            for (int u = 0; u < UL; u++) {
+                if (t0 + u >= C) continue;
+                const long idx = (out0 + G * (t0 + u)) + (long)ul;
+                const double v = Yp[HZ + G * (t0 + u) + ul];
+                if (Op<OP>::FUSED) Op<OP>::store_fused(p, idx, v);
+                else               Op<OP>::finish(p, idx, ex[u], v);
+            }
+        }
+    } else
     if (live && !(plan.ablate & 2)) {
 #pragma unroll
         for (int t0 = 0; t0 < C; t0 += UL) {

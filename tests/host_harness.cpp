@@ -142,8 +142,19 @@ int chunk_fibre(const double *y, const double *w, double lam, int len, int H, in
         std::shuffle(order.begin(), order.end(), rng);
         for (int wave : order) {
             const int cs = cs_wg + wave * C, ce = std::min(cs + C, len);
-            rebuild_owned<F, WEIGHTED, C>(win, recs[(size_t)wave], cs, ce, len, starts[(size_t)wave], !bad[(size_t)wave], cs_wg,
-                                                 wave == NW - 1 || ce == len, lam);
+            // (a whole chunk strictly inside the fibre: the forms that skip the per-row range tests (FULL = 1) and that keep the chunk in
+            //  registers (FULL = 2), as the kernels' interior blocks / segments run them -- in turn with the general form, so that every
+            //  form meets every kind of neighbour)
+            const int form = (ce - cs == C && ce <= len - 1) ? (q + wave) % 3 : 0;
+            if (form == 2 && !WEIGHTED)
+                rebuild_owned<F, WEIGHTED, C, 1, false, const double *, 0, 2>(win, recs[(size_t)wave], cs, ce, len, starts[(size_t)wave],
+                                                                              !bad[(size_t)wave], cs_wg, wave == NW - 1 || ce == len, lam);
+            else if (form >= 1)
+                rebuild_owned<F, WEIGHTED, C, 1, false, const double *, 0, 1>(win, recs[(size_t)wave], cs, ce, len, starts[(size_t)wave],
+                                                                              !bad[(size_t)wave], cs_wg, wave == NW - 1 || ce == len, lam);
+            else
+                rebuild_owned<F, WEIGHTED, C>(win, recs[(size_t)wave], cs, ce, len, starts[(size_t)wave], !bad[(size_t)wave], cs_wg,
+                                              wave == NW - 1 || ce == len, lam);
         }
         bool clean = true;
         for (int wave = 0; wave < NW; wave++) clean = clean && !bad[(size_t)wave];

@@ -27,4 +27,17 @@ s1)   # the jobs repair merged as the default, the build split into units: the w
   find $OUT/kc -name "*.db" -delete   # (the databases are tens of MB each; the table and the json are what is kept)
   python -c "import sys; sys.path.insert(0,'.'); from proxtv_amd import build; print('build id', build.build_id())" | tee -a $OUT/summary.txt
   ;;
+s2)   # K1: wave-uniform fast paths (interior segments / inner blocks: nothing tested per element in staging and stream-out), the
+      # rebuild that keeps the chunk in registers, the slow tail skipped when every lane is done -- parity first, then A/B against the
+      # build of s1 (lib_r5a.so) on one box, then the instruction counters of the new kernels
+  FILES="tests/test_gpu_parity_1d.py tests/test_gpu_parity_2d.py tests/test_gpu_parity_nd.py tests/test_gpu_chunk_repair.py tests/test_gpu_large.py tests/test_gpu_fuzz.py"
+  timeout 900 python -m pytest $FILES -m gpu -x -q > $OUT/pytest_parity.log 2>&1; echo "parity files: $(tail -1 $OUT/pytest_parity.log)" | tee $OUT/summary.txt
+  PROXTV_CHUNK_MODE=1 timeout 600 python -m pytest tests/test_gpu_parity_2d.py tests/test_gpu_parity_nd.py tests/test_gpu_chunk_repair.py tests/test_gpu_fuzz.py -m gpu -x -q > $OUT/pytest_mode1.log 2>&1; echo "rung 1: $(tail -1 $OUT/pytest_mode1.log)" | tee -a $OUT/summary.txt
+  ab --reps 7 --rounds 2 --cases c2,c2@0.3,c2@0.5,c3,pd2,c4,c4y,prox0,prox1,wprox0,wprox1,s1024,s512 base old=$W/lib_r5a.so > $OUT/ab_k1.txt 2>&1; cat $OUT/ab_k1.txt
+  cd /tmp; R=$GRAFT_REPO_ROOT
+  KC_SETS=insts,waves timeout 600 python $R/tools/kernel_counters.py collect $R/$OUT/kc calib+dr0.1+prox0+prox1+c3 > $R/$OUT/kc_collect.log 2>&1
+  cd $R
+  python tools/kernel_counters.py report $OUT/kc > $OUT/kernel_counters.txt 2>&1; cat $OUT/kernel_counters.txt
+  find $OUT/kc -name "*.db" -delete
+  ;;
 esac

@@ -32,7 +32,10 @@ CALIB_BYTES = 128 * 1024 * 1024 * 8
 
 def collect(outdir, cases):
     os.makedirs(outdir, exist_ok=True)
+    only = os.environ.get("KC_SETS")   # e.g. KC_SETS=insts,waves : a subset of the passes
     for tag, counters in SETS.items():
+        if only and tag not in only.split(","):
+            continue
         cmd = ["rocprofv3", "--kernel-trace", "--pmc"] + counters + ["-d", os.path.join(outdir, tag), "-o", "k", "--",
                                                                       sys.executable, os.path.join(ROOT, "tools", "profile_cases.py"), cases, "2"]
         print("+", " ".join(cmd), flush=True)
@@ -94,8 +97,8 @@ def report(outdir):
           f"{calib['WRITE_SIZE'] or float('nan'):.3f} (counters in KiB; the corrected figures are below, in MB per launch)")
     print("# per launch: us = average duration; rd / wr = HBM-side bytes; VALU / SALU / LDS = wave-instructions issued (millions); "
           "waves; wcyc = wave-cycles (M); busy = SQ busy cycles (M); bank = LDS bank-conflict cycles (M); "
-          "valu% = SQ_ACTIVE_INST_VALU x 4 / wave-cycles ; wait% = SQ_WAIT_INST_ANY / wave-cycles")
-    hdr = f"{'kernel':74s} {'calls':>5s} {'us':>8s} {'VGPR':>4s} {'LDS_B':>6s} {'scr':>4s} {'rd_MB':>7s} {'wr_MB':>7s} {'VALU':>6s} {'SALU':>6s} {'LDS':>5s} {'waves':>6s} {'wcyc':>6s} {'busy':>6s} {'bank':>5s} {'valu%':>5s} {'wait%':>5s}"
+          "issue% = VALU x 4 cycles / (1024 SIMDs x duration x 2.4 GHz): how busy the vector pipes are ; wait% = SQ_WAIT_INST_ANY / wave-cycles")
+    hdr = f"{'kernel':74s} {'calls':>5s} {'us':>8s} {'VGPR':>4s} {'LDS_B':>6s} {'scr':>4s} {'rd_MB':>7s} {'wr_MB':>7s} {'VALU':>6s} {'SALU':>6s} {'LDS':>5s} {'waves':>6s} {'wcyc':>6s} {'busy':>6s} {'bank':>5s} {'issu%':>5s} {'wait%':>5s}"
     print(hdr)
     rows = sorted(per.items(), key=lambda kv: -(kv[1].get("calls", 0) * kv[1].get("avg_us", 0)))
     total = sum(d.get("calls", 0) * d.get("avg_us", 0) for _, d in rows) or 1.0
@@ -106,7 +109,7 @@ def report(outdir):
         rd = g("FETCH_SIZE", 1024.0 * (calib["FETCH_SIZE"] or 1.0) / 1e6)
         wr = g("WRITE_SIZE", 1024.0 * (calib["WRITE_SIZE"] or 1.0) / 1e6)
         wc = g("SQ_WAVE_CYCLES")
-        valu_pct = 100.0 * g("SQ_ACTIVE_INST_VALU") * 4 / wc if wc == wc and wc > 0 else float("nan")
+        valu_pct = 100.0 * g("SQ_INSTS_VALU") * 4 / (1024 * d.get("avg_us", 0) * 2400.0) if d.get("avg_us") else float("nan")
         wait_pct = 100.0 * g("SQ_WAIT_INST_ANY") / wc if wc == wc and wc > 0 else float("nan")
         print(f"{short(name)[:74]:74s} {d.get('calls', 0):5d} {d.get('avg_us', 0):8.2f} {d.get('vgpr', -1):4d} {d.get('lds', -1):6d} {d.get('scratch', -1):4d} "
               f"{rd:7.1f} {wr:7.1f} {g('SQ_INSTS_VALU', 1e-6):6.2f} {g('SQ_INSTS_SALU', 1e-6):6.2f} {g('SQ_INSTS_LDS', 1e-6):5.2f} "
