@@ -684,7 +684,13 @@ __global__ __launch_bounds__(64 * NW, SHORT ? 16 / NW : (FW < 64 ? ((WEIGHTED ? 
 // Chunks are 17 samples long, not 16: lane l walks rows 17 l + t of the linear LDS copy, and 17 is odd, so the 64 lanes
 // of a read hit 32 different bank pairs -- the floor for 8-byte accesses -- without any padding (with 16 they would
 // hit two).
-constexpr int kAlongC = 17;
+#ifndef PTV_ALONG_C
+#define PTV_ALONG_C 17
+#endif
+#ifndef PTV_ALONG_W_C
+#define PTV_ALONG_W_C 17   // weighted sweeps (two LDS planes per wave)
+#endif
+constexpr int kAlongC = PTV_ALONG_C;
 // Chunk length of the robust instantiation (rungs 1 / 2: pieces of a few samples).  Longer chunks walk the zone less often and --
 // what matters more -- shrink the spread between the lanes of a wave, whose walk lasts as long as its slowest lane's: with 31
 // samples a wave walks 2.70 -> 2.03 trips per sample at lambda = 0.5 and 4.24 -> 3.03 at 0.7 on the inputs of DR sweeps (host model:
@@ -692,9 +698,9 @@ constexpr int kAlongC = 17;
 // measured (end of round 3) that price is too high: 4096^2 DR at lambda = 0.5 / 0.7 12.7 -> 16.1, 23.7 -> 33.3 ms with 31, 13.7 / 25.0
 // with 23.  So: 17, like the plain instantiation.  (An odd number, see above; a chunk's piece ends fit the 32-bit masks of ChunkRec.)
 #ifndef PTV_ALONG_ROBUST_C
-#define PTV_ALONG_ROBUST_C 17
+#define PTV_ALONG_ROBUST_C PTV_ALONG_C
 #endif
-constexpr int along_chunk(bool robust, bool weighted) { return robust && !weighted ? PTV_ALONG_ROBUST_C : kAlongC; }
+constexpr int along_chunk(bool robust, bool weighted) { return weighted ? PTV_ALONG_W_C : (robust ? PTV_ALONG_ROBUST_C : kAlongC); }
 #ifndef PTV_ALONG_WAVES
 #define PTV_ALONG_WAVES 4
 #endif
@@ -733,7 +739,7 @@ __global__ __launch_bounds__(64 * kAlongWaves) void sweep_along_kernel(SweepArgs
                                                                         link_t *code_next, int *failflags) {
     constexpr int C = along_chunk(ROBUST, WEIGHTED), SEG = G * C, T = ONESEG ? 0 : along_tail_rows(H, ROBUST), HZ = ONESEG ? 0 : along_zone_rows(H, ROBUST), ROWS = HZ + SEG + T, NG = 64 / G;
     constexpr int NU = (ROWS + G - 1) / G;   // staged elements per lane
-    constexpr int UL = 9;                    // epilogue operand fetches in flight per lane (C = 17 rows per lane: 9 + 8)
+    constexpr int UL = (C + 1) / 2;          // epilogue operand fetches in flight per lane (C = 17 rows per lane: 9 + 8)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (p.gate && *p.gate == 0) return;
     // (the wave number is the same in every lane: said so, everything derived from it -- fibre, segment, base addresses, window

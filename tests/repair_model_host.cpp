@@ -19,8 +19,8 @@
 #include <cstring>
 #include <vector>
 
-#include "../../proxtv_amd/csrc/walker.hpp"
-#include "../../proxtv_amd/csrc/chunkcore.hpp"
+#include "../proxtv_amd/csrc/walker.hpp"
+#include "../proxtv_amd/csrc/chunkcore.hpp"
 
 using namespace ptv;
 

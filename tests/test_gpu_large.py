@@ -176,3 +176,39 @@ def test_bench_two_ranks_on_one_gpu_dry_run():
     assert c5["ranks"] == 2 and c5["images"] == 8 and c5["gather_checked"] is True and c5["gather_ms"] > 0
     assert c5["gather_bytes"] == 4 * 2048 * 2048 * 8
     assert d["roofline"]["frac"] > 0
+    assert d["output_check"]["ok"] is True and d["output_check"]["rel_err"] <= 1e-6   # rank 0's image IS the c2 fixture
+
+
+def test_bench_two_ranks_full_shard_and_no_gather():
+    """The same dry run at the FULL per-rank shard of BASELINE config #5 (64 images of 2048 x 2048 per rank): rank 0 receives every
+    rank's block in one pre-allocated (world, B, N, M) tensor, the block check passes, and the high-water mark of torch's allocations
+    on rank 0 is on record; then once more with --no-gather, which must leave the solver figures and drop the gather's."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PROXTV_BENCH_SHARED_GPU="1")
+
+    def run(extra):
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1"] + extra
+        out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stderr[-3000:]
+        lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, out.stdout[-2000:]
+        return json.loads(lines[0])["c5"]
+
+    c5 = run(["--c5-images", "64"])
+    assert c5["ranks"] == 2 and c5["images"] == 128 and c5["gather_checked"] is True and c5["gather_ms"] > 0
+    assert c5["gather_bytes"] == 64 * 2048 * 2048 * 8
+    # (shared-GPU dry run: the blocks travel as host copies over gloo, so torch's DEVICE high-water mark holds x5 and y5 only;
+    #  on a real node the (world, B, N, M) receive tensor adds world x 2 GiB on rank 0)
+    assert c5["rank0_torch_hbm_peak_bytes"] >= 2 * 64 * 2048 * 2048 * 8
+    c5n = run(["--c5-images", "8", "--no-gather"])
+    assert c5n["ranks"] == 2 and c5n["images"] == 16 and c5n["gather_ms"] is None and c5n["gather_bytes"] is None
+    assert "skipped" in c5n["gather"] and c5n["solve_ms"] > 0

@@ -1,4 +1,4 @@
-"""The stage behind the chunk kernels as a HOST model (tools/study/repair_model.cpp: the device walker compiled with g++, speculative
+"""The stage behind the chunk kernels as a HOST model (tests/repair_model_host.cpp: the device walker compiled with g++, speculative
 chunk walks with the device's ownership rule, then the repairs): the sequential repair that jumps from link in doubt to link in doubt
 -- with the scan behind a jump unbounded, as in round 4, and bounded -- and the repair with one walk per failing link whose validity
 is decided afterwards (sweep_repair_jobs_kernel, option repair_jobs), each against the sequential walk of the whole fibre.  Exact by construction, every one
@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.fixture(scope="module")
 def model():
     out = os.path.join(tempfile.mkdtemp(prefix="ptv_repair_"), "librepair_model.so")
-    subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", out, os.path.join(ROOT, "tools", "study", "repair_model.cpp")], check=True)
+    subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", out, os.path.join(ROOT, "tests", "repair_model_host.cpp")], check=True)
     lib = C.CDLL(out)
     lib.model_fibres.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     lib.model_fibres.restype = C.c_int

@@ -40,4 +40,14 @@ s2)   # K1: wave-uniform fast paths (interior segments / inner blocks: nothing t
   python tools/kernel_counters.py report $OUT/kc > $OUT/kernel_counters.txt 2>&1; cat $OUT/kernel_counters.txt
   find $OUT/kc -name "*.db" -delete
   ;;
+s3)   # occupancy variants of the along-fibre kernel now that it issues 18 % fewer instructions (chunks of 15 / 13 samples: five
+      # workgroups per CU; weighted chunks of 9 / 11: the two LDS planes at 16 / 12 waves per CU; 1- and 2-wave workgroups), the phase
+      # trace of the new build, the lambda sweep
+  timeout 300 python -m pytest tests/test_gpu_parity_2d.py tests/test_gpu_parity_1d.py -m gpu -x -q > $OUT/pytest_default.log 2>&1; echo "default: $(tail -1 $OUT/pytest_default.log)" | tee $OUT/summary.txt
+  for v in c15 c13 w9 aw1; do alt $v timeout 300 python -m pytest tests/test_gpu_parity_2d.py tests/test_gpu_parity_1d.py tests/test_gpu_chunk_repair.py -m gpu -x -q > $OUT/pytest_$v.log 2>&1; echo "$v: $(tail -1 $OUT/pytest_$v.log)" | tee -a $OUT/summary.txt; done
+  ab --reps 7 --rounds 2 --cases c2,c2@0.5,prox0,c4,s1024 base c15=$W/lib_c15.so c13=$W/lib_c13.so aw1=$W/lib_aw1.so aw2=$W/lib_aw2.so > $OUT/ab_occupancy.txt 2>&1; cat $OUT/ab_occupancy.txt
+  ab --reps 7 --rounds 2 --cases c3,wprox0,c3@5 base w9=$W/lib_w9.so w11=$W/lib_w11.so > $OUT/ab_weighted.txt 2>&1; cat $OUT/ab_weighted.txt
+  timeout 60 python tools/wg_trace.py > $OUT/wg_trace.txt 2>&1; grep "^##\|^# mean" $OUT/wg_trace.txt
+  timeout 300 python tools/lambda_probe.py --modes -1 --lams 0.1,0.2,0.3,0.4,0.5,0.6,0.65,0.7,0.75,0.8,1.0,3.0,10.0,30.0 > $OUT/lambda_sweep.txt 2>&1; cat $OUT/lambda_sweep.txt
+  ;;
 esac

@@ -2,10 +2,10 @@
 """HOST-ONLY model of the repair stage behind the chunk kernels (no GPU, no oracle): is the sequential repair's jump sound, is the
 jobs repair (one walk per failing link, validity decided afterwards) sound, and how much does each leave to the other?
 
-    python tools/study/repair_model.py [fibres per case] [jobs per fibre at most] [weighted]
+    python tools/repair_model.py [fibres per case] [jobs per fibre at most] [weighted]
 
 Every chunk of 16 samples is its own workgroup here, so every link is a link across workgroups.  Per data family and lambda:
-fibres with a link in doubt, links in doubt per such fibre, and for the four repairs (see repair_model.cpp) the number of fibres
+fibres with a link in doubt, links in doubt per such fibre, and for the four repairs (see tests/repair_model_host.cpp) the number of fibres
 that end up WRONG (absolute error above 1e-9 against the sequential walk of the whole fibre) -- the point of the exercise.
 """
 import ctypes as C, os, subprocess, sys, tempfile
@@ -13,7 +13,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 so = os.path.join(tempfile.gettempdir(), "repair_model.so")
-subprocess.run(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", so, os.path.join(HERE, "repair_model.cpp")], check=True)
+subprocess.run(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", so, os.path.join(HERE, "..", "tests", "repair_model_host.cpp")], check=True)
 lib = C.CDLL(so)
 lib.model_fibres.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
 
