@@ -687,8 +687,14 @@ __global__ __launch_bounds__(64 * NW, SHORT ? 16 / NW : (FW < 64 ? ((WEIGHTED ? 
 #ifndef PTV_ALONG_C
 #define PTV_ALONG_C 17
 #endif
+// Weighted sweeps hold two LDS planes per wave (samples, penalties): with 17-sample chunks 17.8 KB, i.e. 8 waves per CU, and the kernel
+// idles -- vector pipes 45 % busy, HBM at a third of its rate (profiles/r05_s1_kernel_counters.txt).  Chunks of 9 samples (odd: no bank
+// conflicts) halve the segment and with it the LDS: 16 waves per CU.  The walk costs more per sample (a zone per 9 samples instead of
+// per 17) and still wins: weighted column sweep 143.3 -> 111.2 us, weighted 4096^2 solve 11.64 -> 10.53 ms; 11 samples (12 waves):
+// 117.8 us (profiles/r05_s3_ab_weighted.txt).  (Unweighted: 15 / 13 samples -- 20 waves per CU -- move the column sweep 75.0 ->
+// 75.6 / 72.1 us and cost 512-sample fibres their one-segment instantiation: 17 stays.)
 #ifndef PTV_ALONG_W_C
-#define PTV_ALONG_W_C 17   // weighted sweeps (two LDS planes per wave)
+#define PTV_ALONG_W_C 9
 #endif
 constexpr int kAlongC = PTV_ALONG_C;
 // Chunk length of the robust instantiation (rungs 1 / 2: pieces of a few samples).  Longer chunks walk the zone less often and --

@@ -50,4 +50,14 @@ s3)   # occupancy variants of the along-fibre kernel now that it issues 18 % few
   timeout 60 python tools/wg_trace.py > $OUT/wg_trace.txt 2>&1; grep "^##\|^# mean" $OUT/wg_trace.txt
   timeout 300 python tools/lambda_probe.py --modes -1 --lams 0.1,0.2,0.3,0.4,0.5,0.6,0.65,0.7,0.75,0.8,1.0,3.0,10.0,30.0 > $OUT/lambda_sweep.txt 2>&1; cat $OUT/lambda_sweep.txt
   ;;
+s4)   # weighted chunks of 9 samples as the default (parity + fuzz first), then: 7 samples; the row sweep's s' kept for 12 / 16 of a thread's 16
+      # rows now that the staging addresses live in scalar registers; rung 1 against rung 3 at lambda 0.75 - 1 with the jobs repair;
+      # the phase trace with the number of waves in flight
+  timeout 600 python -m pytest tests/test_gpu_parity_2d.py tests/test_gpu_parity_nd.py tests/test_gpu_large.py tests/test_gpu_fuzz.py tests/test_gpu_chunk_repair.py -m gpu -x -q > $OUT/pytest_default.log 2>&1; echo "default: $(tail -1 $OUT/pytest_default.log)" | tee $OUT/summary.txt
+  { python tools/fuzz.py 90 71; python tools/fuzz.py 30 72 nd; } > $OUT/fuzz.txt 2>&1; grep "^fuzz\|MISMATCH" $OUT/fuzz.txt | tee -a $OUT/summary.txt
+  ab --reps 7 --rounds 2 --cases c3,wprox0,c3@5 base w7=$W/lib_w7.so > $OUT/ab_w7.txt 2>&1; cat $OUT/ab_w7.txt
+  ab --reps 7 --rounds 2 --cases c2,c2@0.5,pd2,c4y,yang2 base keep12=$W/lib_keep12.so keep16=$W/lib_keep16.so > $OUT/ab_keep.txt 2>&1; cat $OUT/ab_keep.txt
+  ab --reps 5 --rounds 1 --cases c2@0.7,c2@0.75,c2@0.8,c2@0.9,c2@1.0 base rung1,chunk_mode=1 rung3,chunk_mode=3 > $OUT/ab_rungs.txt 2>&1; cat $OUT/ab_rungs.txt
+  timeout 60 python tools/wg_trace.py > $OUT/wg_trace.txt 2>&1; grep "^##\|^# " $OUT/wg_trace.txt
+  ;;
 esac

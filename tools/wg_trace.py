@@ -29,6 +29,19 @@ def report(title, rows=16):
     t = buf[:, 1:6].astype(np.int64)
     t = (t - t[:, 0].min()) * 0.01     # microseconds (100 MHz)
     print(f"## {title}: {n} workgroups; kernel span {t[:, 4].max():.1f} us")
+    # how many records are in flight over the kernel's life (resident waves / workgroups), and per CU
+    cuid0 = ((xcc * 8 + se) * 2 + sh) * 16 + cu
+    span = t[:, 4].max()
+    grid = np.linspace(0.0, span, 41)
+    alive = [(int(((t[:, 0] <= g) & (t[:, 4] > g)).sum())) for g in grid]
+    print("# records in flight at 40 instants across the span:", " ".join(str(a) for a in alive))
+    print(f"# mean in flight {np.mean((t[:, 4] - t[:, 0]).sum() / span):.0f} over {len(set(cuid0.tolist()))} CUs = "
+          f"{(t[:, 4] - t[:, 0]).sum() / span / len(set(cuid0.tolist())):.2f} per CU; records per CU: min {np.bincount(cuid0).min()} max {np.bincount(cuid0)[np.bincount(cuid0) > 0].max()}")
+    percu_end = np.array([t[cuid0 == c, 4].max() for c in sorted(set(cuid0.tolist()))])
+    print(f"# last record of a CU ends at: min {percu_end.min():.1f} median {np.median(percu_end):.1f} max {percu_end.max():.1f} us; "
+          f"first records start at {t[:, 0].min():.2f} .. {np.sort(t[:, 0])[min(n - 1, 4095)]:.2f} us (4096th)")
+    if os.environ.get("WG_TRACE_DUMP"):
+        np.savez_compressed(os.path.join(os.environ["WG_TRACE_DUMP"], title.split(",")[0].replace(" ", "_")[:40] + ".npz"), t=t, cuid=cuid0, xcc=xcc)
     print("#    wg xcc se sh cu tg | start staged walked rebuilt end (us)")
     cuid = ((xcc * 8 + se) * 2 + sh) * 16 + cu
     order = np.lexsort((t[:, 0], cuid))
