@@ -170,6 +170,8 @@ void proxtv_release_scratch(void);
      "pin_seed"       1 (default): the pinning solver (rung 3) starts from the knots known a priori, 0: from the fibre ends alone
      "pin_overlap"    1: a strided sweep of the pinning solver moves its transposed copies range by range on a second stream, under
                       the levels of the other ranges ; 0 (default: measured slower): one stream
+     "along_persist"  1 (default): the plain along-fibre kernel is launched with as many workgroups as the device holds at once and
+                      each takes its share of the segments in turn ; 0: one workgroup per four segments
      "repair_jobs"    failed links across the workgroups of a chunked sweep are first repaired one lane per failure, four to a
                       fibre; what that leaves goes to the sequential repair: 1 (default) where the sampled statistic of the sweep's
                       input says such links fail in numbers, 2 always ; 0: the sequential repair alone (same results, bit for bit)

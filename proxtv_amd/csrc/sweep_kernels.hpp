@@ -199,6 +199,7 @@ struct ChunkPlan {
     unsigned long long *trace;   // option "trace": 8 words per workgroup -- where it ran and when its phases ended (100 MHz clock)
     DirtyMark dirty;             // this launch's "something is left for the repair kernel" word
     unsigned long long *xlink;   // links across workgroups / segments: [boundary][fibre] (tile) or [fibre][segment] (along)
+    long along_wgs;              // along-fibre kernel: workgroups' worth of work in the sweep (gridDim.x of them take it in turns)
 };
 
 __device__ __forceinline__ void trace_mark(const ChunkPlan &plan, int slot) {
@@ -358,12 +359,16 @@ __global__ __launch_bounds__(64 * NW, SHORT ? 16 / NW : (FW < 64 ? ((WEIGHTED ? 
     // share of the thread) unless that would not fit the register budget: transposed sweeps stage in two batches (three
     // for two-operand inputs: 48 live doubles spill otherwise), two-operand strided sweeps in two.
     constexpr int NB = TRANSPOSED ? (Op<OP>::NIN > 1 ? (NST + 2) / 3 : (NST + 1) / 2) : (Op<OP>::NIN > 1 ? (NST + 1) / 2 : NST);
-    // (PTV_KEEP_N: how many of a thread's C own rows keep the operand -- the rest is fetched again; all 16 spill dozens of registers:
-    // DR row sweep with -DPTV_KEEP_STAGED 116.7 -> 115.1 / 114.5 / 144 us at 4 / 8 / 16)
+    // (PTV_KEEP_N: how many of a thread's C own rows keep the operand -- the rest is fetched again.  Round 4: all 16 spilled 28 registers
+    // at the 128-VGPR budget (DR row sweep 116.7 -> 115.1 / 114.5 / 144 us at 4 / 8 / 16 rows), so 8 were kept.  Round 5: with the staging
+    // addresses in scalar registers all 16 fit but for eight spilled dwords outside the walk: 108.2 -> 105.1 / 104.0 us at 12 / 16, the
+    // second read of s' is gone and with it a tenth of the row sweep's traffic (profiles/r05_s4_ab_keep.txt).  The 64-fibre x 8-wave
+    // tile (option tile = 0) stays at 8.)
 #ifndef PTV_KEEP_N
-#define PTV_KEEP_N 8
+#define PTV_KEEP_N 16
 #endif
-    constexpr int KN = KEEP ? (PTV_KEEP_N < C ? PTV_KEEP_N : C) : 0;
+    constexpr int KNW = (FW < 64 || WEIGHTED) ? PTV_KEEP_N : (PTV_KEEP_N < 8 ? PTV_KEEP_N : 8);
+    constexpr int KN = KEEP ? (KNW < C ? KNW : C) : 0;
     double kept[KEEP ? KN : 1];
     // `inner` blocks (strided tiles): all FW fibres of the tile exist, the whole window lies inside the fibre (but, first block, the
     // zone before sample 0) and the fibre's last sample beyond it -- nearly every block of a large image.  Uniform over the workgroup,
@@ -775,7 +780,13 @@ __global__ __launch_bounds__(64 * kAlongWaves) void sweep_along_kernel(SweepArgs
     }
     const int len = g.len;
     const int nseg = (len + SEG - 1) / SEG, NC = (len + C - 1) / C;
-    const long wid = (long)blockIdx.x * kAlongWaves + wave;
+    // A workgroup takes its share of the sweep in turn (plan.along_wgs workgroups' worth of segments over gridDim.x workgroups): the
+    // plain instantiations are launched with as many workgroups as the device holds at once, so after the first fill no wave slot
+    // waits for the dispatcher -- measured on the round-5 phase trace: with one workgroup per four segments the slots of a 4096^2
+    // column sweep were 70 % full on average (all waves of a round end together and the refill takes microseconds).  The robust
+    // instantiations, whose waves hand over to each other through the workgroup's LDS, keep one turn per workgroup.
+    for (long wg_turn = blockIdx.x; wg_turn < plan.along_wgs; wg_turn += gridDim.x) {
+    const long wid = wg_turn * kAlongWaves + wave;
     const long unit = wid * NG + gi;         // one group of G lanes = one segment of one fibre
     long j, sg_l;
     divmod_nonneg(unit, (long)nseg, j, sg_l);
@@ -1023,6 +1034,7 @@ __global__ __launch_bounds__(64 * kAlongWaves) void sweep_along_kernel(SweepArgs
         if (why) plan.dirty.set(why);
     }
     if (plan.trace && lane == 0) plan.trace[8 * (size_t)wid + 5] = wall_clock64();
+    }   // (next turn)
 }
 
 // ---- kernel 1b: short fibres, whole in LDS ---------------------------------------------------------------------------------
@@ -2259,7 +2271,21 @@ void launch_along_g(const SweepArgs &args, const FibreGeom &g, hipStream_t strea
             attr_set = true;
         }
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)((waves + kAlongWaves - 1) / kAlongWaves)), dim3(64 * kAlongWaves), lds, stream, args, g,
+    plan.along_wgs = (waves + kAlongWaves - 1) / kAlongWaves;
+    long grid_wgs = plan.along_wgs;
+    if (!ROBUST && options().along_persist) {
+        // as many workgroups as the device holds at once (asked once per instantiation and device)
+        static thread_local long capacity[kMaxDevices] = {};
+        long &cap = capacity[current_device()];
+        if (cap == 0) {
+            int per_cu = 0, dev = current_device(), cus = 0;
+            PTV_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(kern), 64 * kAlongWaves, lds));
+            PTV_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+            cap = (long)(per_cu > 0 ? per_cu : 1) * (cus > 0 ? cus : 1);
+        }
+        if (cap < grid_wgs) grid_wgs = cap;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid_wgs), dim3(64 * kAlongWaves), lds, stream, args, g,
                        plan, chunk_state().code_mine, chunk_state().code_next, chunk_state().failflags);
     count_event(CNT_SWEEP_LAUNCHES);
     if (!plan.ablate) {

@@ -60,4 +60,11 @@ s4)   # weighted chunks of 9 samples as the default (parity + fuzz first), then:
   ab --reps 5 --rounds 1 --cases c2@0.7,c2@0.75,c2@0.8,c2@0.9,c2@1.0 base rung1,chunk_mode=1 rung3,chunk_mode=3 > $OUT/ab_rungs.txt 2>&1; cat $OUT/ab_rungs.txt
   timeout 60 python tools/wg_trace.py > $OUT/wg_trace.txt 2>&1; grep "^##\|^# " $OUT/wg_trace.txt
   ;;
+s5)   # the along-fibre kernel taking its segments in turns (as many workgroups as the device holds: no slot waits for the dispatcher),
+      # s' kept for all 16 rows: parity, A/B by option on one build, the trace; rung / form thresholds re-checked with the new kernels
+  timeout 600 python -m pytest tests/test_gpu_parity_1d.py tests/test_gpu_parity_2d.py tests/test_gpu_parity_nd.py tests/test_gpu_large.py tests/test_gpu_fuzz.py -m gpu -x -q > $OUT/pytest_default.log 2>&1; echo "default: $(tail -1 $OUT/pytest_default.log)" | tee $OUT/summary.txt
+  ab --reps 7 --rounds 2 --cases c2,prox0,c2@0.2,c4,c4y,pd2,s1024,s512 base turns0,along_persist=0 > $OUT/ab_persist.txt 2>&1; cat $OUT/ab_persist.txt
+  ab --reps 5 --rounds 1 --cases c2@0.25,c2@0.3,c2@0.35,c2@0.4 base rung0,chunk_mode=0 noisy35,seed_noisy_e4=3500 form0,dr_form=0 > $OUT/ab_rung0.txt 2>&1; cat $OUT/ab_rung0.txt
+  timeout 60 python tools/wg_trace.py > $OUT/wg_trace.txt 2>&1; grep "^##\|^# " $OUT/wg_trace.txt
+  ;;
 esac
