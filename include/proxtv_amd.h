@@ -177,6 +177,8 @@ void proxtv_release_scratch(void);
                       input says such links fail in numbers, 2 always ; 0: the sequential repair alone (same results, bit for bit)
      "tile"           strided sweeps on rungs 0 and 1 (the robust instantiation follows the same knob): 1 (default) tiles of 32 fibres x 8 chunks in 4 waves, four workgroups per CU ;
                       0: the 64-fibre x 8-wave tile, two per CU
+     "tile_persist"   1 (default): tile kernels are launched with as many workgroups as the device holds at once and each takes its
+                      share of the (fibre group, block range) turns ; 0: one workgroup per turn
      "host_register"  1: page-lock large caller arrays around the transfers of the host-pointer entry points (default 0: no gain measured)
      "verbose"        1: log every decision of the geometry policy to stderr
      "profile"        1: hipEvent pair around every sweep launch (proxtv_last_kernel_ms / _launches)

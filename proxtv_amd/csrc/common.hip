@@ -49,6 +49,7 @@ constexpr OptionEntry kOptionTable[] = {
     {"xlink", &Options::xlink},
     {"dr_form", &Options::dr_form},
     {"tile", &Options::tile},
+    {"tile_persist", &Options::tile_persist},
     {"host_register", &Options::host_register},
     {"verbose", &Options::verbose},
     {"profile", &Options::profile},

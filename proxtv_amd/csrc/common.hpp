@@ -69,6 +69,8 @@ struct Options {
                               // reference's split (OP_DR_COL / OP_DR_ROW)
     int tile = 1;             // strided sweeps on rungs 0 and 1 (unweighted and weighted): 1 = tiles of 32 fibres x 8 chunks in 4 waves (four
                               // workgroups per CU), 0 = the 64-fibre x 8-wave tile (two)
+    int tile_persist = 1;     // tile kernels launched with as many workgroups as the device holds at once, each taking its share of the
+                              // (fibre group, block range) turns ; 0 = one workgroup per turn
     int host_register = 0;    // host-pointer entry points: page-lock large caller arrays around their transfers (see cabi.hip)
     int verbose = 0;
     int profile = 0;    // per-kernel-family hipEvent timing

@@ -67,4 +67,10 @@ s5)   # the along-fibre kernel taking its segments in turns (as many workgroups 
   ab --reps 5 --rounds 1 --cases c2@0.25,c2@0.3,c2@0.35,c2@0.4 base rung0,chunk_mode=0 noisy35,seed_noisy_e4=3500 form0,dr_form=0 > $OUT/ab_rung0.txt 2>&1; cat $OUT/ab_rung0.txt
   timeout 60 python tools/wg_trace.py > $OUT/wg_trace.txt 2>&1; grep "^##\|^# " $OUT/wg_trace.txt
   ;;
+s6)   # work queues: waves (along-fibre kernel) / workgroups (tiles) draw their segments / blocks from an atomic counter instead of
+      # waiting for the dispatcher (static turns lost in s5: no rebalancing).  Parity, A/B by option on one build, the trace.
+  timeout 600 python -m pytest tests/test_gpu_parity_1d.py tests/test_gpu_parity_2d.py tests/test_gpu_parity_nd.py tests/test_gpu_large.py tests/test_gpu_fuzz.py tests/test_gpu_chunk_repair.py -m gpu -x -q > $OUT/pytest_default.log 2>&1; echo "default: $(tail -1 $OUT/pytest_default.log)" | tee $OUT/summary.txt
+  ab --reps 7 --rounds 2 --cases c2,prox0,prox1,c2@0.5,c3,c4,c4y,pd2,s1024,s512 base noq,along_persist=0,tile_persist=0 alongq,tile_persist=0 tileq,along_persist=0 > $OUT/ab_queue.txt 2>&1; cat $OUT/ab_queue.txt
+  timeout 60 python tools/wg_trace.py > $OUT/wg_trace.txt 2>&1; grep "^##\|^# " $OUT/wg_trace.txt
+  ;;
 esac
