@@ -191,6 +191,8 @@ __global__ __launch_bounds__(64) void sweep_seq_kernel(SweepArgs p, FibreGeom g,
 }
 
 // ---- kernel 2: speculative chunks over an LDS window -----------------------------------------------------------------
+// work queues of the chunk kernels (see sweep_along_kernel): counters per launch, and their distance in 4-byte words (a cache line each)
+constexpr unsigned kQueues = 64, kQueueStride = 32;
 struct ChunkPlan {
     int Q;      // blocks (NW chunks each) per fibre
     int qpw;    // consecutive blocks of one fibre group processed (software-pipelined) by one workgroup
@@ -334,13 +336,13 @@ __global__ __launch_bounds__(64 * NW, SHORT ? 16 / NW : (FW < 64 ? ((WEIGHTED ? 
     // option tile_persist: as many workgroups launched as the device holds at once) a workgroup's first turn is its own number and
     // every further one is drawn from an atomic counter by thread 0 -- at the START of the turn before, so the round trip hides
     // behind the turn -- and handed to the others through LDS: no slot waits for the dispatcher, and fast workgroups take more turns
-    // (see the along-fibre kernel).  plan.queue == null: one turn per workgroup.
+    // (see the along-fibre kernel, also for why there are kQueues counters and not one).  plan.queue == null: one turn per workgroup.
     const long turns = (long)plan.gx * plan.gy;
     long turn = blockIdx.x;
+    const unsigned my_queue = blockIdx.x % kQueues;
     for (;;) {
-    unsigned drawn = 0u;
-    if (plan.queue && tid == 0) drawn = atomicAdd(plan.queue, 1u);
     const unsigned bx = (unsigned)(turn % plan.gx), by = (unsigned)(turn / plan.gx);
+    unsigned drawn = 0u;
     if (plan.trace && tid == 0) {
         unsigned hwid, xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
@@ -465,6 +467,8 @@ __global__ __launch_bounds__(64 * NW, SHORT ? 16 / NW : (FW < 64 ? ((WEIGHTED ? 
         }
         __syncthreads();
         if (kb == 0) trace_mark(plan, turn, 2);
+        // the workgroup's next turn: asked for now (behind the window loads), handed to the other threads at the end of this one
+        if (kb == 0 && plan.queue && tid == 0) drawn = atomicAdd(plan.queue + my_queue * kQueueStride, 1u);
 
         const int cs_wg = q * NCH * C;
         const int lo = cs_wg - HA;
@@ -692,7 +696,7 @@ __global__ __launch_bounds__(64 * NW, SHORT ? 16 / NW : (FW < 64 ? ((WEIGHTED ? 
     if (!plan.queue) break;
     if (tid == 0) turn_slot[0] = drawn;
     __syncthreads();   // the next turn is known to all -- and every wave is done with this turn's window and link slots
-    turn = (long)gridDim.x + (long)turn_slot[0];
+    turn = (long)gridDim.x + (long)turn_slot[0] * kQueues + my_queue;
     if (turn >= turns) break;   // (thread 0 overwrites the slot a whole turn later, behind that turn's barriers)
     }   // (next turn)
 }
@@ -804,15 +808,16 @@ __global__ __launch_bounds__(64 * kAlongWaves) void sweep_along_kernel(SweepArgs
     // the turn before, so the round trip hides behind the turn.  Measured on the round-5 phase traces (4096^2 column sweep): with one
     // workgroup per four segments the wave slots are 70 % full on average (the waves of a round end together and the dispatcher needs
     // microseconds to refill 4096 slots); with static turns they stay full for half the kernel and then drain over the other half
-    // (workgroups whose waves walk in phase are slower, and nothing rebalances): 76 -> 84 us.  The queue keeps the slots full AND
-    // balanced.  (Every launch has its own counter: ChunkScratch::work_queue.)  plan.queue == null: one turn, wave = segment
+    // (workgroups whose waves walk in phase are slower, and nothing rebalances): 76 -> 84 us.  ONE counter for all waves serialises
+    // 12 288 atomics on one address (~13 ns each: 217 us, session 6); so the segments beyond the launched waves are dealt round-robin
+    // to kQueues counters in separate cache lines, and a wave draws from the counter of its own number -- 64 waves per counter, spread
+    // over the chip, balance each other.  (Every launch has its own counters: ChunkScratch::work_queue.)  plan.queue == null: one turn, wave = segment
     // number (the robust instantiations, whose waves hand over to each other through the workgroup's LDS).
     const long total_waves = plan.along_wgs * kAlongWaves;
     const unsigned launched_waves = gridDim.x * kAlongWaves;
     long wid = (long)blockIdx.x * kAlongWaves + wave;
+    const unsigned my_queue = (unsigned)(wid % kQueues);
     for (;;) {
-    unsigned drawn = 0u;
-    if (plan.queue && lane == 0) drawn = atomicAdd(plan.queue, 1u);   // (the next turn's segment; consumed at the end of this turn)
     const long unit = wid * NG + gi;         // one group of G lanes = one segment of one fibre
     long j, sg_l;
     divmod_nonneg(unit, (long)nseg, j, sg_l);
@@ -899,6 +904,10 @@ __global__ __launch_bounds__(64 * kAlongWaves) void sweep_along_kernel(SweepArgs
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     if (plan.trace && lane == 0) plan.trace[8 * (size_t)wid + 2] = wall_clock64();
+    // the next turn's segment: asked for now -- behind the window loads, which would otherwise wait for the atomic's round trip --
+    // and consumed at the end of this turn
+    unsigned drawn = 0u;
+    if (plan.queue && lane == 0) drawn = atomicAdd(plan.queue + my_queue * kQueueStride, 1u);
 
     // ---- speculative walk of this lane's chunk ---------------------------------------------------------------------------------
     const int cs = seg_s + gl * C;
@@ -1061,8 +1070,8 @@ __global__ __launch_bounds__(64 * kAlongWaves) void sweep_along_kernel(SweepArgs
     }
     if (plan.trace && lane == 0) plan.trace[8 * (size_t)wid + 5] = wall_clock64();
     if (!plan.queue) break;
-    wid = (long)launched_waves + (long)(unsigned)__builtin_amdgcn_readfirstlane((int)drawn);
-    if (wid >= total_waves) break;   // the queue is empty
+    wid = (long)launched_waves + (long)(unsigned)__builtin_amdgcn_readfirstlane((int)drawn) * kQueues + my_queue;
+    if (wid >= total_waves) break;   // this wave's queue is empty
     }   // (next turn)
 }
 
@@ -1969,9 +1978,10 @@ struct ChunkScratch {
     std::unique_ptr<Scratch> queues;
     unsigned queue_next = 0;
     unsigned *work_queue(hipStream_t s) {
-        if (!queues) queues.reset(new Scratch(sizeof(unsigned) * kQueueRing));
-        if (queue_next % kQueueRing == 0) PTV_HIP(hipMemsetAsync(queues->as<unsigned>(), 0, sizeof(unsigned) * kQueueRing, s));
-        return queues->as<unsigned>() + (queue_next++ % kQueueRing);
+        constexpr size_t per_launch = (size_t)kQueues * kQueueStride;   // words
+        if (!queues) queues.reset(new Scratch(sizeof(unsigned) * per_launch * kQueueRing));
+        if (queue_next % kQueueRing == 0) PTV_HIP(hipMemsetAsync(queues->as<unsigned>(), 0, sizeof(unsigned) * per_launch * kQueueRing, s));
+        return queues->as<unsigned>() + per_launch * (queue_next++ % kQueueRing);
     }
     unsigned long long *xlink_for(size_t words, hipStream_t s) {
         if (!options().xlink) return nullptr;

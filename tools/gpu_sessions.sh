@@ -73,4 +73,10 @@ s6)   # work queues: waves (along-fibre kernel) / workgroups (tiles) draw their 
   ab --reps 7 --rounds 2 --cases c2,prox0,prox1,c2@0.5,c3,c4,c4y,pd2,s1024,s512 base noq,along_persist=0,tile_persist=0 alongq,tile_persist=0 tileq,along_persist=0 > $OUT/ab_queue.txt 2>&1; cat $OUT/ab_queue.txt
   timeout 60 python tools/wg_trace.py > $OUT/wg_trace.txt 2>&1; grep "^##\|^# " $OUT/wg_trace.txt
   ;;
+s7)   # work queues again: 64 counters per launch in separate cache lines (one counter serialised 12 288 atomics: 217 us), the draw
+      # issued behind the window loads
+  timeout 600 python -m pytest tests/test_gpu_parity_1d.py tests/test_gpu_parity_2d.py tests/test_gpu_large.py tests/test_gpu_fuzz.py -m gpu -x -q > $OUT/pytest_default.log 2>&1; echo "default: $(tail -1 $OUT/pytest_default.log)" | tee $OUT/summary.txt
+  ab --reps 7 --rounds 2 --cases c2,prox0,prox1,c2@0.5,c3,c4y,pd2,s1024 base noq,along_persist=0,tile_persist=0 alongq,tile_persist=0 tileq,along_persist=0 > $OUT/ab_queue.txt 2>&1; cat $OUT/ab_queue.txt
+  timeout 60 python tools/wg_trace.py > $OUT/wg_trace.txt 2>&1; grep "^##\|^# " $OUT/wg_trace.txt
+  ;;
 esac
