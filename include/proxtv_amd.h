@@ -170,15 +170,11 @@ void proxtv_release_scratch(void);
      "pin_seed"       1 (default): the pinning solver (rung 3) starts from the knots known a priori, 0: from the fibre ends alone
      "pin_overlap"    1: a strided sweep of the pinning solver moves its transposed copies range by range on a second stream, under
                       the levels of the other ranges ; 0 (default: measured slower): one stream
-     "along_persist"  1 (default): the plain along-fibre kernel is launched with as many workgroups as the device holds at once and
-                      each takes its share of the segments in turn ; 0: one workgroup per four segments
      "repair_jobs"    failed links across the workgroups of a chunked sweep are first repaired one lane per failure, four to a
                       fibre; what that leaves goes to the sequential repair: 1 (default) where the sampled statistic of the sweep's
                       input says such links fail in numbers, 2 always ; 0: the sequential repair alone (same results, bit for bit)
      "tile"           strided sweeps on rungs 0 and 1 (the robust instantiation follows the same knob): 1 (default) tiles of 32 fibres x 8 chunks in 4 waves, four workgroups per CU ;
                       0: the 64-fibre x 8-wave tile, two per CU
-     "tile_persist"   1 (default): tile kernels are launched with as many workgroups as the device holds at once and each takes its
-                      share of the (fibre group, block range) turns ; 0: one workgroup per turn
      "host_register"  1: page-lock large caller arrays around the transfers of the host-pointer entry points (default 0: no gain measured)
      "verbose"        1: log every decision of the geometry policy to stderr
      "profile"        1: hipEvent pair around every sweep launch (proxtv_last_kernel_ms / _launches)

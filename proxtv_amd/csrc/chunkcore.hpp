@@ -292,6 +292,9 @@ __device__ __forceinline__ void rebuild_owned(Win &win, const ChunkRec &rec, int
     bool have = false;
     if constexpr (FULL == 2 && !WEIGHTED) {
         double slot[C];   // row u: its sample, or -- once a piece has ended there -- that piece's value
+        // (all C reads in flight at once: one LDS latency per chunk instead of one per row)
+#pragma unroll
+        for (int u = 0; u < C; u++) slot[u] = win.y(cs + u);
         // (unweighted, no fibre end in the chunk: the knot's height is lambda with the sign of the bend type)
         auto height = [&](int u) {
 #ifdef PTV_HOST_TEST
@@ -300,23 +303,37 @@ __device__ __forceinline__ void rebuild_owned(Win &win, const ChunkRec &rec, int
             return __hiloint2double(__double2hiint(lam) ^ (int)((~(rec.types >> u) & 1u) << 31), __double2loint(lam));
 #endif
         };
+        // the length of the piece in hand as an integer: it indexes the reciprocal table as it is (a double count costs a quarter-rate
+        // conversion per piece end)
+        int n = (int)cnt;
+        auto over_n = [&](double num, int count) {
+            if constexpr (TAB) {
+                if (TSZ > 0 && count >= TSZ) {
+                    const SpanDiv over((double)count);
+                    return over(num);
+                }
+                return num * rt[count];
+            } else {
+                const SpanDiv over((double)count);
+                return over(num);
+            }
+        };
 #pragma unroll
         for (int u = 0; u < C; u++) {
-            const double yu = win.y(cs + u);
-            slot[u] = yu;
+            const double yu = slot[u];
             s += yu;
-            cnt += 1.0;
+            n += 1;
             if ((rec.ends >> u) & 1u) {
                 const double hk = height(u);
-                const double v = quotient(s + (hk - hprev), cnt);
+                const double v = over_n(s + (hk - hprev), n);
                 win.put(cs + u, F::fuse(yu, v));
                 slot[u] = v;
                 s = 0.0;
-                cnt = 0.0;
+                n = 0;
                 hprev = hk;
             }
         }
-        have = tail_value(s, cnt, hprev, cur);
+        have = tail_value(s, (double)n, hprev, cur);
 #pragma unroll
         for (int u = C - 1; u >= 0; u--) {
             const bool e = (rec.ends >> u) & 1u;

@@ -34,7 +34,6 @@ constexpr OptionEntry kOptionTable[] = {
     {"blocks_per_wg", &Options::blocks_per_wg},
     {"rounds", &Options::rounds},
     {"along", &Options::along},
-    {"along_persist", &Options::along_persist},
     {"along_min_len", &Options::along_min_len},
     {"row_along", &Options::row_along},
     {"seed_row_along_e4", &Options::seed_row_along_e4},
@@ -49,7 +48,6 @@ constexpr OptionEntry kOptionTable[] = {
     {"xlink", &Options::xlink},
     {"dr_form", &Options::dr_form},
     {"tile", &Options::tile},
-    {"tile_persist", &Options::tile_persist},
     {"host_register", &Options::host_register},
     {"verbose", &Options::verbose},
     {"profile", &Options::profile},

@@ -44,8 +44,6 @@ struct Options {
     int blocks_per_wg = 0;  // blocks pipelined per workgroup in the chunk kernel; 0 = pick from the problem size
     int rounds = 0;         // second-chance rounds of geometry mode 1 (0 = the built-in default)
     int along = 1;            // dimension-0 sweeps: chunks along the fibre (sweep_along_kernel); 0 = the transposed 64-fibre tile
-    int along_persist = 1;    // ... plain instantiations launched with as many workgroups as the device holds at once, each taking its share of
-                              // the segments in turn (no wave slot waits for the dispatcher); 0 = one workgroup per four segments
     int along_min_len = 160;  // ... for fibres at least this long (16, 32 or 64 lanes share a fibre segment of 17-sample chunks)
     int row_along = 1;        // strided sweeps through transposed copies + the along-fibre kernel: bit 0 = rung 2 (64-sample zones),
                               // bit 1 = rung 1 as well (0 = the 64-fibre tile for both)
@@ -69,8 +67,6 @@ struct Options {
                               // reference's split (OP_DR_COL / OP_DR_ROW)
     int tile = 1;             // strided sweeps on rungs 0 and 1 (unweighted and weighted): 1 = tiles of 32 fibres x 8 chunks in 4 waves (four
                               // workgroups per CU), 0 = the 64-fibre x 8-wave tile (two)
-    int tile_persist = 1;     // tile kernels launched with as many workgroups as the device holds at once, each taking its share of the
-                              // (fibre group, block range) turns ; 0 = one workgroup per turn
     int host_register = 0;    // host-pointer entry points: page-lock large caller arrays around their transfers (see cabi.hip)
     int verbose = 0;
     int profile = 0;    // per-kernel-family hipEvent timing

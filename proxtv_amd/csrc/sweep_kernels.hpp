@@ -191,8 +191,6 @@ __global__ __launch_bounds__(64) void sweep_seq_kernel(SweepArgs p, FibreGeom g,
 }
 
 // ---- kernel 2: speculative chunks over an LDS window -----------------------------------------------------------------
-// work queues of the chunk kernels (see sweep_along_kernel): counters per launch, and their distance in 4-byte words (a cache line each)
-constexpr unsigned kQueues = 64, kQueueStride = 32;
 struct ChunkPlan {
     int Q;      // blocks (NW chunks each) per fibre
     int qpw;    // consecutive blocks of one fibre group processed (software-pipelined) by one workgroup
@@ -201,13 +199,11 @@ struct ChunkPlan {
     unsigned long long *trace;   // option "trace": 8 words per workgroup -- where it ran and when its phases ended (100 MHz clock)
     DirtyMark dirty;             // this launch's "something is left for the repair kernel" word
     unsigned long long *xlink;   // links across workgroups / segments: [boundary][fibre] (tile) or [fibre][segment] (along)
-    long along_wgs;              // along-fibre kernel: workgroups' worth of work in the sweep
-    unsigned *queue;             // ... its work queue: segments drawn so far beyond the launched waves (null: one turn per wave)
-    unsigned gx, gy;             // tile kernel: fibre groups x block ranges of workgroup turns (gridDim.x workgroups take them in turn)
 };
 
-__device__ __forceinline__ void trace_mark(const ChunkPlan &plan, long turn, int slot) {
-    if (plan.trace && threadIdx.x == 0) plan.trace[8 * (size_t)turn + slot] = wall_clock64();
+__device__ __forceinline__ void trace_mark(const ChunkPlan &plan, int slot) {
+    if (plan.trace && threadIdx.x == 0)
+        plan.trace[8 * (size_t)(blockIdx.x + gridDim.x * blockIdx.y) + slot] = wall_clock64();
 }
 
 // The LDS window as chunkcore.hpp sees it from one lane: row i of the lane's fibre at Y[(i - lo) * PITCH] (`lo` may be
@@ -308,8 +304,7 @@ __global__ __launch_bounds__(64 * NW, SHORT ? 16 / NW : (FW < 64 ? ((WEIGHTED ? 
     // PROVEN chunks before an unproven one -- rows the repair kernel will not touch -- so those instantiations stop a
     // lane's writes at the nearest unproven chunk before it (GUARD: one flag per lane through LDS, one more barrier).
     constexpr bool GUARD = ROUNDS || H > C;
-    unsigned *turn_slot = reinterpret_cast<unsigned *>(anybad + 2);                      // [2] the turn thread 0 drew for the workgroup (work queue)
-    unsigned long long *unproven = reinterpret_cast<unsigned long long *>(anybad + 4);   // [NW] lane masks (GUARD)
+    unsigned long long *unproven = reinterpret_cast<unsigned long long *>(anybad + 2);   // [NW] lane masks (GUARD)
     // what the first chunk of the workgroup's first block began with, kept for the check at the kernel's end: an LDS row ([64];
     // the pitch-65 tile has no room left for one at two workgroups per CU and keeps it in a register)
     link_t *stash = reinterpret_cast<link_t *>(unproven + NW);
@@ -332,26 +327,15 @@ __global__ __launch_bounds__(64 * NW, SHORT ? 16 / NW : (FW < 64 ? ((WEIGHTED ? 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (uniform over the wave: scalar)
     // fl: this lane's fibre within the tile ; ch: its chunk within the block (FW = 64: the lane and the wave)
     const int fl = FW == 64 ? lane : (lane & (FW - 1)), ch = FW == 64 ? wave : wave * CPW + lane / FW;
-    // The sweep is plan.gx fibre groups x plan.gy block ranges of "workgroup turns", group fastest.  With a work queue (plan.queue;
-    // option tile_persist: as many workgroups launched as the device holds at once) a workgroup's first turn is its own number and
-    // every further one is drawn from an atomic counter by thread 0 -- at the START of the turn before, so the round trip hides
-    // behind the turn -- and handed to the others through LDS: no slot waits for the dispatcher, and fast workgroups take more turns
-    // (see the along-fibre kernel, also for why there are kQueues counters and not one).  plan.queue == null: one turn per workgroup.
-    const long turns = (long)plan.gx * plan.gy;
-    long turn = blockIdx.x;
-    const unsigned my_queue = blockIdx.x % kQueues;
-    for (;;) {
-    const unsigned bx = (unsigned)(turn % plan.gx), by = (unsigned)(turn / plan.gx);
-    unsigned drawn = 0u;
     if (plan.trace && tid == 0) {
         unsigned hwid, xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        plan.trace[8 * (size_t)turn] = ((unsigned long long)xcc << 32) | hwid;
+        plan.trace[8 * (size_t)(blockIdx.x + gridDim.x * blockIdx.y)] = ((unsigned long long)xcc << 32) | hwid;
     }
-    trace_mark(plan, turn, 1);
+    trace_mark(plan, 1);
     const int len = g.len;
-    const long j0 = (long)bx * FW;
+    const long j0 = (long)blockIdx.x * FW;
     const long j = j0 + fl;
     const bool active = j < g.count;
     long base = 0, wbase = 0;
@@ -390,7 +374,7 @@ __global__ __launch_bounds__(64 * NW, SHORT ? 16 / NW : (FW < 64 ? ((WEIGHTED ? 
     // so nothing is tested per element there: the window loads run down the fibre from one address (the zone rows before sample 0,
     // which nothing ever reads, take copies of sample 0: a clamped row instead of a mask), the rebuild takes its FULL form, the
     // stream-out its rows as they come.
-    const bool tile_whole = !TRANSPOSED && !SHORT && j0 + FW <= g.count;
+    const bool tile_whole = !TRANSPOSED && !SHORT && (long)blockIdx.x * FW + FW <= g.count;
     auto inner_block = [&](int q) { return tile_whole && q * NCH * C + NCH * C + TA <= len - 1; };
     auto stage_as = [&](int q, auto inner_tag) {
         constexpr bool inner = decltype(inner_tag)::value;
@@ -454,7 +438,7 @@ __global__ __launch_bounds__(64 * NW, SHORT ? 16 / NW : (FW < 64 ? ((WEIGHTED ? 
         else                stage_as(q, std::false_type{});
     };
 
-    const int q_first = by * plan.qpw;
+    const int q_first = blockIdx.y * plan.qpw;
     const int nblk = min(plan.qpw, plan.Q - q_first);
 
     for (int kb = 0; kb < nblk; kb++) {
@@ -466,9 +450,7 @@ __global__ __launch_bounds__(64 * NW, SHORT ? 16 / NW : (FW < 64 ? ((WEIGHTED ? 
             stage(q);
         }
         __syncthreads();
-        if (kb == 0) trace_mark(plan, turn, 2);
-        // the workgroup's next turn: asked for now (behind the window loads), handed to the other threads at the end of this one
-        if (kb == 0 && plan.queue && tid == 0) drawn = atomicAdd(plan.queue + my_queue * kQueueStride, 1u);
+        if (kb == 0) trace_mark(plan, 2);
 
         const int cs_wg = q * NCH * C;
         const int lo = cs_wg - HA;
@@ -511,7 +493,7 @@ __global__ __launch_bounds__(64 * NW, SHORT ? 16 / NW : (FW < 64 ? ((WEIGHTED ? 
         codes[ch * FW + fl] = rec.next;
         if (ROUNDS && tid == 0) anybad[0] = anybad[1] = 0;
         __syncthreads();   // all walks done: link codes visible, window rows no longer read as walk input
-        if (kb == 0) trace_mark(plan, turn, 3);
+        if (kb == 0) trace_mark(plan, 3);
         const int prev_slot = (ch > 0) ? (ch - 1) * FW + fl : (NCH + ((kb + 1) & 1)) * FW + fl;
         bool bad = false;
         // Second chances inside the block (plan.rounds > 0; data whose walks need more than the zone to meet): a lane
@@ -561,7 +543,7 @@ __global__ __launch_bounds__(64 * NW, SHORT ? 16 / NW : (FW < 64 ? ((WEIGHTED ? 
             code_next[slot] = rec.next;
             // ... and the workgroup's last chunk, right now, what the next workgroup's first chunk must have begun with
             if (plan.xlink && kb == nblk - 1 && ch == NCH - 1)
-                xlink_publish(plan.xlink + (size_t)by * g.count + j, plan.dirty.epoch, rec.next);
+                xlink_publish(plan.xlink + (size_t)blockIdx.y * g.count + j, plan.dirty.epoch, rec.next);
         }
         // (the link INTO this workgroup is checked at the very end, when the workgroup before has surely published)
         if (kb == 0 && ch == 0) {
@@ -608,7 +590,7 @@ __global__ __launch_bounds__(64 * NW, SHORT ? 16 / NW : (FW < 64 ? ((WEIGHTED ? 
             rebuild_owned<Op<OP>, WEIGHTED, C, PTV_TILE_UNROLL, TAB, lds_double *, (ROUNDS ? TS : 0)>(win, rec, cs, ce, len, start, !bad, wlo,
                                                                                                     ch == NCH - 1 || ce == len, p.lam, (lds_double *)rtab);
         __syncthreads();
-        if (kb == 0) trace_mark(plan, turn, 4);
+        if (kb == 0) trace_mark(plan, 4);
 
         // ---- stream the block's NW*C rows out: coalesced 512-byte rows, UL operand fetches in flight per lane ------------------
         if (!(plan.ablate & 2)) {
@@ -685,20 +667,14 @@ __global__ __launch_bounds__(64 * NW, SHORT ? 16 / NW : (FW < 64 ? ((WEIGHTED ? 
         }
         if (kb + 1 < nblk) __syncthreads();   // every wave is done reading this block's window
     }
-    if (plan.xlink && by > 0 && ch == 0 && active) {
+    if (plan.xlink && blockIdx.y > 0 && ch == 0 && active) {
         const link_t began = TRANSPOSED ? began_reg : stash[fl];   // (written by this very thread)
         if (began != kNoCheck) {
-            const int why = xlink_check(plan.xlink + (size_t)(by - 1) * g.count + j, plan.dirty.epoch, began);
+            const int why = xlink_check(plan.xlink + (size_t)(blockIdx.y - 1) * g.count + j, plan.dirty.epoch, began);
             if (why) plan.dirty.set(why);
         }
     }
-    trace_mark(plan, turn, 5);
-    if (!plan.queue) break;
-    if (tid == 0) turn_slot[0] = drawn;
-    __syncthreads();   // the next turn is known to all -- and every wave is done with this turn's window and link slots
-    turn = (long)gridDim.x + (long)turn_slot[0] * kQueues + my_queue;
-    if (turn >= turns) break;   // (thread 0 overwrites the slot a whole turn later, behind that turn's barriers)
-    }   // (next turn)
+    trace_mark(plan, 5);
 }
 
 // ---- kernel 2a: speculative chunks ALONG the fibre (dimension-0 sweeps, unweighted) -------------------------------------
@@ -803,21 +779,7 @@ __global__ __launch_bounds__(64 * kAlongWaves) void sweep_along_kernel(SweepArgs
     }
     const int len = g.len;
     const int nseg = (len + SEG - 1) / SEG, NC = (len + C - 1) / C;
-    // Waves draw their segments from a queue (plan.queue; the plain instantiations, launched with as many workgroups as the device holds
-    // at once): a wave's first segment is its own number, every further one comes from an atomic counter -- asked for at the START of
-    // the turn before, so the round trip hides behind the turn.  Measured on the round-5 phase traces (4096^2 column sweep): with one
-    // workgroup per four segments the wave slots are 70 % full on average (the waves of a round end together and the dispatcher needs
-    // microseconds to refill 4096 slots); with static turns they stay full for half the kernel and then drain over the other half
-    // (workgroups whose waves walk in phase are slower, and nothing rebalances): 76 -> 84 us.  ONE counter for all waves serialises
-    // 12 288 atomics on one address (~13 ns each: 217 us, session 6); so the segments beyond the launched waves are dealt round-robin
-    // to kQueues counters in separate cache lines, and a wave draws from the counter of its own number -- 64 waves per counter, spread
-    // over the chip, balance each other.  (Every launch has its own counters: ChunkScratch::work_queue.)  plan.queue == null: one turn, wave = segment
-    // number (the robust instantiations, whose waves hand over to each other through the workgroup's LDS).
-    const long total_waves = plan.along_wgs * kAlongWaves;
-    const unsigned launched_waves = gridDim.x * kAlongWaves;
-    long wid = (long)blockIdx.x * kAlongWaves + wave;
-    const unsigned my_queue = (unsigned)(wid % kQueues);
-    for (;;) {
+    const long wid = (long)blockIdx.x * kAlongWaves + wave;
     const long unit = wid * NG + gi;         // one group of G lanes = one segment of one fibre
     long j, sg_l;
     divmod_nonneg(unit, (long)nseg, j, sg_l);
@@ -904,10 +866,6 @@ __global__ __launch_bounds__(64 * kAlongWaves) void sweep_along_kernel(SweepArgs
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     if (plan.trace && lane == 0) plan.trace[8 * (size_t)wid + 2] = wall_clock64();
-    // the next turn's segment: asked for now -- behind the window loads, which would otherwise wait for the atomic's round trip --
-    // and consumed at the end of this turn
-    unsigned drawn = 0u;
-    if (plan.queue && lane == 0) drawn = atomicAdd(plan.queue + my_queue * kQueueStride, 1u);
 
     // ---- speculative walk of this lane's chunk ---------------------------------------------------------------------------------
     const int cs = seg_s + gl * C;
@@ -1069,10 +1027,6 @@ __global__ __launch_bounds__(64 * kAlongWaves) void sweep_along_kernel(SweepArgs
         if (why) plan.dirty.set(why);
     }
     if (plan.trace && lane == 0) plan.trace[8 * (size_t)wid + 5] = wall_clock64();
-    if (!plan.queue) break;
-    wid = (long)launched_waves + (long)(unsigned)__builtin_amdgcn_readfirstlane((int)drawn) * kQueues + my_queue;
-    if (wid >= total_waves) break;   // this wave's queue is empty
-    }   // (next turn)
 }
 
 // ---- kernel 1b: short fibres, whole in LDS ---------------------------------------------------------------------------------
@@ -1971,18 +1925,6 @@ struct ChunkScratch {
         if (++epoch == 0u) ++epoch;   // (0 is what freshly allocated words hold)
         return DirtyMark{dirty_word->as<unsigned>(), epoch, options().why ? dirty_word->as<unsigned>() + 1 : nullptr};
     }
-    // work queues of the along-fibre kernel: one counter per launch out of a ring of kQueueRing, all of them zeroed again (in stream
-    // order: after the launches that used them, before the ones that will) every kQueueRing launches -- a launch that died half-way
-    // leaves nothing behind for longer than that
-    static constexpr unsigned kQueueRing = 64;
-    std::unique_ptr<Scratch> queues;
-    unsigned queue_next = 0;
-    unsigned *work_queue(hipStream_t s) {
-        constexpr size_t per_launch = (size_t)kQueues * kQueueStride;   // words
-        if (!queues) queues.reset(new Scratch(sizeof(unsigned) * per_launch * kQueueRing));
-        if (queue_next % kQueueRing == 0) PTV_HIP(hipMemsetAsync(queues->as<unsigned>(), 0, sizeof(unsigned) * per_launch * kQueueRing, s));
-        return queues->as<unsigned>() + per_launch * (queue_next++ % kQueueRing);
-    }
     unsigned long long *xlink_for(size_t words, hipStream_t s) {
         if (!options().xlink) return nullptr;
         if (words > xlink_words) {
@@ -2238,7 +2180,7 @@ void launch_chunk_h(const SweepArgs &args, const FibreGeom &g, hipStream_t strea
 #else
     constexpr size_t tab_bytes = 0;
 #endif
-    constexpr size_t lds = sizeof(double) * PITCH * (size_t)ROWS * (WEIGHTED ? 2 : 1) + sizeof(link_t) * ((NCH + 2) * FW + (TRANSPOSED ? 0 : FW) + 8 + 2 * NW) + tab_bytes;
+    constexpr size_t lds = sizeof(double) * PITCH * (size_t)ROWS * (WEIGHTED ? 2 : 1) + sizeof(link_t) * ((NCH + 2) * FW + (TRANSPOSED ? 0 : FW) + 4 + 2 * NW) + tab_bytes;
     static_assert(WEIGHTED || H > kWarm || NW > 8 || 2 * lds <= 160 * 1024, "the short-zone geometry is meant to run two workgroups per CU");
     static_assert(FW == 64 || (WEIGHTED ? 2 : 4) * lds <= 160 * 1024, "the 32-fibre tile is meant to run four workgroups per CU (weighted: two)");
     if (SHORT && g.len > NCH * C) {
@@ -2266,26 +2208,8 @@ void launch_chunk_h(const SweepArgs &args, const FibreGeom &g, hipStream_t strea
                     WEIGHTED ? " weighted" : "", ROBUST ? " robust" : "", FW, NCH, C, NW, lds, per_cu);
         }
     }
-    plan.gx = (unsigned)groups;
-    plan.gy = (unsigned)WQ;
-    plan.queue = nullptr;
-    long grid_wgs = groups * (long)WQ;
-    if (options().tile_persist) {
-        // as many workgroups as the device holds at once (asked once per instantiation and device)
-        static thread_local long capacity[kMaxDevices] = {};
-        long &cap = capacity[current_device()];
-        if (cap == 0) {
-            int per_cu = 0, cus = 0;
-            PTV_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(kern), 64 * NW, lds));
-            PTV_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, current_device()));
-            cap = (long)(per_cu > 0 ? per_cu : 1) * (cus > 0 ? cus : 1);
-        }
-        if (cap < grid_wgs) {
-            grid_wgs = cap;
-            plan.queue = chunk_state().work_queue(stream);
-        }
-    }
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid_wgs), dim3(64 * NW), lds, stream, args, g, plan, chunk_state().code_mine,
+    const dim3 grid((unsigned)groups, (unsigned)WQ);
+    hipLaunchKernelGGL(kern, grid, dim3(64 * NW), lds, stream, args, g, plan, chunk_state().code_mine,
                        chunk_state().code_next, chunk_state().failflags);
     count_event(CNT_SWEEP_LAUNCHES);
     if (!plan.ablate) {
@@ -2339,25 +2263,11 @@ void launch_along_g(const SweepArgs &args, const FibreGeom &g, hipStream_t strea
             attr_set = true;
         }
     }
-    plan.along_wgs = (waves + kAlongWaves - 1) / kAlongWaves;
-    long grid_wgs = plan.along_wgs;
-    plan.queue = nullptr;
-    if (!ROBUST && options().along_persist) {
-        // as many workgroups as the device holds at once (asked once per instantiation and device)
-        static thread_local long capacity[kMaxDevices] = {};
-        long &cap = capacity[current_device()];
-        if (cap == 0) {
-            int per_cu = 0, dev = current_device(), cus = 0;
-            PTV_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(kern), 64 * kAlongWaves, lds));
-            PTV_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-            cap = (long)(per_cu > 0 ? per_cu : 1) * (cus > 0 ? cus : 1);
-        }
-        if (cap < grid_wgs) {
-            grid_wgs = cap;
-            plan.queue = chunk_state().work_queue(stream);
-        }
-    }
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid_wgs), dim3(64 * kAlongWaves), lds, stream, args, g,
+    // (One workgroup per kAlongWaves segments, dispatched as slots free up.  Tried in round 5 and dropped, profiles/NOTES_r05.md: as many
+    // workgroups as the device holds, each taking its segments in static turns -- 76 -> 84 us, nothing rebalances the slow workgroups --
+    // or drawing them from atomic counters -- the wave slots stay 98 % full instead of 70 % and the sweep takes as long: the vector
+    // pipes, not the dispatcher, are what the waves wait for.)
+    hipLaunchKernelGGL(kern, dim3((unsigned)((waves + kAlongWaves - 1) / kAlongWaves)), dim3(64 * kAlongWaves), lds, stream, args, g,
                        plan, chunk_state().code_mine, chunk_state().code_next, chunk_state().failflags);
     count_event(CNT_SWEEP_LAUNCHES);
     if (!plan.ablate) {
