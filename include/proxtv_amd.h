@@ -170,6 +170,9 @@ void proxtv_release_scratch(void);
      "pin_seed"       1 (default): the pinning solver (rung 3) starts from the knots known a priori, 0: from the fibre ends alone
      "pin_overlap"    1: a strided sweep of the pinning solver moves its transposed copies range by range on a second stream, under
                       the levels of the other ranges ; 0 (default: measured slower): one stream
+     "replay"         1 (default): dimension-0 sweeps on rung 0 keep the piece ends / bend types of every chunk and, from the fourth
+                      sweep of a solve over the same geometry on, verify the last sweep's against the optimality conditions of the prox
+                      instead of walking (per wavefront, all or nothing; exact whatever the record holds) ; 0: always walk
      "repair_jobs"    failed links across the workgroups of a chunked sweep are first repaired one lane per failure, four to a
                       fibre; what that leaves goes to the sequential repair: 1 (default) where the sampled statistic of the sweep's
                       input says such links fail in numbers, 2 always ; 0: the sequential repair alone (same results, bit for bit)
@@ -250,7 +253,8 @@ long   proxtv_last_fixups(void);
 long   proxtv_debug_trace(unsigned long long *dst, long max_wgs);
 /* Tuning aid (option "why" = 1): what left work to the repair kernel since the last call, 8 counters: [0] walks that ran off
    their window, [1] links inside a workgroup / wave that stayed unproven, [2] links across workgroups / segments whose codes
-   differ, [3] ... that were not published in time.  Returns 8, or <= 0. */
+   differ, [3] ... that were not published in time, [4] second chances taken across workgroups, [5] wavefronts of the along-fibre
+   kernel that replayed the recorded structure instead of walking.  Returns 8, or <= 0. */
 int    proxtv_debug_why(unsigned *dst);
 /* What ran (process-wide, cumulative since load; tests and tools take differences): "sweep_launches" (fibre-sweep kernels),
    "repair_launches" (sweep_repair_kernel behind them), "repair_jobs_launches" (option repair_jobs), "pin_sweeps" (sweeps the

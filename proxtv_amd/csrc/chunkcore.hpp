@@ -403,4 +403,98 @@ __device__ __forceinline__ void rebuild_owned(Win &win, const ChunkRec &rec, int
     }
 }
 
+
+// ---- replay: VERIFY a recorded structure instead of walking ----------------------------------------------------------------------
+// Between two sweeps of a splitting loop the knots of a fibre hardly move (DR at lambda = 0.1: 1.3 % of the 17-sample chunks change
+// between iterations 4 and 5, 0.1 % from iteration 12 on: profiles/r04_study_structure.txt), and checking a structure is far cheaper
+// than finding it.  A candidate structure -- piece ends and bend types, as the walk of the previous sweep left them -- is THE solution
+// of a stretch [r, r') between two knots that are known to be true iff every piece in it satisfies the optimality conditions of the
+// prox (the string x - y summed up stays inside the tube; it sits on the wall the bend type says at every knot; x jumps the way the
+// bend type says at every knot):
+//     h_i = h_a + n_i v - S_i,   |h_i| <= lambda for the rows i inside a piece [a, b]  <=>  (S_i - h_a - lambda) / n_i <= v <= (S_i - h_a + lambda) / n_i
+//     v = (S_b + h_b - h_a) / n_b                    (the closed form of rebuild_owned: the wall at both ends is imposed)
+//     v' >= v across a FLOOR knot, v' <= v across a CEIL knot
+// -- the prox is the unique minimiser of a strictly convex problem, the stretch between two true knots is a problem of its own, and
+// these are its KKT conditions.  The true knots at the two ends are bends known a priori (certain_bend_before / _after).  So the
+// result does not depend on where the candidate came from: a stale or corrupted candidate fails a test, or is the solution.
+//
+// One lane checks the rows [r0, r0 + nrows): r0 is the knot its first piece starts at, the pieces END where emask says.  ONE forward
+// pass, no arrays: the running bounds of the tube condition are folded into a max and a min, compared with the piece's value where it
+// ends.  Piece values are computed exactly as rebuild_owned computes them (same expression, same table): what is verified is what
+// will be written.
+struct ReplayLane {
+    int r0 = 0, nrows = 0;         // rows [r0, r0 + nrows) ; nrows <= 32
+    unsigned emask = 0, tmask = 0; // bit k: a piece ends at row r0 + k / ... by a FLOOR bend
+    double h0 = 0.0;               // height of the string at the knot before r0 (+-lambda by the knot's type; 0 at the fibre start)
+    double vfirst = 0.0, vlast = 0.0;   // (out) values of the first / last piece that ends in the rows
+    bool ok = true;                // (out)
+};
+
+template <bool TAB, class RT, class Win>
+__device__ __forceinline__ void replay_lane(const Win &win, ReplayLane &L, int nmax, double lam, RT rt) {
+    double S = 0.0, h = L.h0;
+    int n = 0;
+    double lo = -1.7976931348623157e308, hi = 1.7976931348623157e308;   // running tube bounds on the value of the piece in hand
+    double vprev = 0.0;
+    bool have_prev = false, tprev = false, ok = L.ok;
+#pragma unroll 1
+    for (int k = 0; k < nmax; k++) {
+#ifndef PTV_HOST_TEST
+        if (__builtin_amdgcn_ballot_w64(k < L.nrows) == 0ull) break;   // (every lane of the wave is through its rows)
+#endif
+        if (k < L.nrows) {
+            const double yk = win.y(L.r0 + k);
+            S += yk;
+            n += 1;
+            auto over_n = [&](double num) {   // num / n the way rebuild_owned divides (table product, or SpanDiv)
+                if constexpr (TAB) {
+                    return num * rt[n];
+                } else {
+                    const SpanDiv over((double)n);
+                    return over(num);
+                }
+            };
+            const double t = S - h;
+            if (!((L.emask >> k) & 1u)) {
+                // a row inside the piece: the string must be inside the tube behind it
+                lo = ptv_max(lo, over_n(t - lam));
+                hi = ptv_min(hi, over_n(t + lam));
+            } else {
+                const bool floor_knot = (L.tmask >> k) & 1u;
+                const double hk = floor_knot ? lam : -lam;
+                const double v = over_n(S + (hk - h));        // (rebuild_owned's quotient, to the bit)
+                ok = ok && (lo <= v) && (v <= hi);
+                if (have_prev) ok = ok && (tprev ? (v >= vprev) : (v <= vprev));
+                else L.vfirst = v;
+                vprev = v;
+                tprev = floor_knot;
+                have_prev = true;
+                S = 0.0;
+                n = 0;
+                h = hk;
+                lo = -1.7976931348623157e308;
+                hi = 1.7976931348623157e308;
+            }
+        }
+    }
+    L.vlast = vprev;
+    L.ok = ok;
+}
+
+// The first bend known a priori at or after `from`: edges (k - 1, k), k = from .. from + LOOK - 1 (rows up to from + LOOK - 1 are read).
+// Returns the sample the new piece starts at (-1: none) and the bend type.  Unweighted.
+template <int LOOK, class Win>
+__device__ __forceinline__ int certain_bend_after(const Win &win, int from, double lam, int &type) {
+    int cat = -1;
+    type = 0;
+#pragma unroll
+    for (int u = LOOK - 1; u >= 0; u--) {
+        const double d = win.y(from + u) - win.y(from + u - 1);
+        const bool hit = fabs(d) > 4.0000001 * lam;
+        cat = hit ? from + u : cat;
+        type = hit ? (d > 0 ? BEND_FLOOR : BEND_CEIL) : type;
+    }
+    return cat;
+}
+
 }  // namespace ptv

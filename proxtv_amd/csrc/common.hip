@@ -34,6 +34,7 @@ constexpr OptionEntry kOptionTable[] = {
     {"blocks_per_wg", &Options::blocks_per_wg},
     {"rounds", &Options::rounds},
     {"along", &Options::along},
+    {"replay", &Options::replay},
     {"along_min_len", &Options::along_min_len},
     {"row_along", &Options::row_along},
     {"seed_row_along_e4", &Options::seed_row_along_e4},

@@ -61,6 +61,7 @@ void chunk_stats_reset(hipStream_t s) {
         st.latest_rewritten[f] = 0;
         st.latest_chunks[f] = 0;
     }
+    st.st_sweeps = 0;   // (replay: the first sweeps of a solve only record)
     if (st.failcount) PTV_HIP(hipMemsetAsync(st.failcount, 0, sizeof(int) * ChunkScratch::kCounters, s));
     st.nprobes = 0;
 }

@@ -199,6 +199,8 @@ struct ChunkPlan {
     unsigned long long *trace;   // option "trace": 8 words per workgroup -- where it ran and when its phases ended (100 MHz clock)
     DirtyMark dirty;             // this launch's "something is left for the repair kernel" word
     unsigned long long *xlink;   // links across workgroups / segments: [boundary][fibre] (tile) or [fibre][segment] (along)
+    unsigned *structure;         // along-fibre kernel: [fibre][chunk][ends, types] as the family's last sweep left them (null: none kept)
+    int replay;                  // ... and this sweep tries to verify them instead of walking (the first sweeps of a solve only record)
 };
 
 __device__ __forceinline__ void trace_mark(const ChunkPlan &plan, int slot) {
@@ -876,7 +878,121 @@ __global__ __launch_bounds__(64 * kAlongWaves) void sweep_along_kernel(SweepArgs
     const FarFibre<OP> far{p, fbase, 1, wbase};
     ChunkRec rec;
     bool certain = false;
-    if (has_chunk && !(plan.ablate & 1)) {
+    // ---- replay: the structure the last sweep of this family left for this segment, VERIFIED instead of walked (chunkcore.hpp:
+    // replay_lane; host model: tests/host_harness.cpp host_replay_fibre, line for line).  The stretch between the bend known a priori
+    // at or before the segment (or the fibre start) and the first one at or after its end is a problem of its own; if every recorded
+    // piece in it satisfies the optimality conditions on THIS sweep's data the recorded structure is its solution, whatever it was
+    // recorded from.  All or nothing per wave: one lane in doubt, and the wave walks as if nothing had been recorded.
+    constexpr bool REPLAYABLE = !ROBUST && !WEIGHTED && G == 64 && !ONESEG && TAB;
+    bool verified = false;
+    if constexpr (REPLAYABLE) {
+        if (plan.structure && plan.replay && interior && p.lam > 0.0 && !(plan.ablate & 1)) {
+            const unsigned *S = plan.structure + 2 * ((size_t)j * NC + (size_t)sg * G);   // [chunk of the segment][ends, types]
+            const unsigned own_e = S[2 * gl], own_t = S[2 * gl + 1];
+            bool ok = true;
+            // the knot the segment hangs on, which the record must have with that type (uniform over the wave: every lane looks)
+            int kL = 0, tL = 0;
+            unsigned pre_e = 0u, pre_t = 0u;   // recorded ends in [kL, seg_s), bit = row - kL (they lie in the chunk before the segment)
+            if (sg > 0) {
+                kL = certain_bend_before<false, kWarm - 2>(win, seg_s, len, p.lam, tL);
+                ok = kL >= 0;
+                if (ok) {
+                    const unsigned pe = S[-2], pt = S[-1];
+                    const int sh = kL - 1 - (seg_s - C);       // bit of row kL - 1 in the chunk before
+                    ok = ((pe >> sh) & 1u) && (int)((pt >> sh) & 1u) == tL;
+                    const unsigned keep = (seg_s - kL) ? ((1u << (seg_s - kL)) - 1u) : 0u;
+                    pre_e = (pe >> (sh + 1)) & keep;
+                    pre_t = (pt >> (sh + 1)) & keep;
+                }
+            }
+            // ... and the knot behind it
+            int tR = 0;
+            const int kR = certain_bend_after<T>(win, seg_e, p.lam, tR);
+            unsigned nx_e = 0u, nx_t = 0u;     // recorded ends in [seg_e, kR), bit = row - seg_e (the chunk after the segment)
+            ok = ok && kR >= 0;
+            if (ok && kR > seg_e) {
+                const unsigned keep = (1u << (kR - seg_e)) - 1u;
+                nx_e = S[2 * G] & keep;
+                nx_t = S[2 * G + 1] & keep;
+                const int sh = kR - 1 - seg_e;
+                ok = ((nx_e >> sh) & 1u) && (int)((nx_t >> sh) & 1u) == tR;
+            }
+            // (kR == seg_e: the knot is the last lane's own last row -- tested with everything else below)
+            // the last piece end of every lane's chunk (lane 0: the rows before the segment count as its own)
+            int rl = -1, rtp = 0;
+            if (own_e) {
+                const int b = 31 - __clz((int)own_e);
+                rl = cs + b;
+                rtp = (int)((own_t >> b) & 1u);
+            } else if (gl == 0 && pre_e) {
+                const int b = 31 - __clz((int)pre_e);
+                rl = kL + b;
+                rtp = (int)((pre_t >> b) & 1u);
+            }
+            if (gl == G - 1 && kR == seg_e) ok = ok && ((own_e >> (C - 1)) & 1u) && (int)((own_t >> (C - 1)) & 1u) == tR;
+            // the knot a lane's first piece starts at: behind the last piece end of the nearest lower lane that has one, else kL
+            const unsigned long long has_end = __ballot(rl >= 0);
+            const unsigned long long lower = has_end & ((1ull << gl) - 1ull);
+            const int pl = lower ? 63 - __clzll((long long)lower) : 0;
+            const int s_end = __shfl(rl, pl), s_typ = __shfl(rtp, pl);
+            const bool from_kL = lower == 0ull;
+            const int s0 = from_kL ? kL : s_end + 1, st = from_kL ? tL : s_typ;
+            const bool fs = from_kL && sg == 0;                      // the fibre start: no knot, height 0
+            ReplayLane R;
+            const int rbeg = gl == 0 ? kL : s0, rend = gl == G - 1 ? kR : ce;
+            const bool has_rows = gl == G - 1 || rl >= 0;            // (a lane with no piece end checks nothing: a later lane's rows)
+            R.r0 = rbeg;
+            R.nrows = has_rows ? rend - rbeg : 0;
+            ok = ok && R.nrows <= 32 && !(fs && gl > 0 && has_rows);   // (a first piece of more than a chunk: the walk's)
+            R.h0 = (gl == 0 ? sg == 0 : fs) ? 0.0 : ((gl == 0 ? tL : st) == BEND_FLOOR ? p.lam : -p.lam);
+            if (ok && has_rows) {
+                const int so = cs - rbeg;                            // (0 .. 15 once nrows <= 32)
+                R.emask = own_e << so;
+                R.tmask = own_t << so;
+                if (gl == 0) { R.emask |= pre_e; R.tmask |= pre_t; }
+                if (gl == G - 1 && kR > seg_e) { R.emask |= nx_e << (ce - rbeg); R.tmask |= nx_t << (ce - rbeg); }
+            }
+            R.ok = ok;
+            if (__ballot(!ok) == 0ull) {
+                replay_lane<true>(win, R, 32, p.lam, (lds_double *)rtab);
+                // the jump across the knot a lane's rows start at: against the last piece of the nearest lower lane that has pieces
+                const unsigned long long has_piece = __ballot(R.emask != 0u);
+                const unsigned long long lowp = has_piece & ((1ull << gl) - 1ull);
+                const int pp = lowp ? 63 - __clzll((long long)lowp) : 0;
+                const double vbefore = __shfl(R.vlast, pp);
+                if (gl > 0 && R.emask != 0u && lowp != 0ull)
+                    R.ok = R.ok && (st == BEND_FLOOR ? R.vfirst >= vbefore : R.vfirst <= vbefore);
+                verified = __ballot(!R.ok) == 0ull;
+            }
+            if (verified) {
+                // the record stands: what the walk would have left behind, from the record
+                int a0r = s0, atr = st;
+                bool startr = fs;
+                if (gl == 0) {
+                    a0r = kL; atr = tL; startr = sg == 0;
+                    if (pre_e) {
+                        const int b = 31 - __clz((int)pre_e);
+                        a0r = kL + b + 1;
+                        atr = (int)((pre_t >> b) & 1u);
+                        startr = false;
+                    }
+                }
+                rec.ends = own_e;
+                rec.types = own_t;
+                rec.mine = startr ? 0u : (((link_t)a0r << 1) | (link_t)atr);
+                rec.next = rl >= cs ? (((link_t)(rl + 1) << 1) | (link_t)rtp) : rec.mine;
+                rec.last = rec.next;
+                rec.done = true;
+                if (gl == G - 1 && !((own_e >> (C - 1)) & 1u)) {   // the bend that closes the piece covering the segment's last sample
+                    const int b = __ffs((int)nx_e) - 1;           // (kR > seg_e here: nx_e holds the bit of row kR - 1 at least)
+                    rec.last = ((link_t)(ce + b + 1) << 1) | (link_t)((nx_t >> b) & 1u);
+                }
+                certain = !startr;   // (a start at the fibre start is exact as it is; everything else begins at a verified knot)
+                if (gl == 0) plan.dirty.note(5);   // (option "why": waves that replayed)
+            }
+        }
+    }
+    if (has_chunk && !verified && !(plan.ablate & 1)) {
         Walker w;
         // (robust: the whole zone is searched -- a lane that starts at a bend known a priori has no link that could fail)
         constexpr int kLook = ROBUST ? kWarm - 2 : 8;
@@ -962,6 +1078,11 @@ __global__ __launch_bounds__(64 * kAlongWaves) void sweep_along_kernel(SweepArgs
         code_next[j * NC + chunk] = rec.next;
         // the segment's last chunk: what the next segment's first chunk must have begun with (checked by that segment at its end)
         if (plan.xlink && gl == G - 1 && sg + 1 < nseg) xlink_publish(plan.xlink + (size_t)j * nseg + sg, plan.dirty.epoch, rec.next);
+        // the record the next sweep of this family may replay (a verified record stands as it is; an unproven chunk records nothing)
+        if (REPLAYABLE && plan.structure && !verified) {
+            plan.structure[2 * ((size_t)j * NC + chunk)] = bad ? 0u : rec.ends;
+            plan.structure[2 * ((size_t)j * NC + chunk) + 1] = rec.types;
+        }
     }
     // a lane's writes stop at the nearest unproven chunk before it (see GUARD in sweep_chunk_kernel; needed for H > C)
     int wlo = seg_s;
@@ -1925,6 +2046,27 @@ struct ChunkScratch {
         if (++epoch == 0u) ++epoch;   // (0 is what freshly allocated words hold)
         return DirtyMark{dirty_word->as<unsigned>(), epoch, options().why ? dirty_word->as<unsigned>() + 1 : nullptr};
     }
+    // The record of the along-fibre kernel's last sweep over this geometry (replay: sweep_along_kernel): ends / types of every chunk.
+    // Nothing in it is trusted -- a sweep VERIFIES what it finds -- so it is never cleared; but verifying costs a quarter of a walk
+    // where it fails, and between the first sweeps of a solve a third of the chunks still change (profiles/r04_study_structure.txt:
+    // 28 % / 4 % / 1.3 % of them at iterations 2 / 3 / 5 of a DR solve at lambda 0.1): the first kReplayAfter sweeps of a solve over a
+    // geometry only record.
+    static constexpr int kReplayAfter = 3;
+    std::unique_ptr<Scratch> structure;
+    long st_len = -1, st_count = -1;
+    int st_sweeps = 0;
+    unsigned *structure_for(const FibreGeom &g, int NC, int &replay) {
+        const size_t need = sizeof(unsigned) * 2 * (size_t)g.count * (size_t)NC;
+        if (!structure || structure->bytes() < need || st_len != g.len || st_count != g.count) {
+            if (!structure || structure->bytes() < need) structure.reset(new Scratch(need));
+            st_len = g.len;
+            st_count = g.count;
+            st_sweeps = 0;
+        }
+        replay = st_sweeps >= kReplayAfter;
+        st_sweeps++;
+        return structure->as<unsigned>();
+    }
     unsigned long long *xlink_for(size_t words, hipStream_t s) {
         if (!options().xlink) return nullptr;
         if (words > xlink_words) {
@@ -2154,7 +2296,7 @@ void launch_chunk_h(const SweepArgs &args, const FibreGeom &g, hipStream_t strea
     constexpr int PITCH = TRANSPOSED ? 65 : FW;
     constexpr int NCH = NW * (64 / FW);   // chunks per block
     constexpr int ROWS = SHORT ? NCH * C : H + NCH * C + T;
-    ChunkPlan plan;
+    ChunkPlan plan{};
     plan.Q = (g.len + NCH * C - 1) / (NCH * C);
     // blocks per workgroup: enough workgroups to fill the chip a few times over
     const long groups = (g.count + FW - 1) / FW;
@@ -2252,6 +2394,8 @@ void launch_along_g(const SweepArgs &args, const FibreGeom &g, hipStream_t strea
     plan.trace = options().trace ? chunk_state().trace_buffer((size_t)waves) : nullptr;
     plan.dirty = chunk_state().next_dirty(stream);
     plan.xlink = chunk_state().xlink_for((size_t)g.count * (size_t)nseg, stream);
+    if (!ROBUST && !WEIGHTED && G == 64 && !ONESEG && options().replay)
+        plan.structure = chunk_state().structure_for(g, NC, plan.replay);
     constexpr size_t lds = sizeof(double) * (size_t)(ROWS + 2) * NG * kAlongWaves * (WEIGHTED ? 2 : 1) + (ROBUST ? 64 + sizeof(double) * kRecipTableRobust : sizeof(double) * kRecipTable);
     static_assert(lds <= 160 * 1024, "along-fibre geometry does not fit the LDS of a CU");
     auto kern = sweep_along_kernel<OP, WEIGHTED, H, G, ROBUST, ONESEG>;

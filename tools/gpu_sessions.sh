@@ -79,4 +79,27 @@ s7)   # work queues again: 64 counters per launch in separate cache lines (one c
   ab --reps 7 --rounds 2 --cases c2,prox0,prox1,c2@0.5,c3,c4y,pd2,s1024 base noq,along_persist=0,tile_persist=0 alongq,tile_persist=0 tileq,along_persist=0 > $OUT/ab_queue.txt 2>&1; cat $OUT/ab_queue.txt
   timeout 60 python tools/wg_trace.py > $OUT/wg_trace.txt 2>&1; grep "^##\|^# " $OUT/wg_trace.txt
   ;;
+s8)   # replay: the along-fibre kernel verifies the structure its previous sweep recorded instead of walking (from the fourth sweep of
+      # a solve on; all or nothing per wave).  Parity first (the whole suite), then A/B by option, the share of waves that replayed
+  timeout 900 python -m pytest tests -m gpu -x -q > $OUT/pytest_default.log 2>&1; echo "default: $(tail -1 $OUT/pytest_default.log)" | tee $OUT/summary.txt
+  { python tools/fuzz.py 60 81; } > $OUT/fuzz.txt 2>&1; grep "^fuzz\|MISMATCH" $OUT/fuzz.txt | tee -a $OUT/summary.txt
+  ab --reps 7 --rounds 2 --cases c2,c2@0.05,c2@0.2,pd2,c4,s1024,s2048 base walk,replay=0 > $OUT/ab_replay.txt 2>&1; cat $OUT/ab_replay.txt
+  python - > $OUT/replay_share.txt 2>&1 <<'PY'
+import numpy as np, torch, sys
+sys.path.insert(0, '.')
+from proxtv_amd import _lib, device
+lib = _lib.require_device()
+lib.proxtv_set_option(b"why", 1)
+x = device.to_colmajor(torch.from_numpy(np.random.default_rng(0).standard_normal((4096, 4096))).cuda())
+buf = np.zeros(8, dtype=np.uint32)
+for lam in (0.05, 0.1, 0.15, 0.2):
+    lib.proxtv_debug_why(buf.ctypes.data)
+    for iters in (5, 10, 20, 35):
+        device.tv1_2d(x, lam, max_iters=iters)
+        lib.proxtv_debug_why(buf.ctypes.data)
+        waves = 16384 * iters      # column sweeps: iterations 1 .. iters - 1 and the final one
+        print(f"lambda {lam} {iters:2d} iterations: {int(buf[5]):7d} wavefronts replayed of {waves} launched in {iters} column sweeps = {buf[5] / waves:.3f}")
+PY
+  cat $OUT/replay_share.txt
+  ;;
 esac
