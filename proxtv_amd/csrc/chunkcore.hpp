@@ -223,9 +223,21 @@ struct NoFar {
 // between the two passes, so the forward pass costs a row one LDS read, the backward pass none, and ops whose output needs the row's
 // own sample (DR_COL) take the same array-free passes as the others instead of a dynamic back-fill loop per piece.  Same arithmetic
 // in the same order as the general form: bit-identical (tests/host_harness.cpp runs all three).
+// FULL == 3 (replay: sweep_along_kernel): FULL == 2 that CHECKS the structure it is given while it rebuilds from it -- `rec` is not a
+// walk's record but a candidate (the last sweep's), and `chk` comes back saying whether every piece the lane is responsible for (those
+// that end in its chunk; the last lane: the one that runs out of the segment too) satisfies the optimality conditions of the prox:
+// the string stays inside the tube behind every row inside a piece -- (S_i - h_a - lambda) / n_i <= v <= (S_i - h_a + lambda) / n_i,
+// folded into a running max and min -- and x jumps the way the bend type says between two pieces (between lanes: the caller, with
+// vfirst / vlast).  See replay_lane below for why that is enough.  The rows are written as they are rebuilt: a caller whose check fails
+// stages its window again.
+struct ReplayCheck {
+    bool ok = true;
+    bool has = false;                  // a piece the lane is responsible for exists
+    double vfirst = 0.0, vlast = 0.0;  // value of the first / last of them
+};
 template <class F, bool WEIGHTED, int C, int UNROLL = 1, bool TAB = false, class RT = const double *, int TSZ = 0, int FULL = 0, class Win>
 __device__ __forceinline__ void rebuild_owned(Win &win, const ChunkRec &rec, int cs, int ce, int len, int start, bool link_ok,
-                                              int wlo, bool block_last, double lam, RT rt = RT()) {
+                                              int wlo, bool block_last, double lam, RT rt = RT(), ReplayCheck *chk = nullptr) {
     auto quotient = [&](double num, double count) {
         if constexpr (TAB) {
             if (TSZ > 0 && count >= (double)TSZ) {
@@ -290,7 +302,8 @@ __device__ __forceinline__ void rebuild_owned(Win &win, const ChunkRec &rec, int
     };
     double cur = 0.0;
     bool have = false;
-    if constexpr (FULL == 2 && !WEIGHTED) {
+    if constexpr (FULL >= 2 && !WEIGHTED) {
+        constexpr bool VERIFY = FULL == 3;
         double slot[C];   // row u: its sample, or -- once a piece has ended there -- that piece's value
         // (all C reads in flight at once: one LDS latency per chunk instead of one per row)
 #pragma unroll
@@ -318,6 +331,34 @@ __device__ __forceinline__ void rebuild_owned(Win &win, const ChunkRec &rec, int
                 return over(num);
             }
         };
+        // VERIFY: the bounds the tube puts on the value of the piece in hand, what the pieces before it were, the verdict
+        double lo = -1.7976931348623157e308, hi = 1.7976931348623157e308, vprev = 0.0;
+        bool ok = true, have_prev = false, tprev = false;
+        auto inside_row = [&](double sum, int count) {   // a row INSIDE a piece: the string behind it must be inside the tube
+            const double t = sum - hprev;
+            lo = ptv_max(lo, over_n(t - lam, count));
+            hi = ptv_min(hi, over_n(t + lam, count));
+        };
+        auto piece_ends = [&](double v, bool floor_knot) {
+            ok = ok && lo <= v && v <= hi;
+            if (have_prev) ok = ok && (tprev ? v >= vprev : v <= vprev);
+            else chk->vfirst = v;
+            vprev = v;
+            tprev = floor_knot;
+            have_prev = true;
+            lo = -1.7976931348623157e308;
+            hi = 1.7976931348623157e308;
+        };
+        if constexpr (VERIFY) {
+            // the rows of earlier chunks that belong to the piece ending here were summed above: their bounds now
+            double ps = 0.0;
+            int pn = 0;
+            for (int k = a0; k < cs; k++) {
+                ps += win.y(k);
+                pn += 1;
+                inside_row(ps, pn);
+            }
+        }
 #pragma unroll
         for (int u = 0; u < C; u++) {
             const double yu = slot[u];
@@ -326,14 +367,38 @@ __device__ __forceinline__ void rebuild_owned(Win &win, const ChunkRec &rec, int
             if ((rec.ends >> u) & 1u) {
                 const double hk = height(u);
                 const double v = over_n(s + (hk - hprev), n);
+                if constexpr (VERIFY) piece_ends(v, (rec.types >> u) & 1u);
                 win.put(cs + u, F::fuse(yu, v));
                 slot[u] = v;
                 s = 0.0;
                 n = 0;
                 hprev = hk;
+            } else if constexpr (VERIFY) {
+                inside_row(s, n);
             }
         }
-        have = tail_value(s, (double)n, hprev, cur);
+        if constexpr (VERIFY) {
+            // the piece that runs out of the segment (last lane): its rows beyond the chunk, its value, its tests
+            have = false;
+            if (block_last && !((rec.ends >> (C - 1)) & 1u)) {
+                const int brk = (int)(rec.last >> 1) - 1;
+                for (int k = ce; k <= brk; k++) {
+                    s += win.y(k);
+                    n += 1;
+                    if (k < brk) inside_row(s, n);
+                }
+                const bool floor_knot = rec.last & 1u;
+                const double hk = floor_knot ? lam : -lam;
+                cur = over_n(s + (hk - hprev), n);
+                piece_ends(cur, floor_knot);
+                have = true;
+            }
+            chk->ok = ok;
+            chk->has = have_prev;
+            chk->vlast = vprev;
+        } else {
+            have = tail_value(s, (double)n, hprev, cur);
+        }
 #pragma unroll
         for (int u = C - 1; u >= 0; u--) {
             const bool e = (rec.ends >> u) & 1u;

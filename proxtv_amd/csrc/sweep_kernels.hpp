@@ -805,7 +805,7 @@ __global__ __launch_bounds__(64 * kAlongWaves) void sweep_along_kernel(SweepArgs
     // Uniform over the wave for whole-wave segments (G = 64: fibre and segment are scalar values there).
     const bool interior = G == 64 && !ONESEG && live && seg_s + SEG + T <= len - 1;
     const unsigned ul = (unsigned)gl;
-    if (interior && !(plan.ablate & 4)) {
+    auto stage_interior = [&]() {
         constexpr int NB = NU <= 20 ? NU : (NU + 1) / 2;
         const long row0 = fbase + lo, wrow0 = wbase + lo;   // (scalar; the first segment: lo = -HZ, element 0 is clamped below)
 #pragma unroll
@@ -840,6 +840,9 @@ __global__ __launch_bounds__(64 * kAlongWaves) void sweep_along_kernel(SweepArgs
                 }
             }
         }
+    };
+    if (interior && !(plan.ablate & 4)) {
+        stage_interior();
     } else
     if (live && !(plan.ablate & 4)) {
         // every load of a batch is issued before the first is waited for; NB rows per lane and batch (the 31-sample chunks stage
@@ -879,10 +882,13 @@ __global__ __launch_bounds__(64 * kAlongWaves) void sweep_along_kernel(SweepArgs
     ChunkRec rec;
     bool certain = false;
     // ---- replay: the structure the last sweep of this family left for this segment, VERIFIED instead of walked (chunkcore.hpp:
-    // replay_lane; host model: tests/host_harness.cpp host_replay_fibre, line for line).  The stretch between the bend known a priori
-    // at or before the segment (or the fibre start) and the first one at or after its end is a problem of its own; if every recorded
-    // piece in it satisfies the optimality conditions on THIS sweep's data the recorded structure is its solution, whatever it was
-    // recorded from.  All or nothing per wave: one lane in doubt, and the wave walks as if nothing had been recorded.
+    // rebuild_owned FULL = 3 and the note at replay_lane; host model: tests/host_harness.cpp host_replay_fibre, line for line).  The
+    // stretch between the bend known a priori at or before the segment (or the fibre start) and the first one at or after its end is a
+    // problem of its own; if every recorded piece in it satisfies the optimality conditions on THIS sweep's data, the recorded
+    // structure is its solution, whatever it was recorded from.  The check rides on the rebuild (a quarter on top of it; a pass of its
+    // own cost a wave more than the walk it saves: session 8), so a wave whose record fails has written rows it must not keep: it
+    // stages its window again and walks.  All or nothing per wave.  This form takes the segments whose record has no piece end
+    // between the two known bends and the segment (three in four).
     constexpr bool REPLAYABLE = !ROBUST && !WEIGHTED && G == 64 && !ONESEG && TAB;
     bool verified = false;
     if constexpr (REPLAYABLE) {
@@ -890,47 +896,35 @@ __global__ __launch_bounds__(64 * kAlongWaves) void sweep_along_kernel(SweepArgs
             const unsigned *S = plan.structure + 2 * ((size_t)j * NC + (size_t)sg * G);   // [chunk of the segment][ends, types]
             const unsigned own_e = S[2 * gl], own_t = S[2 * gl + 1];
             bool ok = true;
-            // the knot the segment hangs on, which the record must have with that type (uniform over the wave: every lane looks)
+            // the knot the segment hangs on, which the record must have with that type and nothing behind it before the segment
+            // (uniform over the wave: every lane looks)
             int kL = 0, tL = 0;
-            unsigned pre_e = 0u, pre_t = 0u;   // recorded ends in [kL, seg_s), bit = row - kL (they lie in the chunk before the segment)
             if (sg > 0) {
                 kL = certain_bend_before<false, kWarm - 2>(win, seg_s, len, p.lam, tL);
                 ok = kL >= 0;
                 if (ok) {
                     const unsigned pe = S[-2], pt = S[-1];
                     const int sh = kL - 1 - (seg_s - C);       // bit of row kL - 1 in the chunk before
-                    ok = ((pe >> sh) & 1u) && (int)((pt >> sh) & 1u) == tL;
-                    const unsigned keep = (seg_s - kL) ? ((1u << (seg_s - kL)) - 1u) : 0u;
-                    pre_e = (pe >> (sh + 1)) & keep;
-                    pre_t = (pt >> (sh + 1)) & keep;
+                    ok = ((pe >> sh) & 1u) && (int)((pt >> sh) & 1u) == tL && (pe >> (sh + 1)) == 0u;
                 }
             }
-            // ... and the knot behind it
+            // ... and the knot behind it, with nothing recorded between the segment and it
             int tR = 0;
             const int kR = certain_bend_after<T>(win, seg_e, p.lam, tR);
-            unsigned nx_e = 0u, nx_t = 0u;     // recorded ends in [seg_e, kR), bit = row - seg_e (the chunk after the segment)
             ok = ok && kR >= 0;
             if (ok && kR > seg_e) {
                 const unsigned keep = (1u << (kR - seg_e)) - 1u;
-                nx_e = S[2 * G] & keep;
-                nx_t = S[2 * G + 1] & keep;
-                const int sh = kR - 1 - seg_e;
-                ok = ((nx_e >> sh) & 1u) && (int)((nx_t >> sh) & 1u) == tR;
+                ok = (S[2 * G] & keep) == (1u << (kR - 1 - seg_e)) && (int)((S[2 * G + 1] >> (kR - 1 - seg_e)) & 1u) == tR;
             }
-            // (kR == seg_e: the knot is the last lane's own last row -- tested with everything else below)
-            // the last piece end of every lane's chunk (lane 0: the rows before the segment count as its own)
+            if (gl == G - 1 && kR == seg_e) ok = ok && ((own_e >> (C - 1)) & 1u) && (int)((own_t >> (C - 1)) & 1u) == tR;
+            // the last piece end of every lane's chunk; the knot a lane's first piece starts at: behind the last piece end of the
+            // nearest lower lane that has one, else kL
             int rl = -1, rtp = 0;
             if (own_e) {
                 const int b = 31 - __clz((int)own_e);
                 rl = cs + b;
                 rtp = (int)((own_t >> b) & 1u);
-            } else if (gl == 0 && pre_e) {
-                const int b = 31 - __clz((int)pre_e);
-                rl = kL + b;
-                rtp = (int)((pre_t >> b) & 1u);
             }
-            if (gl == G - 1 && kR == seg_e) ok = ok && ((own_e >> (C - 1)) & 1u) && (int)((own_t >> (C - 1)) & 1u) == tR;
-            // the knot a lane's first piece starts at: behind the last piece end of the nearest lower lane that has one, else kL
             const unsigned long long has_end = __ballot(rl >= 0);
             const unsigned long long lower = has_end & ((1ull << gl) - 1ull);
             const int pl = lower ? 63 - __clzll((long long)lower) : 0;
@@ -938,57 +932,41 @@ __global__ __launch_bounds__(64 * kAlongWaves) void sweep_along_kernel(SweepArgs
             const bool from_kL = lower == 0ull;
             const int s0 = from_kL ? kL : s_end + 1, st = from_kL ? tL : s_typ;
             const bool fs = from_kL && sg == 0;                      // the fibre start: no knot, height 0
-            ReplayLane R;
-            const int rbeg = gl == 0 ? kL : s0, rend = gl == G - 1 ? kR : ce;
-            const bool has_rows = gl == G - 1 || rl >= 0;            // (a lane with no piece end checks nothing: a later lane's rows)
-            R.r0 = rbeg;
-            R.nrows = has_rows ? rend - rbeg : 0;
-            ok = ok && R.nrows <= 32 && !(fs && gl > 0 && has_rows);   // (a first piece of more than a chunk: the walk's)
-            R.h0 = (gl == 0 ? sg == 0 : fs) ? 0.0 : ((gl == 0 ? tL : st) == BEND_FLOOR ? p.lam : -p.lam);
-            if (ok && has_rows) {
-                const int so = cs - rbeg;                            // (0 .. 15 once nrows <= 32)
-                R.emask = own_e << so;
-                R.tmask = own_t << so;
-                if (gl == 0) { R.emask |= pre_e; R.tmask |= pre_t; }
-                if (gl == G - 1 && kR > seg_e) { R.emask |= nx_e << (ce - rbeg); R.tmask |= nx_t << (ce - rbeg); }
-            }
-            R.ok = ok;
+            const bool has_rows = gl == G - 1 || rl >= 0;            // (a lane with no piece end is responsible for nothing)
+            // (a first piece of more than a chunk, a piece longer than the table: the walk's)
+            ok = ok && !(fs && gl > 0 && has_rows) && (!has_rows || (gl == G - 1 ? kR : ce) - s0 < kRecipTable);
             if (__ballot(!ok) == 0ull) {
-                replay_lane<true>(win, R, 32, p.lam, (lds_double *)rtab);
-                // the jump across the knot a lane's rows start at: against the last piece of the nearest lower lane that has pieces
-                const unsigned long long has_piece = __ballot(R.emask != 0u);
+                // what the walk would have left behind, from the record
+                ChunkRec cand;
+                cand.ends = own_e;
+                cand.types = own_t;
+                cand.mine = fs ? 0u : (((link_t)s0 << 1) | (link_t)st);
+                cand.next = rl >= 0 ? (((link_t)(rl + 1) << 1) | (link_t)rtp) : cand.mine;
+                cand.last = gl == G - 1 ? (((link_t)kR << 1) | (link_t)tR) : cand.next;
+                cand.done = true;
+                ReplayCheck chk;
+                rebuild_owned<Op<OP>, false, C, PTV_ALONG_UNROLL, TAB, lds_double *, 0, 3>(win, cand, cs, ce, len, start, true, seg_s, gl == G - 1, p.lam,
+                                                                                       (lds_double *)rtab, &chk);
+                // the jump across the knot a lane's first piece starts at: against the last piece of the nearest lower lane that has one
+                const unsigned long long has_piece = __ballot(chk.has);
                 const unsigned long long lowp = has_piece & ((1ull << gl) - 1ull);
                 const int pp = lowp ? 63 - __clzll((long long)lowp) : 0;
-                const double vbefore = __shfl(R.vlast, pp);
-                if (gl > 0 && R.emask != 0u && lowp != 0ull)
-                    R.ok = R.ok && (st == BEND_FLOOR ? R.vfirst >= vbefore : R.vfirst <= vbefore);
-                verified = __ballot(!R.ok) == 0ull;
-            }
-            if (verified) {
-                // the record stands: what the walk would have left behind, from the record
-                int a0r = s0, atr = st;
-                bool startr = fs;
-                if (gl == 0) {
-                    a0r = kL; atr = tL; startr = sg == 0;
-                    if (pre_e) {
-                        const int b = 31 - __clz((int)pre_e);
-                        a0r = kL + b + 1;
-                        atr = (int)((pre_t >> b) & 1u);
-                        startr = false;
-                    }
+                const double vbefore = __shfl(chk.vlast, pp);
+                if (chk.has && lowp != 0ull) chk.ok = chk.ok && (st == BEND_FLOOR ? chk.vfirst >= vbefore : chk.vfirst <= vbefore);
+                verified = __ballot(!chk.ok) == 0ull;
+                if (verified) {
+                    rec = cand;
+                    certain = !fs;   // (a start at the fibre start is exact as it is; everything else begins at a verified knot)
+                    if (gl == 0) plan.dirty.note(5);   // (option "why": waves that replayed)
+                } else {
+                    // rows were rewritten from a record that does not hold: the window again, then the walk as if nothing had happened
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    stage_interior();
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    if (gl == 0) plan.dirty.note(6);   // (... that tried and walked after all)
                 }
-                rec.ends = own_e;
-                rec.types = own_t;
-                rec.mine = startr ? 0u : (((link_t)a0r << 1) | (link_t)atr);
-                rec.next = rl >= cs ? (((link_t)(rl + 1) << 1) | (link_t)rtp) : rec.mine;
-                rec.last = rec.next;
-                rec.done = true;
-                if (gl == G - 1 && !((own_e >> (C - 1)) & 1u)) {   // the bend that closes the piece covering the segment's last sample
-                    const int b = __ffs((int)nx_e) - 1;           // (kR > seg_e here: nx_e holds the bit of row kR - 1 at least)
-                    rec.last = ((link_t)(ce + b + 1) << 1) | (link_t)((nx_t >> b) & 1u);
-                }
-                certain = !startr;   // (a start at the fibre start is exact as it is; everything else begins at a verified knot)
-                if (gl == 0) plan.dirty.note(5);   // (option "why": waves that replayed)
             }
         }
     }
@@ -1092,7 +1070,8 @@ __global__ __launch_bounds__(64 * kAlongWaves) void sweep_along_kernel(SweepArgs
         const unsigned long long below = grp & ((1ull << gl) - 1ull);
         if (below) wlo = seg_s + (63 - __clzll((long long)below)) * C;
     }
-    if (!WEIGHTED && interior && !(plan.ablate & 1))   // (every lane of the wave holds a whole chunk: the form that keeps it in registers)
+    if (verified) {}   // (rebuilt while it was verified)
+    else if (!WEIGHTED && interior && !(plan.ablate & 1))   // (every lane of the wave holds a whole chunk: the form that keeps it in registers)
         rebuild_owned<Op<OP>, WEIGHTED, C, PTV_ALONG_UNROLL, TAB, lds_double *, (ROBUST ? TS : 0), 2>(win, rec, cs, ce, len, start, !bad, wlo, gl == G - 1, p.lam,
                                                                                       (lds_double *)rtab);
     else if (has_chunk && !(plan.ablate & 1))

@@ -592,8 +592,11 @@ extern "C" void host_structure(const double *y, double lam, int len, int C, unsi
 // look-ahead T = 8 rows.  For every INTERIOR segment (window inside the fibre): the two bends known a priori that enclose it, the lanes'
 // rows, replay_lane, the jump test across lanes; a verified segment is rebuilt from the candidate masks (rebuild_owned, FULL = 2) into
 // x and seg_ok[sg] = 1; the others are left alone (seg_ok = 0: the kernel walks them).  Returns the number of verified segments.
+static int host_replay_fused(const double *y, double lam, int len, const unsigned *cand_ends, const unsigned *cand_types, double *x, int *seg_ok);
+
 extern "C" int host_replay_fibre(const double *y, double lam, int len, const unsigned *cand_ends, const unsigned *cand_types, double *x,
-                                 int *seg_ok) {
+                                 int *seg_ok, int fused) {
+    if (fused) return host_replay_fused(y, lam, len, cand_ends, cand_types, x, seg_ok);
     constexpr int C = 17, G = 64, SEG = G * C, H = 16, T = 8, LOOKL = 14;
     const int nseg = (len + SEG - 1) / SEG;
     int verified = 0;
@@ -700,6 +703,83 @@ extern "C" int host_replay_fibre(const double *y, double lam, int len, const uns
             rebuild_owned<Identity, false, C, 1, false, const double *, 0, 2>(win, rec, cs, ce, len, start0[l] ? 0 : std::max(1, cs - H), true, seg_s,
                                                                              l == G - 1, lam);
         }
+        for (int k = seg_s; k < seg_e; k++) x[k] = win.y(k);
+        seg_ok[sg] = 1;
+        verified++;
+    }
+    return verified;
+}
+
+// The form the kernel runs (sweep_along_kernel, replay): the check rides on the rebuild (rebuild_owned FULL = 3), and only segments whose
+// record has no piece end between the two known bends and the segment are taken.
+static int host_replay_fused(const double *y, double lam, int len, const unsigned *cand_ends, const unsigned *cand_types, double *x, int *seg_ok) {
+    constexpr int C = 17, G = 64, SEG = G * C, H = 16, T = 8, LOOKL = 14;
+    const int nseg = (len + SEG - 1) / SEG;
+    int verified = 0;
+    auto cand_end = [&](int r) { return (cand_ends[r / C] >> (r % C)) & 1u; };
+    auto cand_type = [&](int r) { return (int)((cand_types[r / C] >> (r % C)) & 1u); };
+    for (int sg = 0; sg < nseg; sg++) {
+        seg_ok[sg] = 0;
+        const int seg_s = sg * SEG, seg_e = seg_s + SEG;
+        if (!(seg_s + SEG + T <= len - 1)) continue;
+        HostWin win;
+        win.lo = std::max(0, seg_s - H);
+        win.hi = seg_s + SEG + T;
+        win.yy.assign(y + win.lo, y + win.hi);
+        win.yy.push_back(1e300);
+        win.yy.push_back(1e300);
+        win.writes.assign(win.yy.size(), 0);
+        const int c0 = sg * G;
+        int kL = 0, tL = 0;
+        bool ok = true;
+        if (sg > 0) {
+            kL = certain_bend_before<false, LOOKL>(win, seg_s, len, lam, tL);
+            ok = kL >= 0 && cand_end(kL - 1) && cand_type(kL - 1) == tL;
+            for (int r = kL; ok && r < seg_s; r++) ok = !cand_end(r);
+        }
+        int tR = 0;
+        const int kR = certain_bend_after<T>(win, seg_e, lam, tR);
+        ok = ok && kR >= 0 && cand_end(kR - 1) && cand_type(kR - 1) == tR;
+        for (int r = seg_e; ok && r < kR - 1; r++) ok = !cand_end(r);
+        if (!ok) continue;
+        int rl[G], rtp[G];
+        for (int l = 0; l < G; l++) {
+            const unsigned e = cand_ends[c0 + l];
+            rl[l] = e ? seg_s + l * C + (31 - __builtin_clz(e)) : -1;
+            rtp[l] = e ? (int)((cand_types[c0 + l] >> (31 - __builtin_clz(e))) & 1u) : 0;
+        }
+        ReplayCheck chk[G];
+        int stl[G];
+        for (int l = 0; l < G && ok; l++) {
+            const int cs = seg_s + l * C, ce = cs + C;
+            int s0 = kL, st = tL;
+            bool fs = (sg == 0);
+            for (int q = l - 1; q >= 0; q--)
+                if (rl[q] >= 0) { s0 = rl[q] + 1; st = rtp[q]; fs = false; break; }
+            stl[l] = st;
+            const bool has_rows = l == G - 1 || rl[l] >= 0;
+            if ((fs && l > 0 && has_rows) || (has_rows && (l == G - 1 ? kR : ce) - s0 >= 48)) { ok = false; break; }
+            ChunkRec cand;
+            cand.ends = cand_ends[c0 + l];
+            cand.types = cand_types[c0 + l];
+            cand.mine = fs ? 0u : (((unsigned)s0 << 1) | (unsigned)st);
+            cand.next = rl[l] >= 0 ? (((unsigned)(rl[l] + 1) << 1) | (unsigned)rtp[l]) : cand.mine;
+            cand.last = l == G - 1 ? (((unsigned)kR << 1) | (unsigned)tR) : cand.next;
+            cand.done = true;
+            rebuild_owned<Identity, false, C, 1, false, const double *, 0, 3>(win, cand, cs, ce, len, std::max(0, cs - H), true, seg_s, l == G - 1, lam,
+                                                                             (const double *)nullptr, &chk[l]);
+        }
+        if (!ok) continue;
+        for (int l = 0; l < G && ok; l++) {
+            ok = chk[l].ok;
+            if (!ok || !chk[l].has) continue;
+            for (int q = l - 1; q >= 0; q--)
+                if (chk[q].has) {
+                    ok = stl[l] == BEND_FLOOR ? chk[l].vfirst >= chk[q].vlast : chk[l].vfirst <= chk[q].vlast;
+                    break;
+                }
+        }
+        if (!ok) continue;
         for (int k = seg_s; k < seg_e; k++) x[k] = win.y(k);
         seg_ok[sg] = 1;
         verified++;

@@ -22,7 +22,7 @@ def harness():
                     os.path.join(HERE, "host_harness.cpp")], check=True)
     lib = C.CDLL(out)
     lib.host_structure.argtypes = [C.c_void_p, C.c_double, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
-    lib.host_replay_fibre.argtypes = [C.c_void_p, C.c_double, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.host_replay_fibre.argtypes = [C.c_void_p, C.c_double, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
     return lib
 
 
@@ -33,11 +33,15 @@ def structure(lib, y, lam):
     return e, t
 
 
-def replay(lib, y, lam, e, t):
+FORMS = (0, 1)   # 0: a verification pass of its own (replay_lane), every interior segment ; 1: the check rides on the rebuild
+                 # (rebuild_owned FULL = 3: what sweep_along_kernel runs), segments with nothing recorded between the known bends and them
+
+
+def replay(lib, y, lam, e, t, fused=1):
     x = np.full(y.size, np.nan)
     nseg = (y.size + SEG - 1) // SEG
     ok = np.zeros(nseg, np.int32)
-    n = lib.host_replay_fibre(y.ctypes.data, lam, y.size, e.ctypes.data, t.ctypes.data, x.ctypes.data, ok.ctypes.data)
+    n = lib.host_replay_fibre(y.ctypes.data, lam, y.size, e.ctypes.data, t.ctypes.data, x.ctypes.data, ok.ctypes.data, fused)
     assert n == int(ok.sum())
     return x, ok
 
@@ -74,13 +78,19 @@ def test_own_structure_always_verifies_and_is_exact(harness, oracle):
         lam = float(rng.choice([0.05, 0.1, 0.2, 0.3]))
         truth = oracle.tv1_hybrid(y, lam)
         e, t = structure(harness, y, lam)
-        x, ok = replay(harness, y, lam, e, t)
+        x, ok = replay(harness, y, lam, e, t, fused=0)
         got = check_verified(x, ok, truth, f"own structure trial {trial}")
         # every interior segment that has its two bends known a priori verifies: where most edges are such bends, nearly all do
         total += got
         if np.mean(np.abs(np.diff(y)) > 4.0000001 * lam) >= 0.5:
             assert got >= interior_segments(n) - 1, (trial, got, interior_segments(n))
+        xf, okf = replay(harness, y, lam, e, t, fused=1)
+        gotf = check_verified(xf, okf, truth, f"own structure, fused, trial {trial}")
+        assert np.all(okf <= ok)          # the fused form takes a subset of the segments ...
+        fused_total = globals().setdefault("_fused_total", [0])
+        fused_total[0] += gotf
     assert total > 80
+    assert globals()["_fused_total"][0] > 0.4 * total   # ... most of them on noisy data
 
 
 def test_neighbouring_iterate_verified_segments_are_exact(harness, oracle):
@@ -95,9 +105,13 @@ def test_neighbouring_iterate_verified_segments_are_exact(harness, oracle):
         e, t = structure(harness, y_old, lam)
         for eps in seen:
             y = y_old + eps * rng.standard_normal(n)
-            x, ok = replay(harness, y, lam, e, t)
-            seen[eps][0] += check_verified(x, ok, oracle.tv1_hybrid(y, lam), f"eps {eps} trial {trial}")
-            seen[eps][1] += interior_segments(n)
+            truth = oracle.tv1_hybrid(y, lam)
+            for form in FORMS:
+                x, ok = replay(harness, y, lam, e, t, fused=form)
+                got = check_verified(x, ok, truth, f"eps {eps} trial {trial} form {form}")
+                if form == 0:
+                    seen[eps][0] += got
+                    seen[eps][1] += interior_segments(n)
     assert seen[1e-4][0] > 0.5 * seen[1e-4][1]      # small moves keep most segments' structure
     assert seen[1.0][0] < 0.1 * seen[1.0][1]        # another fibre's structure is (all but) never this fibre's
 
@@ -126,8 +140,9 @@ def test_corrupted_and_unrelated_candidates_never_verify_wrongly(harness, oracle
                 t2[:] = 0
             else:              # the structure of an unrelated fibre
                 e2, t2 = structure(harness, families(rng, n, (trial + 1) % 4), lam)
-            x, ok = replay(harness, y, lam, e2, t2)
-            accepted += check_verified(x, ok, truth, f"corruption {mode} trial {trial}")
-            if mode == 3:
-                assert ok.sum() == 0
+            for form in FORMS:
+                x, ok = replay(harness, y, lam, e2, t2, fused=form)
+                accepted += check_verified(x, ok, truth, f"corruption {mode} trial {trial} form {form}")
+                if mode == 3:
+                    assert ok.sum() == 0
     assert accepted > 0   # (flips that land outside a segment leave it verifiable: the test must have seen acceptances too)

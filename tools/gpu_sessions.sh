@@ -102,4 +102,25 @@ for lam in (0.05, 0.1, 0.15, 0.2):
 PY
   cat $OUT/replay_share.txt
   ;;
+s9)   # replay, fused: the check rides on the rebuild (a pass of its own cost a wave more than the walk it saves: s8)
+  timeout 600 python -m pytest tests/test_gpu_replay.py tests/test_gpu_parity_2d.py tests/test_gpu_large.py tests/test_gpu_fuzz.py tests/test_gpu_boundary.py -m gpu -x -q > $OUT/pytest_default.log 2>&1; echo "default: $(tail -1 $OUT/pytest_default.log)" | tee $OUT/summary.txt
+  ab --reps 7 --rounds 2 --cases c2,c2@0.05,c2@0.2,s2048 base walk,replay=0 > $OUT/ab_replay.txt 2>&1; cat $OUT/ab_replay.txt
+  python - > $OUT/replay_share.txt 2>&1 <<'PY'
+import numpy as np, torch, sys
+sys.path.insert(0, '.')
+from proxtv_amd import _lib, device
+lib = _lib.require_device()
+lib.proxtv_set_option(b"why", 1)
+x = device.to_colmajor(torch.from_numpy(np.random.default_rng(0).standard_normal((4096, 4096))).cuda())
+buf = np.zeros(8, dtype=np.uint32)
+for lam in (0.05, 0.1, 0.2):
+    lib.proxtv_debug_why(buf.ctypes.data)
+    for iters in (5, 10, 20, 35):
+        device.tv1_2d(x, lam, max_iters=iters)
+        lib.proxtv_debug_why(buf.ctypes.data)
+        waves = 16384 * iters
+        print(f"lambda {lam} {iters:2d} iterations: {int(buf[5]):7d} wavefronts replayed, {int(buf[6]):6d} tried and walked, of {waves} launched in {iters} column sweeps = {buf[5] / waves:.3f}")
+PY
+  cat $OUT/replay_share.txt
+  ;;
 esac
