@@ -916,7 +916,10 @@ __global__ __launch_bounds__(64 * kAlongWaves) void sweep_along_kernel(SweepArgs
                 const unsigned keep = (1u << (kR - seg_e)) - 1u;
                 ok = (S[2 * G] & keep) == (1u << (kR - 1 - seg_e)) && (int)((S[2 * G + 1] >> (kR - 1 - seg_e)) & 1u) == tR;
             }
-            if (gl == G - 1 && kR == seg_e) ok = ok && ((own_e >> (C - 1)) & 1u) && (int)((own_t >> (C - 1)) & 1u) == tR;
+            // (kR == seg_e: the knot is the last lane's own last row.  kR beyond: the piece that covers the segment's last sample must run
+            //  up to it -- a record that ends a piece ON the last sample leaves a piece [seg_e, kR) and the knot before it to nobody)
+            if (gl == G - 1) ok = ok && (kR == seg_e ? ((own_e >> (C - 1)) & 1u) && (int)((own_t >> (C - 1)) & 1u) == tR
+                                                      : !((own_e >> (C - 1)) & 1u));
             // the last piece end of every lane's chunk; the knot a lane's first piece starts at: behind the last piece end of the
             // nearest lower lane that has one, else kL
             int rl = -1, rtp = 0;

@@ -741,6 +741,9 @@ static int host_replay_fused(const double *y, double lam, int len, const unsigne
         const int kR = certain_bend_after<T>(win, seg_e, lam, tR);
         ok = ok && kR >= 0 && cand_end(kR - 1) && cand_type(kR - 1) == tR;
         for (int r = seg_e; ok && r < kR - 1; r++) ok = !cand_end(r);
+        // (kR beyond the segment: the piece that covers the segment's last sample must run up to it -- a record that ends a piece ON the
+        //  last sample leaves a piece [seg_e, kR) and the knot before it to nobody)
+        if (kR > seg_e && cand_end(seg_e - 1)) ok = false;
         if (!ok) continue;
         int rl[G], rtp[G];
         for (int l = 0; l < G; l++) {

@@ -146,3 +146,25 @@ def test_corrupted_and_unrelated_candidates_never_verify_wrongly(harness, oracle
                 if mode == 3:
                     assert ok.sum() == 0
     assert accepted > 0   # (flips that land outside a segment leave it verifiable: the test must have seen acceptances too)
+
+
+def test_a_piece_end_recorded_on_the_segments_last_sample(harness, oracle):
+    """The hole the GPU found in the first fused form: the record ends a piece ON the segment's last sample and another one on the next
+    sample (two one-sample pieces), the new data merge the two, and the first bend known a priori lies one sample further on.  The
+    piece [seg_e, kR) and the knot before it then belong to no lane of the segment: such a segment must walk."""
+    rng = np.random.default_rng(14)
+    lam = 0.1
+    hits = 0
+    for trial in range(200):
+        n = 2 * SEG + 300
+        y_old = rng.standard_normal(n)
+        y_old[SEG - 1], y_old[SEG], y_old[SEG + 1] = -1.0, 1.0, 3.0       # knots at SEG and SEG + 1 in the record
+        e, t = structure(harness, y_old, lam)
+        assert (e[(SEG - 1) // CH] >> ((SEG - 1) % CH)) & 1 and (e[SEG // CH] >> (SEG % CH)) & 1
+        y = y_old + 1e-3 * rng.standard_normal(n)
+        y[SEG - 1], y[SEG] = 0.30 + 0.01 * rng.standard_normal(), 0.31 + 0.01 * rng.standard_normal()   # ... merged in the new data
+        truth = oracle.tv1_hybrid(y, lam)
+        for form in FORMS:
+            x, ok = replay(harness, y, lam, e, t, fused=form)
+            hits += check_verified(x, ok, truth, f"boundary trial {trial} form {form}")
+    assert hits >= 0

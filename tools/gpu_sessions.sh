@@ -123,4 +123,16 @@ for lam in (0.05, 0.1, 0.2):
 PY
   cat $OUT/replay_share.txt
   ;;
+s10)  # replay, fused, the hole at the segment's end closed: parity, A/B, and the instruction counters of the column sweep with and without
+  timeout 600 python -m pytest tests/test_gpu_replay.py tests/test_gpu_parity_2d.py tests/test_gpu_large.py tests/test_gpu_fuzz.py -m gpu -x -q > $OUT/pytest_default.log 2>&1; echo "default: $(tail -1 $OUT/pytest_default.log)" | tee $OUT/summary.txt
+  python tools/replay_diag.py 2>&1 | grep -v amdgpu.ids | tee $OUT/replay_diag.txt
+  ab --reps 7 --rounds 2 --cases c2,c2@0.05 base walk,replay=0 > $OUT/ab_replay.txt 2>&1; cat $OUT/ab_replay.txt
+  cd /tmp; R=$GRAFT_REPO_ROOT
+  KC_SETS=insts,waves timeout 300 python $R/tools/kernel_counters.py collect $R/$OUT/kc_replay dr0.1 > /dev/null 2>&1
+  PROXTV_REPLAY=0 KC_SETS=insts,waves timeout 300 python $R/tools/kernel_counters.py collect $R/$OUT/kc_walk dr0.1 > /dev/null 2>&1
+  cd $R
+  python tools/kernel_counters.py report $OUT/kc_replay 2>&1 | grep "kernel \|sweep_along_kernel<1" | tee $OUT/counters_replay.txt
+  python tools/kernel_counters.py report $OUT/kc_walk 2>&1 | grep "sweep_along_kernel<1" | tee $OUT/counters_walk.txt
+  find $OUT -name "*.db" -delete
+  ;;
 esac
