@@ -170,9 +170,9 @@ void proxtv_release_scratch(void);
      "pin_seed"       1 (default): the pinning solver (rung 3) starts from the knots known a priori, 0: from the fibre ends alone
      "pin_overlap"    1: a strided sweep of the pinning solver moves its transposed copies range by range on a second stream, under
                       the levels of the other ranges ; 0 (default: measured slower): one stream
-     "replay"         1 (default): dimension-0 sweeps on rung 0 keep the piece ends / bend types of every chunk and, from the fourth
-                      sweep of a solve over the same geometry on, verify the last sweep's against the optimality conditions of the prox
-                      instead of walking (per wavefront, all or nothing; exact whatever the record holds) ; 0: always walk
+     "replay"         1: dimension-0 sweeps on rung 0 keep the piece ends / bend types of every chunk and, from the fourth sweep of a
+                      solve over the same geometry on, verify the last sweep's against the optimality conditions of the prox instead of
+                      walking (per wavefront, all or nothing; exact whatever the record holds) ; 0 (default: measured slower): always walk
      "repair_jobs"    failed links across the workgroups of a chunked sweep are first repaired one lane per failure, four to a
                       fibre; what that leaves goes to the sequential repair: 1 (default) where the sampled statistic of the sweep's
                       input says such links fail in numbers, 2 always ; 0: the sequential repair alone (same results, bit for bit)

@@ -44,9 +44,11 @@ struct Options {
     int blocks_per_wg = 0;  // blocks pipelined per workgroup in the chunk kernel; 0 = pick from the problem size
     int rounds = 0;         // second-chance rounds of geometry mode 1 (0 = the built-in default)
     int along = 1;            // dimension-0 sweeps: chunks along the fibre (sweep_along_kernel); 0 = the transposed 64-fibre tile
-    int replay = 1;           // ... the plain along-fibre kernel keeps every chunk's piece ends / bend types and, from the fourth sweep of a solve
-                              // over the same geometry on, VERIFIES the last sweep's against the optimality conditions instead of walking
-                              // (all or nothing per wave; exact whatever the record holds: chunkcore.hpp replay_lane) ; 0 = always walk
+    int replay = 0;           // ... 1: the plain along-fibre kernel keeps every chunk's piece ends / bend types and, from the fourth sweep of a solve
+                              // over the same geometry on, VERIFIES the last sweep's against the optimality conditions instead of walking (all or
+                              // nothing per wave; exact whatever the record holds: chunkcore.hpp rebuild_owned FULL = 3).  Measured and NOT the
+                              // default: 60 % of a DR solve's column waves replay at lambda 0.1 and the sweep is slower (75.3 -> 81.3 us): as
+                              // compiled, the check costs a wave nearly what the walk does (profiles/NOTES_r05.md, sessions 8-10)
     int along_min_len = 160;  // ... for fibres at least this long (16, 32 or 64 lanes share a fibre segment of 17-sample chunks)
     int row_along = 1;        // strided sweeps through transposed copies + the along-fibre kernel: bit 0 = rung 2 (64-sample zones),
                               // bit 1 = rung 1 as well (0 = the 64-fibre tile for both)
