@@ -50,6 +50,9 @@ def run(budget=60.0, seed=0, tol=1e-9, sizes=(2, 3, 17, 95, 96, 97, 130, 257, 40
             tile, seeds = int(rng.integers(0, 2)), int(rng.integers(0, 2))
             lib.proxtv_set_option(b"tile", tile)                               # (32-fibre x 4-wave or 64-fibre x 8-wave tiles)
             lib.proxtv_set_option(b"pin_seed", seeds)                          # (the pinning solver with / without the knots known a priori)
+            jobs, rep = int(rng.integers(0, 3)), int(rng.integers(0, 2))
+            lib.proxtv_set_option(b"repair_jobs", jobs)                        # (failed links across workgroups one lane each: never / seeded / always)
+            lib.proxtv_set_option(b"replay", rep)                              # (the along-fibre kernel verifying its last sweep's structure)
             what = int(rng.integers(0, 6))
             if what == 0:
                 got, want, name = ptv.tv1_2d(X, lam), orc.dr2(X, lam)[0], "dr2"
@@ -69,7 +72,7 @@ def run(budget=60.0, seed=0, tol=1e-9, sizes=(2, 3, 17, 95, 96, 97, 130, 257, 40
                 want = np.apply_along_axis(lambda f: orc.tv1_hybrid(np.ascontiguousarray(f), lam), d - 1, X)
                 name = f"prox dim {d}"
             e = rel(got, want, np.max(np.abs(X)))
-            desc = f"{name} {M}x{N} lam={lam:.4g} mode={mode} dr_form={form} tile={tile} pin_seed={seeds}"
+            desc = f"{name} {M}x{N} lam={lam:.4g} mode={mode} dr_form={form} tile={tile} pin_seed={seeds} repair_jobs={jobs} replay={rep}"
             if e > worst:
                 worst, worst_case = e, desc
             cases += 1
@@ -80,6 +83,8 @@ def run(budget=60.0, seed=0, tol=1e-9, sizes=(2, 3, 17, 95, 96, 97, 130, 257, 40
         lib.proxtv_set_option(b"dr_form", 1)
         lib.proxtv_set_option(b"tile", 1)
         lib.proxtv_set_option(b"pin_seed", 1)
+        lib.proxtv_set_option(b"repair_jobs", 1)
+        lib.proxtv_set_option(b"replay", 0)
     return cases, worst, worst_case
 
 

@@ -135,4 +135,20 @@ s10)  # replay, fused, the hole at the segment's end closed: parity, A/B, and th
   python tools/kernel_counters.py report $OUT/kc_walk 2>&1 | grep "sweep_along_kernel<1" | tee $OUT/counters_walk.txt
   find $OUT -name "*.db" -delete
   ;;
+s11)  # validation of the round's final build: the whole suite under the default policy, the parity / repair / fuzz / pinning / boundary
+      # files pinned to rungs 1 and 3, on the 64-fibre tile, with replay on, with the jobs repair always on; the soak
+  timeout 900 python -m pytest tests -m gpu -q > $OUT/pytest_default.log 2>&1; echo "default policy, whole suite: $(tail -1 $OUT/pytest_default.log)" | tee $OUT/summary.txt
+  FILES="tests/test_gpu_chunk_repair.py tests/test_gpu_parity_2d.py tests/test_gpu_parity_1d.py tests/test_gpu_parity_nd.py tests/test_gpu_fuzz.py tests/test_gpu_pin.py tests/test_gpu_boundary.py tests/test_gpu_replay.py"
+  PROXTV_CHUNK_MODE=1 timeout 600 python -m pytest $FILES -m gpu -q > $OUT/pytest_mode1.log 2>&1; echo "pinned to rung 1: $(tail -1 $OUT/pytest_mode1.log)" | tee -a $OUT/summary.txt
+  PROXTV_CHUNK_MODE=3 timeout 600 python -m pytest $FILES -m gpu -q > $OUT/pytest_mode3.log 2>&1; echo "pinned to rung 3: $(tail -1 $OUT/pytest_mode3.log)" | tee -a $OUT/summary.txt
+  PROXTV_TILE=0 timeout 600 python -m pytest $FILES -m gpu -q > $OUT/pytest_tile0.log 2>&1; echo "64-fibre tile: $(tail -1 $OUT/pytest_tile0.log)" | tee -a $OUT/summary.txt
+  PROXTV_REPLAY=1 timeout 600 python -m pytest $FILES tests/test_gpu_large.py -m gpu -q > $OUT/pytest_replay.log 2>&1; echo "replay on: $(tail -1 $OUT/pytest_replay.log)" | tee -a $OUT/summary.txt
+  PROXTV_REPAIR_JOBS=2 timeout 600 python -m pytest tests/test_gpu_chunk_repair.py tests/test_gpu_parity_2d.py tests/test_gpu_fuzz.py -m gpu -q > $OUT/pytest_jobs2.log 2>&1; echo "jobs repair always on: $(tail -1 $OUT/pytest_jobs2.log)" | tee -a $OUT/summary.txt
+  { echo "# python tools/fuzz.py <seconds> <seed> [nd|long] on one MI355X box; assertion: relative error <= 1e-9"
+    python tools/fuzz.py 100 91; PROXTV_REPLAY=1 python tools/fuzz.py 50 92; python tools/fuzz.py 30 93 nd; python tools/fuzz.py 40 94 long; } > $OUT/fuzz_soak.txt 2>&1; grep "^fuzz\|MISMATCH" $OUT/fuzz_soak.txt | tee -a $OUT/summary.txt
+  python -c "import sys; sys.path.insert(0,'.'); from proxtv_amd import build; print('build id', build.build_id())" | tee -a $OUT/summary.txt
+  ;;
+s12)  # the profiles of the round's final build
+  bash tools/collect_profiles.sh r05 > $OUT/collect.log 2>&1; tail -60 $OUT/collect.log
+  ;;
 esac
