@@ -151,4 +151,9 @@ s11)  # validation of the round's final build: the whole suite under the default
 s12)  # the profiles of the round's final build
   bash tools/collect_profiles.sh r05 > $OUT/collect.log 2>&1; tail -60 $OUT/collect.log
   ;;
+s13)  # knobs re-checked against the round's kernels (the second form of the DR iteration on rung 0, blocks per tile workgroup), a longer soak
+  ab --reps 7 --rounds 2 --cases c2,prox1,c3,pd2 base form2,dr_form=2 bpw2,blocks_per_wg=2 bpw4,blocks_per_wg=4 > $OUT/ab_knobs.txt 2>&1; cat $OUT/ab_knobs.txt
+  { echo "# python tools/fuzz.py <seconds> <seed> [nd|long] on one MI355X box; assertion: relative error <= 1e-9"
+    python tools/fuzz.py 120 101; python tools/fuzz.py 40 102 nd; python tools/fuzz.py 60 103 long; } > $OUT/fuzz_soak2.txt 2>&1; grep "^fuzz\|MISMATCH" $OUT/fuzz_soak2.txt
+  ;;
 esac
