@@ -156,4 +156,9 @@ s13)  # knobs re-checked against the round's kernels (the second form of the DR 
   { echo "# python tools/fuzz.py <seconds> <seed> [nd|long] on one MI355X box; assertion: relative error <= 1e-9"
     python tools/fuzz.py 120 101; python tools/fuzz.py 40 102 nd; python tools/fuzz.py 60 103 long; } > $OUT/fuzz_soak2.txt 2>&1; grep "^fuzz\|MISMATCH" $OUT/fuzz_soak2.txt
   ;;
+s14)  # work queues once more, along-fibre kernel of one-operand sweeps only: 16 counters, a wave moves to the next queue when one runs dry
+  timeout 600 python -m pytest tests/test_gpu_parity_1d.py tests/test_gpu_parity_2d.py tests/test_gpu_parity_nd.py tests/test_gpu_large.py tests/test_gpu_fuzz.py tests/test_gpu_replay.py -m gpu -x -q > $OUT/pytest_default.log 2>&1; echo "default: $(tail -1 $OUT/pytest_default.log)" | tee $OUT/summary.txt
+  ab --reps 7 --rounds 2 --cases c2,prox0,c2@0.2,c4,pd2,s1024,s2048 base noq,along_queue=0 > $OUT/ab_queue.txt 2>&1; cat $OUT/ab_queue.txt
+  timeout 60 python tools/wg_trace.py > $OUT/wg_trace.txt 2>&1; grep "^## col\|^# rec\|^# mean" $OUT/wg_trace.txt | sed -n 4,8p
+  ;;
 esac
