@@ -170,8 +170,6 @@ void proxtv_release_scratch(void);
      "pin_seed"       1 (default): the pinning solver (rung 3) starts from the knots known a priori, 0: from the fibre ends alone
      "pin_overlap"    1: a strided sweep of the pinning solver moves its transposed copies range by range on a second stream, under
                       the levels of the other ranges ; 0 (default: measured slower): one stream
-     "along_queue"    1 (default): the plain along-fibre kernel of one-operand sweeps is launched with as many workgroups as the device
-                      holds at once and its wavefronts draw further segments from atomic counters ; 0: one wavefront per segment
      "replay"         1: dimension-0 sweeps on rung 0 keep the piece ends / bend types of every chunk and, from the fourth sweep of a
                       solve over the same geometry on, verify the last sweep's against the optimality conditions of the prox instead of
                       walking (per wavefront, all or nothing; exact whatever the record holds) ; 0 (default: measured slower): always walk

@@ -35,7 +35,6 @@ constexpr OptionEntry kOptionTable[] = {
     {"rounds", &Options::rounds},
     {"along", &Options::along},
     {"replay", &Options::replay},
-    {"along_queue", &Options::along_queue},
     {"along_min_len", &Options::along_min_len},
     {"row_along", &Options::row_along},
     {"seed_row_along_e4", &Options::seed_row_along_e4},

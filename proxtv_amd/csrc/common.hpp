@@ -49,8 +49,6 @@ struct Options {
                               // nothing per wave; exact whatever the record holds: chunkcore.hpp rebuild_owned FULL = 3).  Measured and NOT the
                               // default: 60 % of a DR solve's column waves replay at lambda 0.1 and the sweep is slower (75.3 -> 81.3 us): as
                               // compiled, the check costs a wave nearly what the walk does (profiles/NOTES_r05.md, sessions 8-10)
-    int along_queue = 1;      // ... the plain one-operand instantiations launched with as many workgroups as the device holds at once, their
-                              // waves drawing further segments from atomic counters (no wave slot waits for the dispatcher) ; 0 = one wave per segment
     int along_min_len = 160;  // ... for fibres at least this long (16, 32 or 64 lanes share a fibre segment of 17-sample chunks)
     int row_along = 1;        // strided sweeps through transposed copies + the along-fibre kernel: bit 0 = rung 2 (64-sample zones),
                               // bit 1 = rung 1 as well (0 = the 64-fibre tile for both)

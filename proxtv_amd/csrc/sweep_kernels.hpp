@@ -191,9 +191,6 @@ __global__ __launch_bounds__(64) void sweep_seq_kernel(SweepArgs p, FibreGeom g,
 }
 
 // ---- kernel 2: speculative chunks over an LDS window -----------------------------------------------------------------
-// work queues of the along-fibre kernel (see sweep_along_kernel): counters per launch, and their distance in 4-byte words (a cache
-// line each)
-constexpr unsigned kQueues = 16, kQueueStride = 32;
 struct ChunkPlan {
     int Q;      // blocks (NW chunks each) per fibre
     int qpw;    // consecutive blocks of one fibre group processed (software-pipelined) by one workgroup
@@ -202,8 +199,6 @@ struct ChunkPlan {
     unsigned long long *trace;   // option "trace": 8 words per workgroup -- where it ran and when its phases ended (100 MHz clock)
     DirtyMark dirty;             // this launch's "something is left for the repair kernel" word
     unsigned long long *xlink;   // links across workgroups / segments: [boundary][fibre] (tile) or [fibre][segment] (along)
-    long along_waves;            // along-fibre kernel: waves' worth of segments in the sweep
-    unsigned *queue;             // ... its work queues: kQueues counters of segments drawn beyond the launched waves (null: one wave per segment)
     unsigned *structure;         // along-fibre kernel: [fibre][chunk][ends, types] as the family's last sweep left them (null: none kept)
     int replay;                  // ... and this sweep tries to verify them instead of walking (the first sweeps of a solve only record)
 };
@@ -752,7 +747,7 @@ constexpr int along_zone_rows(int H, bool robust) { return robust && H < 64 ? 64
 // instantiation's 64 + 64 rows of look-back / look-ahead are not allocated: a third of its LDS for 512-sample fibres, and with it
 // twelve waves per CU become sixteen.
 template <int OP, bool WEIGHTED, int H, int G, bool ROBUST, bool ONESEG = false>
-__global__ __launch_bounds__(64 * kAlongWaves, 4) void sweep_along_kernel(SweepArgs p, FibreGeom g, ChunkPlan plan, link_t *code_mine,
+__global__ __launch_bounds__(64 * kAlongWaves) void sweep_along_kernel(SweepArgs p, FibreGeom g, ChunkPlan plan, link_t *code_mine,
                                                                         link_t *code_next, int *failflags) {
     constexpr int C = along_chunk(ROBUST, WEIGHTED), SEG = G * C, T = ONESEG ? 0 : along_tail_rows(H, ROBUST), HZ = ONESEG ? 0 : along_zone_rows(H, ROBUST), ROWS = HZ + SEG + T, NG = 64 / G;
     constexpr int NU = (ROWS + G - 1) / G;   // staged elements per lane
@@ -786,21 +781,7 @@ __global__ __launch_bounds__(64 * kAlongWaves, 4) void sweep_along_kernel(SweepA
     }
     const int len = g.len;
     const int nseg = (len + SEG - 1) / SEG, NC = (len + C - 1) / C;
-    // Waves draw their segments from queues (plan.queue: the plain one-operand instantiations, launched with as many workgroups as the
-    // device holds at once).  A wave's first segment is its own number; every further one comes from an atomic counter, asked for
-    // behind the window loads of the turn before so that the round trip hides behind the turn.  Why: with one wave per segment the
-    // 4096 wave slots of a 4096^2 sweep are 70 % full on average -- the waves of a round end together and the dispatcher needs
-    // microseconds to refill them (round-5 phase traces).  Static turns keep the slots full and lose more in the end than they win
-    // (nothing rebalances the slow workgroups: 76 -> 84 us); ONE counter serialises 12 288 atomics on one address (217 us); counters a
-    // wave is tied to leave the last segments to too few waves.  So: kQueues counters in separate cache lines, the segments beyond
-    // the launched waves dealt to them round-robin, a wave starts with the counter of its own number and moves on to the next when
-    // one runs dry.  (Every launch has its own counters: ChunkScratch::work_queue.)  plan.queue == null: one turn.
-    constexpr bool QUEUED = !ROBUST && !WEIGHTED && G == 64 && !ONESEG && Op<OP>::NIN == 1 && Op<OP>::FUSED;   // (the others: one turn, no loop)
-    const long launched_waves = (long)gridDim.x * kAlongWaves;
-    const long queued_waves = plan.along_waves - launched_waves;      // segments to be drawn
-    long wid = (long)blockIdx.x * kAlongWaves + wave;
-    unsigned my_queue = (unsigned)(wid % kQueues);
-    for (;;) {
+    const long wid = (long)blockIdx.x * kAlongWaves + wave;
     const long unit = wid * NG + gi;         // one group of G lanes = one segment of one fibre
     long j, sg_l;
     divmod_nonneg(unit, (long)nseg, j, sg_l);
@@ -890,9 +871,6 @@ __global__ __launch_bounds__(64 * kAlongWaves, 4) void sweep_along_kernel(SweepA
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     if (plan.trace && lane == 0) plan.trace[8 * (size_t)wid + 2] = wall_clock64();
-    // the next turn's segment: asked for now -- behind the window loads, which would otherwise wait for the atomic's round trip
-    unsigned drawn = 0u;
-    if (QUEUED && plan.queue && lane == 0) drawn = atomicAdd(plan.queue + my_queue * kQueueStride, 1u);
 
     // ---- speculative walk of this lane's chunk ---------------------------------------------------------------------------------
     const int cs = seg_s + gl * C;
@@ -1152,24 +1130,6 @@ __global__ __launch_bounds__(64 * kAlongWaves, 4) void sweep_along_kernel(SweepA
         if (why) plan.dirty.set(why);
     }
     if (plan.trace && lane == 0) plan.trace[8 * (size_t)wid + 5] = wall_clock64();
-    if (!QUEUED || !plan.queue) break;
-    // the d-th draw of queue q is segment launched_waves + d * kQueues + q ; a queue that has run dry sends the wave to the next one
-    long next = -1;
-    unsigned d = (unsigned)__builtin_amdgcn_readfirstlane((int)drawn);
-    for (unsigned tried = 0; tried < kQueues; tried++) {
-        const long r = (long)d * kQueues + my_queue;
-        if (r < queued_waves) {
-            next = launched_waves + r;
-            break;
-        }
-        my_queue = (my_queue + 1u) % kQueues;
-        unsigned again = 0u;
-        if (lane == 0) again = atomicAdd(plan.queue + my_queue * kQueueStride, 1u);
-        d = (unsigned)__builtin_amdgcn_readfirstlane((int)again);
-    }
-    if (next < 0) break;   // every queue is dry
-    wid = next;
-    }   // (next turn)
 }
 
 // ---- kernel 1b: short fibres, whole in LDS ---------------------------------------------------------------------------------
@@ -2089,18 +2049,6 @@ struct ChunkScratch {
         st_sweeps++;
         return structure->as<unsigned>();
     }
-    // work queues of the along-fibre kernel: kQueues counters per launch out of a ring of kQueueRing launches, all of them zeroed again
-    // (in stream order: after the launches that used them, before the ones that will) every kQueueRing launches -- a launch that died
-    // half-way leaves nothing behind for longer than that
-    static constexpr unsigned kQueueRing = 64;
-    std::unique_ptr<Scratch> queues;
-    unsigned queue_next = 0;
-    unsigned *work_queue(hipStream_t s) {
-        constexpr size_t per_launch = (size_t)kQueues * kQueueStride;   // words
-        if (!queues) queues.reset(new Scratch(sizeof(unsigned) * per_launch * kQueueRing));
-        if (queue_next % kQueueRing == 0) PTV_HIP(hipMemsetAsync(queues->as<unsigned>(), 0, sizeof(unsigned) * per_launch * kQueueRing, s));
-        return queues->as<unsigned>() + per_launch * (queue_next++ % kQueueRing);
-    }
     unsigned long long *xlink_for(size_t words, hipStream_t s) {
         if (!options().xlink) return nullptr;
         if (words > xlink_words) {
@@ -2441,27 +2389,11 @@ void launch_along_g(const SweepArgs &args, const FibreGeom &g, hipStream_t strea
             attr_set = true;
         }
     }
-    plan.along_waves = waves;
-    plan.queue = nullptr;
-    long grid_wgs = (waves + kAlongWaves - 1) / kAlongWaves;
-    // work queues (see the kernel): the plain instantiations of one-operand fused ops -- the two-operand sweeps are bandwidth-bound and
-    // lose with more waves in flight (PD2's column sweep 140 -> 160 us, session 7), the robust ones hand over between the waves of a
-    // workgroup
-    if (!ROBUST && !WEIGHTED && G == 64 && !ONESEG && Op<OP>::NIN == 1 && Op<OP>::FUSED && options().along_queue) {
-        static thread_local long capacity[kMaxDevices] = {};   // workgroups the device holds at once (asked once per instantiation and device)
-        long &cap = capacity[current_device()];
-        if (cap == 0) {
-            int per_cu = 0, cus = 0;
-            PTV_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(kern), 64 * kAlongWaves, lds));
-            PTV_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, current_device()));
-            cap = (long)(per_cu > 0 ? per_cu : 1) * (cus > 0 ? cus : 1);
-        }
-        if (cap < grid_wgs && waves % kAlongWaves == 0) {   // (whole workgroups only: a launched wave is a segment)
-            grid_wgs = cap;
-            plan.queue = chunk_state().work_queue(stream);
-        }
-    }
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid_wgs), dim3(64 * kAlongWaves), lds, stream, args, g,
+    // (One workgroup per kAlongWaves segments, dispatched as slots free up.  Tried in round 5 and dropped, profiles/NOTES_r05.md: as many
+    // workgroups as the device holds, each taking its segments in static turns -- 76 -> 84 us, nothing rebalances the slow workgroups --
+    // or drawing them from atomic counters -- the wave slots stay 98 % full instead of 70 % and the sweep takes as long: the vector
+    // pipes, not the dispatcher, are what the waves wait for.)
+    hipLaunchKernelGGL(kern, dim3((unsigned)((waves + kAlongWaves - 1) / kAlongWaves)), dim3(64 * kAlongWaves), lds, stream, args, g,
                        plan, chunk_state().code_mine, chunk_state().code_next, chunk_state().failflags);
     count_event(CNT_SWEEP_LAUNCHES);
     if (!plan.ablate) {
