@@ -161,4 +161,11 @@ s14)  # work queues once more, along-fibre kernel of one-operand sweeps only: 16
   ab --reps 7 --rounds 2 --cases c2,prox0,c2@0.2,c4,pd2,s1024,s2048 base noq,along_queue=0 > $OUT/ab_queue.txt 2>&1; cat $OUT/ab_queue.txt
   timeout 60 python tools/wg_trace.py > $OUT/wg_trace.txt 2>&1; grep "^## col\|^# rec\|^# mean" $OUT/wg_trace.txt | sed -n 4,8p
   ;;
+s15)  # the remaining settings of the earlier rounds' validation matrix on the final build: the hill-climbing policy, the in-kernel link
+      # check off, pinned to the sequential rung
+  FILES="tests/test_gpu_chunk_repair.py tests/test_gpu_parity_2d.py tests/test_gpu_parity_1d.py tests/test_gpu_parity_nd.py tests/test_gpu_fuzz.py tests/test_gpu_pin.py tests/test_gpu_boundary.py"
+  PROXTV_DETERMINISTIC=0 timeout 600 python -m pytest $FILES -m gpu -q > $OUT/pytest_hillclimb.log 2>&1; echo "hill-climbing policy: $(tail -1 $OUT/pytest_hillclimb.log)" | tee $OUT/summary.txt
+  PROXTV_XLINK=0 timeout 600 python -m pytest $FILES -m gpu -q > $OUT/pytest_xlink0.log 2>&1; echo "in-kernel link check off: $(tail -1 $OUT/pytest_xlink0.log)" | tee -a $OUT/summary.txt
+  PROXTV_CHUNK_MODE=5 timeout 600 python -m pytest $FILES -m gpu -q > $OUT/pytest_mode5.log 2>&1; echo "pinned to rung 5: $(tail -1 $OUT/pytest_mode5.log)" | tee -a $OUT/summary.txt
+  ;;
 esac
