@@ -189,6 +189,15 @@ def test_fibre_lengths_around_chunk_and_block_edges(ptv, clib, oracle, modes):
             assert_close(got, want.T, tol=1e-11, what=f"dim1 n={n} lam={lam} mode={m}")
 
 
+def _needs_xlink(clib):
+    """The jobs repair hangs on the sweep's `dirty` word, which exists only with the in-kernel link check (option xlink, default 1)."""
+    was = clib.proxtv_set_option(b"xlink", 1)
+    clib.proxtv_set_option(b"xlink", was)
+    if was == 0:
+        pytest.skip("option xlink = 0 (PROXTV_XLINK): no dirty word, the jobs repair is never launched")
+
+
+
 def test_jobs_repair_equals_the_sequential_repair(clib, oracle, modes):
     """Option repair_jobs: failed links across workgroups repaired one lane per failure (sweep_repair_jobs_kernel) before the
     sequential repair kernel takes what is left.  Rung 1 at lambda 0.65-0.9 on unit noise is where such links fail in numbers.
@@ -196,6 +205,7 @@ def test_jobs_repair_equals_the_sequential_repair(clib, oracle, modes):
     results must be the same to the last bit -- a job parks exactly the values the sequential walk would write -- and exact."""
     import torch
     from proxtv_amd import device
+    _needs_xlink(clib)
     rng = np.random.default_rng(5)
     dev = lambda a: device.to_colmajor(torch.from_numpy(np.ascontiguousarray(a)).cuda())
     before = clib.proxtv_set_option(b"repair_jobs", 1)
@@ -248,6 +258,7 @@ def test_jobs_repair_is_gated_by_the_sampled_statistic(clib):
     workgroups fail in numbers (lambda >= 0.65 on unit noise); the headline regime never pays for it."""
     import torch
     from proxtv_amd import device
+    _needs_xlink(clib)
     X = device.to_colmajor(torch.from_numpy(np.random.default_rng(7).standard_normal((2048, 2048))).cuda())
     assert clib.proxtv_set_option(b"repair_jobs", 1) in (0, 1, 2)
     if clib.proxtv_set_option(b"chunk_mode", -1) != -1:
