@@ -235,9 +235,30 @@ struct ReplayCheck {
     bool has = false;                  // a piece the lane is responsible for exists
     double vfirst = 0.0, vlast = 0.0;  // value of the first / last of them
 };
+// The rows BEFORE a lane's chunk that belong to the first piece ending in it: their sum and count.  rebuild_owned reads them itself where
+// nothing can have replaced them yet (lanes of one wave, in lockstep); where the lanes of a fibre sit in different waves (the strided
+// tiles) an UNPROVEN lane's rows before its chunk may be somebody else's to write -- the two walks disagree, that is what unproven
+// means -- so the caller takes the sums while the window still holds samples only, before the barrier behind the walks.
+struct PiecePrefix {
+    double s = 0.0, cnt = 0.0;
+};
+template <class Win>
+__device__ __forceinline__ PiecePrefix first_piece_prefix(const Win &win, const ChunkRec &rec, int cs, int start) {
+    PiecePrefix pre;
+    int a0 = cs;
+    if (rec.mine != 0 && rec.mine != kCodeBad) a0 = (int)(rec.mine >> 1);
+    else if (start == 0) a0 = 0;
+    for (int k = a0; k < cs; k++) {
+        pre.s += win.y(k);
+        pre.cnt += 1.0;
+    }
+    return pre;
+}
+
 template <class F, bool WEIGHTED, int C, int UNROLL = 1, bool TAB = false, class RT = const double *, int TSZ = 0, int FULL = 0, class Win>
 __device__ __forceinline__ void rebuild_owned(Win &win, const ChunkRec &rec, int cs, int ce, int len, int start, bool link_ok,
-                                              int wlo, bool block_last, double lam, RT rt = RT(), ReplayCheck *chk = nullptr) {
+                                              int wlo, bool block_last, double lam, RT rt = RT(), ReplayCheck *chk = nullptr,
+                                              const PiecePrefix *pre = nullptr) {
     auto quotient = [&](double num, double count) {
         if constexpr (TAB) {
             if (TSZ > 0 && count >= (double)TSZ) {
@@ -250,22 +271,33 @@ __device__ __forceinline__ void rebuild_owned(Win &win, const ChunkRec &rec, int
             return over(num);
         }
     };
-    // An unproven lane keeps to its own rows -- but if its own walk bent exactly at the chunk start, the piece that
-    // begins there must still come out right: a repair walk that arrives at that very bend hands over to this chunk.
-    int a0 = cs;
+    // An unproven lane keeps to its own rows (w0 = cs) -- but what it writes there must be what ITS walk found, the first piece
+    // included: a repair walk whose last bend is this lane's `mine` hands over to this chunk and trusts every row of it behind the
+    // piece the repair walk itself was in.  So the first piece is summed from its true first row (a0 = the bend `mine`) whether the
+    // link is proven or not.  (Until round 5 an unproven lane summed from cs: harmless as long as the repair walk and the lane's
+    // walk end that piece in the same place -- the repair walk rewrites exactly those rows -- and wrong when a knot with a jump of
+    // exactly zero, as the late iterations of a Dykstra / DR loop produce them, is a bend to one walk and none to the other: the two
+    // walks round differently.  tools/case_diag.py, profiles/NOTES_r05.md "session 17".)
+    int a0 = cs, w0 = cs;
     double hprev = 0.0;
     if (rec.mine != 0 && rec.mine != kCodeBad) {
         const int at = (int)(rec.mine >> 1);
         const double r = WEIGHTED ? win.r(at - 1) : lam;
         hprev = (rec.mine & 1u) ? r : -r;
-        a0 = link_ok ? at : cs;
+        a0 = at;
+        w0 = link_ok ? at : cs;
     } else if (link_ok && start == 0) {
-        a0 = 0;   // no bend yet and the walk began at the fibre start: the first piece starts at sample 0, height 0
+        a0 = w0 = 0;   // no bend yet and the walk began at the fibre start: the first piece starts at sample 0, height 0
     }
     double s = 0.0, cnt = 0.0;
-    for (int k = a0; k < cs; k++) {   // rows of earlier chunks that belong to the piece ending here (usually none or a few)
-        s += win.y(k);
-        cnt += 1.0;
+    if (pre && a0 < cs) {             // (summed by the caller while the window held samples only: first_piece_prefix, same order)
+        s = pre->s;
+        cnt = pre->cnt;
+    } else {
+        for (int k = a0; k < cs; k++) {   // rows of earlier chunks that belong to the piece ending here (usually none or a few)
+            s += win.y(k);
+            cnt += 1.0;
+        }
     }
     // the piece that covers ce - 1 and ends beyond it: the block's last lane writes its rows inside the block
     auto tail_value = [&](double s_, double cnt_, double hprev_, double &cur_) {
@@ -440,7 +472,7 @@ __device__ __forceinline__ void rebuild_owned(Win &win, const ChunkRec &rec, int
         // first (it is in a register), the earlier ones -- none for a one-sample piece -- in a short loop.  No second pass,
         // nothing waits in registers (sixteen parked values spill at the 128-VGPR budget of two workgroups per CU).
         // Same recurrence, same branch form: everything but the running sum and the count happens where a piece ends.
-        int first = a0 > wlo ? a0 : wlo;
+        int first = w0 > wlo ? w0 : wlo;
 #pragma unroll UNROLL
         for (int u = 0; u < C; u++) {
             const bool in = FULL != 0 || cs + u < ce;
@@ -463,7 +495,7 @@ __device__ __forceinline__ void rebuild_owned(Win &win, const ChunkRec &rec, int
         return;
     }
     if (have) {
-        const int from = a0 > wlo ? a0 : wlo;
+        const int from = w0 > wlo ? w0 : wlo;
         for (int k = cs - 1; k >= from; k--) win.put(k, F::fuse(win.y(k), cur));
     }
 }

@@ -465,6 +465,7 @@ __global__ __launch_bounds__(64 * NW, SHORT ? 16 / NW : (FW < 64 ? ((WEIGHTED ? 
         const int start = max(0, cs - H);
         const LdsWin<WEIGHTED, PITCH> win{(lds_double *)Yp + fl, (lds_double *)Wp + fl, lo};
         ChunkRec rec;
+        PiecePrefix head;
         bool certain = false;
         if (has_chunk && !(plan.ablate & 1)) {
             Walker w;
@@ -490,6 +491,9 @@ __global__ __launch_bounds__(64 * NW, SHORT ? 16 / NW : (FW < 64 ? ((WEIGHTED ? 
                 walker_start<WEIGHTED>(w, win, start, p.lam);
             }
             walk_chunk<OP, WEIGHTED, PITCH, ROUNDS, TAB>(w, rec, win, far, hi, cs, ce, len, p.lam, (unsigned)(unsigned long long)rtab);
+            // (the rows before the chunk that belong to its first piece, summed while the window holds samples only: an unproven lane's
+            //  are not its own to rely on once the rebuild has begun in other waves -- chunkcore.hpp first_piece_prefix)
+            if (!GUARD) head = first_piece_prefix(win, rec, cs, start);
         }
         // ---- prove the links between consecutive chunks ------------------------------------------------------------------
         codes[ch * FW + fl] = rec.next;
@@ -574,6 +578,8 @@ __global__ __launch_bounds__(64 * NW, SHORT ? 16 / NW : (FW < 64 ? ((WEIGHTED ? 
         }
         int wlo = cs_wg;   // first row this lane may write
         if (GUARD) {
+            // (second chances may have replaced the record: the sums of first_piece_prefix now, before the barrier every rebuild waits behind)
+            if (has_chunk && !(plan.ablate & 1)) head = first_piece_prefix(win, rec, cs, start);
             // one lane mask per wave: FW = 64 -> the wave's chunk ; FW = 32 -> its two chunks, the later one in the high half
             const unsigned long long mask = __ballot(bad);
             if (lane == 0) unproven[wave] = mask;
@@ -587,10 +593,10 @@ __global__ __launch_bounds__(64 * NW, SHORT ? 16 / NW : (FW < 64 ? ((WEIGHTED ? 
         const bool inner = inner_block(q);   // (uniform over the workgroup)
         if (inner && !(plan.ablate & 1))
             rebuild_owned<Op<OP>, WEIGHTED, C, PTV_TILE_UNROLL, TAB, lds_double *, (ROUNDS ? TS : 0), 1>(win, rec, cs, ce, len, start, !bad, wlo,
-                                                                                                       ch == NCH - 1, p.lam, (lds_double *)rtab);
+                                                                                                       ch == NCH - 1, p.lam, (lds_double *)rtab, nullptr, &head);
         else if (has_chunk && !(plan.ablate & 1))
             rebuild_owned<Op<OP>, WEIGHTED, C, PTV_TILE_UNROLL, TAB, lds_double *, (ROUNDS ? TS : 0)>(win, rec, cs, ce, len, start, !bad, wlo,
-                                                                                                    ch == NCH - 1 || ce == len, p.lam, (lds_double *)rtab);
+                                                                                                    ch == NCH - 1 || ce == len, p.lam, (lds_double *)rtab, nullptr, &head);
         __syncthreads();
         if (kb == 0) trace_mark(plan, 4);
 

@@ -135,6 +135,35 @@ int chunk_fibre(const double *y, const double *w, double lam, int len, int H, in
             if (bad[(size_t)wave] && *first_bad < 0) *first_bad = cur;
             if (*first_bad < 0 && rec.next != 0) cur = (int)(rec.next >> 1);
         }
+        // the rows before each chunk that belong to its first piece, summed before anything is replaced (chunkcore.hpp first_piece_prefix:
+        // the tile kernels take them before the barrier behind the walks, the lanes of an along-fibre wave read them in lockstep)
+        std::vector<PiecePrefix> pres((size_t)NW);
+        for (int wave = 0; wave < NW; wave++)
+            if (has[(size_t)wave] && !recs[(size_t)wave].failed)
+                pres[(size_t)wave] = first_piece_prefix(win, recs[(size_t)wave], cs_wg + wave * C, starts[(size_t)wave]);
+        // An UNPROVEN lane's own rows, up to the last piece that ends in its chunk, must be what a walk restarted at the lane's `mine` bend
+        // produces: a repair walk whose last bend is that one hands over to the chunk and trusts them (sweep_kernels.hpp RepairBook::bend).
+        // Checked on a copy of the window -- in the block itself lanes that are right overwrite rows of lanes that are wrong.
+        for (int wave = 0; wave < NW; wave++) {
+            const ChunkRec &rec = recs[(size_t)wave];
+            if (!has[(size_t)wave] || !bad[(size_t)wave] || rec.failed || rec.mine == 0 || rec.ends == 0) continue;
+            const int cs = cs_wg + wave * C, ce = std::min(cs + C, len);
+            HostWin copy = win;
+            rebuild_owned<Identity, WEIGHTED, C>(copy, rec, cs, ce, len, starts[(size_t)wave], false, cs_wg, wave == NW - 1 || ce == len, lam,
+                                                 (const double *)nullptr, nullptr, &pres[(size_t)wave]);
+            const int e_last = cs + 31 - __builtin_clz(rec.ends);
+            std::vector<double> xr((size_t)len, 0.0);
+            HostSource src{y, w, xr.data(), e_last};
+            Walker wk;
+            walker_restart<WEIGHTED>(wk, src, (int)(rec.mine >> 1), (int)(rec.mine & 1u), len, lam);
+            walker_run<WEIGHTED>(wk, src, len, lam);
+            double scale = 1.0;
+            for (int k = cs; k <= e_last; k++) scale = std::max(scale, std::fabs(y[k]));
+            for (int k = cs; k <= e_last; k++)
+                if (!(std::fabs(copy.y(k) - xr[(size_t)k]) <= 1e-12 * scale)) (*write_errors)++;
+            for (int k = win.lo; k < cs; k++)
+                if (copy.writes[(size_t)(k - win.lo)] != 0) (*write_errors)++;   // ... and it keeps to its own rows
+        }
         // rebuild, lanes in random order (they run concurrently on the device)
         std::vector<int> order;
         for (int wave = 0; wave < NW; wave++)
@@ -146,15 +175,18 @@ int chunk_fibre(const double *y, const double *w, double lam, int len, int H, in
             //  registers (FULL = 2), as the kernels' interior blocks / segments run them -- in turn with the general form, so that every
             //  form meets every kind of neighbour)
             const int form = (ce - cs == C && ce <= len - 1) ? (q + wave) % 3 : 0;
+            const PiecePrefix *pre = &pres[(size_t)wave];
             if (form == 2 && !WEIGHTED)
                 rebuild_owned<F, WEIGHTED, C, 1, false, const double *, 0, 2>(win, recs[(size_t)wave], cs, ce, len, starts[(size_t)wave],
-                                                                              !bad[(size_t)wave], cs_wg, wave == NW - 1 || ce == len, lam);
+                                                                              !bad[(size_t)wave], cs_wg, wave == NW - 1 || ce == len, lam,
+                                                                              (const double *)nullptr, nullptr, pre);
             else if (form >= 1)
                 rebuild_owned<F, WEIGHTED, C, 1, false, const double *, 0, 1>(win, recs[(size_t)wave], cs, ce, len, starts[(size_t)wave],
-                                                                              !bad[(size_t)wave], cs_wg, wave == NW - 1 || ce == len, lam);
+                                                                              !bad[(size_t)wave], cs_wg, wave == NW - 1 || ce == len, lam,
+                                                                              (const double *)nullptr, nullptr, pre);
             else
                 rebuild_owned<F, WEIGHTED, C>(win, recs[(size_t)wave], cs, ce, len, starts[(size_t)wave], !bad[(size_t)wave], cs_wg,
-                                              wave == NW - 1 || ce == len, lam);
+                                              wave == NW - 1 || ce == len, lam, (const double *)nullptr, nullptr, pre);
         }
         bool clean = true;
         for (int wave = 0; wave < NW; wave++) clean = clean && !bad[(size_t)wave];

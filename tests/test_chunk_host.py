@@ -110,3 +110,20 @@ def test_short_fibres_whole_in_window(harness, oracle):
         assert bad == 0, (t, n, lam, bad)
         assert np.max(np.abs(x - oracle.tv1_linearized(y, lam))) <= 1e-13 * max(1.0, np.max(np.abs(y))), (t, n, lam)
 
+
+
+def test_unproven_lane_is_right_about_its_own_rows_degenerate_knot(harness, oracle):
+    """tests/golden/degenerate_knot_fibre.npz (make_degenerate_knot.py): a knot whose jump is zero up to rounding between samples 93 and 94.
+    On the device the repair walk bends there and the chunk's own walk does not; the repair walk hands over to the chunk because both
+    came from the same bend at 80, and rows 94, 95 are then the chunk's -- right only if an UNPROVEN lane values its first piece from the
+    piece's true first row (chunkcore.hpp rebuild_owned, a0 / w0).  The harness checks that for every unproven lane (write_errors)."""
+    g = np.load(os.path.join(HERE, "golden", "degenerate_knot_fibre.npz"))
+    y, lam = np.ascontiguousarray(g["y"]), float(g["lam"])
+    assert np.max(np.abs(oracle.tv1_linearized(y, lam) - g["expected"])) == 0.0
+    unproven = 0
+    for seed in range(4):
+        for (H, T, NW) in ((16, 8, 64), (16, 8, 32), (16, 8, 8), (64, 64, 64)):
+            x, fb, we = run(harness, y, lam, H=H, T=T, NW=NW, seed=seed)
+            assert we == 0, (seed, H, T, NW, we)
+            unproven += fb >= 0
+    assert unproven > 0   # (at this lambda nothing is known a priori: the links fail and the repair walk is what the device runs)

@@ -268,3 +268,31 @@ def test_jobs_repair_is_gated_by_the_sampled_statistic(clib):
     assert clib.proxtv_debug_counter(b"repair_jobs_launches") == c0
     device.tv1_2d(X, 0.7)
     assert clib.proxtv_debug_counter(b"repair_jobs_launches") > c0
+
+
+def test_hand_over_at_a_knot_with_zero_jump(ptv, clib, oracle, modes):
+    """tests/golden/degenerate_knot_fibre.npz: late in a Dykstra loop the operand reproduces the previous result on whole stretches and the
+    string has knots whose jump is zero up to rounding -- a bend to the repair walk, none to the chunk's own walk, which round differently.
+    The repair walk hands over to a chunk that began at the same bend; the chunk's rows behind it must be what the chunk's walk found
+    (round 5, fuzz seed 111 case 1260: rows 94, 95 were off by 0.028 in pinned mode 0).  As columns (along-fibre kernel) and as rows
+    (tiles), alone and among noise, every pinned rung."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "degenerate_knot_fibre.npz"))
+    y, lam, want = g["y"], float(g["lam"]), g["expected"]
+    rng = np.random.default_rng(47)
+    cols = np.asfortranarray(np.repeat(y[:, None], 96, axis=1))
+    cols[:, 1::3] += 1e-3 * rng.standard_normal((y.size, 32))          # (neighbours that are not the same fibre)
+    want_cols = np.apply_along_axis(lambda f: oracle.tv1_hybrid(np.ascontiguousarray(f), lam), 0, cols)
+    assert np.max(np.abs(want_cols[:, 0] - want)) <= 1e-14
+    for m in (0, 1, 2, 3, 4, 5, -1):
+        modes(m)
+        assert_close(ptv.tv1_1d(y, lam), want, tol=1e-12, what=f"the fibre alone, mode {m}")
+        assert_close(ptv.tvgen(cols, [lam], [1], [1]), want_cols, tol=1e-12, what=f"as columns, mode {m}")
+        rows = np.asfortranarray(cols.T)
+        assert_close(ptv.tvgen(rows, [lam], [2], [1]), want_cols.T, tol=1e-12, what=f"as rows, mode {m}")
+        for jobs in (0, 2):
+            before = clib.proxtv_set_option(b"repair_jobs", jobs)
+            try:
+                assert_close(ptv.tvgen(cols, [lam], [1], [1]), want_cols, tol=1e-12, what=f"as columns, mode {m}, repair_jobs {jobs}")
+            finally:
+                clib.proxtv_set_option(b"repair_jobs", before)

@@ -3,6 +3,7 @@
 decades, every geometry mode pinned or adaptive, weighted / unweighted, every 2-D solver and both sweep directions.
 
     python tools/fuzz.py [seconds] [seed] [nd | long]
+    python tools/fuzz.py <seconds> <seed> from <case>     # the same sequence, run from case number <case> on (tools/case_diag.py)
 """
 import os, sys, time
 import numpy as np
@@ -29,8 +30,9 @@ def rel(a, b, scale=0.0):
     return float(np.max(np.abs(a - b))) / max(float(np.max(np.abs(b))), float(scale), 1e-300)
 
 
-def run(budget=60.0, seed=0, tol=1e-9, sizes=(2, 3, 17, 95, 96, 97, 130, 257, 400, 700, 1100)):
-    """Returns (cases, worst relative error, description of the worst case); raises AssertionError on a mismatch."""
+def run(budget=60.0, seed=0, tol=1e-9, sizes=(2, 3, 17, 95, 96, 97, 130, 257, 400, 700, 1100), skip=0):
+    """Returns (cases, worst relative error, description of the worst case); raises AssertionError on a mismatch.
+    `skip`: the first cases of the seed are drawn but not run (to replay a run from shortly before a case of interest)."""
     lib = _lib.require_device()
     orc = cpu.oracle()
     rng = np.random.default_rng(seed)
@@ -54,20 +56,25 @@ def run(budget=60.0, seed=0, tol=1e-9, sizes=(2, 3, 17, 95, 96, 97, 130, 257, 40
             lib.proxtv_set_option(b"repair_jobs", jobs)                        # (failed links across workgroups one lane each: never / seeded / always)
             lib.proxtv_set_option(b"replay", rep)                              # (the along-fibre kernel verifying its last sweep's structure)
             what = int(rng.integers(0, 6))
+            W1 = W2 = None
+            its = d = 0
+            if what == 1: W1, W2 = rng.uniform(0, 2 * lam, (M - 1, N)), rng.uniform(0, 2 * lam, (M, N - 1))
+            elif what == 4: its = int(rng.integers(1, 40))
+            elif what == 5: d = int(rng.integers(1, 3))
+            if cases < skip:          # (replaying a run up to a case of interest: the draws only)
+                cases += 1
+                continue
             if what == 0:
                 got, want, name = ptv.tv1_2d(X, lam), orc.dr2(X, lam)[0], "dr2"
             elif what == 1:
-                W1, W2 = rng.uniform(0, 2 * lam, (M - 1, N)), rng.uniform(0, 2 * lam, (M, N - 1))
                 got, want, name = ptv.tv1w_2d(X, W1, W2), orc.dr2w(X, W1, W2)[0], "dr2w"
             elif what == 2:
                 got, want, name = ptv.tv1_2d(X, lam, method="pd"), orc.pd2(X, [lam, lam], [1, 2])[0], "pd2"
             elif what == 3:
                 got, want, name = ptv.tv1_2d(X, lam, method="yang"), orc.yang2(X, lam)[0], "yang2"
             elif what == 4:
-                its = int(rng.integers(1, 40))
                 got, want, name = ptv.tv1_2d(X, lam, method="kolmogorov", max_iters=its), orc.kolmogorov2(X, lam, its)[0], "kolmogorov"
             else:
-                d = int(rng.integers(1, 3))
                 got = ptv.tvgen(X, [lam], [d], [1])
                 want = np.apply_along_axis(lambda f: orc.tv1_hybrid(np.ascontiguousarray(f), lam), d - 1, X)
                 name = f"prox dim {d}"
@@ -150,6 +157,10 @@ if __name__ == "__main__":
     if len(sys.argv) > 3 and sys.argv[3] == "long":   # fibres of 2-4 segments / 9-34 blocks: the machinery across workgroups
         n, w, where = run(float(sys.argv[1]), int(sys.argv[2]), sizes=(96, 130, 1089, 2177, 3300, 4353))
         print(f"fuzz long fibres: {n} cases, worst relative error {w:.2e} ({where})")
+        sys.exit(0)
+    if len(sys.argv) > 4 and sys.argv[3] == "from":
+        n, w, where = run(float(sys.argv[1]), int(sys.argv[2]), skip=int(sys.argv[4]))
+        print(f"fuzz from case {sys.argv[4]}: {n} cases, worst relative error {w:.2e} ({where})")
         sys.exit(0)
     n, w, where = run(float(sys.argv[1]) if len(sys.argv) > 1 else 60.0, int(sys.argv[2]) if len(sys.argv) > 2 else 0)
     print(f"fuzz: {n} cases, worst relative error {w:.2e} ({where})")

@@ -168,4 +168,36 @@ s15)  # the remaining settings of the earlier rounds' validation matrix on the f
   PROXTV_XLINK=0 timeout 600 python -m pytest $FILES -m gpu -q > $OUT/pytest_xlink0.log 2>&1; echo "in-kernel link check off: $(tail -1 $OUT/pytest_xlink0.log)" | tee -a $OUT/summary.txt
   PROXTV_CHUNK_MODE=5 timeout 600 python -m pytest $FILES -m gpu -q > $OUT/pytest_mode5.log 2>&1; echo "pinned to rung 5: $(tail -1 $OUT/pytest_mode5.log)" | tee -a $OUT/summary.txt
   ;;
+s16)  # the table of tools/seed_check.py with the round's kernels, one more soak (which found: pinned rung 0, PD2, lambda = 6 -- s17, s18)
+  timeout 300 python tools/seed_check.py > $OUT/seed_check.txt 2>&1
+  { python tools/fuzz.py 80 111; python tools/fuzz.py 30 112 long; } 2>&1 | grep "^fuzz\|MISMATCH" | tee $OUT/fuzz3.txt
+  ;;
+s17)  # the mismatch of s16 localised: which iteration of the Dykstra loop, which fibre (the case travels as an .npy next to the call)
+  timeout 150 python tools/case_diag.py $CASE_NPY $CASE_LAMBDA $OUT > $OUT/diag.txt 2>&1; cat $OUT/diag.txt
+  ;;
+s18)  # ... and the fibre: the operand of the 1-D prox that case_diag.py saved, one column alone, the pinned rungs, the kernel options
+  timeout 120 python tools/case_diag2.py $CASE_NPZ 797 $OUT > $OUT/diag2.txt 2>&1; cat $OUT/diag2.txt
+  ;;
+s19)  # the hand-over of a repair walk to an unproven chunk made right (chunkcore.hpp: the first piece of an unproven lane is summed from
+      # its true first row; tiles: before the barrier behind the walks): the whole suite, the soak from the case that failed on, the
+      # headline's HBM counters and kernel stats and bench line for the new build
+  timeout 600 python -m pytest tests -m gpu -x -q > $OUT/pytest_default.log 2>&1; echo "default: $(tail -1 $OUT/pytest_default.log)" | tee $OUT/summary.txt
+  grep -q " passed" $OUT/pytest_default.log && ! grep -q "failed" $OUT/pytest_default.log || { tail -40 $OUT/pytest_default.log; exit 1; }
+  { timeout 100 python tools/fuzz.py 45 111 from 1256; timeout 60 python tools/fuzz.py 25 113; } 2>&1 | grep "^fuzz\|MISMATCH" | tee $OUT/fuzz.txt
+  R=$GRAFT_REPO_ROOT
+  (cd /tmp; KC_SETS=fetch,write timeout 300 python $R/tools/kernel_counters.py collect $R/$OUT/kc calib+dr0.1 > $R/$OUT/kc_collect.log 2>&1
+   timeout 120 rocprofv3 --kernel-trace --stats -d $R/$OUT/prof_bench -o x -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-c5 > $R/$OUT/bench_under_rocprof.log 2>&1)
+  python tools/rocprof_summary.py $(find $OUT/prof_bench -name "x_results.db" | head -1) > $OUT/kernel_stats.txt 2>&1; head -12 $OUT/kernel_stats.txt
+  python tools/kernel_counters.py report $OUT/kc > $OUT/kernel_counters.txt 2>&1
+  python tools/kernel_counters.py traffic $OUT/kc > $OUT/pmc_traffic.json 2>&1; cat $OUT/pmc_traffic.json
+  rm -rf $OUT/prof_bench; find $OUT/kc -name "*.db" -delete
+  cp $OUT/pmc_traffic.json profiles/r05_pmc_traffic.json   # (bench.py reads the traffic of the build it runs)
+  timeout 300 python bench.py > $OUT/bench_line.json 2> $OUT/bench.err; cat $OUT/bench_line.json
+  ;;
+s20)  # the build of s19 under the settings that steer work to the repair kernels and the tiles' robust instantiations
+  FILES="tests/test_gpu_chunk_repair.py tests/test_gpu_parity_2d.py"
+  PROXTV_CHUNK_MODE=1 timeout 100 python -m pytest $FILES -m gpu -x -q > $OUT/pytest_mode1.log 2>&1; echo "pinned to rung 1: $(tail -1 $OUT/pytest_mode1.log)" | tee $OUT/summary.txt
+  PROXTV_REPAIR_JOBS=2 timeout 100 python -m pytest $FILES -m gpu -x -q > $OUT/pytest_jobs2.log 2>&1; echo "repair_jobs=2: $(tail -1 $OUT/pytest_jobs2.log)" | tee -a $OUT/summary.txt
+  PROXTV_CHUNK_MODE=0 timeout 100 python -m pytest $FILES -m gpu -x -q > $OUT/pytest_mode0.log 2>&1; echo "pinned to rung 0: $(tail -1 $OUT/pytest_mode0.log)" | tee -a $OUT/summary.txt
+  ;;
 esac
