@@ -41,6 +41,10 @@ struct Fibre {
 // one chunk's speculative walk: from a bend known a priori, else from a free end H samples before the chunk; it owns the pieces that
 // END inside the chunk -- their rows before the chunk too if its link is proven, else only its own rows (the rows between the last
 // true bend and an unproven chunk belong to the repair walk) -- and stops when the piece over its last sample is closed
+// g_legacy (unweighted): an UNPROVEN chunk values the first piece that ends in it the way the device's rebuild did until round 5 -- the
+// closed form over its OWN rows only, (sum_{cs..to} y + h_to - h_mine) / (to - cs + 1) -- instead of the piece's value.  Harmless while
+// the repair walk and the chunk's walk end that piece in the same place; test_repair_model_host.py shows that it is not with g_mirror.
+int g_legacy = 0;
 struct SpecSource {
     const Fibre &f;
     double *x;       // nullptr: codes only
@@ -48,18 +52,52 @@ struct SpecSource {
     bool proven;
     link_t mine = 0, next = 0;
     bool done = false;
+    int pend_to = -1;          // (g_legacy: the piece waits for the bend that ends it -- its type is part of the closed form)
+    link_t began = 0;          // the bend the piece in hand began at (0: the walk's free end)
     double y(int i) const { return f.y[i]; }
     double r(int i) const { return f.w[i]; }
+    void legacy_flush(int end_type) {   // end_type < 0: the fibre's end
+        if (pend_to < 0) return;
+        double sum = 0.0;
+        for (int k = cs; k <= pend_to; k++) sum += f.y[k];
+        const double hprev = began ? ((began & 1u) ? f.lam : -f.lam) : 0.0;
+        const double hk = end_type < 0 ? 0.0 : (end_type ? f.lam : -f.lam);
+        const double v = (sum + (hk - hprev)) / (double)(pend_to - cs + 1);
+        for (int k = cs; k <= pend_to; k++) x[k] = v;
+        pend_to = -1;
+    }
     void piece(int from, int to, double v) {
-        if (x && to >= cs && to < ce) for (int k = proven ? from : std::max(from, cs); k <= to; k++) x[k] = v;
+        if (x && to >= cs && to < ce) {
+            if (g_legacy && !f.w && !proven && from < cs) pend_to = to;
+            else for (int k = proven ? from : std::max(from, cs); k <= to; k++) x[k] = v;
+        }
         if (to >= ce - 1) done = true;
     }
     void bend(int at, int type) {
+        if (x) legacy_flush(type);
         const link_t code = ((link_t)at << 1) | (link_t)type;
+        began = code;
         if (at <= cs) mine = code;
         if (at <= ce) next = code;
     }
     bool keep_going(int) const { return !done; }
+};
+
+// The same walk on the mirrored fibre scaled by three (-3 y, penalties x 3, bend types swapped): the same problem, so a valid walk of it
+// -- but every product and quotient rounds differently (the walker by itself is mirror-symmetric: the scaling is what does it).  With
+// g_mirror set the speculative chunk walks run like that while the repair walks do not: two walks that cut a fibre differently wherever
+// the string touches the tube to the last bit, as the device's two walks do (walk_interior's table reciprocals against walker_run's
+// quotients).  What the repairs join must agree to rounding all the same.
+int g_mirror = 0;
+constexpr double kMirrorScale = 3.0;
+template <class S>
+struct Mirrored {
+    S &s;
+    double y(int i) const { return -kMirrorScale * s.y(i); }
+    double r(int i) const { return kMirrorScale * s.r(i); }
+    void piece(int from, int to, double v) { s.piece(from, to, -v / kMirrorScale); }
+    void bend(int at, int type) { s.bend(at, type ^ 1); }
+    bool keep_going(int i) const { return s.keep_going(i); }
 };
 
 struct CertainWin {
@@ -80,21 +118,34 @@ void speculate(Fibre &f) {
         SpecSource s{f, pass ? f.spec.data() : nullptr, cs, ce, pass ? !f.doubt[c] : false};
         Walker w;
         bool certain = false;
+        Mirrored<SpecSource> ms{s};
+        // (EVERY chunk walk, the ones from the fibre's start too: on the device all lanes of a chunk kernel run the same instructions, and
+        //  two of them that have bent at the same place are in the same state to the last bit -- walker_restart_with is walk_interior's
+        //  post-bend state -- so they cut the fibre alike from there on.  A model that mixed roundings AMONG the chunk walks leaves rows
+        //  unwritten between a chunk that starts at a bend known a priori and its predecessor; the device cannot.)
+        const bool mirror = g_mirror != 0;
         if (cs - f.H <= 0) {
-            walker_start<W>(w, s, 0, f.lam);
+            if (mirror) walker_start<W>(w, ms, 0, kMirrorScale * f.lam);
+            else walker_start<W>(w, s, 0, f.lam);
         } else {
             int type = 0;
             CertainWin win{f.y, f.w};
             const int cat = certain_bend_before<W, 14>(win, cs, f.len, f.lam, type);
             if (cat >= 0) {
-                walker_restart<W>(w, s, cat, type, f.len, f.lam);
+                if (mirror) walker_restart<W>(w, ms, cat, type ^ 1, f.len, kMirrorScale * f.lam);
+                else walker_restart<W>(w, s, cat, type, f.len, f.lam);
                 s.mine = s.next = ((link_t)cat << 1) | (link_t)type;
                 certain = true;
+            } else if (mirror) {
+                walker_start<W>(w, ms, cs - f.H, kMirrorScale * f.lam);
             } else {
                 walker_start<W>(w, s, cs - f.H, f.lam);
             }
         }
-        walker_run<W>(w, s, f.len, f.lam);
+        s.began = s.mine;   // (a start at a bend known a priori: the first piece began there)
+        if (mirror) walker_run<W>(w, ms, f.len, kMirrorScale * f.lam);
+        else walker_run<W>(w, s, f.len, f.lam);
+        if (pass) s.legacy_flush(-1);
         if (pass) continue;
         f.mine[c] = certain ? (s.mine | kCertain) : s.mine;
         f.next[c] = s.next;
@@ -359,6 +410,17 @@ extern "C" {
 //             fibres JOBS / JOBS_G declined (2) ; stale records read by SEQ_OLD ; fibres where the speculation alone is already exact ;
 //             chunks in doubt although their recorded start is the true bend (it happens)
 // worst[0..3]: largest absolute error of the four repairs.  Returns the index of the first fibre SEQ_OLD gets wrong (-1: none).
+void model_set_mirror(int on) { g_mirror = on; }
+void model_set_legacy(int on) { g_legacy = on; }
+// one unweighted fibre laid open: the speculative outputs, the codes, the links in doubt, the bounded sequential repair's result
+void model_one(const double *y, int len, double lam, int C, int H, double *spec, double *repaired, unsigned *mine, unsigned *next, char *doubt) {
+    Fibre f{y, nullptr, len, C, H, (len + C - 1) / C, lam, {}, {}, {}, {}};
+    speculate<false>(f);
+    std::vector<double> x = f.spec;
+    repair_seq<false>(f, x.data(), true, nullptr);
+    for (int k = 0; k < len; k++) { spec[k] = f.spec[k]; repaired[k] = x[k]; }
+    for (int c = 0; c < f.NC; c++) { mine[c] = f.mine[c]; next[c] = f.next[c]; doubt[c] = f.doubt[c]; }
+}
 int model_fibres(const double *Y, const double *Wt, int count, int len, double lam, int C, int H, int window, int max_jobs, long *out, double *worst) {
     return Wt ? model_run<true>(Y, Wt, count, len, lam, C, H, window, max_jobs, out, worst)
               : model_run<false>(Y, nullptr, count, len, lam, C, H, window, max_jobs, out, worst);

@@ -127,3 +127,55 @@ def test_unproven_lane_is_right_about_its_own_rows_degenerate_knot(harness, orac
             assert we == 0, (seed, H, T, NW, we)
             unproven += fb >= 0
     assert unproven > 0   # (at this lambda nothing is known a priori: the links fail and the repair walk is what the device runs)
+
+
+def _zero_jump_fibre(rng, n, lam):
+    """A fibre built backwards from its solution: x piecewise constant with some knots whose jump is exactly zero, dual z with |z| <= 1,
+    z = +-1 at every knot (the zero-jump ones too) and at some rows inside pieces; y = x + lam (z_{i-1} - z_i).  In floating point the
+    string touches the tube to the last bit at those places: a bend to one rounding of the walk, none to another -- what the operands
+    of the late iterations of a Dykstra / DR loop look like."""
+    x = np.empty(n)
+    z = rng.uniform(-0.95, 0.95, n - 1) if n > 1 else np.zeros(0)
+    i, v = 0, float(rng.standard_normal())
+    while i < n:
+        L = int(rng.integers(1, 41))
+        x[i:i + L] = v
+        e = i + L - 1                      # the piece's last row; edge e joins it to the next piece
+        if e < n - 1:
+            kind = rng.random()
+            if kind < 0.4:                 # zero jump, the wall touched all the same
+                z[e] = float(rng.choice([-1.0, 1.0]))
+                nv = v
+            else:
+                step = float(abs(rng.standard_normal())) * rng.choice([1e-3, 1.0])
+                up = rng.random() < 0.5
+                z[e] = 1.0 if up else -1.0
+                nv = v + step if up else v - step
+            for k in range(i, min(e, n - 1)):   # rows inside the piece that touch a wall without bending
+                if rng.random() < 0.05:
+                    z[k] = float(rng.choice([-1.0, 1.0]))
+            v = nv
+        i += L
+    zz = np.concatenate(([0.0], z, [0.0]))
+    return x + lam * (zz[:-1] - zz[1:]), x
+
+
+def test_chunked_walk_on_fibres_with_zero_jump_knots(harness, oracle):
+    """Ties everywhere (see _zero_jump_fibre): walks that round differently may cut such a fibre differently, and every place where the
+    scheme joins what two walks found has to survive that -- the links (code equality), the rebuild's ownership, and an unproven lane's
+    own rows, which a repair walk may hand over to (round 5: tests/golden/degenerate_knot_fibre.npz).  Values agree to rounding whatever
+    the cut."""
+    rng = np.random.default_rng(7)
+    covered = total = 0
+    for t in range(400):
+        n = int(rng.integers(2, 900))
+        lam = float(rng.choice([0.05, 0.5, 3.0]) * (0.5 + rng.random()))
+        y, x = _zero_jump_fibre(rng, n, lam)
+        truth = oracle.tv1_linearized(y, lam)
+        scale = max(1.0, np.max(np.abs(y)))
+        assert np.max(np.abs(truth - x)) <= 1e-12 * scale      # (the construction: x IS the prox of y)
+        for (H, T, NW, past) in ((16, 8, 8, 0), (16, 8, 64, 0), (16, 8, 32, 0), (64, 64, 64, 0), (64, 64, 8, 0), (16, 8, 3, 1)):
+            got, fb, we = run(harness, y, lam, H=H, T=T, NW=NW, past=past, seed=t)
+            covered += check(got, fb, we, truth, H, scale)
+            total += n
+    assert covered > 0.2 * total    # (long pieces at these penalties: most links are the repair kernel's)

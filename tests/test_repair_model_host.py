@@ -2,7 +2,8 @@
 chunk walks with the device's ownership rule, then the repairs): the sequential repair that jumps from link in doubt to link in doubt
 -- with the scan behind a jump unbounded, as in round 4, and bounded -- and the repair with one walk per failing link whose validity
 is decided afterwards (sweep_repair_jobs_kernel, option repair_jobs), each against the sequential walk of the whole fibre.  Exact by construction, every one
-of them, on every fibre: what DESIGN 5 argues, checked here on a sample small enough for the CPU suite."""
+of them, on every fibre: what DESIGN 6 argues, checked here on a sample small enough for the CPU suite -- with both families of walks rounding
+alike, and with the chunk walks rounding differently from the repair walks (ties: knots with zero jump)."""
 import ctypes as C
 import os
 import subprocess
@@ -59,3 +60,50 @@ def test_every_repair_is_exact(model, max_jobs, weighted):
             handled += int(out[0] - out[8])
     assert doubts > 1000          # the sample has links in doubt by the thousand ...
     assert handled > 50           # ... and fibres the jobs repair took on itself
+
+
+def test_repairs_join_walks_that_break_ties_differently(model):
+    """The device's chunk walks (table reciprocals) and repair walks (IEEE quotients) round differently, so where the string touches the tube
+    to the last bit -- knots with zero jump, the operands of late Dykstra / DR iterations -- one bends and the other does not.  Modelled:
+    the speculative walks run on the mirrored fibre (ties break the other way), the repair walks do not, the fibres are built backwards
+    from solutions full of such knots (test_chunk_host._zero_jump_fibre).  Every repair must still end within rounding of the true prox:
+    a hand-over joins two valid walks at a bend, never inside a piece (DESIGN 6 ii')."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_chunk_host import _zero_jump_fibre
+    model.model_set_mirror.argtypes = [C.c_int]
+    rng = np.random.default_rng(33)
+    n, m = 80, 1024
+    doubts = differ = 0
+    try:
+        for lam in (0.3, 1.0, 3.0, 6.0):
+            X = np.ascontiguousarray(np.stack([_zero_jump_fibre(rng, m, lam)[0] for _ in range(n)]))
+            codes = []
+            for mirror in (0, 1):
+                model.model_set_mirror(mirror)
+                out, worst = np.zeros(12, dtype=np.int64), np.zeros(4)
+                first = model.model_fibres(X.ctypes.data, None, n, m, lam, 16, 16, 128, 4, out.ctypes.data, worst.ctypes.data)
+                assert first == -1 and not out[3:7].any(), f"lambda {lam} mirror {mirror}: fibres wrong after seq old / seq new / jobs / jobs+guard {out[3:7]}, worst {worst}"
+                codes.append((int(out[0]), int(out[1])))
+                doubts += int(out[1])
+            differ += codes[0] != codes[1]
+        # ... and the test has teeth: with the rebuild's semantics of rounds 1-4 for an unproven chunk (its first piece valued over its own
+        # rows only: model_set_legacy) the same fibres come out WRONG as soon as the two families of walks round differently -- what the GPU
+        # soak of round 5 found (tests/golden/degenerate_knot_fibre.npz) -- and right as long as they do not, which is why four rounds of
+        # tests never saw it.
+        model.model_set_legacy.argtypes = [C.c_int]
+        wrong = {0: 0, 1: 0}
+        for mirror in (0, 1):
+            model.model_set_mirror(mirror)
+            model.model_set_legacy(1)
+            for lam in (1.0, 3.0, 6.0):
+                X = np.ascontiguousarray(np.stack([_zero_jump_fibre(rng, m, lam)[0] for _ in range(n)]))
+                out, worst = np.zeros(12, dtype=np.int64), np.zeros(4)
+                model.model_fibres(X.ctypes.data, None, n, m, lam, 16, 16, 128, 4, out.ctypes.data, worst.ctypes.data)
+                wrong[mirror] += int(out[4])      # (the bounded sequential repair)
+        assert wrong[0] == 0 and wrong[1] > 0, wrong
+    finally:
+        model.model_set_mirror(0)
+        model.model_set_legacy(0)
+    assert doubts > 1000
+    assert differ > 0     # (the mirrored walks do cut these fibres differently: the links in doubt are not the same set)
