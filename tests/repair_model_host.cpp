@@ -45,6 +45,7 @@ struct Fibre {
 // closed form over its OWN rows only, (sum_{cs..to} y + h_to - h_mine) / (to - cs + 1) -- instead of the piece's value.  Harmless while
 // the repair walk and the chunk's walk end that piece in the same place; test_repair_model_host.py shows that it is not with g_mirror.
 int g_legacy = 0;
+int g_table = 0;
 struct SpecSource {
     const Fibre &f;
     double *x;       // nullptr: codes only
@@ -56,6 +57,9 @@ struct SpecSource {
     link_t began = 0;          // the bend the piece in hand began at (0: the walk's free end)
     double y(int i) const { return f.y[i]; }
     double r(int i) const { return f.w[i]; }
+    // g_table: the quotient by a piece's span the way the device's chunk walks take it (walk_asm.hpp, table loops: ONE product with the
+    // correctly rounded reciprocal) while the repair walks divide (walker.hpp over_span): the device's two roundings, on the host
+    double over_span(double a, int span) const { return g_table ? a * (1.0 / (double)span) : a / span; }
     void legacy_flush(int end_type) {   // end_type < 0: the fibre's end
         if (pend_to < 0) return;
         double sum = 0.0;
@@ -412,6 +416,7 @@ extern "C" {
 // worst[0..3]: largest absolute error of the four repairs.  Returns the index of the first fibre SEQ_OLD gets wrong (-1: none).
 void model_set_mirror(int on) { g_mirror = on; }
 void model_set_legacy(int on) { g_legacy = on; }
+void model_set_table(int on) { g_table = on; }
 // one unweighted fibre laid open: the speculative outputs, the codes, the links in doubt, the bounded sequential repair's result
 void model_one(const double *y, int len, double lam, int C, int H, double *spec, double *repaired, unsigned *mine, unsigned *next, char *doubt) {
     Fibre f{y, nullptr, len, C, H, (len + C - 1) / C, lam, {}, {}, {}, {}};

@@ -87,6 +87,17 @@ def test_repairs_join_walks_that_break_ties_differently(model):
                 codes.append((int(out[0]), int(out[1])))
                 doubts += int(out[1])
             differ += codes[0] != codes[1]
+        # the device's own pair of roundings (model_set_table: chunk walks multiply by the rounded reciprocal of the span, repair walks divide)
+        model.model_set_table.argtypes = [C.c_int]
+        model.model_set_mirror(0)
+        model.model_set_table(1)
+        for lam in (0.3, 1.0, 3.0, 6.0):
+            X = np.ascontiguousarray(np.stack([_zero_jump_fibre(rng, m, lam)[0] for _ in range(n)]))
+            for Cc in (16, 17):
+                out, worst = np.zeros(12, dtype=np.int64), np.zeros(4)
+                first = model.model_fibres(X.ctypes.data, None, n, m, lam, Cc, 16, 128, 4, out.ctypes.data, worst.ctypes.data)
+                assert first == -1 and not out[3:7].any(), f"lambda {lam} table, chunks of {Cc}: wrong after seq old / seq new / jobs / jobs+guard {out[3:7]}, worst {worst}"
+        model.model_set_table(0)
         # ... and the test has teeth: with the rebuild's semantics of rounds 1-4 for an unproven chunk (its first piece valued over its own
         # rows only: model_set_legacy) the same fibres come out WRONG as soon as the two families of walks round differently -- what the GPU
         # soak of round 5 found (tests/golden/degenerate_knot_fibre.npz) -- and right as long as they do not, which is why four rounds of
@@ -105,5 +116,40 @@ def test_repairs_join_walks_that_break_ties_differently(model):
     finally:
         model.model_set_mirror(0)
         model.model_set_legacy(0)
+        model.model_set_table(0)
     assert doubts > 1000
     assert differ > 0     # (the mirrored walks do cut these fibres differently: the links in doubt are not the same set)
+
+
+def test_the_gpu_failure_of_round_5_on_the_host(model):
+    """tests/golden/degenerate_knot_fibre.npz through the model with the DEVICE's two roundings -- chunk walks take the quotient by a piece's
+    span as one product with the rounded reciprocal (the table loops of walk_asm.hpp), repair walks divide -- in the along-fibre kernel's
+    geometry (chunks of 17, zones of 16).  With the rebuild's semantics of rounds 1-4 the model gives what the GPU gave: rows 94 and 95 off
+    by 0.0277, everything else exact.  With the semantics as they are now: exact."""
+    from oracle import cpu
+    g = np.load(os.path.join(ROOT, "tests", "golden", "degenerate_knot_fibre.npz"))
+    y, lam, want = np.ascontiguousarray(g["y"]), float(g["lam"]), g["expected"]
+    assert np.array_equal(cpu.oracle().tv1_linearized(y, lam), want)
+    for fn in (model.model_set_legacy, model.model_set_table, model.model_set_mirror):
+        fn.argtypes = [C.c_int]
+    model.model_one.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_int] + [C.c_void_p] * 5
+    n, Cc = y.size, 17
+    NC = (n + Cc - 1) // Cc
+
+    def run(legacy, table):
+        model.model_set_legacy(legacy)
+        model.model_set_table(table)
+        spec, rep = np.zeros(n), np.zeros(n)
+        mine, nxt, doubt = np.zeros(NC, dtype=np.uint32), np.zeros(NC, dtype=np.uint32), np.zeros(NC, dtype=np.int8)
+        model.model_one(y.ctypes.data, n, lam, Cc, 16, spec.ctypes.data, rep.ctypes.data, mine.ctypes.data, nxt.ctypes.data, doubt.ctypes.data)
+        return rep
+    try:
+        assert np.max(np.abs(run(0, 0) - want)) <= 1e-13
+        assert np.max(np.abs(run(1, 0) - want)) <= 1e-13          # (old semantics, one rounding for all walks: nothing to see)
+        assert np.max(np.abs(run(0, 1) - want)) <= 1e-13          # (the device's roundings, the semantics as they are now)
+        err = np.abs(run(1, 1) - want)                            # (the device's roundings, the old semantics: the GPU's result)
+        assert sorted(np.nonzero(err > 1e-12)[0].tolist()) == [94, 95], np.nonzero(err > 1e-12)[0]
+        assert abs(err[94] - 0.02768669311175276) < 1e-12 and abs(err[95] - err[94]) < 1e-15, err[94:96]
+    finally:
+        model.model_set_legacy(0)
+        model.model_set_table(0)
