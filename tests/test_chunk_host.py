@@ -12,10 +12,14 @@ import pytest
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-@pytest.fixture(scope="module")
-def harness():
+@pytest.fixture(scope="module", params=["quotients", "table reciprocals"])
+def harness(request):
+    """Twice: every span quotient an IEEE division (one rounding for all walks), and -DPTV_TABLE_RECIP -- the chunk walks and the rebuild
+    multiply by the rounded reciprocal of the span as the device's table loops do, while walker_run (the reference of the unproven-lane
+    check, the device's repair walks) divides: the device's two roundings, ties cut differently."""
     out = os.path.join(tempfile.mkdtemp(prefix="ptv_ch_"), "libchunk_host.so")
-    subprocess.run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-pthread", "-o", out,
+    flags = ["-DPTV_TABLE_RECIP"] if request.param == "table reciprocals" else []
+    subprocess.run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-pthread", *flags, "-o", out,
                     os.path.join(HERE, "host_harness.cpp")], check=True)
     lib = C.CDLL(out)
     lib.host_whole_fibre.argtypes = [C.c_void_p, C.c_double, C.c_int, C.c_int, C.c_void_p]
