@@ -72,6 +72,13 @@ struct Identity {
     static double fuse(double, double x) { return x; }
 };
 
+// What the chunk kernels leave for the repair kernel, per chunk (global index: block * NW + lane): the published codes and the flag.
+// Filled by chunk_fibre when set (host_set_state_buffers): tests/test_sweep_end_to_end_host.py hands them, with the outputs, to the repair
+// model (tests/repair_model_host.cpp model_repair_state) -- one sweep end to end on the host.
+unsigned *g_state_mine = nullptr, *g_state_next = nullptr;
+char *g_state_bad = nullptr;
+int g_state_cap = 0, g_state_C = 0;
+
 template <bool WEIGHTED, bool PAST, class F, int C = 16>
 int chunk_fibre(const double *y, const double *w, double lam, int len, int H, int T, int NW, int seed, double *x,
                 int *first_bad, int *write_errors) {
@@ -134,6 +141,17 @@ int chunk_fibre(const double *y, const double *w, double lam, int len, int H, in
             bad[(size_t)wave] = rec.failed || (linked && (rec.mine == 0 || rec.mine != prev));
             if (bad[(size_t)wave] && *first_bad < 0) *first_bad = cur;
             if (*first_bad < 0 && rec.next != 0) cur = (int)(rec.next >> 1);
+        }
+        if (g_state_mine) {   // as sweep_chunk_kernel / sweep_along_kernel publish them
+            g_state_C = C;
+            for (int wave = 0; wave < NW; wave++) {
+                const int c = q * NW + wave;
+                if (!has[(size_t)wave] || c >= g_state_cap) continue;
+                const ChunkRec &rec = recs[(size_t)wave];
+                g_state_mine[c] = rec.failed ? kCodeBad : ((certain[(size_t)wave] && rec.mine != kCodeBad) ? (rec.mine | kCodeCertain) : rec.mine);
+                g_state_next[c] = rec.failed ? 0u : rec.next;
+                g_state_bad[c] = bad[(size_t)wave];
+            }
         }
         // the rows before each chunk that belong to its first piece, summed before anything is replaced (chunkcore.hpp first_piece_prefix:
         // the tile kernels take them before the barrier behind the walks, the lanes of an along-fibre wave read them in lockstep)
@@ -388,6 +406,12 @@ extern "C" {
 // sample from which the repair kernel would rewrite (the restart of the last proven bend before the first unproven
 // chunk): outputs before it are final.  write_errors counts rows of clean blocks that were not
 // written exactly once, and rows outside a block that were written at all.
+// (nullptr: off)  Returns nothing; host_state_chunk() tells the chunk length of the last run.
+void host_set_state_buffers(unsigned *mine, unsigned *next, char *bad, int cap) {
+    g_state_mine = mine; g_state_next = next; g_state_bad = bad; g_state_cap = cap;
+}
+int host_state_chunk() { return g_state_C; }
+
 int host_chunk_fibre(const double *y, const double *w, double lam, int len, int H, int T, int NW, int past, int seed,
                      double *x, int *first_bad, int *write_errors) {
     const bool refl = seed & 1;   // both rebuild flavours: outputs that depend on the row's own sample, and that do not

@@ -414,6 +414,24 @@ extern "C" {
 //             fibres JOBS / JOBS_G declined (2) ; stale records read by SEQ_OLD ; fibres where the speculation alone is already exact ;
 //             chunks in doubt although their recorded start is the true bend (it happens)
 // worst[0..3]: largest absolute error of the four repairs.  Returns the index of the first fibre SEQ_OLD gets wrong (-1: none).
+// The repairs on a state that was NOT speculated here: outputs, codes and flags as tests/host_harness.cpp's chunk_fibre left them (the
+// device's lane code: walk_interior, the links, rebuild_owned).  which: 0 = bounded sequential repair, 1 = jobs (what it declines: sequential).
+// Returns the number of walks (sequential) or 1 / 0 (jobs took the fibre / declined).
+int model_repair_state(const double *y, int len, double lam, int C, int H, double *x, const unsigned *mine, const unsigned *next, const char *bad,
+                       int which) {
+    Fibre f{y, nullptr, len, C, H, (len + C - 1) / C, lam, {}, {}, {}, {}};
+    f.mine.assign(mine, mine + f.NC);
+    f.next.assign(next, next + f.NC);
+    f.doubt.assign(bad, bad + f.NC);
+    f.doubt[0] = 0;
+    f.spec.assign(x, x + len);
+    if (which == 0) return repair_seq<false>(f, x, true, nullptr);
+    if (!repair_jobs<false>(f, x, true, 128, 4)) {
+        repair_seq<false>(f, x, true, nullptr);
+        return 0;
+    }
+    return 1;
+}
 void model_set_mirror(int on) { g_mirror = on; }
 void model_set_legacy(int on) { g_legacy = on; }
 void model_set_table(int on) { g_table = on; }

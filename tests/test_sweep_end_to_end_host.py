@@ -1,0 +1,94 @@
+"""One sweep of the speculative-chunk scheme END TO END on the host: the lanes' own code (tests/host_harness.cpp: walk_interior, the links,
+rebuild_owned with the ownership rule) leaves outputs, codes and flags; the repair stage (tests/repair_model_host.cpp: the scan that jumps,
+the hand-over of a repair walk to a chunk, the jobs) finishes from exactly that state; the result must be the prox of the fibre everywhere.
+
+Rounds 1-4 tested the two halves apart -- the harness up to the first unproven link, the repair model on idealised chunk outputs -- and the
+seam between them is where round 5's GPU soak found a wrong result (an unproven lane's rows, trusted by a repair walk that handed over to
+it).  Run with one rounding for all walks and with the device's two (-DPTV_TABLE_RECIP: chunk walks and rebuild multiply by the rounded
+reciprocal of a span, repair walks divide), on ordinary fibres and on fibres full of knots with zero jump.
+
+Checked against the code before the fix (rebuild_owned summing an unproven lane's first piece from its own first row): with one rounding
+both tests pass; with the device's two the fixture comes out with rows 94, 95 off by 0.027686693111752758 -- the GPU's number -- in the
+along-fibre geometry, and the random sweeps find a case of their own."""
+import ctypes as C
+import os
+import subprocess
+import tempfile
+
+import numpy as np
+import pytest
+
+from test_chunk_host import _zero_jump_fibre, families
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module", params=["quotients", "table reciprocals"])
+def stage(request):
+    d = tempfile.mkdtemp(prefix="ptv_e2e_")
+    flags = ["-DPTV_TABLE_RECIP"] if request.param == "table reciprocals" else []
+    subprocess.run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-pthread", *flags, "-o", os.path.join(d, "lanes.so"),
+                    os.path.join(HERE, "host_harness.cpp")], check=True)
+    subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", os.path.join(d, "repair.so"), os.path.join(HERE, "repair_model_host.cpp")], check=True)
+    lanes, repair = C.CDLL(os.path.join(d, "lanes.so")), C.CDLL(os.path.join(d, "repair.so"))
+    lanes.host_chunk_fibre.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                       C.c_void_p, C.c_void_p, C.c_void_p]
+    lanes.host_set_state_buffers.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    repair.model_repair_state.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    return lanes, repair
+
+
+def sweep(stage, y, lam, H, T, NW, seed, which):
+    """-> (outputs after the repair, chunks flagged, walks)"""
+    lanes, repair = stage
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    n = y.size
+    cap = n // 16 + 2
+    mine, nxt, bad = np.zeros(cap, dtype=np.uint32), np.zeros(cap, dtype=np.uint32), np.zeros(cap, dtype=np.int8)
+    x = np.full(n, np.nan)
+    fb, we = C.c_int(0), C.c_int(0)
+    lanes.host_set_state_buffers(mine.ctypes.data, nxt.ctypes.data, bad.ctypes.data, cap)
+    try:
+        lanes.host_chunk_fibre(y.ctypes.data, None, lam, n, H, T, NW, 0, seed & ~1, x.ctypes.data, C.byref(fb), C.byref(we))   # (even seed: outputs are the prox values)
+        Cn = lanes.host_state_chunk()
+    finally:
+        lanes.host_set_state_buffers(None, None, None, 0)
+    assert we.value == 0
+    walks = repair.model_repair_state(y.ctypes.data, n, lam, Cn, H, x.ctypes.data, mine.ctypes.data, nxt.ctypes.data, bad.ctypes.data, which)
+    return x, int(bad[:(n + Cn - 1) // Cn].sum()), walks
+
+
+GEOMETRIES = ((16, 8, 64), (16, 8, 8), (16, 8, 32), (16, 8, 3))   # along-fibre kernel (chunks of 17) ; tiles (chunks of 16)
+
+
+def test_fixture_of_round_5_end_to_end(stage, oracle):
+    g = np.load(os.path.join(HERE, "golden", "degenerate_knot_fibre.npz"))
+    y, lam, want = g["y"], float(g["lam"]), g["expected"]
+    for (H, T, NW) in GEOMETRIES:
+        for which in (0, 1):
+            x, flagged, _ = sweep(stage, y, lam, H, T, NW, 0, which)
+            assert flagged > 0
+            assert np.max(np.abs(x - want)) <= 1e-13, (H, T, NW, which, np.nonzero(np.abs(x - want) > 1e-13)[0][:8])
+
+
+def test_sweeps_end_to_end(stage, oracle):
+    rng = np.random.default_rng(17)
+    flagged = fibres = 0
+    for t in range(500):
+        n = int(rng.integers(40, 1500))
+        if t % 2:
+            lam = float(rng.choice([0.05, 0.5, 3.0]) * (0.5 + rng.random()))
+            y = _zero_jump_fibre(rng, n, lam)[0]
+        else:
+            y = families(rng, n)
+            lam = float(rng.choice([0.02, 0.1, 0.3, 1.0, 4.0]) * abs(rng.standard_normal()) + 1e-3)
+        want = oracle.tv1_linearized(np.ascontiguousarray(y), lam)
+        scale = max(1.0, float(np.max(np.abs(y))))
+        for (H, T, NW) in GEOMETRIES:
+            for which in (0, 1):
+                x, nf, _ = sweep(stage, y, lam, H, T, NW, 2 * t, which)
+                e = np.max(np.abs(x - want))
+                assert e <= 1e-12 * scale, (t, n, lam, (H, T, NW), which, e, np.nonzero(np.abs(x - want) > 1e-12 * scale)[0][:8])
+                flagged += nf
+                fibres += 1
+    assert flagged > 5 * fibres     # (the repair stage had work on this mix: several flagged chunks per fibre on average)
