@@ -406,6 +406,15 @@ int model_run(const double *Y, const double *Wt, int count, int len, double lam,
     }
     return first_bad;
 }
+template <bool W>
+int repair_state(Fibre &f, double *x, int which) {
+    if (which == 0) return repair_seq<W>(f, x, true, nullptr);
+    if (!repair_jobs<W>(f, x, true, 128, 4)) {
+        repair_seq<W>(f, x, true, nullptr);
+        return 0;
+    }
+    return 1;
+}
 }  // namespace
 
 extern "C" {
@@ -417,20 +426,16 @@ extern "C" {
 // The repairs on a state that was NOT speculated here: outputs, codes and flags as tests/host_harness.cpp's chunk_fibre left them (the
 // device's lane code: walk_interior, the links, rebuild_owned).  which: 0 = bounded sequential repair, 1 = jobs (what it declines: sequential).
 // Returns the number of walks (sequential) or 1 / 0 (jobs took the fibre / declined).
-int model_repair_state(const double *y, int len, double lam, int C, int H, double *x, const unsigned *mine, const unsigned *next, const char *bad,
-                       int which) {
-    Fibre f{y, nullptr, len, C, H, (len + C - 1) / C, lam, {}, {}, {}, {}};
+// (wt: per-edge penalties, len - 1 of them, or nullptr: lam on every edge)
+int model_repair_state(const double *y, const double *wt, int len, double lam, int C, int H, double *x, const unsigned *mine, const unsigned *next,
+                       const char *bad, int which) {
+    Fibre f{y, wt, len, C, H, (len + C - 1) / C, lam, {}, {}, {}, {}};
     f.mine.assign(mine, mine + f.NC);
     f.next.assign(next, next + f.NC);
     f.doubt.assign(bad, bad + f.NC);
     f.doubt[0] = 0;
     f.spec.assign(x, x + len);
-    if (which == 0) return repair_seq<false>(f, x, true, nullptr);
-    if (!repair_jobs<false>(f, x, true, 128, 4)) {
-        repair_seq<false>(f, x, true, nullptr);
-        return 0;
-    }
-    return 1;
+    return wt ? repair_state<true>(f, x, which) : repair_state<false>(f, x, which);
 }
 void model_set_mirror(int on) { g_mirror = on; }
 void model_set_legacy(int on) { g_legacy = on; }

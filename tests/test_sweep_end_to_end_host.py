@@ -34,14 +34,16 @@ def stage(request):
     lanes.host_chunk_fibre.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                        C.c_void_p, C.c_void_p, C.c_void_p]
     lanes.host_set_state_buffers.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
-    repair.model_repair_state.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    repair.model_repair_state.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
     return lanes, repair
 
 
-def sweep(stage, y, lam, H, T, NW, seed, which):
-    """-> (outputs after the repair, chunks flagged, walks)"""
+def sweep(stage, y, lam, H, T, NW, seed, which, w=None):
+    """-> (outputs after the repair, chunks flagged, walks); w: per-edge penalties (y.size - 1) instead of lam"""
     lanes, repair = stage
     y = np.ascontiguousarray(y, dtype=np.float64)
+    if w is not None:
+        w = np.ascontiguousarray(w, dtype=np.float64)
     n = y.size
     cap = n // 16 + 2
     mine, nxt, bad = np.zeros(cap, dtype=np.uint32), np.zeros(cap, dtype=np.uint32), np.zeros(cap, dtype=np.int8)
@@ -49,12 +51,12 @@ def sweep(stage, y, lam, H, T, NW, seed, which):
     fb, we = C.c_int(0), C.c_int(0)
     lanes.host_set_state_buffers(mine.ctypes.data, nxt.ctypes.data, bad.ctypes.data, cap)
     try:
-        lanes.host_chunk_fibre(y.ctypes.data, None, lam, n, H, T, NW, 0, seed & ~1, x.ctypes.data, C.byref(fb), C.byref(we))   # (even seed: outputs are the prox values)
+        lanes.host_chunk_fibre(y.ctypes.data, None if w is None else w.ctypes.data, lam, n, H, T, NW, 0, seed & ~1, x.ctypes.data, C.byref(fb), C.byref(we))   # (even seed: outputs are the prox values)
         Cn = lanes.host_state_chunk()
     finally:
         lanes.host_set_state_buffers(None, None, None, 0)
     assert we.value == 0
-    walks = repair.model_repair_state(y.ctypes.data, n, lam, Cn, H, x.ctypes.data, mine.ctypes.data, nxt.ctypes.data, bad.ctypes.data, which)
+    walks = repair.model_repair_state(y.ctypes.data, None if w is None else w.ctypes.data, n, lam, Cn, H, x.ctypes.data, mine.ctypes.data, nxt.ctypes.data, bad.ctypes.data, which)
     return x, int(bad[:(n + Cn - 1) // Cn].sum()), walks
 
 
@@ -92,3 +94,22 @@ def test_sweeps_end_to_end(stage, oracle):
                 flagged += nf
                 fibres += 1
     assert flagged > 5 * fibres     # (the repair stage had work on this mix: several flagged chunks per fibre on average)
+
+
+def test_weighted_sweeps_end_to_end(stage, oracle):
+    rng = np.random.default_rng(19)
+    flagged = fibres = 0
+    for t in range(300):
+        n = int(rng.integers(40, 1200))
+        y = families(rng, n)
+        w = rng.uniform(0.05, 1.0, n - 1) * float(rng.choice([0.1, 0.5, 2.0, 6.0]))
+        want = oracle.tv1_weighted(np.ascontiguousarray(y), np.ascontiguousarray(w))
+        scale = max(1.0, float(np.max(np.abs(y))))
+        for (H, T, NW) in ((16, 8, 8), (16, 8, 3)):
+            for which in (0, 1):
+                x, nf, _ = sweep(stage, y, 0.0, H, T, NW, 2 * t, which, w=w)
+                e = np.max(np.abs(x - want))
+                assert e <= 1e-12 * scale, (t, n, (H, T, NW), which, e, np.nonzero(np.abs(x - want) > 1e-12 * scale)[0][:8])
+                flagged += nf
+                fibres += 1
+    assert flagged > 2 * fibres
