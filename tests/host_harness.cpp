@@ -178,7 +178,7 @@ int chunk_fibre(const double *y, const double *w, double lam, int len, int H, in
             double scale = 1.0;
             for (int k = cs; k <= e_last; k++) scale = std::max(scale, std::fabs(y[k]));
             for (int k = cs; k <= e_last; k++)
-                if (!(std::fabs(copy.y(k) - xr[(size_t)k]) <= 1e-12 * scale)) (*write_errors)++;
+                if (!(std::fabs(copy.y(k) - xr[(size_t)k]) <= 1e-10 * scale)) (*write_errors)++;   // (the fibre's last piece: closed form against the walker's kEps tests, ~1e-11)
             for (int k = win.lo; k < cs; k++)
                 if (copy.writes[(size_t)(k - win.lo)] != 0) (*write_errors)++;   // ... and it keeps to its own rows
         }
