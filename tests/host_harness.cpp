@@ -194,16 +194,22 @@ int chunk_fibre(const double *y, const double *w, double lam, int len, int H, in
             //  form meets every kind of neighbour)
             const int form = (ce - cs == C && ce <= len - 1) ? (q + wave) % 3 : 0;
             const PiecePrefix *pre = &pres[(size_t)wave];
+            // zones longer than a chunk: a lane's writes stop at the nearest unproven chunk before it (GUARD in sweep_chunk_kernel, `wlo` in
+            // sweep_along_kernel) -- there may be PROVEN chunks before that one, rows the repair kernel will not touch
+            int wlo = cs_wg;
+            if (H > C)
+                for (int k = wave - 1; k >= 0; k--)
+                    if (bad[(size_t)k]) { wlo = cs_wg + k * C; break; }
             if (form == 2 && !WEIGHTED)
                 rebuild_owned<F, WEIGHTED, C, 1, false, const double *, 0, 2>(win, recs[(size_t)wave], cs, ce, len, starts[(size_t)wave],
-                                                                              !bad[(size_t)wave], cs_wg, wave == NW - 1 || ce == len, lam,
+                                                                              !bad[(size_t)wave], wlo, wave == NW - 1 || ce == len, lam,
                                                                               (const double *)nullptr, nullptr, pre);
             else if (form >= 1)
                 rebuild_owned<F, WEIGHTED, C, 1, false, const double *, 0, 1>(win, recs[(size_t)wave], cs, ce, len, starts[(size_t)wave],
-                                                                              !bad[(size_t)wave], cs_wg, wave == NW - 1 || ce == len, lam,
+                                                                              !bad[(size_t)wave], wlo, wave == NW - 1 || ce == len, lam,
                                                                               (const double *)nullptr, nullptr, pre);
             else
-                rebuild_owned<F, WEIGHTED, C>(win, recs[(size_t)wave], cs, ce, len, starts[(size_t)wave], !bad[(size_t)wave], cs_wg,
+                rebuild_owned<F, WEIGHTED, C>(win, recs[(size_t)wave], cs, ce, len, starts[(size_t)wave], !bad[(size_t)wave], wlo,
                                               wave == NW - 1 || ce == len, lam, (const double *)nullptr, nullptr, pre);
         }
         bool clean = true;

@@ -60,7 +60,10 @@ def sweep(stage, y, lam, H, T, NW, seed, which, w=None):
     return x, int(bad[:(n + Cn - 1) // Cn].sum()), walks
 
 
-GEOMETRIES = ((16, 8, 64), (16, 8, 8), (16, 8, 32), (16, 8, 3))   # along-fibre kernel (chunks of 17) ; tiles (chunks of 16)
+GEOMETRIES = ((16, 8, 64), (16, 8, 8), (16, 8, 32), (16, 8, 3),   # along-fibre kernel (chunks of 17) ; tiles (chunks of 16)
+              (64, 64, 64), (64, 64, 16), (64, 64, 8))            # 64-sample zones: chunks of 31 / 16, a lane's writes stop at the nearest
+                                                                  # unproven chunk before it (without that guard this test fails: proven
+                                                                  # chunks of a walk that is off write over rows the repair never visits)
 
 
 def test_fixture_of_round_5_end_to_end(stage, oracle):
@@ -69,7 +72,7 @@ def test_fixture_of_round_5_end_to_end(stage, oracle):
     for (H, T, NW) in GEOMETRIES:
         for which in (0, 1):
             x, flagged, _ = sweep(stage, y, lam, H, T, NW, 0, which)
-            assert flagged > 0
+            assert flagged > 0 or H > 16     # (64-sample zones prove every link of this fibre)
             assert np.max(np.abs(x - want)) <= 1e-13, (H, T, NW, which, np.nonzero(np.abs(x - want) > 1e-13)[0][:8])
 
 

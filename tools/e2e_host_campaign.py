@@ -4,7 +4,7 @@ sample of this that the CPU suite runs).  The lanes' own code (tests/host_harnes
 rebuild_owned) leaves outputs, codes and flags; the repair model (tests/repair_model_host.cpp) finishes; the oracle judges.  Fibres: every
 third column of the operands of iterations 26 / 31 / 34 of PD2 on the image of round 5's failing soak case, then -- until the time is up --
 operands of iterations 20 and 32 of emulated PD2 and DR loops on random images of tools/fuzz.py's families, and fibres built backwards from
-solutions full of zero-jump knots.  Geometries: the along-fibre kernel's (64 / 32 / 16 chunks of 17) and the tiles' (8 / 3 chunks of 16);
+solutions full of zero-jump knots.  Geometries: the along-fibre kernel's (64 / 32 / 16 chunks of 17; 64-sample zones: chunks of 31) and the tiles' (8 / 3 chunks of 16, zones of 16 and 64);
 sequential and jobs repair.
 
 A deviation above 1e-12 (relative to the fibre's largest sample) is reported with where it is: END = inside the fibre's last piece, where the
@@ -24,7 +24,7 @@ import test_sweep_end_to_end_host as e2e
 from test_chunk_host import _zero_jump_fibre
 import make_degenerate_knot as mk
 
-GEO = ((16, 8, 64), (16, 8, 32), (16, 8, 16), (16, 8, 8), (16, 8, 3))
+GEO = ((16, 8, 64), (16, 8, 32), (16, 8, 16), (16, 8, 8), (16, 8, 3), (64, 64, 64), (64, 64, 16), (64, 64, 8))
 
 
 class Request:
