@@ -75,6 +75,7 @@ struct Identity {
 // What the chunk kernels leave for the repair kernel, per chunk (global index: block * NW + lane): the published codes and the flag.
 // Filled by chunk_fibre when set (host_set_state_buffers): tests/test_sweep_end_to_end_host.py hands them, with the outputs, to the repair
 // model (tests/repair_model_host.cpp model_repair_state) -- one sweep end to end on the host.
+int g_rounds = 0;   // second-chance rounds inside a block (host_set_rounds; 0 = the plain instantiations)
 unsigned *g_state_mine = nullptr, *g_state_next = nullptr;
 char *g_state_bad = nullptr;
 int g_state_cap = 0, g_state_C = 0;
@@ -88,6 +89,7 @@ int chunk_fibre(const double *y, const double *w, double lam, int len, int H, in
     *first_bad = -1;
     *write_errors = 0;
     unsigned carried = 0;       // `next` code of the previous block's last lane
+    bool carried_proven = false;   // ... and whether that lane's link was proven (second chances walk from proven predecessors only)
     int cur = 0;                // restart of the true walk's last bend so far (what the repair kernel would restart from)
     int bends = 0;
     for (int q = 0; q < Q; q++) {
@@ -133,14 +135,54 @@ int chunk_fibre(const double *y, const double *w, double lam, int len, int H, in
             bends += __builtin_popcount(rec.ends);
         }
         // links (kernel: through LDS inside the block, by the repair kernel between blocks)
+        auto examine = [&]() {
+            for (int wave = 0; wave < NW; wave++) {
+                if (!has[(size_t)wave]) continue;
+                const ChunkRec &rec = recs[(size_t)wave];
+                const bool linked = !(starts[(size_t)wave] == 0 || certain[(size_t)wave]) && (wave > 0 || q > 0);
+                const unsigned prev = wave > 0 ? recs[(size_t)wave - 1].next : carried;
+                bad[(size_t)wave] = rec.failed || (linked && (rec.mine == 0 || rec.mine != prev));
+            }
+        };
+        examine();
+        // Second chances (the robust instantiations, plan.rounds > 0): a lane whose link fails while its predecessor's holds walks its chunk
+        // again from the predecessor's last bend; links are looked at afresh after every round (sweep_chunk_kernel / sweep_along_kernel).
+        for (int round = 0; round < g_rounds; round++) {
+            bool any = false;
+            for (int wave = 0; wave < NW; wave++) any = any || (has[(size_t)wave] && bad[(size_t)wave]);
+            if (!any) break;
+            std::vector<char> proven((size_t)NW, 0);
+            for (int wave = 0; wave < NW; wave++) proven[(size_t)wave] = has[(size_t)wave] && !bad[(size_t)wave];
+            std::vector<ChunkRec> again((size_t)NW);
+            std::vector<char> walked((size_t)NW, 0);
+            for (int wave = 0; wave < NW; wave++) {
+                if (!has[(size_t)wave] || !bad[(size_t)wave] || !(wave > 0 || q > 0)) continue;
+                const unsigned prev = wave > 0 ? recs[(size_t)wave - 1].next : carried;
+                const bool prev_proven = wave > 0 ? proven[(size_t)wave - 1] != 0 : carried_proven;
+                const int at = (int)(prev >> 1);
+                if (!prev_proven || prev == 0 || at <= std::max(win.lo, 0)) continue;
+                const int cs = cs_wg + wave * C, ce = std::min(cs + C, len);
+                ChunkRec &rec = again[(size_t)wave];
+                Walker wk;
+                walker_restart_with<WEIGHTED>(wk, at, (int)(prev & 1u), len, lam, win.y(at), WEIGHTED ? win.r(at - 1) : 0.0,
+                                              (WEIGHTED && at < len - 1) ? win.r(at) : 0.0);
+                rec.mine = rec.next = rec.last = prev;
+                walk_interior<WEIGHTED>(wk, rec, win, std::min(len - 1, win.hi), cs, ce, lam);
+                TailSource<WEIGHTED, PAST, 48, HostWin, HostFar> tail{win, far, rec, cs, ce, win.hi, len};
+                walker_run<WEIGHTED>(wk, tail, len, lam);
+                walked[(size_t)wave] = !rec.failed;
+            }
+            for (int wave = 0; wave < NW; wave++)
+                if (walked[(size_t)wave]) {
+                    recs[(size_t)wave] = again[(size_t)wave];
+                    certain[(size_t)wave] = 0;   // from now on the chunk hangs on its predecessor like any other
+                }
+            examine();
+        }
         for (int wave = 0; wave < NW; wave++) {
             if (!has[(size_t)wave]) continue;
-            const ChunkRec &rec = recs[(size_t)wave];
-            const bool linked = !(starts[(size_t)wave] == 0 || certain[(size_t)wave]) && (wave > 0 || q > 0);
-            const unsigned prev = wave > 0 ? recs[(size_t)wave - 1].next : carried;
-            bad[(size_t)wave] = rec.failed || (linked && (rec.mine == 0 || rec.mine != prev));
             if (bad[(size_t)wave] && *first_bad < 0) *first_bad = cur;
-            if (*first_bad < 0 && rec.next != 0) cur = (int)(rec.next >> 1);
+            if (*first_bad < 0 && recs[(size_t)wave].next != 0) cur = (int)(recs[(size_t)wave].next >> 1);
         }
         if (g_state_mine) {   // as sweep_chunk_kernel / sweep_along_kernel publish them
             g_state_C = C;
@@ -197,7 +239,7 @@ int chunk_fibre(const double *y, const double *w, double lam, int len, int H, in
             // zones longer than a chunk: a lane's writes stop at the nearest unproven chunk before it (GUARD in sweep_chunk_kernel, `wlo` in
             // sweep_along_kernel) -- there may be PROVEN chunks before that one, rows the repair kernel will not touch
             int wlo = cs_wg;
-            if (H > C)
+            if (H > C || g_rounds > 0)   // (second-chance walks reach back anywhere in the block)
                 for (int k = wave - 1; k >= 0; k--)
                     if (bad[(size_t)k]) { wlo = cs_wg + k * C; break; }
             if (form == 2 && !WEIGHTED)
@@ -226,6 +268,7 @@ int chunk_fibre(const double *y, const double *w, double lam, int len, int H, in
         int lastw = NW - 1;
         while (lastw > 0 && !has[(size_t)lastw]) lastw--;
         carried = recs[(size_t)lastw].next;
+        carried_proven = !bad[(size_t)lastw];
     }
     return bends;
 }
@@ -417,6 +460,7 @@ void host_set_state_buffers(unsigned *mine, unsigned *next, char *bad, int cap) 
     g_state_mine = mine; g_state_next = next; g_state_bad = bad; g_state_cap = cap;
 }
 int host_state_chunk() { return g_state_C; }
+void host_set_rounds(int rounds) { g_rounds = rounds; }
 
 int host_chunk_fibre(const double *y, const double *w, double lam, int len, int H, int T, int NW, int past, int seed,
                      double *x, int *first_bad, int *write_errors) {

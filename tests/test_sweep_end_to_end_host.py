@@ -34,6 +34,7 @@ def stage(request):
     lanes.host_chunk_fibre.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                        C.c_void_p, C.c_void_p, C.c_void_p]
     lanes.host_set_state_buffers.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    lanes.host_set_rounds.argtypes = [C.c_int]
     repair.model_repair_state.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
     return lanes, repair
 
@@ -89,13 +90,21 @@ def test_sweeps_end_to_end(stage, oracle):
             lam = float(rng.choice([0.02, 0.1, 0.3, 1.0, 4.0]) * abs(rng.standard_normal()) + 1e-3)
         want = oracle.tv1_linearized(np.ascontiguousarray(y), lam)
         scale = max(1.0, float(np.max(np.abs(y))))
-        for (H, T, NW) in GEOMETRIES:
-            for which in (0, 1):
-                x, nf, _ = sweep(stage, y, lam, H, T, NW, 2 * t, which)
-                e = np.max(np.abs(x - want))
-                assert e <= 1e-10 * scale, (t, n, lam, (H, T, NW), which, e, np.nonzero(np.abs(x - want) > 1e-10 * scale)[0][:8])   # (1e-11: the reference's own two solvers at a fibre's last piece)
-                flagged += nf
-                fibres += 1
+        # every third fibre also with second-chance rounds inside the blocks (the robust instantiations of rung 1: a lane whose link fails
+        # walks again from its proven predecessor's last bend; writes guarded as for long zones)
+        for rounds in ((0, 4) if t % 3 == 0 else (0,)):
+            stage[0].host_set_rounds(rounds)
+            try:
+                for (H, T, NW) in GEOMETRIES:
+                    for which in (0, 1):
+                        x, nf, _ = sweep(stage, y, lam, H, T, NW, 2 * t, which)
+                        e = np.max(np.abs(x - want))
+                        # (1e-11: the reference's own two solvers at a fibre's last piece)
+                        assert e <= 1e-10 * scale, (t, n, lam, (H, T, NW), which, rounds, e, np.nonzero(np.abs(x - want) > 1e-10 * scale)[0][:8])
+                        flagged += nf
+                        fibres += 1
+            finally:
+                stage[0].host_set_rounds(0)
     assert flagged > 5 * fibres     # (the repair stage had work on this mix: several flagged chunks per fibre on average)
 
 

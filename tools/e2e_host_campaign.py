@@ -5,7 +5,7 @@ rebuild_owned) leaves outputs, codes and flags; the repair model (tests/repair_m
 third column of the operands of iterations 26 / 31 / 34 of PD2 on the image of round 5's failing soak case, then -- until the time is up --
 operands of iterations 20 and 32 of emulated PD2 and DR loops on random images of tools/fuzz.py's families, and fibres built backwards from
 solutions full of zero-jump knots.  Geometries: the along-fibre kernel's (64 / 32 / 16 chunks of 17; 64-sample zones: chunks of 31) and the tiles' (8 / 3 chunks of 16, zones of 16 and 64);
-sequential and jobs repair.
+sequential and jobs repair; every other fibre with four second-chance rounds inside the blocks (rung 1).
 
 A deviation above 1e-12 (relative to the fibre's largest sample) is reported with where it is: END = inside the fibre's last piece, where the
 closed form of the rebuild (free end at height exactly 0) is MORE exact than the reference's last-sample tests (they leave up to EPSILON =
@@ -36,6 +36,7 @@ def main():
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
     orc = cpu.oracle()
     stage = e2e.stage.__wrapped__(Request) if hasattr(e2e.stage, "__wrapped__") else e2e.stage.__pytest_wrapped__.obj(Request)
+    stage[0].host_set_rounds.argtypes = [__import__("ctypes").c_int]
     tally = {"sweeps": 0, "flagged": 0, "end": 0, "inside": 0, "worst end": 0.0, "worst inside": 0.0, "worst": 0.0}
 
     def one(y, lam, tag):
@@ -46,6 +47,7 @@ def main():
         tail = int(knots[-1]) + 1 if knots.size else 0        # first row of the fibre's last piece
         for (H, T, NW) in GEO:
             for which in (0, 1):
+                stage[0].host_set_rounds(4 if (tally["sweeps"] // 16) % 2 else 0)   # (every other fibre: second-chance rounds, as on rung 1)
                 x, nf, _ = e2e.sweep(stage, y, lam, H, T, NW, 2 * tally["sweeps"], which)
                 d = np.abs(x - want) / scale
                 tally["sweeps"] += 1
