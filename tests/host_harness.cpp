@@ -473,6 +473,9 @@ int host_chunk_fibre(const double *y, const double *w, double lam, int len, int 
         return refl ? chunk_fibre<false, false, Reflect, 17>(y, w, lam, len, H, T, NW, seed, x, first_bad, write_errors)
                     : chunk_fibre<false, false, Identity, 17>(y, w, lam, len, H, T, NW, seed, x, first_bad, write_errors);
     }
+    if (w && (NW == 64 || NW == 32 || NW == 16))   // the along-fibre kernel's weighted geometry: chunks of 9 samples (two LDS planes), zones of 16
+        return refl ? chunk_fibre<true, false, Reflect, 9>(y, w, lam, len, H, T, NW, seed, x, first_bad, write_errors)
+                    : chunk_fibre<true, false, Identity, 9>(y, w, lam, len, H, T, NW, seed, x, first_bad, write_errors);
     if (w) {
         if (refl) return past ? chunk_fibre<true, true, Reflect>(y, w, lam, len, H, T, NW, seed, x, first_bad, write_errors)
                               : chunk_fibre<true, false, Reflect>(y, w, lam, len, H, T, NW, seed, x, first_bad, write_errors);

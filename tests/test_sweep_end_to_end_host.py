@@ -46,7 +46,7 @@ def sweep(stage, y, lam, H, T, NW, seed, which, w=None):
     if w is not None:
         w = np.ascontiguousarray(w, dtype=np.float64)
     n = y.size
-    cap = n // 16 + 2
+    cap = n // 9 + 2
     mine, nxt, bad = np.zeros(cap, dtype=np.uint32), np.zeros(cap, dtype=np.uint32), np.zeros(cap, dtype=np.int8)
     x = np.full(n, np.nan)
     fb, we = C.c_int(0), C.c_int(0)
@@ -117,7 +117,7 @@ def test_weighted_sweeps_end_to_end(stage, oracle):
         w = rng.uniform(0.05, 1.0, n - 1) * float(rng.choice([0.1, 0.5, 2.0, 6.0]))
         want = oracle.tv1_weighted(np.ascontiguousarray(y), np.ascontiguousarray(w))
         scale = max(1.0, float(np.max(np.abs(y))))
-        for (H, T, NW) in ((16, 8, 8), (16, 8, 3)):
+        for (H, T, NW) in ((16, 8, 8), (16, 8, 3), (16, 8, 64), (16, 8, 16)):   # tiles (chunks of 16) ; along-fibre kernel (chunks of 9)
             for which in (0, 1):
                 x, nf, _ = sweep(stage, y, 0.0, H, T, NW, 2 * t, which, w=w)
                 e = np.max(np.abs(x - want))
