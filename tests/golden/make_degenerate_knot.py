@@ -53,6 +53,8 @@ def main():
         xn = prox(z + q, 1); q = q + (z - xn)
         x = xn
     y = np.ascontiguousarray(a_in[:, 797])
+    if cpu.have_reference():   # (pinned: the compiled reference gives the expected values bit for bit -- checked when the fixture was made)
+        assert np.array_equal(cpu.reference().tv1_linearized(y, lam), orc.tv1_linearized(y, lam))
     np.savez(os.path.join(HERE, "degenerate_knot_fibre.npz"), y=y, lam=lam, expected=orc.tv1_linearized(y, lam))
     print("samples 92..96:", y[92:97], "lambda", lam)
 
