@@ -48,7 +48,7 @@ def main():
         for (H, T, NW) in GEO:
             for which in (0, 1):
                 stage[0].host_set_rounds(4 if (tally["sweeps"] // 16) % 2 else 0)   # (every other fibre: second-chance rounds, as on rung 1)
-                x, nf, _ = e2e.sweep(stage, y, lam, H, T, NW, 2 * tally["sweeps"], which)
+                x, nf, _ = e2e.sweep(stage, y, lam, H, T, NW, tally["sweeps"], which)   # (odd: the op whose output needs the row's own sample)
                 d = np.abs(x - want) / scale
                 tally["sweeps"] += 1
                 tally["flagged"] += nf
