@@ -192,3 +192,22 @@ def test_seeded_pinning_equals_oracle_and_saves_levels(harness, oracle):
             saved += plain - levels
             total += plain
     assert saved > 0.1 * total, (saved, total)
+
+
+def test_pinning_on_fibres_with_zero_jump_knots(harness, oracle):
+    """Fibres built backwards from solutions whose string touches the tube to the last bit (knots with zero jump, rows inside pieces that
+    touch a wall): the operands of late Dykstra / DR iterations, which the seeded policy sends to this solver from lambda ~ 0.75 on.
+    Where the taut string is degenerate the pins may fall differently; the values may not."""
+    from test_chunk_host import _zero_jump_fibre
+    rng = np.random.default_rng(9)
+    for trial in range(300):
+        n = int(rng.choice([17, 64, 100, 257, 1000, 1025, 4096, 5000]))
+        lam = float(rng.choice([0.05, 0.5, 3.0, 6.0]) * (0.5 + rng.random()))
+        y, x_built = _zero_jump_fibre(rng, n, lam)
+        want = oracle.tv1_linearized(y.copy(), lam)
+        for P in (16, 64) if trial % 3 else (4, 32):
+            x, levels = pin(harness, y, lam, P=P)
+            assert np.abs(x - want).max() <= tol(y), (n, lam, P, np.abs(x - want).max())
+            assert levels <= 64
+            xs, _ = pin_seeded(harness, y, lam, P=P)
+            assert np.abs(xs - want).max() <= tol(y), ("seeded", n, lam, P, np.abs(xs - want).max())
