@@ -183,3 +183,17 @@ def test_chunked_walk_on_fibres_with_zero_jump_knots(harness, oracle):
             covered += check(got, fb, we, truth, H, scale)
             total += n
     assert covered > 0.2 * total    # (long pieces at these penalties: most links are the repair kernel's)
+
+
+def test_short_fibres_with_zero_jump_knots(harness, oracle):
+    """sweep_whole_kernel's loop (outputs 32 samples at a time, each 32 restarting at the last bend at or before its first sample) on short
+    fibres full of ties."""
+    rng = np.random.default_rng(13)
+    for t in range(1500):
+        n = int(rng.integers(2, 97))
+        lam = float(rng.choice([0.05, 0.5, 3.0]) * (0.5 + rng.random()))
+        y = np.ascontiguousarray(_zero_jump_fibre(rng, n, lam)[0])
+        x = np.full(n, np.nan)
+        bad = harness.host_whole_fibre(y.ctypes.data, lam, n, t & 1, x.ctypes.data)
+        assert bad == 0, (t, n, lam, bad)
+        assert np.max(np.abs(x - oracle.tv1_linearized(y, lam))) <= 1e-10 * max(1.0, np.max(np.abs(y))), (t, n, lam)
