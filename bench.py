@@ -21,6 +21,12 @@ Extra objects on that line:
   step_ms      -- min / median / max of the K timed steps.
   c5           -- BASELINE config #5 per rank: 64 independent 2048x2048 images through proxtv_DR2_TV_batch_dev, solver
                   time and (N > 1) the RCCL gather to rank 0 timed separately.
+  c3, c4, hard, lambda_1 -- the other BASELINE configurations and two neighbours of the headline, clocked by whoever runs this file
+                  (rank 0, N = 1 only; outside the timed region): c3 = tv1w_2d weighted DR 4096^2; c4 = the 512x512x64 volume through
+                  PD_TV (what tvgen runs) and Yang3; hard = SURVEY 8(d)'s back-tracking image (8 x 8 blocks + 0.2 N(0,1)) at 4096^2,
+                  lambda = 0.5; lambda_1 = the headline image at lambda = 1.  Each: median ms of 3 solves, Mpixel/s, the solve-level
+                  fraction of 8 TB/s from SURVEY 8(d)'s byte formulas, and an output check against the compiled reference's digest
+                  in tests/golden/golden_large.npz.
   cpu_baseline -- the compiled reference (oracle/_ref, kind "reference") or, if it did not travel, this repo's
                   C restatement (kind "port"), timed on the host cores on a bounded sample (rank 0, N = 1 only): the headline
                   size at the best thread count of a probe, plus the 1024^2 probe at one thread and at all logical cores.
@@ -88,12 +94,86 @@ def cpu_baseline():
             "best_on_sample": {"value": 1024 * 1024 / best_t / 1e6, "unit": "Mpixel/s", "cores": best_thr, "sample": "one DR2_TV solve, 1024x1024 f64"}}
 
 
+def digest_check(y, g, key, tol=1e-6):
+    """Compare a column-major device result with the fixture's digest of the compiled reference's output for the same input."""
+    flat = y.permute(*reversed(range(y.dim()))).reshape(-1).cpu().numpy()   # storage order (the permuted view is contiguous)
+    sub, ref = flat[::int(g["step"])], g[f"{key}/sub"]
+    rel = float(np.max(np.abs(sub - ref)) / np.max(np.abs(ref)))
+    rel_sum = float(abs(np.abs(flat).sum() - float(g[f"{key}/abs"])) / float(g[f"{key}/abs"]))
+    return {"against": f"tests/golden/golden_large.npz {key} (compiled reference)", "rel_err": rel, "rel_err_abs_sum": rel_sum,
+            "samples": int(sub.size), "tolerance": tol, "ok": bool(rel <= tol and rel_sum <= tol)}
+
+
+def other_configs(device, torch, g):
+    """BASELINE configs #3 / #4 and two neighbours of the headline: wall time of the device-resident solve (median of 3 after one
+    warm-up; every solve returns synchronised), and the last result against the reference digest."""
+    out = {}
+
+    def dev(a):
+        return device.to_colmajor(torch.from_numpy(np.ascontiguousarray(a)).cuda())
+
+    def clock(fn):
+        fn()
+        ts = []
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            res = fn()
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        return float(np.median(ts)) * 1e3, res
+
+    def entry(workload, ms, px, nbytes, y, info, key, want_iters):
+        e = {"workload": workload, "ms": ms, "value": px / ms / 1e3, "unit": "Mpixel/s", "algorithmic_bytes": int(nbytes),
+             "frac": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "iterations": int(info[0])}
+        try:
+            e["output_check"] = digest_check(y, g, key)
+            e["ok"] = bool(e["output_check"]["ok"] and int(info[0]) == want_iters)
+        except KeyError as exc:
+            e["output_check"] = {"error": f"no digest {exc} in the fixture"}
+            e["ok"] = False
+        return e
+
+    px = M * N
+    # config #3: weighted DR, per-pixel penalties ~ U(0.05, 0.15) -- inputs as tests/test_gpu_large.py::test_c3_weighted_dr_4096
+    rng = np.random.default_rng(0)
+    X = dev(rng.standard_normal((M, N)))
+    W1, W2 = dev(rng.uniform(0.05, 0.15, (M - 1, N))), dev(rng.uniform(0.05, 0.15, (M, N - 1)))
+    yo = device.colmajor_empty((M, N))
+    ms, (y, info) = clock(lambda: device.tv1w_2d(X, W1, W2, out=yo))
+    out["c3"] = entry("tv1w_2d (DR2L1W_TV, 35 iterations) 4096x4096 f64, per-pixel penalties U(0.05, 0.15)", ms, px,
+                      8 * px * (8 * ITERS + 9), y, info, "c3/dr2w", ITERS)
+    del W1, W2
+    # the headline image at lambda = 1 (pieces of ~100 samples: the long-piece rungs)
+    ms, (y, info) = clock(lambda: device.tv1_2d(X, 1.0, out=yo))
+    out["lambda_1"] = entry("tv1_2d (DR2_TV, 35 iterations) on the headline image at lambda=1.0", ms, px, 8 * px * (6 * ITERS + 7),
+                            y, info, "lam1/dr2", ITERS)
+    # SURVEY 8(d)'s hard variant at the headline size: 8 x 8 random blocks + 0.2 N(0,1), lambda = 0.5
+    r7 = np.random.default_rng(7)
+    Xh = dev(np.kron(r7.standard_normal((8, 8)), np.ones((M // 8, N // 8))) + 0.2 * r7.standard_normal((M, N)))
+    ms, (y, info) = clock(lambda: device.tv1_2d(Xh, 0.5, out=yo))
+    out["hard"] = entry("tv1_2d (DR2_TV, 35 iterations) 4096x4096 f64: 8x8 random blocks of 512x512 + 0.2 N(0,1), lambda=0.5", ms, px,
+                        8 * px * (6 * ITERS + 7), y, info, "hard4096/dr2", ITERS)
+    del X, Xh, yo
+    # config #4: 512 x 512 x 64 volume (float32 values up-cast, like the reference's Python surface), lambda = [0.1, 0.1, 0.05]
+    V = dev(np.random.default_rng(0).standard_normal((512, 512, 64)).astype(np.float32).astype(np.float64))
+    vo = device.colmajor_empty((512, 512, 64))
+    nv = 512 * 512 * 64
+    ms, (y, info) = clock(lambda: device.tvgen(V, [0.1, 0.1, 0.05], [1, 2, 3], out=vo))
+    pd = entry("tvgen (PD_TV, 3 terms) 512x512x64 f64, lambda=[0.1, 0.1, 0.05]", ms, nv, 8 * nv * 17 * int(info[0]), y, info, "c4/pd", 35)
+    ms, (y, info) = clock(lambda: device.tvgen(V, [0.1, 0.1, 0.1], [1, 2, 3], method="yang", out=vo))
+    ya = entry("Yang3_TV (35 ADMM iterations) 512x512x64 f64, lambda=0.1", ms, nv, 8 * nv * 20 * (int(info[0]) - 1), y, info, "c4/yang3", 36)
+    out["c4"] = {"pd_tv": pd, "yang3": ya, "ok": bool(pd["ok"] and ya["ok"])}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-others", action="store_true", help="skip the c3 / c4 / hard / lambda_1 objects")
     ap.add_argument("--no-c5", action="store_true", help="skip the config-#5 object (64 x 2048^2 per rank, ~13 GiB of HBM)")
     ap.add_argument("--no-gather", action="store_true", help="config #5 without the final gather to rank 0 (solver scaling and "
                     "gather time separable on a multi-GPU node)")
@@ -256,6 +336,12 @@ def main():
               "ranks": world, "backend": (dist.get_backend() if world > 1 else None)}
         del x5, y5
 
+    # ---- the other configurations, clocked here so that whoever runs this file clocks them (N = 1 only) -----------------------------
+    others = None
+    if world == 1 and not args.no_others:
+        del xd, yd
+        others = other_configs(device, torch, np.load(os.path.join(ROOT, "tests", "golden", "golden_large.npz")))
+
     # who took part: what the process group itself reports, and every rank's device (rank 0 prints them)
     ranks_info = [{"rank": 0, "device": torch.cuda.get_device_name(torch.cuda.current_device()), "index": torch.cuda.current_device()}]
     if world > 1:
@@ -290,6 +376,7 @@ def main():
         # separate passes, calibrated on an 8-B/lane copy of known size).  bench.py cannot run under the profiler
         # itself, so the figure is read from profiles/ -- and only if it was measured on THIS build of the kernels.
         traffic = None
+        traffic_source = None
         try:
             from proxtv_amd import build as _build
             import glob
@@ -303,6 +390,8 @@ def main():
             if pmc:
                 label = ["column sweep (DR_COL)", "row sweep (DR_ROW)"][dom]
                 traffic = pmc["kernels"][label]["hbm_total"]
+                traffic_source = (f"{os.path.relpath(path, ROOT)}: rocprofv3 --pmc passes of this workload run by the builder on build "
+                                  f"{pmc.get('build_id')} (= this build); not measured by this run -- bench.py cannot profile itself")
         except (OSError, KeyError, ValueError):
             pass
         line = {
@@ -317,7 +406,7 @@ def main():
                                          "backend": dist.get_backend() if world > 1 else None, "ranks": ranks_info}},
             "roofline": {"bound": "hbm", "kernel": ["column sweep (DR_COL)", "row sweep (DR_ROW, fused reflections+combiner)"][dom],
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "avg_launch_ms": avg_ms, "launches": fam_n[dom],
+                         "traffic": traffic, "traffic_source": traffic_source, "avg_launch_ms": avg_ms, "launches": fam_n[dom],
                          "measured": f"hipEvents around every sweep launch during {args.steps} further solves of the same input "
                                      f"({dt_events / args.steps * 1e3:.2f} ms per solve with the events in the stream; every event pair serialises its "
                                      f"launch, tail included, so family_ms_per_solve sums to slightly MORE than ms_per_step of the un-instrumented solves)",
@@ -335,6 +424,8 @@ def main():
         }
         if c5 is not None:
             line["c5"] = c5
+        if others:
+            line.update(others)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)

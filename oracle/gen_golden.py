@@ -295,6 +295,27 @@ def gen_large(ref, threads):
     np.savez_compressed(os.path.join(GOLD, "golden_large.npz"), **out)
 
 
+def gen_large_extra(ref, threads):
+    """Cases the bench line reports beside the headline (round 6), ADDED to the existing golden_large.npz (its other entries are kept
+    byte for byte): `hard4096` = SURVEY 8(d)'s back-tracking-heavy image at the headline size (8 x 8 random blocks of 512 x 512 + 0.2
+    N(0,1), lambda = 0.5) and `lam1` = the headline image at lambda = 1 (pieces of ~100 samples: the long-piece rungs)."""
+    path = os.path.join(GOLD, "golden_large.npz")
+    with np.load(path) as g:
+        out = {k: g[k] for k in g.files}
+    t0 = time.time()
+    rng = np.random.default_rng(7)
+    Xh = np.asfortranarray(np.kron(rng.standard_normal((8, 8)), np.ones((512, 512))) + 0.2 * rng.standard_normal((4096, 4096)))
+    put(out, "hard4096/X", digest(Xh, 4099))
+    y, info, rc = ref.dr2(Xh, 0.5, n_threads=threads)
+    put(out, "hard4096/dr2", digest(y, 4099)); out["hard4096/dr2_info"] = info
+    print("hard4096 done", time.time() - t0)
+    X = np.asfortranarray(np.random.default_rng(0).standard_normal((4096, 4096)))
+    y, info, rc = ref.dr2(X, 1.0, n_threads=threads)
+    put(out, "lam1/dr2", digest(y, 4099)); out["lam1/dr2_info"] = info
+    print("lam1 done", time.time() - t0)
+    np.savez_compressed(path, **out)
+
+
 def gen_p2(ref):
     """TV-L2 (p = 2) fibres: what the compiled reference returns -- single-threaded (its fibres warm-start each other per
     OpenMP thread, so its output depends on the thread count) and to its own accuracy (duality gap 1e-5).  The exact
@@ -333,6 +354,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--large", action="store_true")
     ap.add_argument("--only-large", action="store_true")
+    ap.add_argument("--only-large-extra", action="store_true", help="add the round-6 bench cases to golden_large.npz")
     ap.add_argument("--only-primal-dual", action="store_true", help="regenerate golden_2d_primal_dual.npz only")
     ap.add_argument("--only-p2", action="store_true", help="regenerate golden_p2.npz only")
     ap.add_argument("--threads", type=int, default=os.cpu_count() or 1)
@@ -343,6 +365,9 @@ def main():
     os.makedirs(GOLD, exist_ok=True)
     if args.only_p2:
         gen_p2(ref)
+        return
+    if args.only_large_extra:
+        gen_large_extra(ref, args.threads)
         return
     if args.only_primal_dual:
         gen_1d_other_methods(ref)
@@ -357,6 +382,7 @@ def main():
         gen_p2(ref)
     if args.large or args.only_large:
         gen_large(ref, args.threads)
+        gen_large_extra(ref, args.threads)
 
 
 if __name__ == "__main__":
