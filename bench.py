@@ -192,6 +192,9 @@ def main():
     # One rank per GPU over RCCL.  (PROXTV_BENCH_SHARED_GPU=1 is a plumbing dry run for boxes with a single GPU: every
     # rank uses device 0 and the two scalar collectives go over gloo -- never a measurement.)
     shared = os.environ.get("PROXTV_BENCH_SHARED_GPU") == "1"
+    if shared and world > 1 and torch.cuda.device_count() >= world:
+        raise SystemExit(f"PROXTV_BENCH_SHARED_GPU=1 with {torch.cuda.device_count()} devices visible for {world} ranks: the dry run is for "
+                         "single-GPU boxes only -- unset it and every rank gets its own GPU over RCCL")
     torch.cuda.set_device(0 if shared else local)
     if world > 1:
         if shared:

@@ -37,7 +37,27 @@ def _worker(rank, world, port, n_items, out_path):
     def solve(x):
         return torch.from_numpy(np.stack([orc.dr2(im, 0.2)[0] for im in x.numpy()]) if x.shape[0] else np.zeros((0, 12, 17)))
 
-    local, full = sharding.solve_sharded(get_images, n_items, solve, gather_to=0)
+    # what rank 0 may allocate for the gather: the (n_items, ...) result and nothing else -- no list of per-rank buffers, no padding,
+    # no concatenation (16 GiB instead of 2 x 16 GiB + a copy at BASELINE config #5)
+    allocated = []
+    real_alloc = sharding._alloc
+
+    def counting_alloc(shape, like):
+        t = real_alloc(shape, like)
+        allocated.append(t.numel() * t.element_size())
+        return t
+
+    def no_cat(*a, **k):
+        raise AssertionError("solve_sharded must not concatenate")
+
+    sharding._alloc = counting_alloc
+    real_cat, torch.cat = torch.cat, no_cat
+    try:
+        local, full = sharding.solve_sharded(get_images, n_items, solve, gather_to=0)
+    finally:
+        torch.cat = real_cat
+        sharding._alloc = real_alloc
+    assert allocated == ([n_items * 12 * 17 * 8] if rank == 0 else []), allocated
     a, b = sharding.shard_bounds(n_items, world, rank)
     assert local.shape[0] == b - a
     if rank == 0:
