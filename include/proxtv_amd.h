@@ -153,7 +153,7 @@ const char *proxtv_last_error(void);
 void proxtv_release_scratch(void);
 
 /* Knobs (process-wide; returns the previous value, -1 for an unknown key).  Each also has an environment variable
-   PROXTV_<KEY> read at load time.
+   PROXTV_<KEY> read at load time.  Nineteen in all; none is needed for correct results.
      "chunk"          non-zero: speculative-chunk kernels ; 0: sequential lane-per-fibre kernels only
      "chunk_mode"     -1: the geometry policy chooses per sweep (default) ; 0..5: pin a rung of the ladder (see proxtv_chunk_mode)
      "deterministic"  1 (default): the rung of a sweep is a function of sampled statistics of its input and of lambda alone --
@@ -161,27 +161,32 @@ void proxtv_release_scratch(void);
                       the same statistics (results then agree to ~1e-13 between calls, not bit for bit)
      "chunk_min_len"  fibres shorter than this do not take the multi-block chunk kernels (default 96)
      "whole"          fibres of 16 .. chunk_min_len samples: 1 (default) by length and data, 2 whole fibres in LDS, 0 sequential
-     "rounds"         second-chance rounds of geometry mode 1 (0 = built-in default: 4 in the tile, 8 along the fibre)
+     "along"          1 (default): dimension-0 sweeps by chunks along the fibre ; 0: through the transposing 64-fibre tile
      "xlink"          1 (default): chunk kernels check the links across their workgroups themselves ; 0: the repair kernel does
      "dr_form"        DR2_TV / DR2L1W_TV: which sweep does the pointwise work of an iteration.  1 (default): the column sweep leaves
                       the row sweep's input and epilogue operand when the row sweep will run on the robust 64-fibre tile (decided
                       from the same sampled statistics as the rung) ; 2: on the plain tile too ; 0: never (the reference's split).
                       Same iterates either way, to a few ulps
+     "pin"            1 (default): rung 3 is the pinning solver ; 0: the global-memory chunk kernel
      "pin_seed"       1 (default): the pinning solver (rung 3) starts from the knots known a priori, 0: from the fibre ends alone
-     "pin_overlap"    1: a strided sweep of the pinning solver moves its transposed copies range by range on a second stream, under
-                      the levels of the other ranges ; 0 (default: measured slower): one stream
-     "replay"         1: dimension-0 sweeps on rung 0 keep the piece ends / bend types of every chunk and, from the fourth sweep of a
-                      solve over the same geometry on, verify the last sweep's against the optimality conditions of the prox instead of
-                      walking (per wavefront, all or nothing; exact whatever the record holds) ; 0 (default: measured slower): always walk
      "repair_jobs"    failed links across the workgroups of a chunked sweep are first repaired one lane per failure, four to a
                       fibre; what that leaves goes to the sequential repair: 1 (default) where the sampled statistic of the sweep's
-                      input says such links fail in numbers, 2 always ; 0: the sequential repair alone (same results, bit for bit)
-     "tile"           strided sweeps on rungs 0 and 1 (the robust instantiation follows the same knob): 1 (default) tiles of 32 fibres x 8 chunks in 4 waves, four workgroups per CU ;
-                      0: the 64-fibre x 8-wave tile, two per CU
-     "host_register"  1: page-lock large caller arrays around the transfers of the host-pointer entry points (default 0: no gain measured)
+                      input says such links fail in numbers (an unsampled input counts as such), 2 always ; 0: the sequential repair
+                      alone (same results, bit for bit)
+     "tile"           strided sweeps on rungs 0 and 1 (the robust instantiation follows the same knob): 1 (default) tiles of 32 fibres
+                      x 8 chunks in 4 waves, four workgroups per CU ; 0: the 64-fibre x 8-wave tile, two per CU
+     "certify"        1: behind every fibre sweep a second kernel checks the optimality conditions of the prox on what the sweep wrote,
+                      fibre by fibre (u = cumsum(y - x): |u_k| <= lambda_k ; u_k = -+lambda_k where x steps up / down ; u_{n-1} = 0),
+                      re-solves a fibre that fails with the sequential walk and counts it (proxtv_debug_counter: certify_failures,
+                      certify_sweeps, certify_skipped) ; 0 (default): sweeps are exact by their own argument and
+                      the check costs a pass over the sweep's arrays
      "verbose"        1: log every decision of the geometry policy to stderr
      "profile"        1: hipEvent pair around every sweep launch (proxtv_last_kernel_ms / _launches)
-     "why", "trace", "ablate", "blocks_per_wg", "seed_noisy_e4", "seed_mid_e4", "seed_row_along_e4", "warmup"   tuning / profiling aids (tools/) */
+     "why", "trace"   tuning / profiling aids (proxtv_debug_why, proxtv_debug_trace)
+     "ablate"         profiling aid: skips phases of the chunk kernels -- RESULTS ARE WRONG while it is non-zero (a warning is printed)
+     "debug_legacy_rebuild"   test aid: 1 plants the rebuild semantics of rounds 1-4 in the along-fibre kernel (an unproven chunk values
+                      its first piece from its own first row: the hole of DESIGN.md 6 (ii')) so that the suite can watch the certifier catch
+                      it -- RESULTS MAY BE WRONG while it is non-zero (a warning is printed) */
 int proxtv_set_option(const char *key, int value);
 
 /* Device-pointer solvers: every double* is an HBM pointer valid on the current device, `stream` is
@@ -219,6 +224,15 @@ int proxtv_CondatChambollePock2_TV_dev(size_t M, size_t N, const double *Y, doub
 int proxtv_tv1_fibres_dev(const double *in, double *out, const int *ns /*host*/, int nds, int dim,
                           double lambda, const double *weights, void *stream);
 
+/* The certificate of that prox, on its own: the number of fibres along `dim` for which `out` is NOT the exact TV-L1 prox of `in` --
+   the optimality conditions of the 1-D problem checked fibre by fibre (u = cumsum(in - out): |u_k| <= lambda_k, u_k = -+lambda_k where
+   out steps up / down, u_{n-1} = 0; reference: what src/TVL1opt.cpp:359-564 solves), within rounding (64 n ulps of the largest sample).
+   0 = `out` is the prox; -1 = nothing to check against (lambda <= 0 without weights, in == out); -2 = the call failed
+   (proxtv_last_error).  Read-only on both arrays; synchronises the stream.  Option "certify" runs the same check behind every sweep
+   of every solver and repairs what fails. */
+long proxtv_certify_fibres_dev(const double *in, const double *out, const int *ns /*host*/, int nds, int dim, double lambda,
+                               const double *weights, void *stream);
+
 /* Batch of B independent MxN images stored back to back (image b at unary + b*M*N), each solved
    with DR2_TV semantics (oracle = loop of DR2_TV).  All B images advance together, one
    launch per sweep over B*N (columns) / B*M (rows) fibres. */
@@ -253,13 +267,13 @@ long   proxtv_last_fixups(void);
 long   proxtv_debug_trace(unsigned long long *dst, long max_wgs);
 /* Tuning aid (option "why" = 1): what left work to the repair kernel since the last call, 8 counters: [0] walks that ran off
    their window, [1] links inside a workgroup / wave that stayed unproven, [2] links across workgroups / segments whose codes
-   differ, [3] ... that were not published in time, [4] second chances taken across workgroups, [5] wavefronts of the along-fibre
-   kernel that replayed the recorded structure instead of walking.  Returns 8, or <= 0. */
+   differ, [3] ... that were not published in time, [4] second chances taken across workgroups.  Returns 8, or <= 0. */
 int    proxtv_debug_why(unsigned *dst);
 /* What ran (process-wide, cumulative since load; tests and tools take differences): "sweep_launches" (fibre-sweep kernels),
    "repair_launches" (sweep_repair_kernel behind them), "repair_jobs_launches" (option repair_jobs), "pin_sweeps" (sweeps the
    pinning solver took), "pin_cap_next_rung" (sweeps its grid-wide variant handed on after the level cap), "tv2_long_fibres"
-   (TV-L2 fibres solved parallel inside the fibre).  -1 for an unknown name. */
+   (TV-L2 fibres solved parallel inside the fibre), "certify_sweeps" / "certify_failures" / "certify_skipped" (option certify:
+   sweeps checked, fibres that failed and were re-solved, sweeps that could not be checked).  -1 for an unknown name. */
 long   proxtv_debug_counter(const char *name);
 /* Geometry policy the adaptive chunk kernel currently uses on this thread (the highest over the sweep families):
    0 = 16-sample warm-up zones (noisy data, small lambda), 1 = the same, robust instantiation (walks may run past

@@ -72,6 +72,7 @@ SIGNATURES = {
     "proxtv_CondatChambollePock2_TV_dev": (C.c_int, [C.c_size_t, C.c_size_t, _dp, C.c_double, _dp, C.c_short, C.c_int, _dp,
                                                      C.c_void_p]),
     "proxtv_tv1_fibres_dev": (C.c_int, [_dp, _dp, _ip, C.c_int, C.c_int, C.c_double, _dp, C.c_void_p]),
+    "proxtv_certify_fibres_dev": (C.c_long, [_dp, _dp, _ip, C.c_int, C.c_int, C.c_double, _dp, C.c_void_p]),
     "proxtv_DR2_TV_batch_dev": (C.c_int, [C.c_size_t, C.c_size_t, C.c_size_t, _dp, C.c_double, C.c_double, _dp,
                                           C.c_int, _dp, C.c_void_p]),
     "proxtv_DR2_TV_batch": (C.c_int, [C.c_size_t, C.c_size_t, C.c_size_t, _dp, C.c_double, C.c_double, _dp, C.c_int, _dp]),

@@ -111,7 +111,17 @@ def build_variant(name, extra, verbose=False, sweeps_only=True):
     build(verbose=verbose)
     vdir = os.path.join(OBJ, "var_" + name)
     pick = (lambda u: u[1] in ("sweep_unit", "sweep")) if sweeps_only else None
-    objs = _compile_all(vdir, list(extra), False, verbose, only=pick)
+    # the objects of a variant are keyed on its flags: the up-to-date test of _compile_all looks at sources and headers only, so the
+    # same NAME rebuilt with other flags would silently relink the old objects and an A/B run would measure the wrong code
+    os.makedirs(vdir, exist_ok=True)
+    stamp, want = os.path.join(vdir, "flags.txt"), " ".join(extra) + ("\n" if sweeps_only else " [all units]\n")
+    stale = True
+    if os.path.exists(stamp):
+        with open(stamp) as fh:
+            stale = fh.read() != want
+    objs = _compile_all(vdir, list(extra), stale, verbose, only=pick)
+    with open(stamp, "w") as fh:
+        fh.write(want)
     if sweeps_only:
         objs += [os.path.join(OBJ, u + ".o") for u in PLAIN_UNITS if u != "sweep"]
     lib = os.path.join(OBJ, f"lib_{name}.so")

@@ -46,39 +46,19 @@ int guarded(const char *who, double *info, int ok_ret, F &&body) {
     throw HipFailure{hipErrorInvalidValue};
 }
 
-// Option "host_register" (default 0): page-lock the caller's arrays around the transfer (hipHostRegister) when they are
-// large.  Measured (tools/host_api_time.py): the pageable copies already run at the link's rate and
-// locking 134 MB costs more than it saves -- the switch stays for hosts where that differs.
-struct HostPin {
-    void *p = nullptr;
-    HostPin(const void *host, size_t bytes) {
-        if (options().host_register && bytes >= (size_t)8 << 20 &&
-            hipHostRegister(const_cast<void *>(host), bytes, hipHostRegisterDefault) == hipSuccess)
-            p = const_cast<void *>(host);
-        else
-            (void)hipGetLastError();
-    }
-    ~HostPin() {
-        if (p) (void)hipHostUnregister(p);
-    }
-    HostPin(const HostPin &) = delete;
-    HostPin &operator=(const HostPin &) = delete;
-};
-
+// (Page-locking the caller's arrays around the transfers -- hipHostRegister -- was measured in round 4 and removed: the pageable
+//  copies already run at the link's rate and locking 134 MB costs more than it saves.)
 // host array staged into HBM scratch
 struct Staged {
     Scratch buf;
     Staged(const double *host, size_t count, hipStream_t s) : buf(sizeof(double) * (count ? count : 1)) {
         if (!count) return;
-        HostPin pin(host, sizeof(double) * count);
         PTV_HIP(hipMemcpyAsync(buf.d(), host, sizeof(double) * count, hipMemcpyHostToDevice, s));
-        if (pin.p) PTV_HIP(hipStreamSynchronize(s));   // (the lock is released when `pin` goes out of scope)
     }
     double *d() const { return buf.d(); }
 };
 
 void download(double *host, const double *dev, size_t count, hipStream_t s) {
-    HostPin pin(host, sizeof(double) * count);
     if (count) PTV_HIP(hipMemcpyAsync(host, dev, sizeof(double) * count, hipMemcpyDeviceToHost, s));
     PTV_HIP(hipStreamSynchronize(s));
 }
@@ -492,6 +472,8 @@ int proxtv_set_option(const char *key, int value) {
     if (!slot) return -1;
     const int old = *slot;
     *slot = value;
+    if (value != 0 && (!strcmp(key, "ablate") || !strcmp(key, "debug_legacy_rebuild")))
+        fprintf(stderr, "[proxtv_amd] WARNING: option \"%s\" = %d -- a profiling / test aid: results are WRONG while it is non-zero\n", key, value);
     return old;
 }
 
@@ -661,6 +643,17 @@ int proxtv_tv1_fibres_dev(const double *in, double *out, const int *ns, int nds,
         PTV_HIP(hipStreamSynchronize(st));
         scope.finish();
     });
+}
+
+long proxtv_certify_fibres_dev(const double *in, const double *out, const int *ns, int nds, int dim, double lambda, const double *weights,
+                               void *stream) {
+    long failed = -2;
+    guarded("proxtv_certify_fibres_dev", nullptr, 1, [&] {
+        if (dim < 0 || dim >= nds) reject("dimension out of range");
+        hipStream_t st = pick(stream);
+        failed = certify_fibres(in, out, ns, nds, dim, lambda, weights, st);
+    });
+    return failed;
 }
 
 int proxtv_tvp_fibres_dev(const double *in, double *out, const int *ns, int nds, int dim, double lambda, double p,

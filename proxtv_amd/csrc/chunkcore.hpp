@@ -223,18 +223,6 @@ struct NoFar {
 // between the two passes, so the forward pass costs a row one LDS read, the backward pass none, and ops whose output needs the row's
 // own sample (DR_COL) take the same array-free passes as the others instead of a dynamic back-fill loop per piece.  Same arithmetic
 // in the same order as the general form: bit-identical (tests/host_harness.cpp runs all three).
-// FULL == 3 (replay: sweep_along_kernel): FULL == 2 that CHECKS the structure it is given while it rebuilds from it -- `rec` is not a
-// walk's record but a candidate (the last sweep's), and `chk` comes back saying whether every piece the lane is responsible for (those
-// that end in its chunk; the last lane: the one that runs out of the segment too) satisfies the optimality conditions of the prox:
-// the string stays inside the tube behind every row inside a piece -- (S_i - h_a - lambda) / n_i <= v <= (S_i - h_a + lambda) / n_i,
-// folded into a running max and min -- and x jumps the way the bend type says between two pieces (between lanes: the caller, with
-// vfirst / vlast).  See replay_lane below for why that is enough.  The rows are written as they are rebuilt: a caller whose check fails
-// stages its window again.
-struct ReplayCheck {
-    bool ok = true;
-    bool has = false;                  // a piece the lane is responsible for exists
-    double vfirst = 0.0, vlast = 0.0;  // value of the first / last of them
-};
 // The rows BEFORE a lane's chunk that belong to the first piece ending in it: their sum and count.  rebuild_owned reads them itself where
 // nothing can have replaced them yet (lanes of one wave, in lockstep); where the lanes of a fibre sit in different waves (the strided
 // tiles) an UNPROVEN lane's rows before its chunk may be somebody else's to write -- the two walks disagree, that is what unproven
@@ -257,8 +245,8 @@ __device__ __forceinline__ PiecePrefix first_piece_prefix(const Win &win, const 
 
 template <class F, bool WEIGHTED, int C, int UNROLL = 1, bool TAB = false, class RT = const double *, int TSZ = 0, int FULL = 0, class Win>
 __device__ __forceinline__ void rebuild_owned(Win &win, const ChunkRec &rec, int cs, int ce, int len, int start, bool link_ok,
-                                              int wlo, bool block_last, double lam, RT rt = RT(), ReplayCheck *chk = nullptr,
-                                              const PiecePrefix *pre = nullptr) {
+                                              int wlo, bool block_last, double lam, RT rt = RT(), const PiecePrefix *pre = nullptr,
+                                              bool legacy = false) {
     auto quotient = [&](double num, double count) {
         if constexpr (TAB) {
             if (TSZ > 0 && count >= (double)TSZ) {
@@ -284,7 +272,8 @@ __device__ __forceinline__ void rebuild_owned(Win &win, const ChunkRec &rec, int
         const int at = (int)(rec.mine >> 1);
         const double r = WEIGHTED ? win.r(at - 1) : lam;
         hprev = (rec.mine & 1u) ? r : -r;
-        a0 = at;
+        a0 = (legacy && !link_ok) ? cs : at;   // (legacy: option debug_legacy_rebuild -- the hole of rounds 1-4, planted so that a test can watch
+                                               //  the certifier catch it; never set otherwise)
         w0 = link_ok ? at : cs;
     } else if (link_ok && start == 0) {
         a0 = w0 = 0;   // no bend yet and the walk began at the fibre start: the first piece starts at sample 0, height 0
@@ -335,7 +324,6 @@ __device__ __forceinline__ void rebuild_owned(Win &win, const ChunkRec &rec, int
     double cur = 0.0;
     bool have = false;
     if constexpr (FULL >= 2 && !WEIGHTED) {
-        constexpr bool VERIFY = FULL == 3;
         double slot[C];   // row u: its sample, or -- once a piece has ended there -- that piece's value
         // (all C reads in flight at once: one LDS latency per chunk instead of one per row)
 #pragma unroll
@@ -363,34 +351,6 @@ __device__ __forceinline__ void rebuild_owned(Win &win, const ChunkRec &rec, int
                 return over(num);
             }
         };
-        // VERIFY: the bounds the tube puts on the value of the piece in hand, what the pieces before it were, the verdict
-        double lo = -1.7976931348623157e308, hi = 1.7976931348623157e308, vprev = 0.0;
-        bool ok = true, have_prev = false, tprev = false;
-        auto inside_row = [&](double sum, int count) {   // a row INSIDE a piece: the string behind it must be inside the tube
-            const double t = sum - hprev;
-            lo = ptv_max(lo, over_n(t - lam, count));
-            hi = ptv_min(hi, over_n(t + lam, count));
-        };
-        auto piece_ends = [&](double v, bool floor_knot) {
-            ok = ok && lo <= v && v <= hi;
-            if (have_prev) ok = ok && (tprev ? v >= vprev : v <= vprev);
-            else chk->vfirst = v;
-            vprev = v;
-            tprev = floor_knot;
-            have_prev = true;
-            lo = -1.7976931348623157e308;
-            hi = 1.7976931348623157e308;
-        };
-        if constexpr (VERIFY) {
-            // the rows of earlier chunks that belong to the piece ending here were summed above: their bounds now
-            double ps = 0.0;
-            int pn = 0;
-            for (int k = a0; k < cs; k++) {
-                ps += win.y(k);
-                pn += 1;
-                inside_row(ps, pn);
-            }
-        }
 #pragma unroll
         for (int u = 0; u < C; u++) {
             const double yu = slot[u];
@@ -399,38 +359,14 @@ __device__ __forceinline__ void rebuild_owned(Win &win, const ChunkRec &rec, int
             if ((rec.ends >> u) & 1u) {
                 const double hk = height(u);
                 const double v = over_n(s + (hk - hprev), n);
-                if constexpr (VERIFY) piece_ends(v, (rec.types >> u) & 1u);
                 win.put(cs + u, F::fuse(yu, v));
                 slot[u] = v;
                 s = 0.0;
                 n = 0;
                 hprev = hk;
-            } else if constexpr (VERIFY) {
-                inside_row(s, n);
             }
         }
-        if constexpr (VERIFY) {
-            // the piece that runs out of the segment (last lane): its rows beyond the chunk, its value, its tests
-            have = false;
-            if (block_last && !((rec.ends >> (C - 1)) & 1u)) {
-                const int brk = (int)(rec.last >> 1) - 1;
-                for (int k = ce; k <= brk; k++) {
-                    s += win.y(k);
-                    n += 1;
-                    if (k < brk) inside_row(s, n);
-                }
-                const bool floor_knot = rec.last & 1u;
-                const double hk = floor_knot ? lam : -lam;
-                cur = over_n(s + (hk - hprev), n);
-                piece_ends(cur, floor_knot);
-                have = true;
-            }
-            chk->ok = ok;
-            chk->has = have_prev;
-            chk->vlast = vprev;
-        } else {
-            have = tail_value(s, (double)n, hprev, cur);
-        }
+        have = tail_value(s, (double)n, hprev, cur);
 #pragma unroll
         for (int u = C - 1; u >= 0; u--) {
             const bool e = (rec.ends >> u) & 1u;
@@ -500,98 +436,5 @@ __device__ __forceinline__ void rebuild_owned(Win &win, const ChunkRec &rec, int
     }
 }
 
-
-// ---- replay: VERIFY a recorded structure instead of walking ----------------------------------------------------------------------
-// Between two sweeps of a splitting loop the knots of a fibre hardly move (DR at lambda = 0.1: 1.3 % of the 17-sample chunks change
-// between iterations 4 and 5, 0.1 % from iteration 12 on: profiles/r04_study_structure.txt), and checking a structure is far cheaper
-// than finding it.  A candidate structure -- piece ends and bend types, as the walk of the previous sweep left them -- is THE solution
-// of a stretch [r, r') between two knots that are known to be true iff every piece in it satisfies the optimality conditions of the
-// prox (the string x - y summed up stays inside the tube; it sits on the wall the bend type says at every knot; x jumps the way the
-// bend type says at every knot):
-//     h_i = h_a + n_i v - S_i,   |h_i| <= lambda for the rows i inside a piece [a, b]  <=>  (S_i - h_a - lambda) / n_i <= v <= (S_i - h_a + lambda) / n_i
-//     v = (S_b + h_b - h_a) / n_b                    (the closed form of rebuild_owned: the wall at both ends is imposed)
-//     v' >= v across a FLOOR knot, v' <= v across a CEIL knot
-// -- the prox is the unique minimiser of a strictly convex problem, the stretch between two true knots is a problem of its own, and
-// these are its KKT conditions.  The true knots at the two ends are bends known a priori (certain_bend_before / _after).  So the
-// result does not depend on where the candidate came from: a stale or corrupted candidate fails a test, or is the solution.
-//
-// One lane checks the rows [r0, r0 + nrows): r0 is the knot its first piece starts at, the pieces END where emask says.  ONE forward
-// pass, no arrays: the running bounds of the tube condition are folded into a max and a min, compared with the piece's value where it
-// ends.  Piece values are computed exactly as rebuild_owned computes them (same expression, same table): what is verified is what
-// will be written.
-struct ReplayLane {
-    int r0 = 0, nrows = 0;         // rows [r0, r0 + nrows) ; nrows <= 32
-    unsigned emask = 0, tmask = 0; // bit k: a piece ends at row r0 + k / ... by a FLOOR bend
-    double h0 = 0.0;               // height of the string at the knot before r0 (+-lambda by the knot's type; 0 at the fibre start)
-    double vfirst = 0.0, vlast = 0.0;   // (out) values of the first / last piece that ends in the rows
-    bool ok = true;                // (out)
-};
-
-template <bool TAB, class RT, class Win>
-__device__ __forceinline__ void replay_lane(const Win &win, ReplayLane &L, int nmax, double lam, RT rt) {
-    double S = 0.0, h = L.h0;
-    int n = 0;
-    double lo = -1.7976931348623157e308, hi = 1.7976931348623157e308;   // running tube bounds on the value of the piece in hand
-    double vprev = 0.0;
-    bool have_prev = false, tprev = false, ok = L.ok;
-#pragma unroll 1
-    for (int k = 0; k < nmax; k++) {
-#ifndef PTV_HOST_TEST
-        if (__builtin_amdgcn_ballot_w64(k < L.nrows) == 0ull) break;   // (every lane of the wave is through its rows)
-#endif
-        if (k < L.nrows) {
-            const double yk = win.y(L.r0 + k);
-            S += yk;
-            n += 1;
-            auto over_n = [&](double num) {   // num / n the way rebuild_owned divides (table product, or SpanDiv)
-                if constexpr (TAB) {
-                    return num * rt[n];
-                } else {
-                    const SpanDiv over((double)n);
-                    return over(num);
-                }
-            };
-            const double t = S - h;
-            if (!((L.emask >> k) & 1u)) {
-                // a row inside the piece: the string must be inside the tube behind it
-                lo = ptv_max(lo, over_n(t - lam));
-                hi = ptv_min(hi, over_n(t + lam));
-            } else {
-                const bool floor_knot = (L.tmask >> k) & 1u;
-                const double hk = floor_knot ? lam : -lam;
-                const double v = over_n(S + (hk - h));        // (rebuild_owned's quotient, to the bit)
-                ok = ok && (lo <= v) && (v <= hi);
-                if (have_prev) ok = ok && (tprev ? (v >= vprev) : (v <= vprev));
-                else L.vfirst = v;
-                vprev = v;
-                tprev = floor_knot;
-                have_prev = true;
-                S = 0.0;
-                n = 0;
-                h = hk;
-                lo = -1.7976931348623157e308;
-                hi = 1.7976931348623157e308;
-            }
-        }
-    }
-    L.vlast = vprev;
-    L.ok = ok;
-}
-
-// The first bend known a priori at or after `from`: edges (k - 1, k), k = from .. from + LOOK - 1 (rows up to from + LOOK - 1 are read).
-// Returns the sample the new piece starts at (-1: none) and the bend type.  Unweighted.
-template <int LOOK, class Win>
-__device__ __forceinline__ int certain_bend_after(const Win &win, int from, double lam, int &type) {
-    int cat = -1;
-    type = 0;
-#pragma unroll
-    for (int u = LOOK - 1; u >= 0; u--) {
-        const double d = win.y(from + u) - win.y(from + u - 1);
-        const bool hit = fabs(d) > 4.0000001 * lam;
-        cat = hit ? from + u : cat;
-        type = hit ? (d > 0 ? BEND_FLOOR : BEND_CEIL) : type;
-    }
-    return cat;
-}
 
 }  // namespace ptv

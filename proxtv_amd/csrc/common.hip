@@ -28,33 +28,24 @@ struct OptionEntry {
 };
 constexpr OptionEntry kOptionTable[] = {
     {"chunk", &Options::chunk},
-    {"warmup", &Options::warmup},
     {"chunk_mode", &Options::chunk_mode},
     {"deterministic", &Options::deterministic},
-    {"blocks_per_wg", &Options::blocks_per_wg},
-    {"rounds", &Options::rounds},
     {"along", &Options::along},
-    {"replay", &Options::replay},
-    {"along_min_len", &Options::along_min_len},
-    {"row_along", &Options::row_along},
-    {"seed_row_along_e4", &Options::seed_row_along_e4},
-    {"seed_noisy_e4", &Options::seed_noisy_e4},
-    {"seed_mid_e4", &Options::seed_mid_e4},
     {"pin", &Options::pin},
     {"pin_seed", &Options::pin_seed},
-    {"pin_overlap", &Options::pin_overlap},
     {"repair_jobs", &Options::repair_jobs},
     {"whole", &Options::whole},
     {"chunk_min_len", &Options::chunk_min_len},
     {"xlink", &Options::xlink},
     {"dr_form", &Options::dr_form},
     {"tile", &Options::tile},
-    {"host_register", &Options::host_register},
+    {"certify", &Options::certify},
     {"verbose", &Options::verbose},
     {"profile", &Options::profile},
     {"why", &Options::why},
     {"trace", &Options::trace},
     {"ablate", &Options::ablate},
+    {"debug_legacy_rebuild", &Options::debug_legacy_rebuild},
 };
 }  // namespace
 
@@ -87,7 +78,8 @@ Options &options() {
 namespace {
 std::atomic<long> g_counters[CNT_COUNT];
 constexpr const char *kCounterNames[CNT_COUNT] = {"sweep_launches", "repair_launches", "repair_jobs_launches", "pin_sweeps",
-                                                  "pin_cap_next_rung", "tv2_long_fibres"};
+                                                  "pin_cap_next_rung", "tv2_long_fibres", "certify_sweeps", "certify_failures",
+                                                  "certify_skipped"};
 }  // namespace
 void count_event(Counter c, long n) { g_counters[c].fetch_add(n, std::memory_order_relaxed); }
 long counter_value(const char *name) {
@@ -165,8 +157,6 @@ void ensure_device() {
 
 struct ThreadState {
     hipStream_t stream = nullptr;
-    hipStream_t helper = nullptr;            // second stream of this thread (StreamFork)
-    hipEvent_t fork = nullptr, join = nullptr;
     std::multimap<size_t, void *> free_blocks;
     size_t cached = 0;   // bytes in free_blocks
 };
@@ -196,24 +186,6 @@ hipStream_t thread_stream() {
     ThreadState &t = g_ts.dev[current_device()];
     if (!t.stream) PTV_HIP(hipStreamCreateWithFlags(&t.stream, hipStreamNonBlocking));
     return t.stream;
-}
-
-// A helper stream ordered after everything enqueued on `main` so far; join() orders `main` after everything enqueued on the helper.
-StreamFork::StreamFork(hipStream_t main) : main_(main) {
-    ThreadState &t = g_ts.dev[current_device()];
-    if (!t.helper) {
-        PTV_HIP(hipStreamCreateWithFlags(&t.helper, hipStreamNonBlocking));
-        PTV_HIP(hipEventCreateWithFlags(&t.fork, hipEventDisableTiming));
-        PTV_HIP(hipEventCreateWithFlags(&t.join, hipEventDisableTiming));
-    }
-    helper_ = t.helper;
-    PTV_HIP(hipEventRecord(t.fork, main_));
-    PTV_HIP(hipStreamWaitEvent(helper_, t.fork, 0));
-}
-void StreamFork::join() {
-    ThreadState &t = g_ts.dev[current_device()];
-    PTV_HIP(hipEventRecord(t.join, helper_));
-    PTV_HIP(hipStreamWaitEvent(main_, t.join, 0));
 }
 
 // ---- scratch pool --------------------------------------------------------------------------------------------------

@@ -37,30 +37,14 @@ struct HipFailure {
 // ---- options (see proxtv_set_option) ---------------------------------------------------------------------------
 struct Options {
     int chunk = 16;     // non-zero: speculative-chunk kernels (16-sample chunks); 0 = sequential lane-per-fibre kernels only
-    int warmup = 16;    // (reserved) warm-up zone in samples; the chunk kernels are built for kWarm = 16
     int chunk_mode = -1;    // -1 = chosen per sweep (see `deterministic`); 0..5 pin the chunk geometry policy
     int deterministic = 1;  // 1: the rung of a sweep is a function of (input statistics, lambda) only -- reproducible to the last
                             // bit; 0: hill climb on measured sweep times, seeded by the same statistics (policy.hpp)
-    int blocks_per_wg = 0;  // blocks pipelined per workgroup in the chunk kernel; 0 = pick from the problem size
-    int rounds = 0;         // second-chance rounds of geometry mode 1 (0 = the built-in default)
     int along = 1;            // dimension-0 sweeps: chunks along the fibre (sweep_along_kernel); 0 = the transposed 64-fibre tile
-    int replay = 0;           // ... 1: the plain along-fibre kernel keeps every chunk's piece ends / bend types and, from the fourth sweep of a solve
-                              // over the same geometry on, VERIFIES the last sweep's against the optimality conditions instead of walking (all or
-                              // nothing per wave; exact whatever the record holds: chunkcore.hpp rebuild_owned FULL = 3).  Measured and NOT the
-                              // default: 60 % of a DR solve's column waves replay at lambda 0.1 and the sweep is slower (75.3 -> 81.3 us): as
-                              // compiled, the check costs a wave nearly what the walk does (profiles/NOTES_r05.md, sessions 8-10)
-    int along_min_len = 160;  // ... for fibres at least this long (16, 32 or 64 lanes share a fibre segment of 17-sample chunks)
-    int row_along = 1;        // strided sweeps through transposed copies + the along-fibre kernel: bit 0 = rung 2 (64-sample zones),
-                              // bit 1 = rung 1 as well (0 = the 64-fibre tile for both)
-    int seed_row_along_e4 = 0;   // tuning aid: kSeedRowAlong (policy.hpp) in units of 1e-4 ; 0 = built in
-    int seed_noisy_e4 = 0, seed_mid_e4 = 0;   // tuning aid: the policy seed's thresholds (policy.hpp) in units of 1e-4 ; 0 = built in
     int pin = 1;              // geometry rung 3: the pinning solver (pin.hip) where it applies; 0 = global-memory chunks
     int repair_jobs = 1;      // chunked sweeps: failed links across workgroups are repaired one lane per failure first (sweep_repair_jobs_kernel), what that
                               // leaves by the sequential repair kernel: 1 = where the sampled certain fraction says such links fail in numbers
                               // (policy.hpp: kSeedJobs), 2 = always, 0 = the sequential repair alone
-    int pin_overlap = 0;      // strided sweeps of the pinning solver: 1 = the transpositions of one range of fibres run on a second stream
-                              // under the levels of another.  Measured and NOT kept (4096^2 DR, lambda 0.8 / 1 / 3: 25.1 -> 27.1, 29.3 -> 30.9,
-                              // 18.2 -> 21.0 ms): four quarter-size launches per sweep lose more than the hidden copies win
     int pin_seed = 1;         // the pinning solver starts from the knots known a priori (|dy| > 4 lambda) instead of the fibre ends alone
     int whole = 1;            // fibres of 16 .. chunk_min_len samples: 1 = by length and data (sequential up to 32 samples; one block of the
                               // chunk kernel on noisy data, else whole fibres in LDS), 2 = the whole-fibre-in-LDS kernel, 0 = the sequential kernel
@@ -72,12 +56,15 @@ struct Options {
                               // reference's split (OP_DR_COL / OP_DR_ROW)
     int tile = 1;             // strided sweeps on rungs 0 and 1 (unweighted and weighted): 1 = tiles of 32 fibres x 8 chunks in 4 waves (four
                               // workgroups per CU), 0 = the 64-fibre x 8-wave tile (two)
-    int host_register = 0;    // host-pointer entry points: page-lock large caller arrays around their transfers (see cabi.hip)
+    int certify = 0;          // 1: every fibre sweep is followed by a check of the prox's optimality conditions on what it wrote, fibre by fibre;
+                              // a fibre that fails is re-solved by the sequential walk and counted (sweep_kernels.hpp: certify_*_kernel)
     int verbose = 0;
     int profile = 0;    // per-kernel-family hipEvent timing
     int why = 0;        // tuning aid: count what marks sweeps dirty (proxtv_debug_why)
     int trace = 0;      // profiling aid: per-workgroup phase timestamps of the chunk kernel (proxtv_debug_trace)
     int ablate = 0;     // profiling aid, see ChunkPlan::ablate (results are WRONG when non-zero)
+    int debug_legacy_rebuild = 0;   // test aid: the along-fibre kernel's rebuild with the semantics of rounds 1-4 (an unproven chunk values its first
+                                    // piece from its own first row) -- results MAY BE WRONG; exists so that the suite can watch `certify` catch it
 };
 Options &options();
 int *option_slot(const char *key);   // null for an unknown key
@@ -90,6 +77,9 @@ enum Counter {
     CNT_PIN_SWEEPS,            // sweeps the pinning solver took
     CNT_PIN_CAP_NEXT_RUNG,     // ... of which the grid-wide variant hit its level cap and handed the sweep to the next rung
     CNT_TV2_LONG_FIBRES,       // TV-L2 fibres solved parallel inside the fibre (tv2.hip: tv2_long_fibre)
+    CNT_CERTIFY_SWEEPS,        // option certify: sweeps whose output was checked against the optimality conditions of the prox
+    CNT_CERTIFY_FAILURES,      // ... fibres that failed the check and were re-solved by the sequential walk
+    CNT_CERTIFY_SKIPPED,       // ... sweeps that could not be checked (an output aliases an operand; lambda <= 0)
     CNT_COUNT
 };
 void count_event(Counter c, long n = 1);
@@ -110,17 +100,6 @@ void warm_pinlong();
 void warm_pointwise();
 void warm_tv2();
 hipStream_t thread_stream();
-// Two-stream sections (a memory-bound pass of one range of fibres under the compute-bound pass of another): a per-thread helper
-// stream, ordered after what `main` holds at construction; join() makes `main` wait for what the helper holds then.
-class StreamFork {
-  public:
-    explicit StreamFork(hipStream_t main);
-    hipStream_t helper() const { return helper_; }
-    void join();
-
-  private:
-    hipStream_t main_, helper_ = nullptr;
-};
 
 // ---- HBM scratch pool ------------------------------------------------------------------------------------------
 // Per-thread, per-device cache of device allocations: solvers ask for a handful of image-sized arrays per call and

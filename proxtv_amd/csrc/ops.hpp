@@ -9,6 +9,9 @@
 //   ext = Op::fetch(args, idx)         the operand values the epilogue needs (global loads only, so a kernel can
 //                                      issue a batch of them before any dependent work)
 //   Op::finish(args, idx, ext, x)      x = prox value at idx; computes and writes every output of the sweep
+//   x   = Op::recover(args, idx, y, scale)   (option certify) the prox value at idx read back from what the sweep WROTE, for the
+//                                      check of the optimality conditions behind the sweep; `scale` grows to the magnitude of
+//                                      every operand the recovery touches (its rounding noise is a few ulps of that)
 // The arithmetic follows the reference's operation order (cited per op) except where noted, so results agree to
 // the last ulps with the CPU path.
 #pragma once
@@ -132,6 +135,10 @@ template <> struct Op<OP_PROX> : InA {
     __device__ static __forceinline__ void store_fused(const SweepArgs &p, long idx, double v) { st_once2(p.o0 + idx, v); }
     __device__ static __forceinline__ Ext fetch(const SweepArgs &, long) { return Ext{0, 0}; }
     __device__ static __forceinline__ void finish(const SweepArgs &p, long idx, const Ext &, double x) { st_once2(p.o0 + idx, x); }
+    __device__ static __forceinline__ double recover(const SweepArgs &p, long idx, double y, double &scale) {
+        (void)y; (void)scale;
+        return p.o0[idx];
+    }
 };
 
 // DR, columns (a = t): s = t - prox(t) ; s' = 2 s - t          (src/TV2Dopt.cpp:408-411, 539-547)
@@ -148,6 +155,11 @@ template <> struct Op<OP_DR_COL> : InA {
     __device__ static __forceinline__ void finish(const SweepArgs &p, long idx, const Ext &e, double x) {
         st_once2(p.o0 + idx, fuse(e.e0, x));
     }
+    __device__ static __forceinline__ double recover(const SweepArgs &p, long idx, double y, double &scale) {
+        const double o = p.o0[idx];   // o = 2 (y - x) - y
+        scale = fmax(scale, fabs(o));
+        return 0.5 * (y - o);
+    }
 };
 // final projection: s = t - prox(t)                              (src/TV2Dopt.cpp:427)
 template <> struct Op<OP_DR_COL_FINAL> : InA {
@@ -158,6 +170,11 @@ template <> struct Op<OP_DR_COL_FINAL> : InA {
     __device__ static __forceinline__ void store_fused(const SweepArgs &p, long idx, double v) { st_once2(p.o0 + idx, v); }
     __device__ static __forceinline__ Ext fetch(const SweepArgs &p, long idx) { return Ext{p.a[idx], 0}; }
     __device__ static __forceinline__ void finish(const SweepArgs &p, long idx, const Ext &e, double x) { st_once2(p.o0 + idx, e.e0 - x); }
+    __device__ static __forceinline__ double recover(const SweepArgs &p, long idx, double y, double &scale) {
+        const double o = p.o0[idx];   // o = y - x
+        scale = fmax(scale, fabs(o));
+        return y - o;
+    }
 };
 
 // DR, rows (a = s', b = unary, c = t_old, o0 = t_new).  Reference (src/TV2Dopt.cpp:417-422, 514-520):
@@ -187,6 +204,13 @@ template <> struct Op<OP_DR_ROW> : InBminusA, NotFused {
         const double tb = e.e0 + 2 * x;
         st_once(p.o0 + idx, 0.5 * (e.e1 + tb));
     }
+    __device__ static __forceinline__ double recover(const SweepArgs &p, long idx, double y, double &scale) {
+        const double tn = p.o0[idx], t = p.c[idx], sp = p.a[idx];   // tn = 0.5 (t + (sp + 2 x))
+        scale = fmax(scale, fabs(tn));
+        scale = fmax(scale, fabs(t));
+        scale = fmax(scale, fabs(sp));
+        return 0.5 * ((2 * tn - t) - sp);
+    }
 };
 // The same iteration with the work split the other way round (round 3; dr2 in solvers.hip picks it when the row sweep runs
 // on the 64-fibre tile).  The row tile is the kernel with barriers, halos and two workgroups per CU; the along-fibre column
@@ -204,11 +228,22 @@ template <> struct Op<OP_DR_COL_V> : InA, NotFused {
         st_once2(p.o0 + idx, e.e1 - sp);
         st_once2(p.o1 + idx, s);
     }
+    __device__ static __forceinline__ double recover(const SweepArgs &p, long idx, double y, double &scale) {
+        const double sv = p.o1[idx];   // s = y - x
+        scale = fmax(scale, fabs(sv));
+        return y - sv;
+    }
 };
 template <> struct Op<OP_DR_ROW_V> : InA, NotFused {
     static constexpr unsigned IN_MASK = 3, OUT_MASK = 1;
     __device__ static __forceinline__ Ext fetch(const SweepArgs &p, long idx) { return Ext{ld_once2(p.b + idx), 0}; }
     __device__ static __forceinline__ void finish(const SweepArgs &p, long idx, const Ext &e, double x) { st_once2(p.o0 + idx, e.e0 + x); }
+    __device__ static __forceinline__ double recover(const SweepArgs &p, long idx, double y, double &scale) {
+        const double tn = p.o0[idx], sv = p.b[idx];   // tn = s + x
+        scale = fmax(scale, fabs(tn));
+        scale = fmax(scale, fabs(sv));
+        return tn - sv;
+    }
 };
 // recovery (a = s, b = unary): out = (U - (v - prox(v))) - s                         (src/TV2Dopt.cpp:429-430)
 template <> struct Op<OP_DR_ROW_FINAL> : InBminusA, NotFused {
@@ -219,6 +254,13 @@ template <> struct Op<OP_DR_ROW_FINAL> : InBminusA, NotFused {
         const double tb = e.e0 - (y - x);
         st_once2(p.o0 + idx, tb - e.e1);
     }
+    __device__ static __forceinline__ double recover(const SweepArgs &p, long idx, double y, double &scale) {
+        const double out = p.o0[idx], U = p.b[idx], sv = p.a[idx];   // out = (U - (y - x)) - s
+        scale = fmax(scale, fabs(out));
+        scale = fmax(scale, fabs(U));
+        scale = fmax(scale, fabs(sv));
+        return y - (U - (out + sv));
+    }
 };
 // weighted recovery: tbw = (v - prox(v)) - U ; out = -s - tbw                          (src/TV2DWopt.cpp:124-126, 218)
 template <> struct Op<OP_DRW_ROW_FINAL> : InBminusA, NotFused {
@@ -228,6 +270,13 @@ template <> struct Op<OP_DRW_ROW_FINAL> : InBminusA, NotFused {
         const double y = e.e0 - e.e1;
         const double tb = (y - x) - e.e0;
         st_once2(p.o0 + idx, -e.e1 - tb);
+    }
+    __device__ static __forceinline__ double recover(const SweepArgs &p, long idx, double y, double &scale) {
+        const double out = p.o0[idx], U = p.b[idx], sv = p.a[idx];   // out = -s - ((y - x) - U)
+        scale = fmax(scale, fabs(out));
+        scale = fmax(scale, fabs(U));
+        scale = fmax(scale, fabs(sv));
+        return y - ((U - sv) - out);
     }
 };
 
@@ -241,6 +290,11 @@ template <> struct Op<OP_PD2_A> : InAplusB, NotFused {
         st_once2(p.o0 + idx, x);
         st_once2(p.o1 + idx, e.e1 + (e.e0 - x));
     }
+    __device__ static __forceinline__ double recover(const SweepArgs &p, long idx, double y, double &scale) {
+        scale = fmax(scale, fmax(fabs(p.a[idx]), fabs(p.b[idx])));   // (y = a + b)
+        (void)y;
+        return p.o0[idx];
+    }
 };
 // Dykstra term 2 (a = z, b = q_in, o0 = x, o1 = q_out): x = prox(z + q) ; q += z - x    (src/TV2Dopt.cpp:234-263)
 template <> struct Op<OP_PD2_B> : InAplusB, NotFused {
@@ -251,6 +305,11 @@ template <> struct Op<OP_PD2_B> : InAplusB, NotFused {
     __device__ static __forceinline__ void finish(const SweepArgs &p, long idx, const Ext &e, double x) {
         st_once2(p.o0 + idx, x);
         st_once2(p.o1 + idx, e.e1 + (e.e0 - x));
+    }
+    __device__ static __forceinline__ double recover(const SweepArgs &p, long idx, double y, double &scale) {
+        scale = fmax(scale, fmax(fabs(p.a[idx]), fabs(p.b[idx])));   // (y = a + b)
+        (void)y;
+        return p.o0[idx];
     }
 };
 
@@ -268,6 +327,11 @@ template <> struct Op<OP_YANG> : NotFused, NoKeep {
     __device__ static __forceinline__ void finish(const SweepArgs &p, long idx, const Ext &e, double x) {
         st_once2(p.o0 + idx, x);
         st_once2(p.o1 + idx, e.e1 + p.s0 * (x - e.e0));
+    }
+    __device__ static __forceinline__ double recover(const SweepArgs &p, long idx, double y, double &scale) {
+        scale = fmax(scale, fmax(fabs(p.a[idx]), fabs(p.b[idx]) / p.s0));   // (y = -U / rho + X)
+        (void)y;
+        return p.o0[idx];
     }
 };
 

@@ -228,11 +228,8 @@ struct GaveUp {
 static thread_local GaveUp g_gaveup[kMaxDevices];
 static thread_local int g_seeded = 1;   // this sweep starts from the knots known a priori (launch_pin's argument, for the launchers below)
 
-// fibre0: the sweep is fibres [fibre0, fibre0 + g.count) of a larger one (operand pointers already moved): only the "gave up" flags --
-// one array for the whole sweep, so that ranges running on two streams do not share entries -- need to know; flags_for: fibres of
-// the whole sweep
 template <int OP, bool WEIGHTED, int P, int G>
-void launch_geom(const SweepArgs &args, const FibreGeom &g, hipStream_t stream, int *pieces, long fibre0 = 0, long flags_for = 0) {
+void launch_geom(const SweepArgs &args, const FibreGeom &g, hipStream_t stream, int *pieces) {
     using Geo = PinGeom<P, G, WEIGHTED>;
     auto kern = sweep_pin_kernel<OP, WEIGHTED, P, G>;
     if (Geo::lds > 64 * 1024) {   // above the default dynamic-LDS limit
@@ -244,7 +241,7 @@ void launch_geom(const SweepArgs &args, const FibreGeom &g, hipStream_t stream, 
         }
     }
     const long wgs = (g.count + Geo::NG - 1) / Geo::NG;
-    int *gaveup = g_gaveup[current_device()].get(flags_for > 0 ? flags_for : g.count, stream) + fibre0;
+    int *gaveup = g_gaveup[current_device()].get(g.count, stream);
     hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(kPinThreads), Geo::lds, stream, args, g, pieces, gaveup, g_seeded);
     PTV_HIP(hipGetLastError());
     // fibres that hit the level cap (none on anything but periodic data: the kernel returns at once)
@@ -253,24 +250,11 @@ void launch_geom(const SweepArgs &args, const FibreGeom &g, hipStream_t stream, 
 
 // contiguous fibres: pick the group geometry from the fibre length
 template <int OP, bool WEIGHTED>
-void launch_contig(const SweepArgs &args, const FibreGeom &g, hipStream_t stream, int *pieces, long fibre0 = 0, long flags_for = 0) {
-    if (g.len <= 64 * 16)        launch_geom<OP, WEIGHTED, 16, 64>(args, g, stream, pieces, fibre0, flags_for);
-    else if (g.len <= 256 * 16)  launch_geom<OP, WEIGHTED, 16, 256>(args, g, stream, pieces, fibre0, flags_for);
-    else if (g.len <= 256 * 32)  launch_geom<OP, WEIGHTED, 32, 256>(args, g, stream, pieces, fibre0, flags_for);
-    else if constexpr (!WEIGHTED) launch_geom<OP, false, 64, 256>(args, g, stream, pieces, fibre0, flags_for);
-}
-
-// fibres [j0, j1) of a sweep on transposed copies: every operand moved to its fibre j0
-inline SweepArgs fibres_from(const SweepArgs &t, long j0, int len) {
-    SweepArgs a = t;
-    const long off = j0 * len;
-    if (a.a) a.a += off;
-    if (a.b) a.b += off;
-    if (a.c) a.c += off;
-    if (a.o0) a.o0 += off;
-    if (a.o1) a.o1 += off;
-    if (a.w) a.w += j0 * (long)(len - 1);
-    return a;
+void launch_contig(const SweepArgs &args, const FibreGeom &g, hipStream_t stream, int *pieces) {
+    if (g.len <= 64 * 16)        launch_geom<OP, WEIGHTED, 16, 64>(args, g, stream, pieces);
+    else if (g.len <= 256 * 16)  launch_geom<OP, WEIGHTED, 16, 256>(args, g, stream, pieces);
+    else if (g.len <= 256 * 32)  launch_geom<OP, WEIGHTED, 32, 256>(args, g, stream, pieces);
+    else if constexpr (!WEIGHTED) launch_geom<OP, false, 64, 256>(args, g, stream, pieces);
 }
 
 template <int OP, bool WEIGHTED>
@@ -280,28 +264,9 @@ void launch_op(const SweepArgs &args, const FibreGeom &g, hipStream_t stream, in
         return;
     }
     // strided: the same sweep along dimension 0 of transposed copies (transposed.hpp)
-    // Option pin_overlap (off: measured slower, see common.hpp).  The transpositions are memory-bound (2 x 47 us per 4096^2 DR row
-    // sweep, of 390-480), the levels LDS- and instruction-bound: cut the fibres into ranges, alternate the ranges between the
-    // caller's stream and a helper, and the copies of one range move while the other range's levels run.  (One slab only: a range
-    // of fibres is then a block of rows of one column-major array.)
-    constexpr int kParts = 4;
-    if (options().pin_overlap && g.count == g.inc && g.count >= 1024 * kParts) {
-        TransposedOperands tr(args, Op<OP>::IN_MASK, Op<OP>::OUT_MASK, g, stream, true);
-        g_gaveup[current_device()].get(g.count, stream);   // (sized before the two streams share it)
-        StreamFork fork(stream);
-        const long step = ((g.count / kParts + 31) / 32) * 32;
-        int k = 0;
-        for (long j0 = 0; j0 < g.count; j0 += step, k++) {
-            const long j1 = j0 + step < g.count ? j0 + step : g.count;
-            hipStream_t q = (k & 1) ? fork.helper() : stream;
-            tr.stage_part(j0, j1, q);
-            launch_contig<OP, WEIGHTED>(fibres_from(tr.args(), j0, g.len), FibreGeom{1, g.len, j1 - j0}, q, pieces, j0, g.count);
-            tr.finish_part(j0, j1, q);
-        }
-        fork.join();
-        tr.finish();
-        return;
-    }
+    // (Tried in round 5 and removed: ranges of fibres alternating between two streams so that the copies of one range move under the
+    //  levels of another -- four quarter-size launches per sweep lose more than the hidden copies win: 4096^2 DR at lambda 0.8 / 1 / 3
+    //  25.1 -> 27.1, 29.3 -> 30.9, 18.2 -> 21.0 ms.)
     TransposedOperands tr(args, Op<OP>::IN_MASK, Op<OP>::OUT_MASK, g, stream);
     launch_contig<OP, WEIGHTED>(tr.args(), tr.geom(), stream, pieces);
     tr.finish();

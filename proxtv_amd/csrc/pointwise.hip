@@ -602,10 +602,9 @@ void TransposeCache::forget(const double *p) {
         if (entries[k].src == p) entries.erase(entries.begin() + (long)k);
 }
 
-TransposedOperands::TransposedOperands(const SweepArgs &args, unsigned in_mask, unsigned out_mask, const FibreGeom &g, hipStream_t s,
-                                       bool by_parts)
+TransposedOperands::TransposedOperands(const SweepArgs &args, unsigned in_mask, unsigned out_mask, const FibreGeom &g, hipStream_t s)
     : orig_(args), t_(args), g_(g), s_(s), out_mask_(out_mask), slabs_(g.count / g.inc),
-      bytes_(sizeof(double) * (size_t)g.count * (size_t)g.len), by_parts_(by_parts) {
+      bytes_(sizeof(double) * (size_t)g.count * (size_t)g.len) {
     if (in_mask & 1u) t_.a = input(args.a, ia_, g.len);
     if (in_mask & 2u) t_.b = input(args.b, ib_, g.len);
     if (in_mask & 4u) t_.c = input(args.c, ic_, g.len);
@@ -619,33 +618,21 @@ const double *TransposedOperands::input(const double *src, std::unique_ptr<Scrat
     if (cache.active)
         if (Scratch *c = cache.find(src, shape(len))) return c->d();
     std::unique_ptr<Scratch> copy(new Scratch(sizeof(double) * (size_t)g_.count * (size_t)len));
-    if (by_parts_) pending_.push_back(Pending{src, copy->d(), len});   // transposed range by range: stage_part()
-    else slab_transpose(src, copy->d(), g_.inc, len, slabs_, s_);
+    slab_transpose(src, copy->d(), g_.inc, len, slabs_, s_);
     const double *p = copy->d();
     if (cache.active) cache.remember(src, shape(len), std::move(copy));
     else own = std::move(copy);
     return p;
 }
 
-// by_parts (one slab): fibres [j0, j1) of every input that was not at hand in transposed form, on stream q
-void TransposedOperands::stage_part(long j0, long j1, hipStream_t q) {
-    for (const Pending &p : pending_) block_transpose(p.src + j0, p.dst + j0 * p.len, j1 - j0, p.len, g_.inc, p.len, q);
-}
-
-// ... and the outputs of those fibres back to where the caller wants them
-void TransposedOperands::finish_part(long j0, long j1, hipStream_t q) {
-    if (out_mask_ & 1u) block_transpose(o0_->d() + j0 * g_.len, orig_.o0 + j0, g_.len, j1 - j0, g_.len, g_.inc, q);
-    if (out_mask_ & 2u) block_transpose(o1_->d() + j0 * g_.len, orig_.o1 + j0, g_.len, j1 - j0, g_.len, g_.inc, q);
-}
-
 void TransposedOperands::finish() {
     TransposeCache &cache = transpose_cache();
     if (out_mask_ & 1u) {
-        if (!by_parts_) slab_transpose(o0_->d(), orig_.o0, g_.len, g_.inc, slabs_, s_);
+        slab_transpose(o0_->d(), orig_.o0, g_.len, g_.inc, slabs_, s_);
         if (cache.active) cache.remember(orig_.o0, shape(g_.len), std::move(o0_));   // (what was just written, in the form the next strided sweep wants)
     }
     if (out_mask_ & 2u) {
-        if (!by_parts_) slab_transpose(o1_->d(), orig_.o1, g_.len, g_.inc, slabs_, s_);
+        slab_transpose(o1_->d(), orig_.o1, g_.len, g_.inc, slabs_, s_);
         if (cache.active) cache.remember(orig_.o1, shape(g_.len), std::move(o1_));
     }
 }

@@ -27,7 +27,8 @@
 namespace ptv {
 
 constexpr int kModeSeq = 5;
-constexpr int kRounds = 4;          // second-chance rounds of mode 1 (option "rounds" overrides)
+constexpr int kRounds = 4;          // second-chance rounds of mode 1
+constexpr int kAlongMinLen = 160;   // dimension-0 sweeps take the along-fibre kernel from this fibre length on (16, 32 or 64 lanes share a segment of 17-sample chunks)
 // rewritten-chunk fraction above which the next rung is worth a trial, per rung (from mode 0 the next rung is the same
 // geometry made robust: a handful of repaired fibres per sweep already costs more than that), and below which the rung
 // below is
@@ -63,9 +64,6 @@ constexpr double kSeedPins = 0.001;    // rung 3: the pinning solver searches fo
 constexpr double kSeedJobs = 0.055;    // rung 1, option "repair_jobs" = 1: f below (as sampled: lambda >= 0.65 on unit noise -- 0.6 gives 0.065, 0.65 gives 0.048) the failed
                                        // links across workgroups go one lane each (4096^2 DR: lambda 0.6 14.27 -> 14.42 ms, 0.65 17.67 -> 17.33, 0.7 21.41 -> 19.97)
 constexpr double kSeedFlat = 0.02;     // more than this fraction of the sampled 16-edge stretches (all but) flat at lambda: rung 3
-constexpr double kSeedRowAlong = 0.0;  // rung 1, strided sweeps, f below: through transposed copies and the along-fibre kernel.  Round 3: 0.06 (lambda >= 0.65
-                                       // on unit noise: the 64-fibre tile left too many links to the repair kernel); with the robust 32-fibre tile of round 4
-                                       // the tile wins there too (4096^2 DR at lambda = 0.65 / 0.7: 19.4 -> 18.4, 22.5 -> 22.2 ms), so: never
 // DR2L1W: the second form of the iteration (ops.hpp, OP_DR_COL_V) pays below this certain fraction only -- the weighted column
 // sweep is the heavier one to begin with (4096^2, weights U(0.5, 1.5) lambda: lambda = 0.4: 17.4 -> 18.1 ms, 0.6: 25.3 -> 24.0)
 constexpr double kSeedDrFormWeighted = 0.2;

@@ -52,6 +52,15 @@ void tv1_fibres(const double *in, double *out, const int *ns, int nds, int dim, 
     launch_sweep(OP_PROX, weights != nullptr, a, fibres_along(ns, nds, dim), s, fam_of_dim(dim), in != out);
 }
 
+long certify_fibres(const double *in, const double *out, const int *ns, int nds, int dim, double lam, const double *weights, hipStream_t s) {
+    SweepArgs a;
+    a.a = in;
+    a.o0 = const_cast<double *>(out);   // (read only: the certifier never writes an operand)
+    a.lam = lam;
+    a.w = weights;
+    return certify_sweep(OP_PROX, weights != nullptr, a, fibres_along(ns, nds, dim), s);
+}
+
 void prox_fibres(const double *in, double *out, const int *ns, int nds, int dim, double lam, double norm, hipStream_t s) {
     if (norm == 2) tv2_fibres(in, out, ns, nds, dim, lam, s);
     else           tv1_fibres(in, out, ns, nds, dim, lam, nullptr, s);

@@ -16,6 +16,9 @@ struct SolveInfo {
 void tv1_fibres(const double *in, double *out, const int *ns, int nds, int dim, double lam, const double *weights,
                 hipStream_t s);
 
+// the certificate of such a sweep: fibres of `out` that are NOT the prox of the same fibre of `in` (-1: cannot be checked: lam <= 0, in == out)
+long certify_fibres(const double *in, const double *out, const int *ns, int nds, int dim, double lam, const double *weights, hipStream_t s);
+
 // out = prox along `dim` with the TV-L1 (norm 1: the sweep kernels) or TV-L2 (norm 2: tv2.hip) penalty; in != out
 void prox_fibres(const double *in, double *out, const int *ns, int nds, int dim, double lam, double norm, hipStream_t s);
 

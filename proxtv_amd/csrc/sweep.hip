@@ -61,7 +61,6 @@ void chunk_stats_reset(hipStream_t s) {
         st.latest_rewritten[f] = 0;
         st.latest_chunks[f] = 0;
     }
-    st.st_sweeps = 0;   // (replay: the first sweeps of a solve only record)
     if (st.failcount) PTV_HIP(hipMemsetAsync(st.failcount, 0, sizeof(int) * ChunkScratch::kCounters, s));
     st.nprobes = 0;
 }
@@ -108,10 +107,8 @@ int strided_tile_rung(const FibreGeom &g, double lam, bool weighted, double *cer
     if (certain_fraction) *certain_fraction = st.certain_fraction(g, lam, weighted);
     if (mode == 0) return 0;
     if (mode != 1) return -1;                         // (unsampled: the pinning rung)
-    if (weighted || !(options().along && g.len >= options().along_min_len)) return 1;
-    if (options().row_along & 2) return -1;
-    const double f = st.certain_fraction(g, lam, weighted);
-    return ((options().row_along & 1) && f >= 0.0 && f < seed_row_along()) ? -1 : 1;
+    if (weighted || !(options().along && g.len >= kAlongMinLen)) return 1;
+    return 1;
 }
 
 long chunk_stats_fixups(hipStream_t s) {
@@ -176,6 +173,15 @@ void launch_sweep(OpId op, bool weighted, const SweepArgs &args, const FibreGeom
     throw HipFailure{hipErrorInvalidValue};
 }
 
+
+long certify_sweep(OpId op, bool weighted, const SweepArgs &args, const FibreGeom &g, hipStream_t stream) {
+#define PTV_CERT(ID, W) \
+    if (op == ID && weighted == W) return unit_certify<ID, W>(args, g, stream);
+    PTV_SWEEP_UNITS(PTV_CERT)
+#undef PTV_CERT
+    set_error("certify_sweep: no %s sweep for op %d", weighted ? "weighted" : "unweighted", (int)op);
+    throw HipFailure{hipErrorInvalidValue};
+}
 
 void warm_sweep() {
 #define PTV_WARM(ID, W) unit_warm<ID, W>();

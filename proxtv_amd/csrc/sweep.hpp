@@ -18,6 +18,11 @@ namespace ptv {
 void launch_sweep(OpId op, bool weighted, const SweepArgs &args, const FibreGeom &g, hipStream_t stream, int fam,
                   bool allow_chunked);
 
+// The certificate alone (option certify runs it behind every sweep): the number of fibres for which what a sweep of `op` wrote is NOT
+// the prox of what it read -- the optimality conditions of the 1-D problem, checked per fibre (sweep_kernels.hpp, kernel 4) -- or -1 when
+// the sweep cannot be checked (lambda <= 0, an output aliasing an operand).  Synchronises `stream`.
+long certify_sweep(OpId op, bool weighted, const SweepArgs &args, const FibreGeom &g, hipStream_t stream);
+
 // Seed of the geometry policy for the solve that is starting: samples the edge statistics of `y` along each of the `ndims`
 // dimensions `dims` (0-based; weights[k], when non-null, are the per-edge penalties of a weighted sweep along dims[k]) and
 // reads them back (one small copy + stream synchronisation per call).  Dimensions whose fibres never reach the chunked

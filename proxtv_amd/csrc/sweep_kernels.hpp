@@ -199,8 +199,7 @@ struct ChunkPlan {
     unsigned long long *trace;   // option "trace": 8 words per workgroup -- where it ran and when its phases ended (100 MHz clock)
     DirtyMark dirty;             // this launch's "something is left for the repair kernel" word
     unsigned long long *xlink;   // links across workgroups / segments: [boundary][fibre] (tile) or [fibre][segment] (along)
-    unsigned *structure;         // along-fibre kernel: [fibre][chunk][ends, types] as the family's last sweep left them (null: none kept)
-    int replay;                  // ... and this sweep tries to verify them instead of walking (the first sweeps of a solve only record)
+    int legacy;                  // option debug_legacy_rebuild (along-fibre kernel): rebuild_owned with the first-piece semantics of rounds 1-4
 };
 
 __device__ __forceinline__ void trace_mark(const ChunkPlan &plan, int slot) {
@@ -593,10 +592,10 @@ __global__ __launch_bounds__(64 * NW, SHORT ? 16 / NW : (FW < 64 ? ((WEIGHTED ? 
         const bool inner = inner_block(q);   // (uniform over the workgroup)
         if (inner && !(plan.ablate & 1))
             rebuild_owned<Op<OP>, WEIGHTED, C, PTV_TILE_UNROLL, TAB, lds_double *, (ROUNDS ? TS : 0), 1>(win, rec, cs, ce, len, start, !bad, wlo,
-                                                                                                       ch == NCH - 1, p.lam, (lds_double *)rtab, nullptr, &head);
+                                                                                                       ch == NCH - 1, p.lam, (lds_double *)rtab, &head);
         else if (has_chunk && !(plan.ablate & 1))
             rebuild_owned<Op<OP>, WEIGHTED, C, PTV_TILE_UNROLL, TAB, lds_double *, (ROUNDS ? TS : 0)>(win, rec, cs, ce, len, start, !bad, wlo,
-                                                                                                    ch == NCH - 1 || ce == len, p.lam, (lds_double *)rtab, nullptr, &head);
+                                                                                                    ch == NCH - 1 || ce == len, p.lam, (lds_double *)rtab, &head);
         __syncthreads();
         if (kb == 0) trace_mark(plan, 4);
 
@@ -887,99 +886,7 @@ __global__ __launch_bounds__(64 * kAlongWaves) void sweep_along_kernel(SweepArgs
     const FarFibre<OP> far{p, fbase, 1, wbase};
     ChunkRec rec;
     bool certain = false;
-    // ---- replay: the structure the last sweep of this family left for this segment, VERIFIED instead of walked (chunkcore.hpp:
-    // rebuild_owned FULL = 3 and the note at replay_lane; host model: tests/host_harness.cpp host_replay_fibre, line for line).  The
-    // stretch between the bend known a priori at or before the segment (or the fibre start) and the first one at or after its end is a
-    // problem of its own; if every recorded piece in it satisfies the optimality conditions on THIS sweep's data, the recorded
-    // structure is its solution, whatever it was recorded from.  The check rides on the rebuild (a quarter on top of it; a pass of its
-    // own cost a wave more than the walk it saves: session 8), so a wave whose record fails has written rows it must not keep: it
-    // stages its window again and walks.  All or nothing per wave.  This form takes the segments whose record has no piece end
-    // between the two known bends and the segment (three in four).
-    constexpr bool REPLAYABLE = !ROBUST && !WEIGHTED && G == 64 && !ONESEG && TAB;
-    bool verified = false;
-    if constexpr (REPLAYABLE) {
-        if (plan.structure && plan.replay && interior && p.lam > 0.0 && !(plan.ablate & 1)) {
-            const unsigned *S = plan.structure + 2 * ((size_t)j * NC + (size_t)sg * G);   // [chunk of the segment][ends, types]
-            const unsigned own_e = S[2 * gl], own_t = S[2 * gl + 1];
-            bool ok = true;
-            // the knot the segment hangs on, which the record must have with that type and nothing behind it before the segment
-            // (uniform over the wave: every lane looks)
-            int kL = 0, tL = 0;
-            if (sg > 0) {
-                kL = certain_bend_before<false, kWarm - 2>(win, seg_s, len, p.lam, tL);
-                ok = kL >= 0;
-                if (ok) {
-                    const unsigned pe = S[-2], pt = S[-1];
-                    const int sh = kL - 1 - (seg_s - C);       // bit of row kL - 1 in the chunk before
-                    ok = ((pe >> sh) & 1u) && (int)((pt >> sh) & 1u) == tL && (pe >> (sh + 1)) == 0u;
-                }
-            }
-            // ... and the knot behind it, with nothing recorded between the segment and it
-            int tR = 0;
-            const int kR = certain_bend_after<T>(win, seg_e, p.lam, tR);
-            ok = ok && kR >= 0;
-            if (ok && kR > seg_e) {
-                const unsigned keep = (1u << (kR - seg_e)) - 1u;
-                ok = (S[2 * G] & keep) == (1u << (kR - 1 - seg_e)) && (int)((S[2 * G + 1] >> (kR - 1 - seg_e)) & 1u) == tR;
-            }
-            // (kR == seg_e: the knot is the last lane's own last row.  kR beyond: the piece that covers the segment's last sample must run
-            //  up to it -- a record that ends a piece ON the last sample leaves a piece [seg_e, kR) and the knot before it to nobody)
-            if (gl == G - 1) ok = ok && (kR == seg_e ? ((own_e >> (C - 1)) & 1u) && (int)((own_t >> (C - 1)) & 1u) == tR
-                                                      : !((own_e >> (C - 1)) & 1u));
-            // the last piece end of every lane's chunk; the knot a lane's first piece starts at: behind the last piece end of the
-            // nearest lower lane that has one, else kL
-            int rl = -1, rtp = 0;
-            if (own_e) {
-                const int b = 31 - __clz((int)own_e);
-                rl = cs + b;
-                rtp = (int)((own_t >> b) & 1u);
-            }
-            const unsigned long long has_end = __ballot(rl >= 0);
-            const unsigned long long lower = has_end & ((1ull << gl) - 1ull);
-            const int pl = lower ? 63 - __clzll((long long)lower) : 0;
-            const int s_end = __shfl(rl, pl), s_typ = __shfl(rtp, pl);
-            const bool from_kL = lower == 0ull;
-            const int s0 = from_kL ? kL : s_end + 1, st = from_kL ? tL : s_typ;
-            const bool fs = from_kL && sg == 0;                      // the fibre start: no knot, height 0
-            const bool has_rows = gl == G - 1 || rl >= 0;            // (a lane with no piece end is responsible for nothing)
-            // (a first piece of more than a chunk, a piece longer than the table: the walk's)
-            ok = ok && !(fs && gl > 0 && has_rows) && (!has_rows || (gl == G - 1 ? kR : ce) - s0 < kRecipTable);
-            if (__ballot(!ok) == 0ull) {
-                // what the walk would have left behind, from the record
-                ChunkRec cand;
-                cand.ends = own_e;
-                cand.types = own_t;
-                cand.mine = fs ? 0u : (((link_t)s0 << 1) | (link_t)st);
-                cand.next = rl >= 0 ? (((link_t)(rl + 1) << 1) | (link_t)rtp) : cand.mine;
-                cand.last = gl == G - 1 ? (((link_t)kR << 1) | (link_t)tR) : cand.next;
-                cand.done = true;
-                ReplayCheck chk;
-                rebuild_owned<Op<OP>, false, C, PTV_ALONG_UNROLL, TAB, lds_double *, 0, 3>(win, cand, cs, ce, len, start, true, seg_s, gl == G - 1, p.lam,
-                                                                                       (lds_double *)rtab, &chk);
-                // the jump across the knot a lane's first piece starts at: against the last piece of the nearest lower lane that has one
-                const unsigned long long has_piece = __ballot(chk.has);
-                const unsigned long long lowp = has_piece & ((1ull << gl) - 1ull);
-                const int pp = lowp ? 63 - __clzll((long long)lowp) : 0;
-                const double vbefore = __shfl(chk.vlast, pp);
-                if (chk.has && lowp != 0ull) chk.ok = chk.ok && (st == BEND_FLOOR ? chk.vfirst >= vbefore : chk.vfirst <= vbefore);
-                verified = __ballot(!chk.ok) == 0ull;
-                if (verified) {
-                    rec = cand;
-                    certain = !fs;   // (a start at the fibre start is exact as it is; everything else begins at a verified knot)
-                    if (gl == 0) plan.dirty.note(5);   // (option "why": waves that replayed)
-                } else {
-                    // rows were rewritten from a record that does not hold: the window again, then the walk as if nothing had happened
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    stage_interior();
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    if (gl == 0) plan.dirty.note(6);   // (... that tried and walked after all)
-                }
-            }
-        }
-    }
-    if (has_chunk && !verified && !(plan.ablate & 1)) {
+    if (has_chunk && !(plan.ablate & 1)) {
         Walker w;
         // (robust: the whole zone is searched -- a lane that starts at a bend known a priori has no link that could fail)
         constexpr int kLook = ROBUST ? kWarm - 2 : 8;
@@ -1065,11 +972,6 @@ __global__ __launch_bounds__(64 * kAlongWaves) void sweep_along_kernel(SweepArgs
         code_next[j * NC + chunk] = rec.next;
         // the segment's last chunk: what the next segment's first chunk must have begun with (checked by that segment at its end)
         if (plan.xlink && gl == G - 1 && sg + 1 < nseg) xlink_publish(plan.xlink + (size_t)j * nseg + sg, plan.dirty.epoch, rec.next);
-        // the record the next sweep of this family may replay (a verified record stands as it is; an unproven chunk records nothing)
-        if (REPLAYABLE && plan.structure && !verified) {
-            plan.structure[2 * ((size_t)j * NC + chunk)] = bad ? 0u : rec.ends;
-            plan.structure[2 * ((size_t)j * NC + chunk) + 1] = rec.types;
-        }
     }
     // a lane's writes stop at the nearest unproven chunk before it (see GUARD in sweep_chunk_kernel; needed for H > C)
     int wlo = seg_s;
@@ -1079,13 +981,20 @@ __global__ __launch_bounds__(64 * kAlongWaves) void sweep_along_kernel(SweepArgs
         const unsigned long long below = grp & ((1ull << gl) - 1ull);
         if (below) wlo = seg_s + (63 - __clzll((long long)below)) * C;
     }
-    if (verified) {}   // (rebuilt while it was verified)
-    else if (!WEIGHTED && interior && !(plan.ablate & 1))   // (every lane of the wave holds a whole chunk: the form that keeps it in registers)
+    // The rows before a lane's chunk that belong to its first piece lie in its predecessor's chunk, and the predecessor may end a piece
+    // there and write them in its own rebuild: they are summed first, by every lane, and the wave is fenced before the first row is
+    // replaced (lockstep execution gives that order today; the fence says so to the compiler, which sees one lane's addresses only and
+    // may otherwise move a store of rows >= cs above loads of rows < cs).
+    PiecePrefix head;
+    if (has_chunk && !(plan.ablate & 1)) head = first_piece_prefix(win, rec, cs, start);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (!WEIGHTED && interior && !(plan.ablate & 1))   // (every lane of the wave holds a whole chunk: the form that keeps it in registers)
         rebuild_owned<Op<OP>, WEIGHTED, C, PTV_ALONG_UNROLL, TAB, lds_double *, (ROBUST ? TS : 0), 2>(win, rec, cs, ce, len, start, !bad, wlo, gl == G - 1, p.lam,
-                                                                                      (lds_double *)rtab);
+                                                                                      (lds_double *)rtab, &head, plan.legacy != 0);
     else if (has_chunk && !(plan.ablate & 1))
         rebuild_owned<Op<OP>, WEIGHTED, C, PTV_ALONG_UNROLL, TAB, lds_double *, (ROBUST ? TS : 0)>(win, rec, cs, ce, len, start, !bad, wlo, gl == G - 1 || ce == len, p.lam,
-                                                                                (lds_double *)rtab);
+                                                                                (lds_double *)rtab, &head, plan.legacy != 0);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     if (plan.trace && lane == 0) plan.trace[8 * (size_t)wid + 4] = wall_clock64();
@@ -1985,6 +1894,118 @@ __global__ __launch_bounds__(64) void sweep_repair_kernel(SweepArgs p, FibreGeom
     atomicAdd(failcount + 1, walks);   // chunks rewritten
 }
 
+// ---- kernel 4 (option certify): the optimality conditions of the prox on what a sweep WROTE ------------------------------------------
+// x = prox(y) minimises 1/2 |x - y|^2 + sum_k r_k |x_{k+1} - x_k| (the problem every solver of the reference's 1-D path solves:
+// src/TVL1opt.cpp:359-564) iff, with u_k = sum_{i <= k} (y_i - x_i):
+//     |u_k| <= r_k for every edge k ;  u_k = -r_k where x_{k+1} > x_k ,  u_k = +r_k where x_{k+1} < x_k ;  u_{n-1} = 0
+// -- the minimiser is unique, so a fibre that passes IS the prox, whatever kernel wrote it and whatever went wrong on the way.  The
+// check reads the sweep's inputs through the op's own input functor and recovers x from the sweep's outputs (Op::recover), so it
+// sees exactly what the next sweep will see.  Tolerances: sums of n terms accumulate ~n ulps of the operands' magnitude, a recovered
+// x carries a few ulps of it -- a violation counts above kCertifyTol * n * 2^-52 * (largest operand), a step of x above
+// kCertifyStep * 2^-52 * that.  A fibre that fails is flagged; the host re-solves the flagged fibres with the sequential walk
+// (sweep_seq_kernel through its fibre gate) and counts them.  Fibres with a negative penalty are not checked (the reference's behaviour
+// there is its code, not a minimisation).
+constexpr double kCertifyTol = 64.0, kCertifyStep = 256.0, kCertifyUlp = 2.220446049250313e-16;
+
+struct CertifyAcc {
+    double u = 0.0, scale = 0.0, viol = 0.0;
+    bool defined = true;
+    // one sample: its y, its x, the next sample's x (the last sample: anything), the penalty of the edge behind it
+    __device__ __forceinline__ void edge(double uk, double x, double xn, double r, bool last) {
+        if (last) {
+            viol = fmax(viol, fabs(uk));
+            return;
+        }
+        defined = defined && r >= 0.0;
+        viol = fmax(viol, fabs(uk) - r);
+        const double dx = xn - x, step = kCertifyStep * kCertifyUlp * scale;
+        if (dx > step)       viol = fmax(viol, fabs(uk + r));
+        else if (dx < -step) viol = fmax(viol, fabs(uk - r));
+    }
+    __device__ __forceinline__ bool failed(int len, double lam) const {
+        return defined && viol > kCertifyTol * (double)len * kCertifyUlp * fmax(scale, fabs(lam));
+    }
+};
+
+template <int OP>
+__device__ __forceinline__ void certify_sample(const SweepArgs &p, long idx, double &y, double &x, double &scale) {
+    double i0, i1;
+    Op<OP>::fetch_in(p, idx, i0, i1);
+    y = Op<OP>::y_of(p, i0, i1);
+    scale = fmax(scale, fmax(fabs(i0), fabs(i1)));
+    x = Op<OP>::recover(p, idx, y, scale);
+    scale = fmax(scale, fabs(x));
+}
+
+// strided fibres: one lane per fibre, 64 adjacent fibres per wave (every access a 512-byte row)
+template <int OP, bool WEIGHTED>
+__global__ __launch_bounds__(64) void certify_strided_kernel(SweepArgs p, FibreGeom g, int *flags, unsigned *count) {
+    const long j = (long)blockIdx.x * 64 + threadIdx.x;
+    if (j >= g.count || g.len <= 0) return;
+    if (p.gate && *p.gate == 0) return;
+    long blk, off;
+    divmod_nonneg(j, g.inc, blk, off);
+    const long base = blk * g.inc * g.len + off, wbase = blk * g.inc * (g.len - 1) + off;
+    CertifyAcc acc;
+    double y, x;
+    certify_sample<OP>(p, base, y, x, acc.scale);
+    for (int k = 0; k < g.len; k++) {
+        const bool last = k == g.len - 1;
+        double yn = 0.0, xn = x;
+        if (!last) certify_sample<OP>(p, base + (long)(k + 1) * g.inc, yn, xn, acc.scale);
+        acc.u += y - x;
+        const double r = last ? 0.0 : (WEIGHTED ? p.w[wbase + (long)k * g.inc] : p.lam);
+        acc.edge(acc.u, x, xn, r, last);
+        y = yn;
+        x = xn;
+    }
+    if (acc.failed(g.len, WEIGHTED ? 0.0 : p.lam)) {
+        flags[j] = 1;
+        atomicAdd(count, 1u);
+    }
+}
+
+// contiguous fibres: one wave per fibre, 64 consecutive samples per trip, the running sum by a scan across the lanes
+template <int OP, bool WEIGHTED>
+__global__ __launch_bounds__(256) void certify_along_kernel(SweepArgs p, FibreGeom g, int *flags, unsigned *count) {
+    const int lane = threadIdx.x & 63;
+    const long j = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (j >= g.count || g.len <= 0) return;
+    if (p.gate && *p.gate == 0) return;
+    const long base = j * g.len, wbase = j * (g.len - 1);
+    CertifyAcc acc;
+    double carry = 0.0;
+    for (int k0 = 0; k0 < g.len; k0 += 64) {
+        const int k = k0 + lane;
+        const bool in = k < g.len, last = k == g.len - 1;
+        double y = 0.0, x = 0.0, xn = 0.0, yd;
+        if (in) certify_sample<OP>(p, base + k, y, x, acc.scale);
+        // the next sample's x: the next lane's; the trip's last lane reads it itself
+        xn = __shfl_down(x, 1);
+        if (lane == 63 && in && !last) certify_sample<OP>(p, base + k + 1, yd, xn, acc.scale);
+        // (every lane tests against the largest operand any lane has seen so far)
+        for (int o = 32; o > 0; o >>= 1) acc.scale = fmax(acc.scale, __shfl_xor(acc.scale, o));
+        double u = in ? y - x : 0.0;
+        for (int o = 1; o < 64; o <<= 1) {
+            const double t = __shfl_up(u, o);
+            if (lane >= o) u += t;
+        }
+        u += carry;
+        carry = __shfl(u, 63);
+        if (in) {
+            const double r = last ? 0.0 : (WEIGHTED ? p.w[wbase + k] : p.lam);
+            acc.edge(u, x, xn, r, last);
+        }
+    }
+    bool bad = acc.failed(g.len, WEIGHTED ? 0.0 : p.lam);
+    // (a lane that met a negative penalty takes the whole fibre out of the check)
+    if (__ballot(!acc.defined) != 0ull) bad = false;
+    if (__ballot(bad) != 0ull && lane == 0) {
+        flags[j] = 1;
+        atomicAdd(count, 1u);
+    }
+}
+
 // ---- host side ---------------------------------------------------------------------------------------------------------
 template <int OP, bool WEIGHTED>
 void launch_seq(const SweepArgs &args, const FibreGeom &g, hipStream_t stream, bool long_pieces, int *fibre_gate = nullptr) {
@@ -2013,6 +2034,16 @@ struct ChunkScratch {
         }
         return handled_buf->as<unsigned>();
     }
+    std::unique_ptr<Scratch> certify_buf;   // option "certify": [0] fibres that failed the last check, [1 ...] their flags (the sequential kernel's fibre gate)
+    size_t certify_count = 0;
+    int *certify_for(size_t count, hipStream_t s) {
+        if (count > certify_count) {
+            certify_buf.reset(new Scratch(sizeof(int) * (count + 1)));
+            certify_count = count;
+            PTV_HIP(hipMemsetAsync(certify_buf->as<int>(), 0, sizeof(int) * (count + 1), s));
+        }
+        return certify_buf->as<int>();
+    }
     std::unique_ptr<Scratch> trace;   // option "trace": phase timestamps of the last chunk-kernel launch
     size_t trace_wgs = 0;
     unsigned long long *trace_buffer(size_t wgs) {
@@ -2033,27 +2064,6 @@ struct ChunkScratch {
         }
         if (++epoch == 0u) ++epoch;   // (0 is what freshly allocated words hold)
         return DirtyMark{dirty_word->as<unsigned>(), epoch, options().why ? dirty_word->as<unsigned>() + 1 : nullptr};
-    }
-    // The record of the along-fibre kernel's last sweep over this geometry (replay: sweep_along_kernel): ends / types of every chunk.
-    // Nothing in it is trusted -- a sweep VERIFIES what it finds -- so it is never cleared; but verifying costs a quarter of a walk
-    // where it fails, and between the first sweeps of a solve a third of the chunks still change (profiles/r04_study_structure.txt:
-    // 28 % / 4 % / 1.3 % of them at iterations 2 / 3 / 5 of a DR solve at lambda 0.1): the first kReplayAfter sweeps of a solve over a
-    // geometry only record.
-    static constexpr int kReplayAfter = 3;
-    std::unique_ptr<Scratch> structure;
-    long st_len = -1, st_count = -1;
-    int st_sweeps = 0;
-    unsigned *structure_for(const FibreGeom &g, int NC, int &replay) {
-        const size_t need = sizeof(unsigned) * 2 * (size_t)g.count * (size_t)NC;
-        if (!structure || structure->bytes() < need || st_len != g.len || st_count != g.count) {
-            if (!structure || structure->bytes() < need) structure.reset(new Scratch(need));
-            st_len = g.len;
-            st_count = g.count;
-            st_sweeps = 0;
-        }
-        replay = st_sweeps >= kReplayAfter;
-        st_sweeps++;
-        return structure->as<unsigned>();
     }
     unsigned long long *xlink_for(size_t words, hipStream_t s) {
         if (!options().xlink) return nullptr;
@@ -2126,11 +2136,6 @@ struct ChunkScratch {
         // Spatially uneven data (half an image flat, sparse spikes on a constant background): whatever the average says, the
         // quiet stretches have pieces far longer than any zone and every chunk in them would go to the repair kernel.
         if (flat_fraction(g, lam, weighted) > kSeedFlat) return 3;
-        if (options().seed_noisy_e4 > 0 || options().seed_mid_e4 > 0) {   // tuning aid: thresholds in units of 1e-4
-            const double noisy = options().seed_noisy_e4 > 0 ? options().seed_noisy_e4 * 1e-4 : kSeedNoisy;
-            const double mid = options().seed_mid_e4 > 0 ? options().seed_mid_e4 * 1e-4 : kSeedMid;
-            return f >= noisy ? 0 : (f >= mid ? 1 : 3);
-        }
         return rung_from_certain_fraction(f);
     }
 
@@ -2249,7 +2254,9 @@ const unsigned *launch_repair_jobs(const SweepArgs &args, const FibreGeom &g, in
                                    long fstride, const DirtyMark &dirty, hipStream_t stream) {
     const int NC = (g.len + C - 1) / C;
     if (!options().repair_jobs || !dirty.word || H > kWarmLong || (NC + chunks_per_wg - 1) / chunks_per_wg > 64) return nullptr;
-    // (1: only where links fail in numbers -- a launch that finds the sweep clean still costs its 2 us ; 2: always)
+    // (1: only where links fail in numbers -- a launch that finds the sweep clean still costs its 2 us ; 2: always.  An UNSAMPLED input
+    //  -- sweep_seed_f = -1: a pinned rung, a problem too small to sample -- counts as "in numbers": nothing says the sweep is clean,
+    //  and the pinned-rung legs of the test suite run the jobs kernel through this door)
     if (options().repair_jobs == 1 && !(chunk_state().sweep_seed_f < kSeedJobs)) return nullptr;
     constexpr size_t lds = sizeof(double) * ((1 + (WEIGHTED ? 1 : 0)) * kJobWindow * 64 + kJobWindow + 2);   // (+ the table of -DPTV_JOB_TABDIV)
     auto kern = sweep_repair_jobs_kernel<OP, WEIGHTED>;
@@ -2288,9 +2295,8 @@ void launch_chunk_h(const SweepArgs &args, const FibreGeom &g, hipStream_t strea
     plan.Q = (g.len + NCH * C - 1) / (NCH * C);
     // blocks per workgroup: enough workgroups to fill the chip a few times over
     const long groups = (g.count + FW - 1) / FW;
-    int qpw = options().blocks_per_wg;
-    if (qpw <= 0) {
-        qpw = 8;
+    int qpw = 8;
+    {
         // (weighted strided sweeps run ONE workgroup per CU -- two LDS planes: as many blocks per workgroup as still gives
         // every CU one; 14.5 -> 14.05 ms on the 4096^2 weighted solve.  Keeping the next block's window share in registers
         // while the current one is processed -- the waves own 256 VGPRs there -- was tried and hid the staging phase, but the
@@ -2382,8 +2388,7 @@ void launch_along_g(const SweepArgs &args, const FibreGeom &g, hipStream_t strea
     plan.trace = options().trace ? chunk_state().trace_buffer((size_t)waves) : nullptr;
     plan.dirty = chunk_state().next_dirty(stream);
     plan.xlink = chunk_state().xlink_for((size_t)g.count * (size_t)nseg, stream);
-    if (!ROBUST && !WEIGHTED && G == 64 && !ONESEG && options().replay)
-        plan.structure = chunk_state().structure_for(g, NC, plan.replay);
+    plan.legacy = options().debug_legacy_rebuild;
     constexpr size_t lds = sizeof(double) * (size_t)(ROWS + 2) * NG * kAlongWaves * (WEIGHTED ? 2 : 1) + (ROBUST ? 64 + sizeof(double) * kRecipTableRobust : sizeof(double) * kRecipTable);
     static_assert(lds <= 160 * 1024, "along-fibre geometry does not fit the LDS of a CU");
     auto kern = sweep_along_kernel<OP, WEIGHTED, H, G, ROBUST, ONESEG>;
@@ -2457,8 +2462,6 @@ void launch_gchunk(const SweepArgs &args, const FibreGeom &g, int C, int H, hipS
 // contiguous; a tiled copy at HBM speed), the sweep runs as a dimension-0 sweep, and the outputs are transposed back.
 // Fibre numbering is unchanged: fibre j = slab * inc + off sits at j * len after the transposition of every
 // (inc x len) slab.
-// (tuning aid: option seed_row_along_e4 overrides policy.hpp's kSeedRowAlong)
-static inline double seed_row_along() { return options().seed_row_along_e4 > 0 ? options().seed_row_along_e4 * 1e-4 : kSeedRowAlong; }
 
 template <int OP, int H>
 void launch_row_along(const SweepArgs &args, const FibreGeom &g, hipStream_t stream, int fam, int rounds) {
@@ -2513,13 +2516,13 @@ void launch_chunk(const SweepArgs &args, const FibreGeom &g, hipStream_t stream,
         measure = pl.wants_measurement(pl.meas);
         if (measure) PTV_HIP(hipEventRecord(pl.t0, stream));
     }
-    const int rounds = (mode == 1 || mode == 2) ? (options().rounds > 0 ? options().rounds : kRounds) : 0;
+    const int rounds = (mode == 1 || mode == 2) ? kRounds : 0;
     // Geometry ladder.  Dimension 0 (chunks along the fibre once a fibre fills most of a lane group): 0 = 16-sample zones,
     // 1 / 2 = 64-sample zones, 3 = the pinning solver (pin.hip; where it does not apply: chunks from global memory, zone
     // 256), 4 = chunks from global memory (zone 1024), 5 = one sequential walk per fibre.
     // Strided sweeps: 0 / 1 = the 64-fibre tile (1: robust instantiation), 2 = transposed copies + the along-fibre kernel
     // with 64-sample zones (or the tile with 64-sample zones), 3 / 4 / 5 as above.
-    const bool along_ok = options().along && g.len >= options().along_min_len;
+    const bool along_ok = options().along && g.len >= kAlongMinLen;
     bool pinned_done = false;
     if (mode == 3 && pin_ok) {
         int *pieces = nullptr;
@@ -2549,14 +2552,8 @@ void launch_chunk(const SweepArgs &args, const FibreGeom &g, hipStream_t stream,
         else if (mode == 1) launch_along<OP, WEIGHTED, kWarm, true>(args, g, stream, fam, 2 * rounds);
         else                launch_along<OP, WEIGHTED, kWarmLong, true>(args, g, stream, fam, 2 * rounds);
     }
-    else if (!TRANSPOSED && !WEIGHTED && along_ok && (options().row_along & 1) && mode == 2) {
+    else if (!TRANSPOSED && !WEIGHTED && along_ok && mode == 2) {
         if constexpr (!WEIGHTED) launch_row_along<OP, kWarmLong>(args, g, stream, fam, rounds);
-    }
-    else if (!TRANSPOSED && !WEIGHTED && along_ok && mode == 1 &&
-             ((options().row_along & 2) || ((options().row_along & 1) && seed_f >= 0.0 && seed_f < seed_row_along()))) {
-        // rung 1 near its upper end (pieces of ~4 samples): the 64-fibre tile leaves the links between its workgroups to the
-        // repair kernel, and those start to fail; chunks along transposed copies settle nearly all links inside the kernel
-        if constexpr (!WEIGHTED) launch_row_along<OP, kWarm>(args, g, stream, fam, rounds);
     }
     else if constexpr (!WEIGHTED) {
         if (mode == 2)      launch_chunk_h<OP, false, TRANSPOSED, kWarmLong>(args, g, stream, fam, 0);
@@ -2598,6 +2595,7 @@ void launch_op_w(const SweepArgs &args, const FibreGeom &g, hipStream_t stream, 
             return;
         }
         if (options().whole == 1 && chunk_state().seed(g, args.lam, false) == 0) {
+            chunk_state().sweep_seed_f = chunk_state().certain_fraction(g, args.lam, false);   // (this sweep's, not the last chunked sweep's: the jobs gate reads it)
             if (g.len <= 64) {
                 if (g.inc == 1) launch_chunk_h<OP, false, true, kWarm, false, 16, 4, kTail, true>(args, g, stream, fam, 0);
                 else            launch_chunk_h<OP, false, false, kWarm, false, 16, 4, kTail, true>(args, g, stream, fam, 0);
@@ -2622,6 +2620,52 @@ void launch_op_w(const SweepArgs &args, const FibreGeom &g, hipStream_t stream, 
     else launch_chunk<OP, WEIGHTED, false>(args, g, stream, fam);
 }
 
+// option certify: check what the sweep just wrote (kernel 4), re-solve the fibres that fail, count them.  One small read-back per
+// sweep: a validation mode, not a fast path.
+// (returns the number of fibres that failed -- their flags are set in `*flags_out` --, or -1 when the sweep cannot be checked)
+template <int OP, bool WEIGHTED>
+long certify_count(const SweepArgs &args, const FibreGeom &g, hipStream_t stream, int **flags_out) {
+    if (g.count <= 0 || g.len <= 0) return 0;
+    // what cannot be checked: no minimisation behind the sweep (lambda <= 0 -- the identity, or the reference's code as it stands),
+    // or an output that IS an operand (in-place sweeps of the sequential kernels: the inputs are gone)
+    const void *ins[3] = {(Op<OP>::IN_MASK & 1u) ? args.a : nullptr, (Op<OP>::IN_MASK & 2u) ? args.b : nullptr,
+                          (Op<OP>::IN_MASK & 4u) ? args.c : nullptr};
+    bool aliased = false;
+    for (const void *in : ins) aliased = aliased || (in && (in == args.o0 || in == args.o1));
+    if (aliased || (!WEIGHTED && !(args.lam > 0.0))) {
+        count_event(CNT_CERTIFY_SKIPPED);
+        return -1;
+    }
+    int *buf = chunk_state().certify_for((size_t)g.count, stream);
+    unsigned *count = reinterpret_cast<unsigned *>(buf);
+    int *flags = buf + 1;
+    if (g.inc == 1 && g.len >= 64)
+        hipLaunchKernelGGL((certify_along_kernel<OP, WEIGHTED>), dim3((unsigned)((g.count + 3) / 4)), dim3(256), 0, stream, args, g, flags, count);
+    else
+        hipLaunchKernelGGL((certify_strided_kernel<OP, WEIGHTED>), dim3((unsigned)((g.count + 63) / 64)), dim3(64), 0, stream, args, g, flags, count);
+    PTV_HIP(hipGetLastError());
+    unsigned failed = 0;
+    PTV_HIP(hipMemcpyAsync(&failed, count, sizeof(unsigned), hipMemcpyDeviceToHost, stream));
+    PTV_HIP(hipStreamSynchronize(stream));
+    count_event(CNT_CERTIFY_SWEEPS);
+    if (failed) PTV_HIP(hipMemsetAsync(count, 0, sizeof(unsigned), stream));
+    if (flags_out) *flags_out = flags;
+    return (long)failed;
+}
+
+template <int OP, bool WEIGHTED>
+void launch_certify(const SweepArgs &args, const FibreGeom &g, hipStream_t stream) {
+    int *flags = nullptr;
+    const long failed = certify_count<OP, WEIGHTED>(args, g, stream, &flags);
+    if (failed > 0) {
+        count_event(CNT_CERTIFY_FAILURES, failed);
+        if (options().verbose)
+            fprintf(stderr, "[proxtv_amd] certify: op %d, %ld fibres of %d samples (stride %ld): %ld failed the optimality conditions -- re-solved sequentially\n",
+                    OP, g.count, g.len, g.inc, failed);
+        launch_seq<OP, WEIGHTED>(args, g, stream, true, flags);   // (walks the flagged fibres only, and clears their flags)
+    }
+}
+
 }  // namespace swp
 
 // One translation unit per (op, weighted) pair defines these two (sweep_unit.hip); sweep.hip dispatches to them.
@@ -2629,6 +2673,7 @@ namespace swp {
 template <int OP, bool WEIGHTED> void unit_launch(const SweepArgs &args, const FibreGeom &g, hipStream_t stream, bool allow_chunked, int fam);
 template <int OP, bool WEIGHTED> void unit_gated(const SweepArgs &args, const FibreGeom &g, hipStream_t stream, int *flags);
 template <int OP, bool WEIGHTED> void unit_warm();
+template <int OP, bool WEIGHTED> long unit_certify(const SweepArgs &args, const FibreGeom &g, hipStream_t stream);
 // (op, weighted) pairs that exist: X(op, weighted)
 #define PTV_SWEEP_UNITS(X)                                                                                                   \
     X(OP_PROX, false) X(OP_PROX, true) X(OP_DR_COL, false) X(OP_DR_COL, true) X(OP_DR_COL_FINAL, false) X(OP_DR_COL_FINAL, true) \
@@ -2637,7 +2682,8 @@ template <int OP, bool WEIGHTED> void unit_warm();
 #define PTV_DECLARE_UNIT(ID, W)                                                                                                         \
     template <> void unit_launch<ID, W>(const SweepArgs &args, const FibreGeom &g, hipStream_t stream, bool allow_chunked, int fam); \
     template <> void unit_gated<ID, W>(const SweepArgs &args, const FibreGeom &g, hipStream_t stream, int *flags);           \
-    template <> void unit_warm<ID, W>();
+    template <> void unit_warm<ID, W>();                                                                                     \
+    template <> long unit_certify<ID, W>(const SweepArgs &args, const FibreGeom &g, hipStream_t stream);
 PTV_SWEEP_UNITS(PTV_DECLARE_UNIT)
 #undef PTV_DECLARE_UNIT
 }  // namespace swp

@@ -14,12 +14,23 @@ namespace swp {
 template <>
 void unit_launch<PTV_UNIT_OP, PTV_UNIT_W>(const SweepArgs &args, const FibreGeom &g, hipStream_t stream, bool allow_chunked, int fam) {
     launch_op_w<PTV_UNIT_OP, PTV_UNIT_W>(args, g, stream, allow_chunked, fam);
+    if (options().certify) launch_certify<PTV_UNIT_OP, PTV_UNIT_W>(args, g, stream);
 }
 
 // the mop-up of a kernel that gave some fibres up (pin.hip's level cap): the sequential walk of the flagged fibres only
 template <>
 void unit_gated<PTV_UNIT_OP, PTV_UNIT_W>(const SweepArgs &args, const FibreGeom &g, hipStream_t stream, int *flags) {
     launch_seq<PTV_UNIT_OP, PTV_UNIT_W>(args, g, stream, true, flags);
+}
+
+// the certifier alone (kernel 4): how many fibres of what a sweep of this op wrote fail the optimality conditions (-1: cannot be checked);
+// the failing fibres stay flagged for nobody -- the flags are cleared by the next certified sweep's re-solve or overwritten
+template <>
+long unit_certify<PTV_UNIT_OP, PTV_UNIT_W>(const SweepArgs &args, const FibreGeom &g, hipStream_t stream) {
+    int *flags = nullptr;
+    const long failed = certify_count<PTV_UNIT_OP, PTV_UNIT_W>(args, g, stream, &flags);
+    if (failed > 0) PTV_HIP(hipMemsetAsync(flags, 0, sizeof(int) * (size_t)g.count, stream));
+    return failed;
 }
 
 // first use of a device: upload this unit's code object at initialisation, not in the first solve (common.hpp: warm_sweep)

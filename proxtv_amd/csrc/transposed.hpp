@@ -61,11 +61,7 @@ class TransposedOperands {
   public:
     // in_mask: arrays the op reads (bit 0 a, 1 b, 2 c); out_mask: arrays it writes (bit 0 o0, 1 o1); args.w (per-edge
     // penalties, len - 1 along the fibre), when set, is transposed as well
-    // by_parts (arrays of ONE slab only): nothing is transposed by the constructor or by finish(); the caller moves ranges of fibres
-    // with stage_part() / finish_part() -- on whichever streams it likes -- and calls finish() last (it only books the copies)
-    TransposedOperands(const SweepArgs &args, unsigned in_mask, unsigned out_mask, const FibreGeom &g, hipStream_t s, bool by_parts = false);
-    void stage_part(long j0, long j1, hipStream_t q);
-    void finish_part(long j0, long j1, hipStream_t q);
+    TransposedOperands(const SweepArgs &args, unsigned in_mask, unsigned out_mask, const FibreGeom &g, hipStream_t s);
     const SweepArgs &args() const { return t_; }                       // the same sweep on the copies ...
     FibreGeom geom() const { return FibreGeom{1, g_.len, g_.count}; }   // ... whose fibres are contiguous
     void finish();                                                      // outputs back to where the caller wants them
@@ -80,13 +76,6 @@ class TransposedOperands {
     long slabs_;
     size_t bytes_;
     std::unique_ptr<Scratch> ia_, ib_, ic_, iw_, o0_, o1_;
-    bool by_parts_ = false;
-    struct Pending {
-        const double *src;
-        double *dst;
-        int len;
-    };
-    std::vector<Pending> pending_;
 };
 
 }  // namespace ptv

@@ -184,3 +184,27 @@ def tv1_fibres(x, w, dim, weights=None, out=None):
                                   _stream(x.device))
     _lib.check("device.tv1_fibres")
     return y
+
+
+def certify_fibres(x, y, w, dim, weights=None):
+    """The certificate of ``y = tv1_fibres(x, w, dim)``: the number of fibres along `dim` for which `y` is NOT the exact TV-L1 prox of
+    `x` (optimality conditions of the 1-D problem, fibre by fibre, within rounding).  0: `y` is the prox.  -1: nothing to check
+    (w <= 0 without weights, or y is x)."""
+    _check(x, "x")
+    _check(y, "y", like=x, shape=x.shape)
+    ns = np.array(x.shape, dtype=np.int32)
+    if not 0 <= int(dim) < x.dim():
+        raise ValueError(f"dim {dim} out of range for a {x.dim()}-D array")
+    wp = 0
+    if weights is not None:
+        wshape = list(x.shape)
+        wshape[int(dim)] -= 1
+        _check(weights, "weights", like=x, shape=wshape)
+        wp = weights.data_ptr()
+    with torch.cuda.device(x.device):
+        lib = _lib.require_device()
+        failed = lib.proxtv_certify_fibres_dev(x.data_ptr(), y.data_ptr(), ns.ctypes.data, x.dim(), int(dim), float(w), wp,
+                                               _stream(x.device))
+    if failed == -2:
+        _lib.check("device.certify_fibres")
+    return int(failed)

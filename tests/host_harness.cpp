@@ -210,7 +210,7 @@ int chunk_fibre(const double *y, const double *w, double lam, int len, int H, in
             const int cs = cs_wg + wave * C, ce = std::min(cs + C, len);
             HostWin copy = win;
             rebuild_owned<Identity, WEIGHTED, C>(copy, rec, cs, ce, len, starts[(size_t)wave], false, cs_wg, wave == NW - 1 || ce == len, lam,
-                                                 (const double *)nullptr, nullptr, &pres[(size_t)wave]);
+                                                 (const double *)nullptr, &pres[(size_t)wave]);
             const int e_last = cs + 31 - __builtin_clz(rec.ends);
             std::vector<double> xr((size_t)len, 0.0);
             HostSource src{y, w, xr.data(), e_last};
@@ -245,14 +245,14 @@ int chunk_fibre(const double *y, const double *w, double lam, int len, int H, in
             if (form == 2 && !WEIGHTED)
                 rebuild_owned<F, WEIGHTED, C, 1, false, const double *, 0, 2>(win, recs[(size_t)wave], cs, ce, len, starts[(size_t)wave],
                                                                               !bad[(size_t)wave], wlo, wave == NW - 1 || ce == len, lam,
-                                                                              (const double *)nullptr, nullptr, pre);
+                                                                              (const double *)nullptr, pre);
             else if (form >= 1)
                 rebuild_owned<F, WEIGHTED, C, 1, false, const double *, 0, 1>(win, recs[(size_t)wave], cs, ce, len, starts[(size_t)wave],
                                                                               !bad[(size_t)wave], wlo, wave == NW - 1 || ce == len, lam,
-                                                                              (const double *)nullptr, nullptr, pre);
+                                                                              (const double *)nullptr, pre);
             else
                 rebuild_owned<F, WEIGHTED, C>(win, recs[(size_t)wave], cs, ce, len, starts[(size_t)wave], !bad[(size_t)wave], wlo,
-                                              wave == NW - 1 || ce == len, lam, (const double *)nullptr, nullptr, pre);
+                                              wave == NW - 1 || ce == len, lam, (const double *)nullptr, pre);
         }
         bool clean = true;
         for (int wave = 0; wave < NW; wave++) clean = clean && !bad[(size_t)wave];
@@ -667,234 +667,4 @@ int policy_sim(const double *cost, const double *frac, int switch_at, int solves
                int start_mode, double *total_ms, int *trace) {
     return policy_sim_pin(cost, frac, switch_at, solves, sweeps, len, weighted, start_mode, 0, total_ms, trace);
 }
-}
-
-// ---- replay (chunkcore.hpp: replay_lane): the along-fibre kernel's "verify the previous structure instead of walking" ------------
-// The true structure of a fibre as per-chunk masks (chunks of C samples): what the chunk kernels store behind a sweep.
-namespace {
-struct StructSource {
-    const double *yy;
-    std::vector<int> end_at, end_type;   // piece ends and the type of the bend behind each (the fibre's last piece: none)
-    double y(int i) const { return yy[i]; }
-    double r(int) const { return 0.0; }
-    void piece(int, int to, double) { end_at.push_back(to); end_type.push_back(-1); }
-    void bend(int, int type) { end_type.back() = type; }
-    bool keep_going(int) const { return true; }
-};
-}  // namespace
-
-extern "C" void host_structure(const double *y, double lam, int len, int C, unsigned *ends, unsigned *types) {
-    StructSource src{y, {}, {}};
-    Walker w;
-    walker_start<false>(w, src, 0, lam);
-    walker_run<false>(w, src, len, lam);
-    const int NC = (len + C - 1) / C;
-    for (int c = 0; c < NC; c++) ends[c] = types[c] = 0u;
-    for (size_t k = 0; k < src.end_at.size(); k++) {
-        const int e = src.end_at[k];
-        ends[e / C] |= 1u << (e % C);
-        if (src.end_type[k] == BEND_FLOOR) types[e / C] |= 1u << (e % C);
-    }
-}
-
-// One fibre through the replay path the way sweep_along_kernel runs it: segments of G = 64 chunks of C = 17 samples, zone H = 16 and
-// look-ahead T = 8 rows.  For every INTERIOR segment (window inside the fibre): the two bends known a priori that enclose it, the lanes'
-// rows, replay_lane, the jump test across lanes; a verified segment is rebuilt from the candidate masks (rebuild_owned, FULL = 2) into
-// x and seg_ok[sg] = 1; the others are left alone (seg_ok = 0: the kernel walks them).  Returns the number of verified segments.
-static int host_replay_fused(const double *y, double lam, int len, const unsigned *cand_ends, const unsigned *cand_types, double *x, int *seg_ok);
-
-extern "C" int host_replay_fibre(const double *y, double lam, int len, const unsigned *cand_ends, const unsigned *cand_types, double *x,
-                                 int *seg_ok, int fused) {
-    if (fused) return host_replay_fused(y, lam, len, cand_ends, cand_types, x, seg_ok);
-    constexpr int C = 17, G = 64, SEG = G * C, H = 16, T = 8, LOOKL = 14;
-    const int nseg = (len + SEG - 1) / SEG;
-    int verified = 0;
-    auto cand_end = [&](int r) { return (cand_ends[r / C] >> (r % C)) & 1u; };
-    auto cand_type = [&](int r) { return (int)((cand_types[r / C] >> (r % C)) & 1u); };
-    for (int sg = 0; sg < nseg; sg++) {
-        seg_ok[sg] = 0;
-        const int seg_s = sg * SEG, seg_e = seg_s + SEG;
-        if (!(seg_s + SEG + T <= len - 1)) continue;   // (interior segments only)
-        HostWin win;
-        win.lo = std::max(0, seg_s - H);
-        win.hi = seg_s + SEG + T;
-        win.yy.assign(y + win.lo, y + win.hi);
-        win.yy.push_back(1e300);
-        win.yy.push_back(1e300);
-        win.writes.assign(win.yy.size(), 0);
-        const int c0 = sg * G;   // first chunk of the segment
-        // the knot the segment hangs on: the fibre start, or the nearest bend known a priori at or before seg_s (14 edges back) --
-        // which the candidate must have, with that type
-        int kL = 0, tL = 0;
-        if (sg > 0) {
-            kL = certain_bend_before<false, LOOKL>(win, seg_s, len, lam, tL);
-            if (kL < 0 || !cand_end(kL - 1) || cand_type(kL - 1) != tL) continue;
-        }
-        // the knot behind the segment: the first bend known a priori at or after its end
-        int tR = 0;
-        const int kR = certain_bend_after<T>(win, seg_e, lam, tR);
-        if (kR < 0 || !cand_end(kR - 1) || cand_type(kR - 1) != tR) continue;
-        // per lane: the last piece end of its chunk (lane 0: the rows [kL, seg_s) before the segment count as its own)
-        int rl[G], rtp[G];
-        for (int l = 0; l < G; l++) {
-            rl[l] = -1;
-            rtp[l] = 0;
-            const int cs = seg_s + l * C;
-            for (int r = cs + C - 1; r >= (l == 0 ? kL : cs); r--)
-                if (cand_end(r)) { rl[l] = r; rtp[l] = cand_type(r); break; }
-        }
-        ReplayLane L[G];
-        int a0[G], at[G];     // for the rebuild: the last candidate knot at or before the lane's chunk start, and its type
-        bool start0[G];       // ... is the fibre start
-        bool all = true;
-        int nmax = 0;
-        for (int l = 0; l < G && all; l++) {
-            const int cs = seg_s + l * C, ce = cs + C;
-            // the knot the lane's first piece starts at: behind the last piece end of the nearest lower lane that has one; else kL
-            int s0 = kL, st = tL;
-            bool fs = (sg == 0);
-            for (int q = l - 1; q >= 0; q--)
-                if (rl[q] >= 0) { s0 = rl[q] + 1; st = rtp[q]; fs = false; break; }
-            ReplayLane &R = L[l];
-            R = ReplayLane{};
-            const int rbeg = (l == 0) ? kL : s0;                  // lane 0 takes the rows before the segment along
-            const int rend = (l == G - 1) ? kR : ce;              // the last lane closes the piece that runs out of the segment
-            const bool has = (l == G - 1) || rl[l] >= 0;          // (a lane with no piece end checks nothing: a later lane's rows)
-            R.r0 = rbeg;
-            R.h0 = (l == 0) ? (sg == 0 ? 0.0 : (tL == BEND_FLOOR ? lam : -lam)) : (fs ? 0.0 : (st == BEND_FLOOR ? lam : -lam));
-            R.nrows = has ? rend - rbeg : 0;
-            if (R.nrows > 32 || rbeg < win.lo) { all = false; break; }
-            for (int r = rbeg; r < rbeg + R.nrows; r++)
-                if (cand_end(r)) {
-                    R.emask |= 1u << (r - rbeg);
-                    if (cand_type(r)) R.tmask |= 1u << (r - rbeg);
-                }
-            nmax = std::max(nmax, R.nrows);
-            // (rebuild) the last candidate knot at or before cs
-            a0[l] = s0; at[l] = st; start0[l] = fs;
-            if (l == 0) {
-                a0[0] = kL; at[0] = tL; start0[0] = (sg == 0);
-                for (int r = cs - 1; r >= kL; r--)
-                    if (cand_end(r)) { a0[0] = r + 1; at[0] = cand_type(r); start0[0] = false; break; }
-            }
-        }
-        if (!all) continue;
-        for (int l = 0; l < G; l++) replay_lane<false>(win, L[l], nmax, lam, (const double *)nullptr);
-        // the jump across the knot a lane's rows start at: against the last piece of the nearest lower lane that has pieces
-        for (int l = 0; l < G && all; l++) {
-            if (!L[l].ok) { all = false; break; }
-            if (l == 0 || !L[l].emask) continue;
-            int p = -1;
-            for (int q = l - 1; q >= 0; q--)
-                if (L[q].emask) { p = q; break; }
-            if (p < 0) continue;   // (its first piece starts at kL: a true knot, nothing to test)
-            const bool up = at[l] == BEND_FLOOR;
-            if (!(up ? L[l].vfirst >= L[p].vlast : L[l].vfirst <= L[p].vlast)) all = false;
-        }
-        if (!all) continue;
-        // verified: rebuild from the candidate, every lane its chunk
-        for (int l = 0; l < G; l++) {
-            const int cs = seg_s + l * C, ce = cs + C;
-            ChunkRec rec;
-            rec.ends = cand_ends[c0 + l];
-            rec.types = cand_types[c0 + l];
-            rec.mine = start0[l] ? 0u : (((unsigned)a0[l] << 1) | (unsigned)at[l]);
-            rec.next = rec.mine;
-            if (rl[l] >= cs) rec.next = ((unsigned)(rl[l] + 1) << 1) | (unsigned)rtp[l];
-            rec.done = true;
-            if (l == G - 1 && !cand_end(ce - 1)) {
-                // the bend that closes the piece covering the segment's last sample: behind the first candidate end at or after ce
-                int e = kR - 1;
-                for (int r = ce; r < kR; r++)
-                    if (cand_end(r)) { e = r; break; }
-                rec.last = ((unsigned)(e + 1) << 1) | (unsigned)cand_type(e);
-            }
-            rebuild_owned<Identity, false, C, 1, false, const double *, 0, 2>(win, rec, cs, ce, len, start0[l] ? 0 : std::max(1, cs - H), true, seg_s,
-                                                                             l == G - 1, lam);
-        }
-        for (int k = seg_s; k < seg_e; k++) x[k] = win.y(k);
-        seg_ok[sg] = 1;
-        verified++;
-    }
-    return verified;
-}
-
-// The form the kernel runs (sweep_along_kernel, replay): the check rides on the rebuild (rebuild_owned FULL = 3), and only segments whose
-// record has no piece end between the two known bends and the segment are taken.
-static int host_replay_fused(const double *y, double lam, int len, const unsigned *cand_ends, const unsigned *cand_types, double *x, int *seg_ok) {
-    constexpr int C = 17, G = 64, SEG = G * C, H = 16, T = 8, LOOKL = 14;
-    const int nseg = (len + SEG - 1) / SEG;
-    int verified = 0;
-    auto cand_end = [&](int r) { return (cand_ends[r / C] >> (r % C)) & 1u; };
-    auto cand_type = [&](int r) { return (int)((cand_types[r / C] >> (r % C)) & 1u); };
-    for (int sg = 0; sg < nseg; sg++) {
-        seg_ok[sg] = 0;
-        const int seg_s = sg * SEG, seg_e = seg_s + SEG;
-        if (!(seg_s + SEG + T <= len - 1)) continue;
-        HostWin win;
-        win.lo = std::max(0, seg_s - H);
-        win.hi = seg_s + SEG + T;
-        win.yy.assign(y + win.lo, y + win.hi);
-        win.yy.push_back(1e300);
-        win.yy.push_back(1e300);
-        win.writes.assign(win.yy.size(), 0);
-        const int c0 = sg * G;
-        int kL = 0, tL = 0;
-        bool ok = true;
-        if (sg > 0) {
-            kL = certain_bend_before<false, LOOKL>(win, seg_s, len, lam, tL);
-            ok = kL >= 0 && cand_end(kL - 1) && cand_type(kL - 1) == tL;
-            for (int r = kL; ok && r < seg_s; r++) ok = !cand_end(r);
-        }
-        int tR = 0;
-        const int kR = certain_bend_after<T>(win, seg_e, lam, tR);
-        ok = ok && kR >= 0 && cand_end(kR - 1) && cand_type(kR - 1) == tR;
-        for (int r = seg_e; ok && r < kR - 1; r++) ok = !cand_end(r);
-        // (kR beyond the segment: the piece that covers the segment's last sample must run up to it -- a record that ends a piece ON the
-        //  last sample leaves a piece [seg_e, kR) and the knot before it to nobody)
-        if (kR > seg_e && cand_end(seg_e - 1)) ok = false;
-        if (!ok) continue;
-        int rl[G], rtp[G];
-        for (int l = 0; l < G; l++) {
-            const unsigned e = cand_ends[c0 + l];
-            rl[l] = e ? seg_s + l * C + (31 - __builtin_clz(e)) : -1;
-            rtp[l] = e ? (int)((cand_types[c0 + l] >> (31 - __builtin_clz(e))) & 1u) : 0;
-        }
-        ReplayCheck chk[G];
-        int stl[G];
-        for (int l = 0; l < G && ok; l++) {
-            const int cs = seg_s + l * C, ce = cs + C;
-            int s0 = kL, st = tL;
-            bool fs = (sg == 0);
-            for (int q = l - 1; q >= 0; q--)
-                if (rl[q] >= 0) { s0 = rl[q] + 1; st = rtp[q]; fs = false; break; }
-            stl[l] = st;
-            const bool has_rows = l == G - 1 || rl[l] >= 0;
-            if ((fs && l > 0 && has_rows) || (has_rows && (l == G - 1 ? kR : ce) - s0 >= 48)) { ok = false; break; }
-            ChunkRec cand;
-            cand.ends = cand_ends[c0 + l];
-            cand.types = cand_types[c0 + l];
-            cand.mine = fs ? 0u : (((unsigned)s0 << 1) | (unsigned)st);
-            cand.next = rl[l] >= 0 ? (((unsigned)(rl[l] + 1) << 1) | (unsigned)rtp[l]) : cand.mine;
-            cand.last = l == G - 1 ? (((unsigned)kR << 1) | (unsigned)tR) : cand.next;
-            cand.done = true;
-            rebuild_owned<Identity, false, C, 1, false, const double *, 0, 3>(win, cand, cs, ce, len, std::max(0, cs - H), true, seg_s, l == G - 1, lam,
-                                                                             (const double *)nullptr, &chk[l]);
-        }
-        if (!ok) continue;
-        for (int l = 0; l < G && ok; l++) {
-            ok = chk[l].ok;
-            if (!ok || !chk[l].has) continue;
-            for (int q = l - 1; q >= 0; q--)
-                if (chk[q].has) {
-                    ok = stl[l] == BEND_FLOOR ? chk[l].vfirst >= chk[q].vlast : chk[l].vfirst <= chk[q].vlast;
-                    break;
-                }
-        }
-        if (!ok) continue;
-        for (int k = seg_s; k < seg_e; k++) x[k] = win.y(k);
-        seg_ok[sg] = 1;
-        verified++;
-    }
-    return verified;
 }

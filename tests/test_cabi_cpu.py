@@ -28,7 +28,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     for must in ["TV", "hybridTautString_TV1", "hybridTautString_TV1_custom", "linearizedTautString_TV1",
                  "classicTautString_TV1", "classicTautString_TV1_offset", "tautString_TV1_Weighted", "TV1D_denoise",
                  "DR2_TV", "DR2L1W_TV", "PD2_TV", "PD_TV", "PDR_TV", "Yang2_TV", "Yang3_TV", "newWorkspace",
-                 "freeWorkspace", "proxtv_DR2_TV_batch_dev", "proxtv_tv1_fibres_dev"]:
+                 "freeWorkspace", "proxtv_DR2_TV_batch_dev", "proxtv_tv1_fibres_dev", "proxtv_certify_fibres_dev"]:
         assert must in names, must
     for n in names:
         assert hasattr(lib, n), f"libproxtv_amd.so does not export {n}"
@@ -165,7 +165,8 @@ def test_every_documented_knob_is_accepted():
     text = open(os.path.join(ROOT, "include", "proxtv_amd.h")).read()
     block = text[text.index("/* Knobs"):text.index("int proxtv_set_option")]
     keys = sorted(set(re.findall(r'"([a-z_0-9]+)"', block)))
-    assert {"chunk", "chunk_mode", "deterministic", "dr_form", "xlink", "verbose", "profile", "host_register"} <= set(keys), keys
+    assert {"chunk", "chunk_mode", "deterministic", "dr_form", "xlink", "verbose", "profile", "certify"} <= set(keys), keys
+    assert len(keys) <= 20, f"{len(keys)} knobs: every A/B that is settled takes its switch with it"
     for k in keys:
         before = lib.proxtv_set_option(k.encode(), 12345)
         assert lib.proxtv_set_option(k.encode(), before) == 12345, f"knob {k!r} is documented but not known to proxtv_set_option"
@@ -180,7 +181,7 @@ def test_every_knob_has_its_environment_variable():
     text = open(os.path.join(ROOT, "include", "proxtv_amd.h")).read()
     block = text[text.index("/* Knobs"):text.index("int proxtv_set_option")]
     keys = sorted(set(re.findall(r'"([a-z_0-9]+)"', block)))
-    assert {"tile", "pin_seed", "why", "host_register", "trace", "profile"} <= set(keys), keys
+    assert {"tile", "pin_seed", "why", "certify", "trace", "profile"} <= set(keys), keys
     code = ("import sys, json; sys.path.insert(0, %r); from proxtv_amd import _lib; lib = _lib.load(); "
             "print(json.dumps({k: lib.proxtv_set_option(k.encode(), 0) for k in %r}))" % (ROOT, keys))
     env = dict(os.environ)

@@ -39,6 +39,7 @@ def run(budget=60.0, seed=0, tol=1e-9, sizes=(2, 3, 17, 95, 96, 97, 130, 257, 40
     t_end = time.time() + budget
     cases, worst, worst_case = 0, 0.0, ""
     before = lib.proxtv_set_option(b"chunk_mode", -1)
+    failures0 = lib.proxtv_debug_counter(b"certify_failures")
     try:
         while time.time() < t_end:
             M, N = (int(v) for v in rng.choice(list(sizes), 2))
@@ -54,7 +55,7 @@ def run(budget=60.0, seed=0, tol=1e-9, sizes=(2, 3, 17, 95, 96, 97, 130, 257, 40
             lib.proxtv_set_option(b"pin_seed", seeds)                          # (the pinning solver with / without the knots known a priori)
             jobs, rep = int(rng.integers(0, 3)), int(rng.integers(0, 2))
             lib.proxtv_set_option(b"repair_jobs", jobs)                        # (failed links across workgroups one lane each: never / seeded / always)
-            lib.proxtv_set_option(b"replay", rep)                              # (the along-fibre kernel verifying its last sweep's structure)
+            lib.proxtv_set_option(b"certify", rep)                             # (every sweep followed by the check of the optimality conditions: no fibre may fail)
             what = int(rng.integers(0, 6))
             W1 = W2 = None
             its = d = 0
@@ -79,7 +80,7 @@ def run(budget=60.0, seed=0, tol=1e-9, sizes=(2, 3, 17, 95, 96, 97, 130, 257, 40
                 want = np.apply_along_axis(lambda f: orc.tv1_hybrid(np.ascontiguousarray(f), lam), d - 1, X)
                 name = f"prox dim {d}"
             e = rel(got, want, np.max(np.abs(X)))
-            desc = f"{name} {M}x{N} lam={lam:.4g} mode={mode} dr_form={form} tile={tile} pin_seed={seeds} repair_jobs={jobs} replay={rep}"
+            desc = f"{name} {M}x{N} lam={lam:.4g} mode={mode} dr_form={form} tile={tile} pin_seed={seeds} repair_jobs={jobs} certify={rep}"
             if e > worst:
                 worst, worst_case = e, desc
             cases += 1
@@ -91,7 +92,9 @@ def run(budget=60.0, seed=0, tol=1e-9, sizes=(2, 3, 17, 95, 96, 97, 130, 257, 40
         lib.proxtv_set_option(b"tile", 1)
         lib.proxtv_set_option(b"pin_seed", 1)
         lib.proxtv_set_option(b"repair_jobs", 1)
-        lib.proxtv_set_option(b"replay", 0)
+        lib.proxtv_set_option(b"certify", 0)
+    caught = lib.proxtv_debug_counter(b"certify_failures") - failures0
+    assert caught == 0, f"the certifier re-solved {caught} fibres during the run: a sweep was wrong before it was repaired"
     return cases, worst, worst_case
 
 
