@@ -226,7 +226,8 @@ int proxtv_tv1_fibres_dev(const double *in, double *out, const int *ns /*host*/,
 
 /* The certificate of that prox, on its own: the number of fibres along `dim` for which `out` is NOT the exact TV-L1 prox of `in` --
    the optimality conditions of the 1-D problem checked fibre by fibre (u = cumsum(in - out): |u_k| <= lambda_k, u_k = -+lambda_k where
-   out steps up / down, u_{n-1} = 0; reference: what src/TVL1opt.cpp:359-564 solves), within rounding (64 n ulps of the largest sample).
+   out steps up / down, u_{n-1} = 0; reference: what src/TVL1opt.cpp:359-564 solves), within rounding (64 n ulps of the largest sample)
+   plus the 4e-10 the reference's own EPSILON tests at a fibre's last sample leave in those sums.
    0 = `out` is the prox; -1 = nothing to check against (lambda <= 0 without weights, in == out); -2 = the call failed
    (proxtv_last_error).  Read-only on both arrays; synchronises the stream.  Option "certify" runs the same check behind every sweep
    of every solver and repairs what fails. */

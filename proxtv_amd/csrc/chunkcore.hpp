@@ -287,6 +287,14 @@ __device__ __forceinline__ void rebuild_owned(Win &win, const ChunkRec &rec, int
             s += win.y(k);
             cnt += 1.0;
         }
+#ifndef PTV_HOST_TEST
+        // Those rows lie in the predecessor's chunk, and the predecessor -- another lane of this wave in the along-fibre kernel -- may end a
+        // piece there and replace them in its own rebuild.  The lanes run in lockstep and the LDS serves a wave's accesses in order, so the
+        // sums above are taken before any lane's first put below AS LONG AS the compiler keeps the order; it reasons about one lane's
+        // addresses (rows < cs read, rows >= cs written: disjoint) and may not.  A scheduling barrier, no instruction: (measured: the sums
+        // in a pass of their own behind a wavefront fence cost the column sweep 1 us of 75, profiles/r06_s2_ab_fence.txt)
+        __builtin_amdgcn_wave_barrier();
+#endif
     }
     // the piece that covers ce - 1 and ends beyond it: the block's last lane writes its rows inside the block
     auto tail_value = [&](double s_, double cnt_, double hprev_, double &cur_) {

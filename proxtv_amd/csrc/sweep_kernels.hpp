@@ -981,20 +981,12 @@ __global__ __launch_bounds__(64 * kAlongWaves) void sweep_along_kernel(SweepArgs
         const unsigned long long below = grp & ((1ull << gl) - 1ull);
         if (below) wlo = seg_s + (63 - __clzll((long long)below)) * C;
     }
-    // The rows before a lane's chunk that belong to its first piece lie in its predecessor's chunk, and the predecessor may end a piece
-    // there and write them in its own rebuild: they are summed first, by every lane, and the wave is fenced before the first row is
-    // replaced (lockstep execution gives that order today; the fence says so to the compiler, which sees one lane's addresses only and
-    // may otherwise move a store of rows >= cs above loads of rows < cs).
-    PiecePrefix head;
-    if (has_chunk && !(plan.ablate & 1)) head = first_piece_prefix(win, rec, cs, start);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
     if (!WEIGHTED && interior && !(plan.ablate & 1))   // (every lane of the wave holds a whole chunk: the form that keeps it in registers)
         rebuild_owned<Op<OP>, WEIGHTED, C, PTV_ALONG_UNROLL, TAB, lds_double *, (ROBUST ? TS : 0), 2>(win, rec, cs, ce, len, start, !bad, wlo, gl == G - 1, p.lam,
-                                                                                      (lds_double *)rtab, &head, plan.legacy != 0);
+                                                                                      (lds_double *)rtab, nullptr, plan.legacy != 0);
     else if (has_chunk && !(plan.ablate & 1))
         rebuild_owned<Op<OP>, WEIGHTED, C, PTV_ALONG_UNROLL, TAB, lds_double *, (ROBUST ? TS : 0)>(win, rec, cs, ce, len, start, !bad, wlo, gl == G - 1 || ce == len, p.lam,
-                                                                                (lds_double *)rtab, &head, plan.legacy != 0);
+                                                                                (lds_double *)rtab, nullptr, plan.legacy != 0);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     if (plan.trace && lane == 0) plan.trace[8 * (size_t)wid + 4] = wall_clock64();
@@ -1902,30 +1894,58 @@ __global__ __launch_bounds__(64) void sweep_repair_kernel(SweepArgs p, FibreGeom
 // check reads the sweep's inputs through the op's own input functor and recovers x from the sweep's outputs (Op::recover), so it
 // sees exactly what the next sweep will see.  Tolerances: sums of n terms accumulate ~n ulps of the operands' magnitude, a recovered
 // x carries a few ulps of it -- a violation counts above kCertifyTol * n * 2^-52 * (largest operand), a step of x above
-// kCertifyStep * 2^-52 * that.  A fibre that fails is flagged; the host re-solves the flagged fibres with the sequential walk
+// kCertifyStep * 2^-52 * that (+ the slack below).  On top of rounding comes the slack the reference itself leaves: its solvers close the fibre's last piece
+// with tests against EPSILON = 1e-10 (src/general.h:64-67, src/TVL1opt.cpp:543-557 -- walker.hpp: kEps), so the string may end up to
+// EPSILON off the tube centre and every sum along the last piece inherits that; the sequential walks of this library (rung 5, the repair
+// kernels) do the same, bit for bit.  kCertifySlack = 4 EPSILON is allowed for it: a wrong sample below ~1e-9 is inside what the
+// reference's own solvers disagree by among themselves.  A fibre that fails is flagged; the host re-solves the flagged fibres with the sequential walk
 // (sweep_seq_kernel through its fibre gate) and counts them.  Fibres with a negative penalty are not checked (the reference's behaviour
 // there is its code, not a minimisation).
-constexpr double kCertifyTol = 64.0, kCertifyStep = 256.0, kCertifyUlp = 2.220446049250313e-16;
+constexpr double kCertifyTol = 64.0, kCertifyStep = 256.0, kCertifyUlp = 2.220446049250313e-16, kCertifySlack = 4.0 * kEps;
 
 struct CertifyAcc {
     double u = 0.0, scale = 0.0, viol = 0.0;
+    int where = -1, kind = 0;   // sample and test of the largest violation (0 the bound, 1 / 2 a step up / down off its wall, 3 the total)
     bool defined = true;
-    // one sample: its y, its x, the next sample's x (the last sample: anything), the penalty of the edge behind it
-    __device__ __forceinline__ void edge(double uk, double x, double xn, double r, bool last) {
+    __device__ __forceinline__ void note(double v, int k, int what) {
+        if (v > viol) {
+            viol = v;
+            where = k;
+            kind = what;
+        }
+    }
+    // one sample: the running sum behind it, its x, the next sample's x (the last sample: anything), the penalty of the edge behind it
+    __device__ __forceinline__ void edge(double uk, double x, double xn, double r, bool last, int k) {
         if (last) {
-            viol = fmax(viol, fabs(uk));
+            note(fabs(uk), k, 3);
             return;
         }
         defined = defined && r >= 0.0;
-        viol = fmax(viol, fabs(uk) - r);
-        const double dx = xn - x, step = kCertifyStep * kCertifyUlp * scale;
-        if (dx > step)       viol = fmax(viol, fabs(uk + r));
-        else if (dx < -step) viol = fmax(viol, fabs(uk - r));
+        note(fabs(uk) - r, k, 0);
+        // (a step counts as one above rounding AND above what the slack at the last sample does to the last piece's value: a knot whose jump
+        //  is zero up to rounding -- late Dykstra / DR iterates are full of them -- next to a last piece that is 1e-10 / n off shows a step
+        //  of either sign: seen on the GPU, PD2 at lambda 0.7, sample 517 of 520)
+        const double dx = xn - x, step = kCertifyStep * kCertifyUlp * scale + kCertifySlack;
+        if (dx > step)       note(fabs(uk + r), k, 1);
+        else if (dx < -step) note(fabs(uk - r), k, 2);
     }
-    __device__ __forceinline__ bool failed(int len, double lam) const {
-        return defined && viol > kCertifyTol * (double)len * kCertifyUlp * fmax(scale, fabs(lam));
+    __device__ __forceinline__ double tolerance(int len, double lam) const {
+        return kCertifyTol * (double)len * kCertifyUlp * fmax(scale, fabs(lam)) + kCertifySlack;
     }
+    __device__ __forceinline__ bool failed(int len, double lam) const { return defined && viol > tolerance(len, lam); }
 };
+// what the first few failing fibres of a launch looked like (option verbose prints them)
+struct CertifyNote {
+    long fibre;
+    int where, kind;
+    double viol, tol;
+};
+constexpr int kCertifyNotes = 8;
+__device__ __forceinline__ void certify_flag(int *flags, unsigned *count, CertifyNote *notes, long j, const CertifyAcc &acc, int len, double lam) {
+    flags[j] = 1;
+    const unsigned slot = atomicAdd(count, 1u);
+    if (notes && slot < (unsigned)kCertifyNotes) notes[slot] = CertifyNote{j, acc.where, acc.kind, acc.viol, acc.tolerance(len, lam)};
+}
 
 template <int OP>
 __device__ __forceinline__ void certify_sample(const SweepArgs &p, long idx, double &y, double &x, double &scale) {
@@ -1939,7 +1959,7 @@ __device__ __forceinline__ void certify_sample(const SweepArgs &p, long idx, dou
 
 // strided fibres: one lane per fibre, 64 adjacent fibres per wave (every access a 512-byte row)
 template <int OP, bool WEIGHTED>
-__global__ __launch_bounds__(64) void certify_strided_kernel(SweepArgs p, FibreGeom g, int *flags, unsigned *count) {
+__global__ __launch_bounds__(64) void certify_strided_kernel(SweepArgs p, FibreGeom g, int *flags, unsigned *count, CertifyNote *notes) {
     const long j = (long)blockIdx.x * 64 + threadIdx.x;
     if (j >= g.count || g.len <= 0) return;
     if (p.gate && *p.gate == 0) return;
@@ -1955,19 +1975,16 @@ __global__ __launch_bounds__(64) void certify_strided_kernel(SweepArgs p, FibreG
         if (!last) certify_sample<OP>(p, base + (long)(k + 1) * g.inc, yn, xn, acc.scale);
         acc.u += y - x;
         const double r = last ? 0.0 : (WEIGHTED ? p.w[wbase + (long)k * g.inc] : p.lam);
-        acc.edge(acc.u, x, xn, r, last);
+        acc.edge(acc.u, x, xn, r, last, k);
         y = yn;
         x = xn;
     }
-    if (acc.failed(g.len, WEIGHTED ? 0.0 : p.lam)) {
-        flags[j] = 1;
-        atomicAdd(count, 1u);
-    }
+    if (acc.failed(g.len, WEIGHTED ? 0.0 : p.lam)) certify_flag(flags, count, notes, j, acc, g.len, WEIGHTED ? 0.0 : p.lam);
 }
 
 // contiguous fibres: one wave per fibre, 64 consecutive samples per trip, the running sum by a scan across the lanes
 template <int OP, bool WEIGHTED>
-__global__ __launch_bounds__(256) void certify_along_kernel(SweepArgs p, FibreGeom g, int *flags, unsigned *count) {
+__global__ __launch_bounds__(256) void certify_along_kernel(SweepArgs p, FibreGeom g, int *flags, unsigned *count, CertifyNote *notes) {
     const int lane = threadIdx.x & 63;
     const long j = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (j >= g.count || g.len <= 0) return;
@@ -1994,16 +2011,14 @@ __global__ __launch_bounds__(256) void certify_along_kernel(SweepArgs p, FibreGe
         carry = __shfl(u, 63);
         if (in) {
             const double r = last ? 0.0 : (WEIGHTED ? p.w[wbase + k] : p.lam);
-            acc.edge(u, x, xn, r, last);
+            acc.edge(u, x, xn, r, last, k);
         }
     }
     bool bad = acc.failed(g.len, WEIGHTED ? 0.0 : p.lam);
     // (a lane that met a negative penalty takes the whole fibre out of the check)
     if (__ballot(!acc.defined) != 0ull) bad = false;
-    if (__ballot(bad) != 0ull && lane == 0) {
-        flags[j] = 1;
-        atomicAdd(count, 1u);
-    }
+    const unsigned long long who = __ballot(bad);
+    if (who != 0ull && lane == __ffsll((long long)who) - 1) certify_flag(flags, count, notes, j, acc, g.len, WEIGHTED ? 0.0 : p.lam);
 }
 
 // ---- host side ---------------------------------------------------------------------------------------------------------
@@ -2035,6 +2050,7 @@ struct ChunkScratch {
         return handled_buf->as<unsigned>();
     }
     std::unique_ptr<Scratch> certify_buf;   // option "certify": [0] fibres that failed the last check, [1 ...] their flags (the sequential kernel's fibre gate)
+    std::unique_ptr<Scratch> certify_notes; // ... and what the first few of them looked like (CertifyNote[kCertifyNotes])
     size_t certify_count = 0;
     int *certify_for(size_t count, hipStream_t s) {
         if (count > certify_count) {
@@ -2639,16 +2655,27 @@ long certify_count(const SweepArgs &args, const FibreGeom &g, hipStream_t stream
     int *buf = chunk_state().certify_for((size_t)g.count, stream);
     unsigned *count = reinterpret_cast<unsigned *>(buf);
     int *flags = buf + 1;
+    if (!chunk_state().certify_notes) chunk_state().certify_notes.reset(new Scratch(sizeof(CertifyNote) * kCertifyNotes));
+    CertifyNote *notes = chunk_state().certify_notes->as<CertifyNote>();
     if (g.inc == 1 && g.len >= 64)
-        hipLaunchKernelGGL((certify_along_kernel<OP, WEIGHTED>), dim3((unsigned)((g.count + 3) / 4)), dim3(256), 0, stream, args, g, flags, count);
+        hipLaunchKernelGGL((certify_along_kernel<OP, WEIGHTED>), dim3((unsigned)((g.count + 3) / 4)), dim3(256), 0, stream, args, g, flags, count, notes);
     else
-        hipLaunchKernelGGL((certify_strided_kernel<OP, WEIGHTED>), dim3((unsigned)((g.count + 63) / 64)), dim3(64), 0, stream, args, g, flags, count);
+        hipLaunchKernelGGL((certify_strided_kernel<OP, WEIGHTED>), dim3((unsigned)((g.count + 63) / 64)), dim3(64), 0, stream, args, g, flags, count, notes);
     PTV_HIP(hipGetLastError());
     unsigned failed = 0;
     PTV_HIP(hipMemcpyAsync(&failed, count, sizeof(unsigned), hipMemcpyDeviceToHost, stream));
     PTV_HIP(hipStreamSynchronize(stream));
     count_event(CNT_CERTIFY_SWEEPS);
     if (failed) PTV_HIP(hipMemsetAsync(count, 0, sizeof(unsigned), stream));
+    if (failed && options().verbose) {
+        CertifyNote h[kCertifyNotes];
+        PTV_HIP(hipMemcpyAsync(h, notes, sizeof(h), hipMemcpyDeviceToHost, stream));
+        PTV_HIP(hipStreamSynchronize(stream));
+        static const char *const kinds[4] = {"|u| above the penalty", "a step up off the floor wall", "a step down off the ceiling wall", "the total"};
+        for (unsigned k = 0; k < failed && k < (unsigned)kCertifyNotes; k++)
+            fprintf(stderr, "[proxtv_amd] certify: op %d%s, fibre %ld of %ld (%d samples, stride %ld, lambda %g): %s at sample %d: %.3e against a tolerance of %.3e\n",
+                    OP, WEIGHTED ? " weighted" : "", h[k].fibre, g.count, g.len, g.inc, args.lam, kinds[h[k].kind & 3], h[k].where, h[k].viol, h[k].tol);
+    }
     if (flags_out) *flags_out = flags;
     return (long)failed;
 }
