@@ -153,7 +153,7 @@ const char *proxtv_last_error(void);
 void proxtv_release_scratch(void);
 
 /* Knobs (process-wide; returns the previous value, -1 for an unknown key).  Each also has an environment variable
-   PROXTV_<KEY> read at load time.  Nineteen in all; none is needed for correct results.
+   PROXTV_<KEY> read at load time.  Twenty in all; none is needed for correct results.
      "chunk"          non-zero: speculative-chunk kernels ; 0: sequential lane-per-fibre kernels only
      "chunk_mode"     -1: the geometry policy chooses per sweep (default) ; 0..5: pin a rung of the ladder (see proxtv_chunk_mode)
      "deterministic"  1 (default): the rung of a sweep is a function of sampled statistics of its input and of lambda alone --
@@ -175,6 +175,9 @@ void proxtv_release_scratch(void);
                       alone (same results, bit for bit)
      "tile"           strided sweeps on rungs 0 and 1 (the robust instantiation follows the same knob): 1 (default) tiles of 32 fibres
                       x 8 chunks in 4 waves, four workgroups per CU ; 0: the 64-fibre x 8-wave tile, two per CU
+     "optimistic"     1 (default): a DR solve whose every sweep will run on rung 0 launches no repair kernel behind its sweeps; a sweep
+                      that leaves anything marks one word, read at the end, and such a solve is run again with the repairs (counters
+                      optimistic_solves / optimistic_redone) ; 0: a repair launch behind every chunked sweep.  Same results, bit for bit
      "certify"        1: behind every fibre sweep a second kernel checks the optimality conditions of the prox on what the sweep wrote,
                       fibre by fibre (u = cumsum(y - x): |u_k| <= lambda_k ; u_k = -+lambda_k where x steps up / down ; u_{n-1} = 0),
                       re-solves a fibre that fails with the sequential walk and counts it (proxtv_debug_counter: certify_failures,
@@ -273,7 +276,7 @@ int    proxtv_debug_why(unsigned *dst);
 /* What ran (process-wide, cumulative since load; tests and tools take differences): "sweep_launches" (fibre-sweep kernels),
    "repair_launches" (sweep_repair_kernel behind them), "repair_jobs_launches" (option repair_jobs), "pin_sweeps" (sweeps the
    pinning solver took), "pin_cap_next_rung" (sweeps its grid-wide variant handed on after the level cap), "tv2_long_fibres"
-   (TV-L2 fibres solved parallel inside the fibre), "certify_sweeps" / "certify_failures" / "certify_skipped" (option certify:
+   (TV-L2 fibres solved parallel inside the fibre), "optimistic_solves" / "optimistic_redone" (option optimistic), "certify_sweeps" / "certify_failures" / "certify_skipped" (option certify:
    sweeps checked, fibres that failed and were re-solved, sweeps that could not be checked).  -1 for an unknown name. */
 long   proxtv_debug_counter(const char *name);
 /* Geometry policy the adaptive chunk kernel currently uses on this thread (the highest over the sweep families):

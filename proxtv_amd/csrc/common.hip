@@ -39,6 +39,7 @@ constexpr OptionEntry kOptionTable[] = {
     {"xlink", &Options::xlink},
     {"dr_form", &Options::dr_form},
     {"tile", &Options::tile},
+    {"optimistic", &Options::optimistic},
     {"certify", &Options::certify},
     {"verbose", &Options::verbose},
     {"profile", &Options::profile},
@@ -78,7 +79,7 @@ Options &options() {
 namespace {
 std::atomic<long> g_counters[CNT_COUNT];
 constexpr const char *kCounterNames[CNT_COUNT] = {"sweep_launches", "repair_launches", "repair_jobs_launches", "pin_sweeps",
-                                                  "pin_cap_next_rung", "tv2_long_fibres", "certify_sweeps", "certify_failures",
+                                                  "pin_cap_next_rung", "tv2_long_fibres", "optimistic_solves", "optimistic_redone", "certify_sweeps", "certify_failures",
                                                   "certify_skipped"};
 }  // namespace
 void count_event(Counter c, long n) { g_counters[c].fetch_add(n, std::memory_order_relaxed); }

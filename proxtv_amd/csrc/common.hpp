@@ -56,6 +56,9 @@ struct Options {
                               // reference's split (OP_DR_COL / OP_DR_ROW)
     int tile = 1;             // strided sweeps on rungs 0 and 1 (unweighted and weighted): 1 = tiles of 32 fibres x 8 chunks in 4 waves (four
                               // workgroups per CU), 0 = the 64-fibre x 8-wave tile (two)
+    int optimistic = 1;       // DR solves whose every sweep will run on rung 0 (decided from the sampled statistics) launch no repair kernels behind
+                              // their sweeps: a sweep that leaves anything marks a sticky word, and a solve whose word is set is run again
+                              // with the repairs (sweep.hpp: OptimisticScope); 0: a repair launch behind every chunked sweep
     int certify = 0;          // 1: every fibre sweep is followed by a check of the prox's optimality conditions on what it wrote, fibre by fibre;
                               // a fibre that fails is re-solved by the sequential walk and counted (sweep_kernels.hpp: certify_*_kernel)
     int verbose = 0;
@@ -77,6 +80,8 @@ enum Counter {
     CNT_PIN_SWEEPS,            // sweeps the pinning solver took
     CNT_PIN_CAP_NEXT_RUNG,     // ... of which the grid-wide variant hit its level cap and handed the sweep to the next rung
     CNT_TV2_LONG_FIBRES,       // TV-L2 fibres solved parallel inside the fibre (tv2.hip: tv2_long_fibre)
+    CNT_OPTIMISTIC_SOLVES,     // solves that ran without repair launches (option optimistic)
+    CNT_OPTIMISTIC_REDONE,     // ... of which a sweep left something: run again with the repairs
     CNT_CERTIFY_SWEEPS,        // option certify: sweeps whose output was checked against the optimality conditions of the prox
     CNT_CERTIFY_FAILURES,      // ... fibres that failed the check and were re-solved by the sequential walk
     CNT_CERTIFY_SKIPPED,       // ... sweeps that could not be checked (an output aliases an operand; lambda <= 0)

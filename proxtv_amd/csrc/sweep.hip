@@ -48,6 +48,7 @@ ChunkScratch &chunk_state() { return g_chunks[current_device()]; }
 // Called at the start of every solve on this thread's stream.
 void chunk_stats_reset(hipStream_t s) {
     ChunkScratch &st = chunk_state();
+    st.optimistic = false;
     const bool adaptive = options().chunk_mode < 0;
     if (st.h_counts) st.poll(true);
     for (int f = 0; f < FAM_COUNT; f++) {
@@ -109,6 +110,27 @@ int strided_tile_rung(const FibreGeom &g, double lam, bool weighted, double *cer
     if (mode != 1) return -1;                         // (unsampled: the pinning rung)
     if (weighted || !(options().along && g.len >= kAlongMinLen)) return 1;
     return 1;
+}
+
+bool optimistic_eligible(const FibreGeom *geoms, const double *lams, int n, bool weighted) {
+    const Options &o = options();
+    if (!o.optimistic || o.chunk <= 0 || o.chunk_mode >= 0 || !o.deterministic || !o.xlink || o.ablate || o.certify) return false;   // (certify: every sweep is
+    // judged as it stands -- a sweep still waiting for its repair would count as a failure)
+    ChunkScratch &st = chunk_state();
+    for (int k = 0; k < n; k++) {
+        if (geoms[k].len < o.chunk_min_len) continue;               // (sequential / whole-fibre kernels: nothing to repair)
+        if (st.seed(geoms[k], lams[k], weighted) != 0) return false;   // (rung 1 and up -- or unsampled: repairs are part of the plan there)
+    }
+    return true;
+}
+OptimisticScope::OptimisticScope(hipStream_t s_, bool on_) : s(s_), on(on_) {
+    if (on) chunk_state().begin_optimistic(s);
+}
+OptimisticScope::~OptimisticScope() { chunk_state().optimistic = false; }
+bool OptimisticScope::clean() {
+    if (!on) return true;
+    on = false;
+    return chunk_state().end_optimistic(s);
 }
 
 long chunk_stats_fixups(hipStream_t s) {

@@ -35,6 +35,19 @@ long chunk_stats_fixups(hipStream_t s);
 // the rung (0 / 1) a strided sweep of this geometry will take on the 64-fibre tile, -1 if it will not run there.  Call after policy_probe.
 // (*certain_fraction: the seed statistic of that sweep's input, -1 when it was not sampled)
 int strided_tile_rung(const FibreGeom &g, double lam, bool weighted, double *certain_fraction = nullptr);
+// Optimistic solves (option "optimistic"; solvers.hip: dr2).  A chunked sweep on rung 0 hardly ever leaves anything to the repair kernel
+// (profiles/r06_dirty_rate.txt: none in 2 130 sweeps of the headline), yet the empty repair launch behind it costs a dependent launch.  A
+// solve whose every sweep will run on rung 0 -- `optimistic_eligible`: decided from the sampled statistics, like the rung itself -- may
+// run between optimistic_begin / optimistic_end: no repair launches, a sticky word instead; optimistic_end (synchronises) says whether
+// every sweep was clean.  If not, the caller runs the solve again outside the bracket: that run is the exact one.
+bool optimistic_eligible(const FibreGeom *geoms, const double *lams, int n, bool weighted);
+struct OptimisticScope {
+    explicit OptimisticScope(hipStream_t s, bool on);
+    ~OptimisticScope();
+    bool clean();   // ends the bracket (synchronises when it was on); true: nothing was left anywhere (always true when it was off)
+    hipStream_t s;
+    bool on;
+};
 // current geometry policy of this thread (highest over the sweep families the last solve used): 0 / 1 / 2 = LDS windows
 // (16-sample zones, the same with second-chance rounds, 64-sample zones), 3 = the pinning solver (or global-memory chunks
 // where it does not apply), 4 = global-memory chunks, 5 = sequential

@@ -43,8 +43,11 @@ struct DirtyMark {
     unsigned *why;    // option "why" (tuning aid): counters of what marked sweeps dirty -- [0] a walk ran off its window,
                       // [1] a link inside a workgroup / wave stayed unproven, [2] a link across workgroups / segments did not match,
                       // [3] ... was not published in time, [4] second chances taken across workgroups
+    unsigned *sticky; // an optimistic solve (solvers.hip: dr2): no repair kernel is launched behind the sweeps; a sweep that leaves anything
+                      // says so here, once and for all, and the solve is run again with the repairs (null otherwise)
     __device__ __forceinline__ void set(int reason) const {
         if (word) __hip_atomic_store(word, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (sticky) __hip_atomic_store(sticky, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (why) atomicAdd(why + reason, 1u);
     }
     __device__ __forceinline__ void note(int reason) const {
@@ -71,8 +74,18 @@ __device__ __forceinline__ void xlink_publish(unsigned long long *slot, unsigned
                        __HIP_MEMORY_SCOPE_AGENT);
 }
 // 0: the link holds ; 2: the codes differ ; 3: no final word of this launch yet
+// The earlier workgroup / wave has a lower linear index: it was dispatched first, is resident or done, and depends on nobody -- so a word
+// that is not there yet is on its way, and the later one waits for it, a bounded while (kXlinkPatience sleeps of ~0.4 us), before it gives
+// the sweep to the repair kernel.  Round 6: without the wait a weighted 4096^2 DR solve marked EVERY row sweep dirty (its tiles run eight
+// blocks per workgroup: both sides of a boundary finish together, 48 000 late words per solve) and lambda = 0.2 one sweep in fifty --
+// each a full scan by the repair kernel, and a whole solve again where the repairs are deferred (profiles/r06_dirty_rate.txt).
+constexpr int kXlinkPatience = 128;
 __device__ __forceinline__ int xlink_check(const unsigned long long *slot, unsigned epoch, link_t mine) {
-    const unsigned long long v = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned long long v = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int patience = kXlinkPatience; patience > 0 && ((unsigned)(v >> 32) != epoch || !((link_t)v & kLinkFinal)); patience--) {
+        __builtin_amdgcn_s_sleep(16);
+        v = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     if ((unsigned)(v >> 32) != epoch || !((link_t)v & kLinkFinal)) return 3;
     return (mine != 0 && (link_t)v == (mine | kLinkFinal)) ? 0 : 2;
 }
@@ -1223,7 +1236,7 @@ __global__ __launch_bounds__(64) void sweep_gchunk_kernel(SweepArgs p, FibreGeom
     walker_start<WEIGHTED>(w, src, max(0, cs - H), p.lam);
     walker_run_blocked<WEIGHTED, kGlobalBlock>(w, src, len, p.lam);
     if (src.failed) {   // nothing this lane recorded may be trusted; the repair walk rewrites its chunk
-        flag_chunk(failflags, j, c, (len + C - 1) / C, DirtyMark{nullptr, 0u, nullptr});
+        flag_chunk(failflags, j, c, (len + C - 1) / C, DirtyMark{nullptr, 0u, nullptr, nullptr});
         src.mine = kLinkBad;
         src.next = 0;
     }
@@ -2073,13 +2086,34 @@ struct ChunkScratch {
     std::unique_ptr<Scratch> dirty_word, xlink;
     size_t xlink_words = 0;
     DirtyMark next_dirty(hipStream_t s) {
-        if (!options().xlink) return DirtyMark{nullptr, 0u, nullptr};
-        if (!dirty_word) {   // [0] the word, [1..8] option "why" counters
-            dirty_word.reset(new Scratch(sizeof(unsigned) * 9));
-            PTV_HIP(hipMemsetAsync(dirty_word->as<unsigned>(), 0, sizeof(unsigned) * 9, s));
-        }
+        if (!options().xlink) return DirtyMark{nullptr, 0u, nullptr, nullptr};
+        ensure_dirty(s);
         if (++epoch == 0u) ++epoch;   // (0 is what freshly allocated words hold)
-        return DirtyMark{dirty_word->as<unsigned>(), epoch, options().why ? dirty_word->as<unsigned>() + 1 : nullptr};
+        return DirtyMark{dirty_word->as<unsigned>(), epoch, options().why ? dirty_word->as<unsigned>() + 1 : nullptr,
+                         optimistic ? dirty_word->as<unsigned>() + 9 : nullptr};
+    }
+    void ensure_dirty(hipStream_t s) {
+        if (!dirty_word) {   // [0] the word, [1..8] option "why" counters, [9] the sticky word of an optimistic solve
+            dirty_word.reset(new Scratch(sizeof(unsigned) * 10));
+            PTV_HIP(hipMemsetAsync(dirty_word->as<unsigned>(), 0, sizeof(unsigned) * 10, s));
+        }
+    }
+    // An optimistic solve: the chunked sweeps launch no repair kernels (an empty one still costs its dependent launch, 2.5-4.5 us behind
+    // every sweep: 5 % of the headline solve, half of a 512^2 one); whatever a sweep leaves is recorded in the sticky word, read once at
+    // the end of the solve.  Exactness rests on the run with the repairs that follows a solve whose word is set.
+    bool optimistic = false;
+    void begin_optimistic(hipStream_t s) {
+        ensure_dirty(s);
+        PTV_HIP(hipMemsetAsync(dirty_word->as<unsigned>() + 9, 0, sizeof(unsigned), s));
+        optimistic = true;
+    }
+    // ends the optimistic stretch; true: every sweep was clean (synchronises the stream)
+    bool end_optimistic(hipStream_t s) {
+        optimistic = false;
+        unsigned mark = 1;
+        PTV_HIP(hipMemcpyAsync(&mark, dirty_word->as<unsigned>() + 9, sizeof(unsigned), hipMemcpyDeviceToHost, s));
+        PTV_HIP(hipStreamSynchronize(s));
+        return mark == 0;
     }
     unsigned long long *xlink_for(size_t words, hipStream_t s) {
         if (!options().xlink) return nullptr;
@@ -2364,7 +2398,7 @@ void launch_chunk_h(const SweepArgs &args, const FibreGeom &g, hipStream_t strea
     hipLaunchKernelGGL(kern, grid, dim3(64 * NW), lds, stream, args, g, plan, chunk_state().code_mine,
                        chunk_state().code_next, chunk_state().failflags);
     count_event(CNT_SWEEP_LAUNCHES);
-    if (!plan.ablate) {
+    if (!plan.ablate && !plan.dirty.sticky) {   // (an optimistic solve: the sweep has marked the sticky word if it left anything)
         constexpr size_t rlds = sizeof(double) * (2 + (WEIGHTED ? 1 : 0)) * kRepairWindow * 64;
         auto rkern = sweep_repair_kernel<OP, WEIGHTED>;
         static thread_local bool rattr_done[kMaxDevices] = {};
@@ -2423,7 +2457,7 @@ void launch_along_g(const SweepArgs &args, const FibreGeom &g, hipStream_t strea
     hipLaunchKernelGGL(kern, dim3((unsigned)((waves + kAlongWaves - 1) / kAlongWaves)), dim3(64 * kAlongWaves), lds, stream, args, g,
                        plan, chunk_state().code_mine, chunk_state().code_next, chunk_state().failflags);
     count_event(CNT_SWEEP_LAUNCHES);
-    if (!plan.ablate) {
+    if (!plan.ablate && !plan.dirty.sticky) {   // (an optimistic solve: the sweep has marked the sticky word if it left anything)
         constexpr size_t rlds = sizeof(double) * (2 + (WEIGHTED ? 1 : 0)) * kRepairWindow * 64;
         auto rkern = sweep_repair_kernel<OP, WEIGHTED>;
         static thread_local bool rattr_done[kMaxDevices] = {};
@@ -2464,7 +2498,7 @@ void launch_gchunk(const SweepArgs &args, const FibreGeom &g, int C, int H, hipS
                        g, C, H, chunk_state().code_mine, chunk_state().code_next, chunk_state().failflags);
     hipLaunchKernelGGL((sweep_repair_kernel<OP, WEIGHTED>), dim3((unsigned)groups), dim3(64), 0, stream, args, g, C, H, 1,
                        chunk_state().code_mine, chunk_state().code_next, chunk_state().failflags, chunk_state().failcount + 2 * fam, (long)g.count, 1L,
-                       DirtyMark{nullptr, 0u, nullptr});
+                       DirtyMark{nullptr, 0u, nullptr, nullptr});
     count_event(CNT_SWEEP_LAUNCHES);
     count_event(CNT_REPAIR_LAUNCHES);
     PTV_HIP(hipGetLastError());

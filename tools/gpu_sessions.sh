@@ -39,5 +39,8 @@ s4)   # the certifier with steps counted above the last-sample slack: new files,
   { PROXTV_VERBOSE=1 python tools/fuzz.py 120 611; python tools/fuzz.py 30 612 nd; PROXTV_VERBOSE=1 python tools/fuzz.py 60 613 long; } > $OUT/fuzz.txt 2>&1; grep "certify:" $OUT/fuzz.txt | cut -c1-260 | head -30 | tee -a $OUT/summary.txt; grep "^fuzz\|MISMATCH\|Error" $OUT/fuzz.txt | tee -a $OUT/summary.txt
   python bench.py --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err; tail -c 600 $OUT/bench.json
   ;;
+s5)   # how often is a sweep of the headline marked dirty at all?
+  python tools/dirty_rate.py 2>&1 | tee $OUT/dirty_rate.txt
+  ;;
 *) echo "unknown session $S";;
 esac
