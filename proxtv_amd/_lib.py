@@ -137,7 +137,13 @@ def load(build_if_missing=True):
     _preload_hip_runtime()
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
-        fn = getattr(lib, name)   # AttributeError here == the C-ABI lost a symbol
+        try:
+            fn = getattr(lib, name)   # AttributeError here == the C-ABI lost a symbol
+        except AttributeError:
+            # (A/B runs against an OLDER build of the library -- the explicit debug switch above -- may lack this round's additions)
+            if os.environ.get("PROXTV_DEBUG_ALT_LIB") == "1" and name in ("proxtv_certify_fibres_dev",):
+                continue
+            raise
         fn.restype, fn.argtypes = res, args
     _lib = lib
     return lib

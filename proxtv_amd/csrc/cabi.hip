@@ -472,6 +472,7 @@ int proxtv_set_option(const char *key, int value) {
     if (!slot) return -1;
     const int old = *slot;
     *slot = value;
+    if (!strcmp(key, "optimistic")) optimistic_forget();
     if (value != 0 && (!strcmp(key, "ablate") || !strcmp(key, "debug_legacy_rebuild")))
         fprintf(stderr, "[proxtv_amd] WARNING: option \"%s\" = %d -- a profiling / test aid: results are WRONG while it is non-zero\n", key, value);
     return old;

@@ -121,8 +121,17 @@ bool optimistic_eligible(const FibreGeom *geoms, const double *lams, int n, bool
         if (geoms[k].len < o.chunk_min_len) continue;               // (sequential / whole-fibre kernels: nothing to repair)
         if (st.seed(geoms[k], lams[k], weighted) != 0) return false;   // (rung 1 and up -- or unsampled: repairs are part of the plan there)
     }
+    // Rung 0 by the statistics is not "no repairs": unit noise at lambda = 0.2 leaves four fibres per 4096^2 solve to the repair kernel,
+    // an image with a few constant rows some in every sweep -- and a solve run twice costs what seventy solves save.  So the bracket
+    // backs off: after a solve that had to be run again, the next kOptimisticBackoff eligible solves of this thread run with their
+    // repairs (same bits either way; proxtv_set_option("optimistic", ...) forgets the history).
+    if (st.optimistic_backoff > 0) {
+        st.optimistic_backoff--;
+        return false;
+    }
     return true;
 }
+void optimistic_forget() { chunk_state().optimistic_backoff = 0; }
 OptimisticScope::OptimisticScope(hipStream_t s_, bool on_) : s(s_), on(on_) {
     if (on) chunk_state().begin_optimistic(s);
 }
@@ -130,7 +139,9 @@ OptimisticScope::~OptimisticScope() { chunk_state().optimistic = false; }
 bool OptimisticScope::clean() {
     if (!on) return true;
     on = false;
-    return chunk_state().end_optimistic(s);
+    const bool clean = chunk_state().end_optimistic(s);
+    if (!clean) chunk_state().optimistic_backoff = kOptimisticBackoff;
+    return clean;
 }
 
 long chunk_stats_fixups(hipStream_t s) {

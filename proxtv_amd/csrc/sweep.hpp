@@ -41,6 +41,8 @@ int strided_tile_rung(const FibreGeom &g, double lam, bool weighted, double *cer
 // run between optimistic_begin / optimistic_end: no repair launches, a sticky word instead; optimistic_end (synchronises) says whether
 // every sweep was clean.  If not, the caller runs the solve again outside the bracket: that run is the exact one.
 bool optimistic_eligible(const FibreGeom *geoms, const double *lams, int n, bool weighted);
+void optimistic_forget();   // (the calling thread's back-off history)
+constexpr int kOptimisticBackoff = 64;
 struct OptimisticScope {
     explicit OptimisticScope(hipStream_t s, bool on);
     ~OptimisticScope();

@@ -2102,6 +2102,7 @@ struct ChunkScratch {
     // every sweep: 5 % of the headline solve, half of a 512^2 one); whatever a sweep leaves is recorded in the sticky word, read once at
     // the end of the solve.  Exactness rests on the run with the repairs that follows a solve whose word is set.
     bool optimistic = false;
+    int optimistic_backoff = 0;   // eligible solves still to run WITH their repairs after one that had to be run again (sweep.hip)
     void begin_optimistic(hipStream_t s) {
         ensure_dirty(s);
         PTV_HIP(hipMemsetAsync(dirty_word->as<unsigned>() + 9, 0, sizeof(unsigned), s));
@@ -2113,6 +2114,10 @@ struct ChunkScratch {
         unsigned mark = 1;
         PTV_HIP(hipMemcpyAsync(&mark, dirty_word->as<unsigned>() + 9, sizeof(unsigned), hipMemcpyDeviceToHost, s));
         PTV_HIP(hipStreamSynchronize(s));
+        // (whoever marked the word also flagged chunks -- per fibre, in units of ITS sweep's geometry -- and no repair kernel came to
+        //  take the flags back: the run that follows must not find them)
+        if (mark != 0 && flags && flag_count > (size_t)kCounters)
+            PTV_HIP(hipMemsetAsync(flags->as<int>() + kCounters, 0, sizeof(int) * (flag_count - (size_t)kCounters), s));
         return mark == 0;
     }
     unsigned long long *xlink_for(size_t words, hipStream_t s) {

@@ -29,7 +29,9 @@ def default_policy(clib):
     if before != -1:
         clib.proxtv_set_option(b"chunk_mode", before)
         pytest.skip("a pinned rung (PROXTV_CHUNK_MODE): the bracket is for the seeded policy")
+    clib.proxtv_set_option(b"optimistic", 1)   # (setting the option also forgets the calling thread's back-off history)
     yield
+    clib.proxtv_set_option(b"optimistic", 1)
 
 
 def test_clean_solves_launch_no_repairs_and_keep_their_bits(ptv, clib, oracle, default_policy):
@@ -74,6 +76,10 @@ def test_a_sweep_that_leaves_something_sends_the_solve_round_again(ptv, clib, or
     assert d["optimistic_solves"] == 1 and d["optimistic_redone"] == 1, d
     assert d["repair_launches"] >= 70, d
     assert_close(y, oracle.dr2(X, 0.1)[0], tol=1e-9, what="dr2, redone")
+    # ... and the bracket backs off: the next solves of this thread run with their repairs from the start, same bits
+    y2, d2 = _delta(clib, lambda: ptv.tv1_2d(X, 0.1))
+    assert d2["optimistic_solves"] == 0 and d2["optimistic_redone"] == 0 and d2["repair_launches"] >= 70, d2
+    np.testing.assert_array_equal(y, y2)
     before = clib.proxtv_set_option(b"optimistic", 0)
     try:
         np.testing.assert_array_equal(y, ptv.tv1_2d(X, 0.1))

@@ -42,5 +42,16 @@ s4)   # the certifier with steps counted above the last-sample slack: new files,
 s5)   # how often is a sweep of the headline marked dirty at all?
   python tools/dirty_rate.py 2>&1 | tee $OUT/dirty_rate.txt
   ;;
+s6)   # optimistic solves + the wait for link words: tests, dirty marks again, A/B by option on one build, small images
+  timeout 600 python -m pytest tests/test_gpu_optimistic.py tests/test_gpu_boundary.py tests/test_gpu_parity_2d.py tests/test_gpu_chunk_repair.py tests/test_gpu_large.py -m gpu -x -q > $OUT/pytest.log 2>&1; echo "tests: $(tail -1 $OUT/pytest.log)" | tee $OUT/summary.txt
+  python tools/dirty_rate.py 2>&1 | tee $OUT/dirty_rate.txt
+  ab --reps 9 --rounds 2 --cases c2,c2@0.2,c3,s2048,s1024,s512,s256 base plain,optimistic=0 r5=$W/lib_r5.so > $OUT/ab_optimistic.txt 2>&1; cat $OUT/ab_optimistic.txt
+  ;;
+s7)   # optimistic solves with the flags cleared before a second run and the back-off: the new file, then everything
+  timeout 600 python -m pytest tests/test_gpu_optimistic.py -m gpu -x -q > $OUT/pytest_new.log 2>&1; echo "new: $(tail -1 $OUT/pytest_new.log)" | tee $OUT/summary.txt
+  timeout 900 python -m pytest tests -m gpu -x -q > $OUT/pytest_default.log 2>&1; echo "default: $(tail -1 $OUT/pytest_default.log)" | tee -a $OUT/summary.txt
+  { python tools/fuzz.py 60 621; python tools/fuzz.py 40 622 long; } > $OUT/fuzz.txt 2>&1; grep "^fuzz\|MISMATCH\|Error" $OUT/fuzz.txt | tee -a $OUT/summary.txt
+  ab --reps 9 --rounds 2 --cases c2,c2@0.2,c3,s512 base plain,optimistic=0 > $OUT/ab_optimistic.txt 2>&1; cat $OUT/ab_optimistic.txt
+  ;;
 *) echo "unknown session $S";;
 esac
