@@ -154,7 +154,9 @@ void proxtv_release_scratch(void);
 
 /* Knobs (process-wide; returns the previous value, -1 for an unknown key).  Each also has an environment variable
    PROXTV_<KEY> read at load time.  Twenty in all; none is needed for correct results.
-     "chunk"          non-zero: speculative-chunk kernels ; 0: sequential lane-per-fibre kernels only
+     "runs"           1 (default): on rung 0, dimension-0 sweeps over data most of whose edges are bends known a priori (|dy| > 4 lambda)
+                      cut the interior segments of their fibres at those bends and solve them run by run -- runs of one and two samples by
+                      rule, longer ones walked one per lane: exact by construction, nothing speculated ; 0: speculative chunks everywhere
      "chunk_mode"     -1: the geometry policy chooses per sweep (default) ; 0..5: pin a rung of the ladder (see proxtv_chunk_mode)
      "deterministic"  1 (default): the rung of a sweep is a function of sampled statistics of its input and of lambda alone --
                       the same call gives the same bits whatever ran before ; 0: hill climb on measured sweep times, seeded by

@@ -444,5 +444,104 @@ __device__ __forceinline__ void rebuild_owned(Win &win, const ChunkRec &rec, int
     }
 }
 
+// ---- known runs: the fibre cut at the bends known a priori (round 6; sweep_along_kernel, RUNS) ---------------------------------------
+// An edge (k - 1, k) with |y_k - y_{k-1}| > 4 lambda is a bend whatever the rest of the fibre looks like (certain_bend_before), and the
+// state right after a bend depends on the bend alone: the stretch between two such edges -- a RUN -- is a problem of its own, with the
+// string's height given at both ends.  On the headline's data 78 % of the edges qualify, and the runs are short:
+//   * one sample (61 % of all samples): a piece of its own, nothing to decide;
+//   * two samples (27 %): the one edge inside bends or does not, and a compare says which -- with d the edge's jump and s0, s2 the
+//     bend types at the run's ends: both CEIL: it bends (CEIL) iff d < 0 ; both FLOOR: (FLOOR) iff d > 0 ; otherwise iff |d| > 2 lambda,
+//     with the jump's sign.  (The walk from the first bend makes exactly these decisions in its two trips: a CEIL start has
+//     h1 = -lambda - d, h2 = 3 lambda - d at the second sample -- it bends there iff d < -2 lambda, and touches the floor, klo = the
+//     second sample, iff d >= 0, which is where the closing bend then breaks; symmetrically for a FLOOR start.  Ties on the last bit
+//     may fall differently: a knot with a jump of zero up to rounding, both cuts of which are the prox to rounding.)
+//   * three and more (12 %): walked -- but a run needs no zone, no link and no second chance: ONE lane walks ONE run from its first
+//     bend to the closing one (walk_chunk with the run as its "chunk"), so a wave of 64 chunks walks its ~44 runs in one pass of
+//     ~8 trips where the chunk-per-lane scheme takes 19.5 (tools/study in the notes: profiles/NOTES_r06.md).
+// What comes out is the ChunkRec the rebuild wants -- piece ends and bend types per chunk, the codes of the bends around it -- with no
+// speculation behind it: a segment solved this way is exact by construction and publishes its codes as certain.
+// Bit b of an edge mask of the lane with chunk start cs: the edge before sample cs + b - kEdgeBias (two edges of the chunk before,
+// the chunk's own C, the first 30 - C of the chunk behind).
+constexpr int kEdgeBias = 2;
+constexpr int kRunMax = 14;    // longest run a lane takes (its piece ends must fit a 32-bit mask behind any offset inside a chunk)
+struct EdgeMasks {
+    unsigned K = 0, P = 0, N = 0, B = 0;   // |d| > 4 lambda (a bend known a priori) ; d > 0 ; d < 0 ; |d| > 2 lambda
+};
+// the chunk's own edges (bits kEdgeBias .. kEdgeBias + C - 1): rows cs - 1 .. cs + C - 1 are read
+template <int C, class Win>
+__device__ __forceinline__ EdgeMasks own_edges(const Win &win, int cs, double lam) {
+    double yv[C + 1];
+#pragma unroll
+    for (int u = 0; u <= C; u++) yv[u] = win.y(cs - 1 + u);
+    EdgeMasks m;
+    const double t4 = 4.0000001 * lam, t2 = 2 * lam;
+#pragma unroll
+    for (int u = C - 1; u >= 0; u--) {
+        const double d = yv[u + 1] - yv[u];
+#ifdef PTV_HOST_TEST
+        const double a = fabs(d);
+        m.K = (m.K << 1) | (unsigned)(a > t4);
+        m.B = (m.B << 1) | (unsigned)(a > t2);
+        m.P = (m.P << 1) | (unsigned)(d > 0);
+        m.N = (m.N << 1) | (unsigned)(d < 0);
+#else
+        // mask = 2 mask + (the compare): one compare into the carry, one add with carry -- two instructions a bit where the compiler
+        // takes three (compare, select 0 / 1, shift-or); 17 edges x 4 masks a lane
+        asm("v_cmp_gt_f64 vcc, |%1|, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(m.K) : "v"(d), "s"(t4) : "vcc");
+        asm("v_cmp_gt_f64 vcc, |%1|, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(m.B) : "v"(d), "s"(t2) : "vcc");
+        asm("v_cmp_lt_f64 vcc, 0, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(m.P) : "v"(d) : "vcc");
+        asm("v_cmp_gt_f64 vcc, 0, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(m.N) : "v"(d) : "vcc");
+#endif
+    }
+    m.K <<= kEdgeBias; m.B <<= kEdgeBias; m.P <<= kEdgeBias; m.N <<= kEdgeBias;
+    return m;
+}
+// one edge on its own (the few around a segment that no chunk owns)
+__device__ __forceinline__ void one_edge(double ya, double yb, double lam, unsigned &k, unsigned &pp, unsigned &nn, unsigned &bb) {
+    const double d = yb - ya, a = fabs(d);
+    k = (unsigned)(a > 4.0000001 * lam);
+    bb = (unsigned)(a > 2 * lam);
+    pp = (unsigned)(d > 0);
+    nn = (unsigned)(d < 0);
+}
+// ... with the last two edges of the chunk before (its own bits C, C + 1) and the first edges of the chunk behind (its own bits 2 ...)
+template <int C>
+__device__ __forceinline__ unsigned edge_ext(unsigned own, unsigned prev_own, unsigned next_own) {
+    return own | ((prev_own >> C) & 3u) | ((next_own >> kEdgeBias) << (C + kEdgeBias));
+}
+// What is settled without a walk: BE = bend edges (known a priori, or the inner edge of a two-sample run that bends), BT their types,
+// WS = first edges of the runs of three and more samples.  (Bits whose neighbours lie outside the mask are the caller's to ignore.)
+__device__ __forceinline__ void settle_short_runs(const EdgeMasks &m, unsigned &BE, unsigned &BT, unsigned &WS) {
+    const unsigned K = m.K, Km = K << 1, Kp = K >> 1;
+    const unsigned mid = ~K & Km & Kp;                       // the inner edge of a two-sample run
+    const unsigned Pm = m.P << 1, Pp = m.P >> 1;             // types of the bends before / behind it
+    const unsigned bend = mid & ((~Pm & ~Pp & m.N) | (Pm & Pp & m.P) | ((Pm ^ Pp) & m.B));
+    BE = K | bend;
+    BT = m.P & BE;
+    WS = K & ~Kp & ~(K >> 2);
+}
+// a run to walk, as the lane that owns its first sample describes it to the lane that will walk it
+struct RunEntry {
+    unsigned word;
+    __device__ __forceinline__ static RunEntry make(int lane, int b, int e, int type, bool free_start) {
+        return RunEntry{(unsigned)lane | ((unsigned)b << 6) | ((unsigned)e << 11) | ((unsigned)type << 16) | ((unsigned)free_start << 17)};
+    }
+    __device__ __forceinline__ int lane() const { return (int)(word & 63u); }
+    __device__ __forceinline__ int b() const { return (int)((word >> 6) & 31u); }     // bit of the run's first edge in its owner's mask
+    __device__ __forceinline__ int e() const { return (int)((word >> 11) & 31u); }    // ... of the bend that closes it
+    __device__ __forceinline__ int type() const { return (int)((word >> 16) & 1u); }
+    __device__ __forceinline__ bool free_start() const { return (word >> 17) & 1u; }
+};
+// the end of the run that starts at edge b: the next bend known a priori (-1: none inside the mask, or further than a lane takes)
+__device__ __forceinline__ int run_end(unsigned K, int b) {
+    const unsigned up = (b >= 31) ? 0u : (K >> (b + 1));
+    if (up == 0u) return -1;
+#ifdef PTV_HOST_TEST
+    const int e = b + 1 + __builtin_ctz(up);
+#else
+    const int e = b + 1 + (__ffs((int)up) - 1);
+#endif
+    return (e - b <= kRunMax) ? e : -1;
+}
 
 }  // namespace ptv

@@ -27,7 +27,7 @@ struct OptionEntry {
     int Options::*field;
 };
 constexpr OptionEntry kOptionTable[] = {
-    {"chunk", &Options::chunk},
+    {"runs", &Options::runs},
     {"chunk_mode", &Options::chunk_mode},
     {"deterministic", &Options::deterministic},
     {"along", &Options::along},

@@ -36,7 +36,8 @@ struct HipFailure {
 
 // ---- options (see proxtv_set_option) ---------------------------------------------------------------------------
 struct Options {
-    int chunk = 16;     // non-zero: speculative-chunk kernels (16-sample chunks); 0 = sequential lane-per-fibre kernels only
+    int runs = 1;             // rung 0, dimension-0 sweeps on data with many bends known a priori: 1 = interior segments are cut at those bends and
+                              // solved run by run (sweep_along_kernel RUNS; exact by construction), 0 = speculative chunks everywhere
     int chunk_mode = -1;    // -1 = chosen per sweep (see `deterministic`); 0..5 pin the chunk geometry policy
     int deterministic = 1;  // 1: the rung of a sweep is a function of (input statistics, lambda) only -- reproducible to the last
                             // bit; 0: hill climb on measured sweep times, seeded by the same statistics (policy.hpp)

@@ -63,6 +63,9 @@ constexpr double kSeedPins = 0.001;    // rung 3: the pinning solver searches fo
                                        // 29.4 against 30.0 ms per 4096^2 DR solve; 0.8: 25.3 against 31.8; 3: none to find, 18.3 against 19.1 with the search)
 constexpr double kSeedJobs = 0.055;    // rung 1, option "repair_jobs" = 1: f below (as sampled: lambda >= 0.65 on unit noise -- 0.6 gives 0.065, 0.65 gives 0.048) the failed
                                        // links across workgroups go one lane each (4096^2 DR: lambda 0.6 14.27 -> 14.42 ms, 0.65 17.67 -> 17.33, 0.7 21.41 -> 19.97)
+constexpr double kSeedRuns = 0.70;     // rung 0, dimension-0 sweeps, f at or above: interior segments are cut at the bends known a priori and solved run by run
+                                       // (sweep_along_kernel RUNS): one pass of a wave takes 64 runs of three and more samples -- 44 per segment at
+                                       // f = 0.78 (lambda = 0.1 on unit noise), 80 at 0.67 (0.15), where the speculative walk is the faster one again
 constexpr double kSeedFlat = 0.02;     // more than this fraction of the sampled 16-edge stretches (all but) flat at lambda: rung 3
 // DR2L1W: the second form of the iteration (ops.hpp, OP_DR_COL_V) pays below this certain fraction only -- the weighted column
 // sweep is the heavier one to begin with (4096^2, weights U(0.5, 1.5) lambda: lambda = 0.4: 17.4 -> 18.1 ms, 0.6: 25.3 -> 24.0)

@@ -70,7 +70,7 @@ void chunk_stats_reset(hipStream_t s) {
 constexpr long kProbeMinElements = 4096;
 
 void policy_probe(const double *y, const double *const *weights, const int *ns, int nds, const int *dims, int ndims, hipStream_t s) {
-    if (options().chunk <= 0 || options().chunk_mode >= 0) return;   // sequential kernels only / a pinned rung: nothing to decide
+    if (options().chunk_mode >= 0) return;   // a pinned rung: nothing to decide
     ChunkScratch &st = chunk_state();
     constexpr size_t kWords = kProbeWords;
     int first = st.nprobes;
@@ -101,7 +101,7 @@ void policy_probe(const double *y, const double *const *weights, const int *ns, 
 // seed alone, like the rung itself under the default policy.  Call after policy_probe.
 int strided_tile_rung(const FibreGeom &g, double lam, bool weighted, double *certain_fraction) {
     if (certain_fraction) *certain_fraction = -1.0;
-    if (options().chunk <= 0 || g.inc == 1 || g.len < options().chunk_min_len) return -1;
+    if (g.inc == 1 || g.len < options().chunk_min_len) return -1;
     ChunkScratch &st = chunk_state();
     int mode = options().chunk_mode;
     if (mode < 0) mode = st.seed(g, lam, weighted);   // (the hill climb starts from the seed too)
@@ -114,7 +114,7 @@ int strided_tile_rung(const FibreGeom &g, double lam, bool weighted, double *cer
 
 bool optimistic_eligible(const FibreGeom *geoms, const double *lams, int n, bool weighted) {
     const Options &o = options();
-    if (!o.optimistic || o.chunk <= 0 || o.chunk_mode >= 0 || !o.deterministic || !o.xlink || o.ablate || o.certify) return false;   // (certify: every sweep is
+    if (!o.optimistic || o.chunk_mode >= 0 || !o.deterministic || !o.xlink || o.ablate || o.certify) return false;   // (certify: every sweep is
     // judged as it stands -- a sweep still waiting for its repair would count as a failure)
     ChunkScratch &st = chunk_state();
     for (int k = 0; k < n; k++) {

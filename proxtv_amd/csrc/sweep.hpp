@@ -11,7 +11,7 @@ namespace ptv {
 // fibre dimension shortened by one); otherwise the uniform penalty args.lam.
 // `fam` tags the launch for the per-family timers (FAM_COL / FAM_ROW / FAM_OTHER).
 //
-// Aliasing contract: outputs may alias operands element-for-element ONLY when options().chunk == 0 or
+// Aliasing contract: outputs may alias operands element-for-element ONLY when
 // `allow_chunked` is false (sequential kernel: each element is read and written by the one lane that owns the
 // fibre, and never re-read after it was written).  The chunked kernels read operand rows that other workgroups
 // write, so their callers pass distinct in/out arrays (ping-pong) -- see solvers.hip.

@@ -764,7 +764,8 @@ constexpr int along_zone_rows(int H, bool robust) { return robust && H < 64 ? 64
 // ONESEG: fibres of at most one segment (G chunks) -- there is no row before the segment and none after it, so the robust
 // instantiation's 64 + 64 rows of look-back / look-ahead are not allocated: a third of its LDS for 512-sample fibres, and with it
 // twelve waves per CU become sixteen.
-template <int OP, bool WEIGHTED, int H, int G, bool ROBUST, bool ONESEG = false>
+constexpr int kRunsWords = 196;   // RUNS: LDS words per wave (64 runs, 64 + 64 masks, the bend before the segment; padded)
+template <int OP, bool WEIGHTED, int H, int G, bool ROBUST, bool ONESEG = false, bool RUNS = false>
 __global__ __launch_bounds__(64 * kAlongWaves) void sweep_along_kernel(SweepArgs p, FibreGeom g, ChunkPlan plan, link_t *code_mine,
                                                                         link_t *code_next, int *failflags) {
     constexpr int C = along_chunk(ROBUST, WEIGHTED), SEG = G * C, T = ONESEG ? 0 : along_tail_rows(H, ROBUST), HZ = ONESEG ? 0 : along_zone_rows(H, ROBUST), ROWS = HZ + SEG + T, NG = 64 / G;
@@ -899,7 +900,169 @@ __global__ __launch_bounds__(64 * kAlongWaves) void sweep_along_kernel(SweepArgs
     const FarFibre<OP> far{p, fbase, 1, wbase};
     ChunkRec rec;
     bool certain = false;
-    if (has_chunk && !(plan.ablate & 1)) {
+    // ---- RUNS: the segment cut at the bends known a priori, run by run (chunkcore.hpp "known runs") ------------------------------------
+    // Interior segments only (every row of the window exists; the fibre's last sample, with its own tests, is another segment's).  Four
+    // phases, all inside the wave: (1) every lane looks at the edges of its chunk -- bends known a priori, and what decides a run of two
+    // samples -- and borrows its neighbours' for the runs that cross into and out of its chunk; (2) runs of three and more samples are
+    // listed; (3) lane i walks run i from its first bend to the closing one; what it finds goes to the chunks it belongs to; (4) every
+    // lane puts its chunk's record together: piece ends and types, the bend before its chunk, the one that closes the segment.
+    // Nothing is written to the window before phase 4 is through, and whatever does not fit -- a run longer than a lane takes, more
+    // than 64 runs, no known bend within two samples of the segment start or eight of its end -- sends the whole wave to the
+    // speculative walk below as if nothing had happened.
+    bool solved = false;
+    if constexpr (RUNS) {
+        if (interior && p.lam > 0.0 && !(plan.ablate & 1)) {
+            typedef __attribute__((address_space(3))) unsigned lds_uint;   // (LDS instructions, not flat ones: the atomics below are ds_or / ds_max)
+            lds_uint *rl = (lds_uint *)(reinterpret_cast<unsigned *>(rtab + TS) + wave * kRunsWords);   // [0, 64) runs ; [64, 128) ends ; [128, 192) types ; [192] the bend before the segment
+            constexpr unsigned CM = (1u << C) - 1u;
+            const bool free0 = sg == 0 && lane == 0;   // the fibre starts here: no bend, height 0
+            // (1) edges
+            const EdgeMasks own = own_edges<C>(win, cs, p.lam);
+            EdgeMasks pv, nx;
+            pv.K = (unsigned)__shfl_up((int)own.K, 1); pv.P = (unsigned)__shfl_up((int)own.P, 1);
+            pv.N = (unsigned)__shfl_up((int)own.N, 1); pv.B = (unsigned)__shfl_up((int)own.B, 1);
+            nx.K = (unsigned)__shfl_down((int)own.K, 1); nx.P = (unsigned)__shfl_down((int)own.P, 1);
+            nx.N = (unsigned)__shfl_down((int)own.N, 1); nx.B = (unsigned)__shfl_down((int)own.B, 1);
+            {   // the edges no chunk of the segment owns: the T = 8 behind it (lanes 0 .. 7), the two before it (lanes 8, 9)
+                unsigned k = 0, pp = 0, nn = 0, bb = 0;
+                if (lane < 8) one_edge(win.y(seg_e - 1 + lane), win.y(seg_e + lane), p.lam, k, pp, nn, bb);
+                else if (lane < 10 && sg > 0) one_edge(win.y(seg_s - 11 + lane), win.y(seg_s - 10 + lane), p.lam, k, pp, nn, bb);
+                const unsigned xk = (unsigned)__ballot(k != 0u), xp = (unsigned)__ballot(pp != 0u), xn = (unsigned)__ballot(nn != 0u),
+                               xb = (unsigned)__ballot(bb != 0u);
+                if (lane == 63) { nx.K = (xk & 0xffu) << kEdgeBias; nx.P = (xp & 0xffu) << kEdgeBias; nx.N = (xn & 0xffu) << kEdgeBias; nx.B = (xb & 0xffu) << kEdgeBias; }
+                if (lane == 0)  { pv.K = ((xk >> 8) & 3u) << C; pv.P = ((xp >> 8) & 3u) << C; pv.N = ((xn >> 8) & 3u) << C; pv.B = ((xb >> 8) & 3u) << C; }
+            }
+            EdgeMasks m;
+            m.K = edge_ext<C>(own.K, pv.K, nx.K); m.P = edge_ext<C>(own.P, pv.P, nx.P);
+            m.N = edge_ext<C>(own.N, pv.N, nx.N); m.B = edge_ext<C>(own.B, pv.B, nx.B);
+            if (free0) m.K = (m.K & ~7u) | 4u;   // (the fibre start delimits the first run like a bend; nothing lies before it)
+            unsigned BE, BT, WS;
+            settle_short_runs(m, BE, BT, WS);
+            if (free0) {   // no rule of thumb across the free end: the first run is walked unless it is one sample long
+                BE = (BE & ~8u) | (m.K & 8u);
+                BT = (BT & ~8u) | (m.P & m.K & 8u);
+                WS = (WS & ~7u) | ((m.K & 8u) ? 0u : 4u);
+            }
+            // (2) this lane's runs: those whose first sample is its own; lane 0 also the one that comes in from before the segment
+            unsigned dom = WS & ((1u << (C + kEdgeBias)) - 1u);
+            if (lane > 0) dom &= ~3u;
+            bool fail = lane == 0 && !free0 && (m.K & 7u) == 0u;   // (no bend known within two samples of the segment start)
+            const int nruns = __popc(dom);
+            int pos = nruns;
+            for (int o = 1; o < 64; o <<= 1) {
+                const int t = __shfl_up(pos, o);
+                if (lane >= o) pos += t;
+            }
+            const int total = __shfl(pos, 63);
+            pos -= nruns;
+            rl[64 + lane] = 0u;
+            rl[128 + lane] = 0u;
+            if (lane == 0) rl[192] = 0u;
+            while (dom) {
+                const int b = __ffs((int)dom) - 1;
+                dom &= dom - 1u;
+                const int e = run_end(m.K, b);
+                if (e < 0) fail = true;
+                else if (pos < 64) rl[pos] = RunEntry::make(lane, b, e, (int)((m.P >> b) & 1u), free0 && b == kEdgeBias).word;
+                pos++;
+            }
+            bool go = __ballot(fail) == 0ull && total <= 64;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            // (3) one run per lane
+            if (go) {
+                bool walked = true;
+                if (lane < total) {
+                    const RunEntry en{rl[lane]};
+                    const int c0 = seg_s + C * en.lane() - kEdgeBias, a = c0 + en.b(), ee = c0 + en.e();
+                    ChunkRec rr;
+                    Walker w;
+                    if (en.free_start()) {
+                        walker_start<false>(w, win, 0, p.lam);
+                    } else {
+                        walker_restart_with<false>(w, a, en.type(), len, p.lam, win.y(a), 0.0, 0.0);
+                        rr.mine = rr.next = rr.last = ((link_t)a << 1) | (link_t)en.type();
+                    }
+                    walk_chunk<OP, false, 1, false, TAB>(w, rr, win, far, hi, a, ee, len, p.lam, (unsigned)(unsigned long long)rtab);
+                    walked = rr.done && !rr.failed;
+                    if (walked) {
+                        const int o = en.b() - kEdgeBias;
+                        if (o >= 0) {
+                            __hip_atomic_fetch_or(&rl[64 + en.lane()], rr.ends << o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            __hip_atomic_fetch_or(&rl[128 + en.lane()], rr.types << o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        } else {   // (lane 0's run from before the segment: the pieces that end before it only say where the segment hangs)
+                            __hip_atomic_fetch_or(&rl[64], rr.ends >> (-o), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            __hip_atomic_fetch_or(&rl[128], rr.types >> (-o), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            const unsigned low = rr.ends & ((1u << (-o)) - 1u);
+                            if (low) {
+                                const int j = 31 - __clz((int)low);
+                                __hip_atomic_fetch_max(&rl[192], ((unsigned)(en.b() + j + 2) << 1) | ((rr.types >> j) & 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            }
+                        }
+                    }
+                }
+                go = __ballot(!walked) == 0ull;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            // (4) the chunk's record
+            if (go) {
+                const unsigned e_own = rl[64 + lane], t_own = rl[128 + lane];
+                const unsigned e_prev = lane ? rl[64 + lane - 1] : 0u, t_prev = lane ? rl[128 + lane - 1] : 0u;
+                const unsigned ends = ((BE >> (kEdgeBias + 1)) | e_own | (e_prev >> C)) & CM;
+                const unsigned types = ((BT >> (kEdgeBias + 1)) | t_own | (t_prev >> C)) & CM & ends;
+                const int lastb = ends ? 31 - __clz((int)ends) : -1;
+                const link_t lcode = lastb >= 0 ? ((((link_t)(cs + lastb + 1)) << 1) | ((types >> lastb) & 1u)) : 0u;
+                // the bend the segment hangs on (lane 0 knows): the last one among the edges before its first sample -- known a priori,
+                // settled by rule, or found by the walk that came in from before the segment
+                link_t hang = 0u;
+                if (lane == 0 && !free0) {
+                    unsigned best = rl[192];
+                    const unsigned kb = BE & 7u;
+                    if (kb) {
+                        const int bi = 31 - __clz((int)kb);
+                        const unsigned cand = ((unsigned)(bi + 1) << 1) | ((BT >> bi) & 1u);   // (edge + 1: zero means none)
+                        best = cand > best ? cand : best;   // (ordered by the edge: the later bend wins; a bend has one type)
+                    }
+                    if (best) hang = (((link_t)(seg_s + (int)(best >> 1) - 1 - kEdgeBias)) << 1) | (best & 1u);
+                }
+                hang = (link_t)__shfl((int)hang, 0);
+                const unsigned long long has = __ballot(lastb >= 0);
+                const unsigned long long lower = has & ((1ull << lane) - 1ull);
+                const int src = lower ? 63 - __clzll((long long)lower) : 0;
+                const link_t from_lower = (link_t)__shfl((int)lcode, src);
+                const link_t mine = lower ? from_lower : hang;
+                bool bad_rec = mine == 0u && !(sg == 0 && lane == 0);   // (a first piece longer than a chunk at the fibre start: the walk's)
+                link_t tail = 0u;
+                if (lane == 63 && !((ends >> (C - 1)) & 1u)) {
+                    // the piece that covers the segment's last sample ends behind it: at the first bend among the T edges there
+                    const unsigned beyond = (BE >> (kEdgeBias + 1 + C)) | (e_own >> C), tbeyond = (BT >> (kEdgeBias + 1 + C)) | (t_own >> C);
+                    if (beyond) {
+                        const int j0 = __ffs((int)beyond) - 1;
+                        tail = (((link_t)(seg_e + j0 + 1)) << 1) | ((tbeyond >> j0) & 1u);
+                    } else {
+                        bad_rec = true;
+                    }
+                }
+                if (__ballot(bad_rec) == 0ull) {
+                    rec.ends = ends;
+                    rec.types = types;
+                    rec.mine = mine;
+                    rec.next = lastb >= 0 ? lcode : mine;
+                    rec.last = lane == 63 && tail ? tail : rec.next;
+                    rec.done = true;
+                    certain = true;
+                    solved = true;
+                    if (lane == 0) plan.dirty.note(5);   // (option "why": waves solved run by run)
+                } else if (lane == 0) {
+                    plan.dirty.note(6);                  // (... that went to the speculative walk after all)
+                }
+            } else if (lane == 0) {
+                plan.dirty.note(6);
+            }
+        }
+    }
+    if (has_chunk && !solved && !(plan.ablate & 1)) {
         Walker w;
         // (robust: the whole zone is searched -- a lane that starts at a bend known a priori has no link that could fail)
         constexpr int kLook = ROBUST ? kWarm - 2 : 8;
@@ -2425,8 +2588,9 @@ void launch_chunk_h(const SweepArgs &args, const FibreGeom &g, hipStream_t strea
 
 // Chunks along the fibre (kernel 2a): dimension-0 sweeps, unweighted.  Codes are laid out [fibre][chunk] (a wave writes
 // the codes of 64 consecutive chunks of one fibre).
-template <int OP, bool WEIGHTED, int H, int G, bool ROBUST, bool ONESEG = false>
+template <int OP, bool WEIGHTED, int H, int G, bool ROBUST, bool ONESEG = false, bool RUNS = false>
 void launch_along_g(const SweepArgs &args, const FibreGeom &g, hipStream_t stream, int fam, int rounds_wanted) {
+    static_assert(!RUNS || (!WEIGHTED && !ROBUST && !ONESEG && G == 64 && H == kWarm), "known runs: the plain unweighted 64-lane instantiation");
     constexpr int C = along_chunk(ROBUST, WEIGHTED), SEG = G * C, ROWS = ONESEG ? SEG : along_zone_rows(H, ROBUST) + SEG + along_tail_rows(H, ROBUST), NG = 64 / G;
     const int nseg = (g.len + SEG - 1) / SEG;
     if (ONESEG && nseg != 1) {
@@ -2444,9 +2608,11 @@ void launch_along_g(const SweepArgs &args, const FibreGeom &g, hipStream_t strea
     plan.dirty = chunk_state().next_dirty(stream);
     plan.xlink = chunk_state().xlink_for((size_t)g.count * (size_t)nseg, stream);
     plan.legacy = options().debug_legacy_rebuild;
-    constexpr size_t lds = sizeof(double) * (size_t)(ROWS + 2) * NG * kAlongWaves * (WEIGHTED ? 2 : 1) + (ROBUST ? 64 + sizeof(double) * kRecipTableRobust : sizeof(double) * kRecipTable);
+    constexpr size_t lds = sizeof(double) * (size_t)(ROWS + 2) * NG * kAlongWaves * (WEIGHTED ? 2 : 1) + (ROBUST ? 64 + sizeof(double) * kRecipTableRobust : sizeof(double) * kRecipTable) +
+                           (RUNS ? sizeof(unsigned) * kRunsWords * kAlongWaves : 0);
     static_assert(lds <= 160 * 1024, "along-fibre geometry does not fit the LDS of a CU");
-    auto kern = sweep_along_kernel<OP, WEIGHTED, H, G, ROBUST, ONESEG>;
+    static_assert(!RUNS || (16 / kAlongWaves) * lds <= 160 * 1024, "known runs: still sixteen waves per CU");
+    auto kern = sweep_along_kernel<OP, WEIGHTED, H, G, ROBUST, ONESEG, RUNS>;
     if (lds > 64 * 1024) {   // above the default dynamic-LDS limit
         static thread_local bool attr_done[kMaxDevices] = {};
         bool &attr_set = attr_done[current_device()];
@@ -2483,9 +2649,15 @@ void launch_along_g(const SweepArgs &args, const FibreGeom &g, hipStream_t strea
 // Chunks along the fibre (kernel 2a): dimension-0 sweeps, unweighted.  Codes are laid out [fibre][chunk] (a group writes
 // the codes of consecutive chunks of one fibre).  Lanes per segment: a whole wave for long fibres; half or a quarter of
 // one when the fibre fits 32 or 16 chunks.
-template <int OP, bool WEIGHTED, int H, bool ROBUST>
+template <int OP, bool WEIGHTED, int H, bool ROBUST, bool RUNS = false>
 void launch_along(const SweepArgs &args, const FibreGeom &g, hipStream_t stream, int fam, int rounds) {
     constexpr int C = along_chunk(ROBUST, WEIGHTED);
+    if constexpr (RUNS) {   // (fibres of more than a segment: the others have no interior segment to solve run by run)
+        if (g.len > 64 * C) {
+            launch_along_g<OP, WEIGHTED, H, 64, ROBUST, false, true>(args, g, stream, fam, rounds);
+            return;
+        }
+    }
     // (fibres of one segment: the robust instantiation without its look-back / look-ahead rows)
     if (g.len <= 16 * C)      launch_along_g<OP, WEIGHTED, H, 16, ROBUST, true>(args, g, stream, fam, rounds);
     else if (g.len <= 32 * C) launch_along_g<OP, WEIGHTED, H, 32, ROBUST, true>(args, g, stream, fam, rounds);
@@ -2603,7 +2775,11 @@ void launch_chunk(const SweepArgs &args, const FibreGeom &g, hipStream_t stream,
         // chunks along the fibre: 0 = 16-sample zones ; 1 = the same, robust (second chances inside the wave and across the
         // waves of a workgroup, walks past the look-ahead rows) ; 2 = 64-sample zones, robust
         // (second chances cost the along-fibre kernel a wave's re-walk, and only in waves that need one: twice the rounds of the tile)
-        if (mode == 0)      launch_along<OP, WEIGHTED, kWarm, false>(args, g, stream, fam, 0);
+        // (rung 0 on data most of whose edges are bends known a priori: interior segments are cut there and solved run by run)
+        if (mode == 0 && !WEIGHTED && options().runs && seed_f >= kSeedRuns) {
+            if constexpr (!WEIGHTED) launch_along<OP, false, kWarm, false, true>(args, g, stream, fam, 0);
+        }
+        else if (mode == 0) launch_along<OP, WEIGHTED, kWarm, false>(args, g, stream, fam, 0);
         else if (mode == 1) launch_along<OP, WEIGHTED, kWarm, true>(args, g, stream, fam, 2 * rounds);
         else                launch_along<OP, WEIGHTED, kWarmLong, true>(args, g, stream, fam, 2 * rounds);
     }
@@ -2635,7 +2811,7 @@ void launch_chunk(const SweepArgs &args, const FibreGeom &g, hipStream_t stream,
 template <int OP, bool WEIGHTED>
 void launch_op_w(const SweepArgs &args, const FibreGeom &g, hipStream_t stream, bool allow_chunked, int fam) {
     // chunking pays once a fibre spans several blocks; short fibres stay sequential
-    const bool chunked = allow_chunked && options().chunk > 0 && g.len >= options().chunk_min_len;
+    const bool chunked = allow_chunked && g.len >= options().chunk_min_len;
     if (!chunked && !WEIGHTED && options().whole && g.len >= 16 && g.len <= kWholeMax && args.lam >= 0.0) {   // (negative
         // penalties -- tvgen lets them through -- keep the sequential kernel, whose reads past the fibre mirror the reference's;
         // so do fibres of a handful of samples: that kernel divides like the CPU, bit for bit, and loops that end at a

@@ -667,4 +667,180 @@ int policy_sim(const double *cost, const double *frac, int switch_at, int solves
                int start_mode, double *total_ms, int *trace) {
     return policy_sim_pin(cost, frac, switch_at, solves, sweeps, len, weighted, start_mode, 0, total_ms, trace);
 }
+
+// ---- known runs (chunkcore.hpp; sweep_along_kernel RUNS): one fibre, segment by segment, the way the kernel's wave does it -------------
+// Interior segments take the four phases of the kernel -- edges, the list of runs, one run per lane, the chunks' records -- with the lanes
+// emulated one after the other; rows of segments that are not interior, or that fall back (stats[1]), come from the exact walk of the
+// whole fibre, as the speculative path would leave them.  stats: [0] segments solved run by run, [1] fallen back, [2] runs walked,
+// [3] most runs in one segment.
+int host_runs_fibre(const double *y, double lam, int len, double *x, int *stats) {
+    constexpr int C = 17, G = 64, H = 16, T = 8, SEG = C * G;
+    constexpr unsigned CM = (1u << C) - 1u;
+    for (int k = 0; k < 10; k++) stats[k] = 0;   // ([4..9]: why segments fell back: no bend at the start, a run without end, > 64 runs, a walk that did not close, no bend before a chunk, no bend behind the segment)
+    {
+        HostSource src{y, nullptr, x, -1};
+        Walker w;
+        walker_start<false>(w, src, 0, lam);
+        walker_run<false>(w, src, len, lam);
+    }
+    const int nseg = (len + SEG - 1) / SEG;
+    for (int sg = 0; sg < nseg; sg++) {
+        const int seg_s = sg * SEG, seg_e = std::min(len, seg_s + SEG);
+        if (!(seg_s + SEG + T <= len - 1) || !(lam > 0.0)) continue;   // (`interior`)
+        HostWin win;
+        win.lo = seg_s - H;
+        win.hi = seg_s + SEG + T;
+        for (int i = win.lo; i < win.hi; i++) win.yy.push_back(y[std::max(i, 0)]);   // (the first segment's zone: copies of sample 0)
+        win.yy.push_back(1e300);
+        win.yy.push_back(1e300);
+        win.writes.assign(win.yy.size(), 0);
+        HostFar far{y, nullptr};
+        // (1) edges
+        EdgeMasks own[G], m[G];
+        for (int l = 0; l < G; l++) own[l] = own_edges<C>(win, seg_s + l * C, lam);
+        unsigned xk = 0, xp = 0, xn = 0, xb = 0;
+        for (int l = 0; l < 10; l++) {
+            unsigned k = 0, pp = 0, nn = 0, bb = 0;
+            if (l < 8) one_edge(win.y(seg_e - 1 + l), win.y(seg_e + l), lam, k, pp, nn, bb);
+            else if (sg > 0) one_edge(win.y(seg_s - 11 + l), win.y(seg_s - 10 + l), lam, k, pp, nn, bb);
+            xk |= k << l; xp |= pp << l; xn |= nn << l; xb |= bb << l;
+        }
+        unsigned BE[G], BT[G], WS[G];
+        for (int l = 0; l < G; l++) {
+            EdgeMasks pv = l ? own[l - 1] : EdgeMasks{}, nx = l < G - 1 ? own[l + 1] : EdgeMasks{};
+            if (l == G - 1) { nx.K = (xk & 0xffu) << kEdgeBias; nx.P = (xp & 0xffu) << kEdgeBias; nx.N = (xn & 0xffu) << kEdgeBias; nx.B = (xb & 0xffu) << kEdgeBias; }
+            if (l == 0)     { pv.K = ((xk >> 8) & 3u) << C; pv.P = ((xp >> 8) & 3u) << C; pv.N = ((xn >> 8) & 3u) << C; pv.B = ((xb >> 8) & 3u) << C; }
+            m[l].K = edge_ext<C>(own[l].K, pv.K, nx.K); m[l].P = edge_ext<C>(own[l].P, pv.P, nx.P);
+            m[l].N = edge_ext<C>(own[l].N, pv.N, nx.N); m[l].B = edge_ext<C>(own[l].B, pv.B, nx.B);
+            const bool free0 = sg == 0 && l == 0;
+            if (free0) m[l].K = (m[l].K & ~7u) | 4u;
+            settle_short_runs(m[l], BE[l], BT[l], WS[l]);
+            if (free0) {
+                BE[l] = (BE[l] & ~8u) | (m[l].K & 8u);
+                BT[l] = (BT[l] & ~8u) | (m[l].P & m[l].K & 8u);
+                WS[l] = (WS[l] & ~7u) | ((m[l].K & 8u) ? 0u : 4u);
+            }
+        }
+        // (2) the list
+        std::vector<unsigned> list;
+        bool fail = sg > 0 && (m[0].K & 7u) == 0u;
+        if (fail) stats[4]++;
+        for (int l = 0; l < G; l++) {
+            unsigned dom = WS[l] & ((1u << (C + kEdgeBias)) - 1u);
+            if (l > 0) dom &= ~3u;
+            while (dom) {
+                const int b = __builtin_ctz(dom);
+                dom &= dom - 1u;
+                const int e = run_end(m[l].K, b);
+                if (e < 0) { fail = true; stats[5]++; }
+                else list.push_back(RunEntry::make(l, b, e, (int)((m[l].P >> b) & 1u), sg == 0 && l == 0 && b == kEdgeBias).word);
+            }
+        }
+        stats[3] = std::max(stats[3], (int)list.size());
+        bool go = !fail && list.size() <= 64;
+        if (list.size() > 64) stats[6]++;
+        // (3) one run per lane
+        unsigned E[G] = {}, Tt[G] = {}, hang_word = 0;
+        if (go) {
+            for (unsigned word : list) {
+                const RunEntry en{word};
+                const int c0 = seg_s + C * en.lane() - kEdgeBias, a = c0 + en.b(), ee = c0 + en.e();
+                ChunkRec rr;
+                Walker w;
+                if (en.free_start()) {
+                    walker_start<false>(w, win, 0, lam);
+                } else {
+                    walker_restart_with<false>(w, a, en.type(), len, lam, win.y(a), 0.0, 0.0);
+                    rr.mine = rr.next = rr.last = ((unsigned)a << 1) | (unsigned)en.type();
+                }
+                walk_interior<false>(w, rr, win, std::min(len - 1, win.hi), a, ee, lam);
+                TailSource<false, false, 48, HostWin, HostFar> tail{win, far, rr, a, ee, win.hi, len};
+                walker_run<false>(w, tail, len, lam);
+                if (!(rr.done && !rr.failed)) { go = false; stats[7]++; break; }
+                stats[2]++;
+                const int o = en.b() - kEdgeBias;
+                if (o >= 0) {
+                    E[en.lane()] |= rr.ends << o;
+                    Tt[en.lane()] |= rr.types << o;
+                } else {
+                    E[0] |= rr.ends >> (-o);
+                    Tt[0] |= rr.types >> (-o);
+                    const unsigned low = rr.ends & ((1u << (-o)) - 1u);
+                    if (low) {
+                        const int j = 31 - __builtin_clz(low);
+                        hang_word = std::max(hang_word, ((unsigned)(en.b() + j + 2) << 1) | ((rr.types >> j) & 1u));
+                    }
+                }
+            }
+        }
+        // (4) the chunks' records
+        ChunkRec recs[G];
+        if (go) {
+            unsigned ends[G], types[G], lcode[G];
+            int lastb[G];
+            for (int l = 0; l < G; l++) {
+                const unsigned e_prev = l ? E[l - 1] : 0u, t_prev = l ? Tt[l - 1] : 0u;
+                ends[l] = ((BE[l] >> (kEdgeBias + 1)) | E[l] | (e_prev >> C)) & CM;
+                types[l] = ((BT[l] >> (kEdgeBias + 1)) | Tt[l] | (t_prev >> C)) & CM & ends[l];
+                lastb[l] = ends[l] ? 31 - __builtin_clz(ends[l]) : -1;
+                lcode[l] = lastb[l] >= 0 ? ((((unsigned)(seg_s + l * C + lastb[l] + 1)) << 1) | ((types[l] >> lastb[l]) & 1u)) : 0u;
+            }
+            unsigned hang = 0;
+            if (sg > 0) {
+                unsigned best = hang_word;
+                const unsigned kb = BE[0] & 7u;
+                if (kb) {
+                    const int bi = 31 - __builtin_clz(kb);
+                    best = std::max(best, ((unsigned)(bi + 1) << 1) | ((BT[0] >> bi) & 1u));
+                }
+                if (best) hang = (((unsigned)(seg_s + (int)(best >> 1) - 1 - kEdgeBias)) << 1) | (best & 1u);
+            }
+            for (int l = 0; l < G && go; l++) {
+                unsigned mine = hang;
+                for (int k = l - 1; k >= 0; k--)
+                    if (lastb[k] >= 0) { mine = lcode[k]; break; }
+                if (mine == 0u && !(sg == 0 && l == 0)) { go = false; stats[8]++; }
+                unsigned tailc = 0;
+                if (l == G - 1 && !((ends[l] >> (C - 1)) & 1u)) {
+                    const unsigned beyond = (BE[l] >> (kEdgeBias + 1 + C)) | (E[l] >> C), tbeyond = (BT[l] >> (kEdgeBias + 1 + C)) | (Tt[l] >> C);
+                    if (beyond) {
+                        const int j0 = __builtin_ctz(beyond);
+                        tailc = (((unsigned)(seg_e + j0 + 1)) << 1) | ((tbeyond >> j0) & 1u);
+                    } else {
+                        go = false;
+                        stats[9]++;
+                    }
+                }
+                ChunkRec &rec = recs[l];
+                rec.ends = ends[l];
+                rec.types = types[l];
+                rec.mine = mine;
+                rec.next = lastb[l] >= 0 ? lcode[l] : mine;
+                rec.last = (l == G - 1 && tailc) ? tailc : rec.next;
+                rec.done = true;
+            }
+        }
+        if (!go) {
+            stats[1]++;
+            continue;
+        }
+        stats[0]++;
+        std::vector<PiecePrefix> pres((size_t)G);
+        for (int l = 0; l < G; l++) pres[(size_t)l] = first_piece_prefix(win, recs[l], seg_s + l * C, std::max(0, seg_s + l * C - H));
+        for (int l = 0; l < G; l++) {
+            const int cs = seg_s + l * C;
+            rebuild_owned<Identity, false, C, 1, false, const double *, 0, 2>(win, recs[l], cs, cs + C, len, std::max(0, cs - H), true, seg_s, l == G - 1, lam,
+                                                                          (const double *)nullptr, &pres[(size_t)l]);
+        }
+        int errs = 0;
+        for (int k = seg_s; k < seg_e; k++) {
+            if (win.writes[(size_t)(k - win.lo)] != 1) errs++;
+            x[k] = win.y(k);
+        }
+        for (int k = win.lo; k < win.hi; k++)
+            if ((k < seg_s || k >= seg_e) && win.writes[(size_t)(k - win.lo)] != 0) errs++;
+        if (errs) return -errs;   // a row of the segment not written exactly once, or a row outside it written at all
+    }
+    return 0;
+}
 }

@@ -165,7 +165,7 @@ def test_every_documented_knob_is_accepted():
     text = open(os.path.join(ROOT, "include", "proxtv_amd.h")).read()
     block = text[text.index("/* Knobs"):text.index("int proxtv_set_option")]
     keys = sorted(set(re.findall(r'"([a-z_0-9]+)"', block)))
-    assert {"chunk", "chunk_mode", "deterministic", "dr_form", "xlink", "verbose", "profile", "certify"} <= set(keys), keys
+    assert {"runs", "chunk_mode", "deterministic", "dr_form", "xlink", "verbose", "profile", "certify"} <= set(keys), keys
     assert len(keys) <= 20, f"{len(keys)} knobs: every A/B that is settled takes its switch with it"
     for k in keys:
         before = lib.proxtv_set_option(k.encode(), 12345)

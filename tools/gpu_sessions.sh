@@ -53,5 +53,30 @@ s7)   # optimistic solves with the flags cleared before a second run and the bac
   { python tools/fuzz.py 60 621; python tools/fuzz.py 40 622 long; } > $OUT/fuzz.txt 2>&1; grep "^fuzz\|MISMATCH\|Error" $OUT/fuzz.txt | tee -a $OUT/summary.txt
   ab --reps 9 --rounds 2 --cases c2,c2@0.2,c3,s512 base plain,optimistic=0 > $OUT/ab_optimistic.txt 2>&1; cat $OUT/ab_optimistic.txt
   ;;
+s8)   # known runs: the new test file, parity files, A/B by option on one build, a certified soak on long fibres
+  timeout 600 python -m pytest tests/test_gpu_runs.py -m gpu -x -q > $OUT/pytest_new.log 2>&1; echo "new: $(tail -1 $OUT/pytest_new.log)" | tee $OUT/summary.txt
+  timeout 900 python -m pytest tests/test_gpu_parity_1d.py tests/test_gpu_parity_2d.py tests/test_gpu_parity_nd.py tests/test_gpu_large.py tests/test_gpu_matrix.py tests/test_gpu_certify.py -m gpu -x -q > $OUT/pytest_parity.log 2>&1; echo "parity: $(tail -1 $OUT/pytest_parity.log)" | tee -a $OUT/summary.txt
+  ab --reps 9 --rounds 2 --cases c2,prox0,c2@0.13,pd2,c4,s2048,s512 base noruns,runs=0 > $OUT/ab_runs.txt 2>&1; cat $OUT/ab_runs.txt
+  { python tools/fuzz.py 60 631 long; python tools/fuzz.py 60 632; } > $OUT/fuzz.txt 2>&1; grep "^fuzz\|MISMATCH\|Error" $OUT/fuzz.txt | tee -a $OUT/summary.txt
+  ;;
+s9)   # known runs with LDS atomics and carry-chain masks: the test file, A/B by option, the phase trace of both
+  timeout 600 python -m pytest tests/test_gpu_runs.py tests/test_gpu_parity_1d.py -m gpu -x -q > $OUT/pytest_new.log 2>&1; echo "new: $(tail -1 $OUT/pytest_new.log)" | tee $OUT/summary.txt
+  ab --reps 9 --rounds 2 --cases c2,prox0,s2048,s512 base noruns,runs=0 > $OUT/ab_runs.txt 2>&1; cat $OUT/ab_runs.txt
+  timeout 120 python tools/wg_trace.py > $OUT/wg_trace_runs.txt 2>&1; grep "^##\|^# mean" $OUT/wg_trace_runs.txt
+  PROXTV_RUNS=0 timeout 120 python tools/wg_trace.py > $OUT/wg_trace_noruns.txt 2>&1; grep "^##\|^# mean" $OUT/wg_trace_noruns.txt
+  ;;
+s10)  # is the along-fibre kernel bound by how fast workgroups are dispatched?  eight waves (two fibres of 4096) per workgroup against four
+  alt aw8 timeout 600 python -m pytest tests/test_gpu_runs.py tests/test_gpu_parity_1d.py tests/test_gpu_parity_2d.py tests/test_gpu_chunk_repair.py -m gpu -x -q > $OUT/pytest_aw8.log 2>&1; echo "aw8: $(tail -1 $OUT/pytest_aw8.log)" | tee $OUT/summary.txt
+  ab --reps 9 --rounds 2 --cases c2,prox0,c2@0.5,c3,c4,pd2,s2048,s512 base aw8=$W/lib_aw8.so > $OUT/ab_aw8.txt 2>&1; cat $OUT/ab_aw8.txt
+  ;;
+s11)  # instruction counters of the column sweep with and without the known-runs path
+  cd /tmp; R=$GRAFT_REPO_ROOT
+  KC_SETS=insts,waves timeout 400 python $R/tools/kernel_counters.py collect $R/$OUT/kc_runs calib+dr0.1 > $R/$OUT/kc_collect.log 2>&1
+  PROXTV_RUNS=0 KC_SETS=insts,waves timeout 400 python $R/tools/kernel_counters.py collect $R/$OUT/kc_noruns calib+dr0.1 >> $R/$OUT/kc_collect.log 2>&1
+  cd $R
+  python tools/kernel_counters.py report $OUT/kc_runs > $OUT/kernel_counters_runs.txt 2>&1; python tools/kernel_counters.py report $OUT/kc_noruns > $OUT/kernel_counters_noruns.txt 2>&1
+  grep -h "along\|kernel  " $OUT/kernel_counters_runs.txt $OUT/kernel_counters_noruns.txt | cut -c1-260
+  find $OUT -name "*.db" -delete
+  ;;
 *) echo "unknown session $S";;
 esac
