@@ -472,7 +472,9 @@ int proxtv_set_option(const char *key, int value) {
     if (!slot) return -1;
     const int old = *slot;
     *slot = value;
-    if (!strcmp(key, "optimistic")) optimistic_forget();
+    if (!strcmp(key, "optimistic")) {
+        try { optimistic_forget(); } catch (...) {}   // (per-device state: nothing to forget where there is no device)
+    }
     if (value != 0 && (!strcmp(key, "ablate") || !strcmp(key, "debug_legacy_rebuild")))
         fprintf(stderr, "[proxtv_amd] WARNING: option \"%s\" = %d -- a profiling / test aid: results are WRONG while it is non-zero\n", key, value);
     return old;
