@@ -104,6 +104,9 @@ struct InA : NoKeep {
 struct InBminusA : NoKeep {
     static constexpr int NIN = 2;
     __device__ static __forceinline__ void fetch_in(const SweepArgs &p, long idx, double &i0, double &i1) { i0 = ld_once(p.b + idx); i1 = p.a[idx]; }
+    // rows that TWO workgroups of a tile sweep stage (a block's zone and look-ahead rows are its neighbours' own): whoever comes first
+    // must leave them in the L2 for the other -- no streaming hint on those (sweep_chunk_kernel: stage_as)
+    __device__ static __forceinline__ void fetch_in_shared(const SweepArgs &p, long idx, double &i0, double &i1) { i0 = p.b[idx]; i1 = p.a[idx]; }
     __device__ static __forceinline__ double y_of(const SweepArgs &, double i0, double i1) { return i0 - i1; }
     __device__ static __forceinline__ double load_y(const SweepArgs &p, long idx) { return p.b[idx] - p.a[idx]; }
 };

@@ -271,6 +271,17 @@ __device__ __forceinline__ void walk_chunk(Walker &w, ChunkRec &rec, const LdsWi
     if (rec.failed) rec.next = 0;   // ran off the window: nothing this lane recorded may be trusted
 }
 
+// fetch_in without an op's streaming hint where the op has one (ops.hpp: InBminusA::fetch_in_shared)
+template <int OP, class = void>
+struct HasSharedFetch : std::false_type {};
+template <int OP>
+struct HasSharedFetch<OP, std::void_t<decltype(&Op<OP>::fetch_in_shared)>> : std::true_type {};
+template <int OP>
+__device__ __forceinline__ void fetch_in_shared_or_plain(const SweepArgs &p, long idx, double &i0, double &i1) {
+    if constexpr (HasSharedFetch<OP>::value) Op<OP>::fetch_in_shared(p, idx, i0, i1);
+    else Op<OP>::fetch_in(p, idx, i0, i1);
+}
+
 // One workgroup = NW waves = NW consecutive chunks (a "block" of NW*C samples) of the same 64 fibres; it processes
 // plan.qpw consecutive blocks of those fibres.  Per block:
 //   1. stage the window [block start - H, block end + T) into LDS through the op's input functor: all loads of a
@@ -421,7 +432,20 @@ __global__ __launch_bounds__(64 * NW, SHORT ? 16 / NW : (FW < 64 ? ((WEIGHTED ? 
                 }
                 ok = ok && u < NST;
                 s0[v] = s1[v] = 0.0;
-                if (ok) Op<OP>::fetch_in(p, idx, s0[v], s1[v]);
+                // (strided tiles: the shares that hold rows two workgroups stage -- the zone and look-ahead rows, and the own rows that are
+                //  a neighbour's: the block's first TA and last HA -- are loaded without the streaming hint an op may put on a window operand)
+                constexpr int kOwn0 = HA / NCH, kOwn1 = HA / NCH + C;
+#ifndef PTV_NO_SHARED_HALO   // (A/B switch)
+                // (measured, profiles/r06_s13_ab_halo.txt: DR row sweep 105.0 -> 103.9 us; the weighted tile, one or two workgroups per CU, lost
+                //  1 % and keeps the hint everywhere)
+                const bool shared_rows = !TRANSPOSED && !SHORT && !WEIGHTED && (u < kOwn0 + (TA + NCH - 1) / NCH || u >= kOwn1 - (HA + NCH - 1) / NCH);
+#else
+                const bool shared_rows = false;
+#endif
+                if (ok) {
+                    if (shared_rows) fetch_in_shared_or_plain<OP>(p, idx, s0[v], s1[v]);
+                    else             Op<OP>::fetch_in(p, idx, s0[v], s1[v]);
+                }
                 if (WEIGHTED) sw[v] = (ok && (inner || r < len - 1)) ? p.w[widx] : 0.0;
             }
 #pragma unroll

@@ -3,7 +3,7 @@
 # bench line, the phase trace, the lambda sweep, first calls, small images, short fibres, the host-pointer path.  Everything lands
 # under gpurun_out/<tag>/ ; what is to be judged is copied into profiles/ afterwards.
 #   QUICK=1: kernel stats of the headline + the counters table + bench line only.
-TAG=${1:-r05}
+TAG=${1:-r06}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$TAG
@@ -27,7 +27,7 @@ for w in dr fibre; do timeout 100 python tools/first_call.py $w >> $O/${TAG}_fir
 timeout 120 python tools/small_images.py > $O/${TAG}_small_images.txt 2>&1
 timeout 120 python tools/long_fibre.py > $O/${TAG}_long_fibre.txt 2>&1
 timeout 200 python tools/short_probe.py > $O/${TAG}_short_fibres.txt 2>&1
-timeout 100 python tools/host_api_time.py > $O/${TAG}_host_api.txt 2>&1
+
 fi
 cd $R
 timeout 400 python bench.py > $O/${TAG}_bench_line.json 2> $O/bench.err

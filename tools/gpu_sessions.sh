@@ -78,5 +78,14 @@ s11)  # instruction counters of the column sweep with and without the known-runs
   grep -h "along\|kernel  " $OUT/kernel_counters_runs.txt $OUT/kernel_counters_noruns.txt | cut -c1-260
   find $OUT -name "*.db" -delete
   ;;
+s12)  # known runs with the waves of a workgroup on the same segment of four fibres: tests, A/B by option, counters
+  timeout 600 python -m pytest tests/test_gpu_runs.py tests/test_gpu_parity_1d.py tests/test_gpu_parity_2d.py tests/test_gpu_large.py -m gpu -x -q > $OUT/pytest_new.log 2>&1; echo "tests: $(tail -1 $OUT/pytest_new.log)" | tee $OUT/summary.txt
+  ab --reps 9 --rounds 2 --cases c2,prox0,pd2,s2048,s512 base noruns,runs=0 > $OUT/ab_runs.txt 2>&1; cat $OUT/ab_runs.txt
+  timeout 120 python tools/wg_trace.py > $OUT/wg_trace_runs.txt 2>&1; grep "^##\|^# mean" $OUT/wg_trace_runs.txt | grep -A3 "column"
+  ;;
+s13)  # the rows two workgroups of a tile sweep stage, loaded without the streaming hint: parity, A/B against the build with the hint
+  timeout 600 python -m pytest tests/test_gpu_parity_2d.py tests/test_gpu_large.py tests/test_gpu_runs.py -m gpu -x -q > $OUT/pytest.log 2>&1; echo "tests: $(tail -1 $OUT/pytest.log)" | tee $OUT/summary.txt
+  ab --reps 9 --rounds 2 --cases c2,c3,c2@0.5,pd2,c4y base nohalo=$W/lib_nohalo.so > $OUT/ab_halo.txt 2>&1; cat $OUT/ab_halo.txt
+  ;;
 *) echo "unknown session $S";;
 esac
