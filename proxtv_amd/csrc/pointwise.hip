@@ -302,6 +302,38 @@ void dr_fill(double *t, long n, long segments, const double *sums, double sign, 
     PTV_HIP(hipGetLastError());
 }
 
+// more terms than a kernel-argument pack holds: pointers from a table in HBM ([0, P) p_i, [P, 2P) z_i)
+template <bool DR>
+__global__ __launch_bounds__(kThreads) void pd_combine_many_kernel(double *const *table, const double *x, double *xo, int P, long n,
+                                                                     double *partials) {
+    double acc = 0;
+    for (long k = (long)blockIdx.x * kThreads + threadIdx.x; k < n; k += (long)gridDim.x * kThreads) {
+        const double xold = x[k];
+        double xn = 0, q = 0;
+        if (DR) {
+            for (int i = 0; i < P; i++) {
+                q += table[i][k] / P;
+                xn += table[P + i][k] / P;
+            }
+            for (int i = 0; i < P; i++) table[P + i][k] += 2 * q - xn - table[i][k];
+        } else {
+            for (int i = 0; i < P; i++) xn += table[i][k] / P;
+            for (int i = 0; i < P; i++) table[P + i][k] += xn - table[i][k];
+        }
+        xo[k] = xn;
+        acc += fabs(xn - xold);
+    }
+    acc = block_sum(acc);
+    if (threadIdx.x == 0) partials[blockIdx.x] = acc;
+}
+void pd_combine_many(double *const *table, const double *x, double *xo, int P, long n, double *partials, double *out, bool dr_variant,
+                     hipStream_t s) {
+    if (dr_variant) hipLaunchKernelGGL((pd_combine_many_kernel<true>), dim3(kReduceBlocks), dim3(kThreads), 0, s, table, x, xo, P, n, partials);
+    else            hipLaunchKernelGGL((pd_combine_many_kernel<false>), dim3(kReduceBlocks), dim3(kThreads), 0, s, table, x, xo, P, n, partials);
+    hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(kThreads), 0, s, partials, kReduceBlocks, out);
+    PTV_HIP(hipGetLastError());
+}
+
 void absdiff_to(const double *a, const double *b, long n, double *partials, double *out, hipStream_t s) {
     hipLaunchKernelGGL(absdiff_kernel, dim3(kReduceBlocks), dim3(kThreads), 0, s, a, b, n, partials);
     hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(kThreads), 0, s, partials, kReduceBlocks, out);

@@ -26,6 +26,10 @@ void pd_combine(const PtrPack &p, const PtrPack &z, const double *x, double *xo,
 // PDR_TV combine (src/TVNDopt.cpp:465-484): q = sum p_i/P ; xo = sum z_i/P ; z_i += 2q - xo - p_i ; *out = sum|xo - x|
 void pdr_combine(const PtrPack &p, const PtrPack &z, const double *x, double *xo, int P, long n, double *partials,
                  double *out, hipStream_t s);
+// The same two for ANY number of terms (the reference takes any npen: src/TVNDopt.cpp:48-110): the array pointers come from a table in
+// HBM ([P] p_i then [P] z_i) instead of the kernel-argument pack; same arithmetic in the same order, one element per lane.
+void pd_combine_many(double *const *table, const double *x, double *xo, int P, long n, double *partials, double *out, bool dr_variant,
+                     hipStream_t s);
 // x = y / P                                                 (PDR initialisation, src/TVNDopt.cpp:362-367)
 void scale_to(const double *y, double *x, double divisor, long n, hipStream_t s);
 // out = ca a + cb b + cc c + cd d   (null pointers are skipped; out may alias any operand).  The unfused splitting loops

@@ -296,11 +296,13 @@ namespace {
 
 struct Family {
     std::vector<std::unique_ptr<Scratch>> blocks;
-    PtrPack pack{};
+    std::vector<double *> ptr;   // every block's address
+    PtrPack pack{};              // ... and the first kMaxTerms of them as a kernel argument
     Family(int count, size_t bytes) {
         for (int i = 0; i < count; i++) {
             blocks.emplace_back(new Scratch(bytes));
-            pack.v[i] = blocks.back()->d();
+            ptr.push_back(blocks.back()->d());
+            if (i < kMaxTerms) pack.v[i] = blocks.back()->d();
         }
     }
 };
@@ -309,24 +311,30 @@ SolveInfo pd_like(bool dr_variant, const double *y, const double *lambdas, const
                   int nds, int npen, int maxIters, hipStream_t s, const double *norms) {
     SolveInfo info;
     info.gap_set = true;
-    if (npen > kMaxTerms) {
-        set_error("at most %d penalty terms are supported per call (got %d)", kMaxTerms, npen);
-        throw HipFailure{hipErrorInvalidValue};
-    }
     if (maxIters <= 0) maxIters = dr_variant ? MAX_ITERS_DR : MAX_ITERS_PD;
     const long n = total(ns, nds);
     const size_t bytes = sizeof(double) * (size_t)n;
 
     Family p(npen, bytes), z(npen, bytes);
     Scratch partials(sizeof(double) * kReduceBlocks), acc(sizeof(double));
+    // more terms than a kernel-argument pack holds (the reference takes any number: :48-110): the combine kernel reads the array
+    // addresses from a table in HBM
+    std::unique_ptr<Scratch> table;
+    if (npen > kMaxTerms) {
+        std::vector<double *> host(p.ptr);
+        host.insert(host.end(), z.ptr.begin(), z.ptr.end());
+        table.reset(new Scratch(sizeof(double *) * host.size()));
+        PTV_HIP(hipMemcpyAsync(table->as<double *>(), host.data(), sizeof(double *) * host.size(), hipMemcpyHostToDevice, s));
+        PTV_HIP(hipStreamSynchronize(s));   // (`host` lives on this frame)
+    }
     if (dr_variant) scale_to(y, x, (double)npen, n, s);               // x = y / npen        (:362-367)
     else            PTV_HIP(hipMemsetAsync(x, 0, bytes, s));          // x = 0               (:126-130)
-    for (int i = 0; i < npen; i++) PTV_HIP(hipMemcpyAsync(z.pack.v[i], y, bytes, hipMemcpyDeviceToDevice, s));
+    for (int i = 0; i < npen; i++) PTV_HIP(hipMemcpyAsync(z.ptr[(size_t)i], y, bytes, hipMemcpyDeviceToDevice, s));
 
     {
-        int swept[kMaxTerms];
-        for (int i = 0; i < npen; i++) swept[i] = (int)(dims[i] - 1);
-        policy_probe(y, nullptr, ns, nds, swept, npen, s);
+        std::vector<int> swept((size_t)npen);
+        for (int i = 0; i < npen; i++) swept[(size_t)i] = (int)(dims[i] - 1);
+        policy_probe(y, nullptr, ns, nds, swept.data(), npen, s);
     }
     double stop = dr_variant ? 0.0 : DBL_MAX;
     int iters = 0;
@@ -334,17 +342,18 @@ SolveInfo pd_like(bool dr_variant, const double *y, const double *lambdas, const
         for (int i = 0; i < npen; i++) {
             const int d = (int)(dims[i] - 1);
             if (norms && norms[i] == 2) {
-                tv2_fibres(z.pack.v[i], p.pack.v[i], ns, nds, d, lambdas[i], s);
+                tv2_fibres(z.ptr[(size_t)i], p.ptr[(size_t)i], ns, nds, d, lambdas[i], s);
                 continue;
             }
             SweepArgs a;
-            a.a = z.pack.v[i]; a.o0 = p.pack.v[i]; a.lam = lambdas[i];
+            a.a = z.ptr[(size_t)i]; a.o0 = p.ptr[(size_t)i]; a.lam = lambdas[i];
             launch_sweep(OP_PROX, false, a, fibres_along(ns, nds, d), s, fam_of_dim(d), true);
         }
         {
             FamilyTimer tm(FAM_OTHER, s);
-            if (dr_variant) pdr_combine(p.pack, z.pack, x, x, npen, n, partials.d(), acc.d(), s);
-            else            pd_combine(p.pack, z.pack, x, x, npen, n, partials.d(), acc.d(), s);
+            if (table)           pd_combine_many(table->as<double *>(), x, x, npen, n, partials.d(), acc.d(), dr_variant, s);
+            else if (dr_variant) pdr_combine(p.pack, z.pack, x, x, npen, n, partials.d(), acc.d(), s);
+            else                 pd_combine(p.pack, z.pack, x, x, npen, n, partials.d(), acc.d(), s);
         }
         if (!dr_variant || iters == maxIters - 1) stop = fetch(acc.d(), s) / n;
         iters++;

@@ -158,3 +158,22 @@ def test_device_api_matches_host_api(ptv, oracle):
     for dim in range(3):
         want = np.apply_along_axis(lambda f: oracle.tv1_hybrid(f, 0.4), dim, V)
         assert_close(device.tv1_fibres(vd, 0.4, dim).cpu().numpy(), want, what=f"fibres dim {dim}")
+
+
+def test_any_number_of_penalty_terms(ptv, clib, oracle):
+    """The reference takes any npen (src/TVNDopt.cpp:48-110).  Up to 16 terms their arrays travel as kernel arguments, beyond that through
+    a pointer table in HBM: PD_TV and PDR_TV with 17, 20 and 33 terms against the oracle, iteration counts and stop values pinned."""
+    rng = np.random.default_rng(77)
+    V = rng.standard_normal((40, 33, 21))
+    for npen in (16, 17, 20, 33):
+        lams = rng.uniform(0.02, 0.2, npen)
+        dims = [int(d) for d in rng.integers(1, 4, npen)]
+        want, winfo, _, _ = oracle.pd(V, lams, dims)
+        assert_close(ptv.tvgen(V, list(lams), dims, [1] * npen), want, tol=1e-9, what=f"tvgen, {npen} terms")
+        out, info, rc, _ = _pd_like(clib.PD_TV, V, lams, dims)
+        assert rc == 1 and info[0] == winfo[0] and abs(info[1] - winfo[1]) <= 1e-9 * abs(winfo[1]) + 1e-18, (npen, info, winfo)
+        assert_close(out, want, tol=1e-9, what=f"PD_TV, {npen} terms")
+        out, info, rc, _ = _pd_like(clib.PDR_TV, V, lams, dims)
+        wantr, winfor, _, _ = oracle.pdr(V, lams, dims)
+        assert rc == 1 and info[0] == winfor[0], (npen, info, winfor)
+        assert_close(out, wantr, tol=1e-9, what=f"PDR_TV, {npen} terms")
