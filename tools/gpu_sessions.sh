@@ -87,5 +87,21 @@ s13)  # the rows two workgroups of a tile sweep stage, loaded without the stream
   timeout 600 python -m pytest tests/test_gpu_parity_2d.py tests/test_gpu_large.py tests/test_gpu_runs.py -m gpu -x -q > $OUT/pytest.log 2>&1; echo "tests: $(tail -1 $OUT/pytest.log)" | tee $OUT/summary.txt
   ab --reps 9 --rounds 2 --cases c2,c3,c2@0.5,pd2,c4y base nohalo=$W/lib_nohalo.so > $OUT/ab_halo.txt 2>&1; cat $OUT/ab_halo.txt
   ;;
+s14)  # wave lives by segment; the many-terms PD test
+  python tools/wave_life.py 2>&1 | tee $OUT/wave_life.txt
+  timeout 600 python -m pytest tests/test_gpu_parity_nd.py -m gpu -x -q > $OUT/pytest.log 2>&1; echo "nd tests: $(tail -1 $OUT/pytest.log)" | tee $OUT/summary.txt
+  ;;
+s15)  # the along-fibre kernel's waves sorted (last segments in workgroups of their own): parity, wave lives, A/B against the unsorted build
+  timeout 900 python -m pytest tests/test_gpu_runs.py tests/test_gpu_parity_1d.py tests/test_gpu_parity_2d.py tests/test_gpu_parity_nd.py tests/test_gpu_large.py tests/test_gpu_chunk_repair.py tests/test_gpu_optimistic.py -m gpu -x -q > $OUT/pytest.log 2>&1; echo "tests: $(tail -1 $OUT/pytest.log)" | tee $OUT/summary.txt
+  python tools/wave_life.py 2>&1 | tee $OUT/wave_life.txt
+  ab --reps 9 --rounds 2 --cases c2,prox0,c3,pd2,c4,c4y,s2048,s512 base unsorted=$W/lib_unsorted.so > $OUT/ab_sorted.txt 2>&1; cat $OUT/ab_sorted.txt
+  ;;
+s16)  # is the along-fibre kernel bound by the rate at which waves are launched?  two / three virtual workgroups per workgroup (sorted waves)
+  for v in turns2 turns3; do alt $v timeout 600 python -m pytest tests/test_gpu_runs.py tests/test_gpu_parity_1d.py tests/test_gpu_parity_2d.py tests/test_gpu_large.py tests/test_gpu_chunk_repair.py -m gpu -x -q > $OUT/pytest_$v.log 2>&1; echo "$v: $(tail -1 $OUT/pytest_$v.log)" | tee -a $OUT/summary.txt; done
+  ab --reps 9 --rounds 2 --cases c2,prox0,pd2,s2048,s512 base unsorted=$W/lib_unsorted.so turns2=$W/lib_turns2.so turns3=$W/lib_turns3.so > $OUT/ab_turns.txt 2>&1; cat $OUT/ab_turns.txt
+  ;;
+s17)  # what does the column sweep cost with its phases switched off (option ablate: 1 walk + rebuild, 2 stream-out, 4 window loads)?  7 = the launch alone
+  ab --reps 9 --rounds 1 --cases prox0,prox1 base a7,ablate=7 a5,ablate=5 a6,ablate=6 a3,ablate=3 a1,ablate=1 a2,ablate=2 a4,ablate=4 2> /dev/null > $OUT/ab_ablate.txt; cat $OUT/ab_ablate.txt
+  ;;
 *) echo "unknown session $S";;
 esac
