@@ -103,5 +103,14 @@ s16)  # is the along-fibre kernel bound by the rate at which waves are launched?
 s17)  # what does the column sweep cost with its phases switched off (option ablate: 1 walk + rebuild, 2 stream-out, 4 window loads)?  7 = the launch alone
   ab --reps 9 --rounds 1 --cases prox0,prox1 base a7,ablate=7 a5,ablate=5 a6,ablate=6 a3,ablate=3 a1,ablate=1 a2,ablate=2 a4,ablate=4 2> /dev/null > $OUT/ab_ablate.txt; cat $OUT/ab_ablate.txt
   ;;
+final)  # the round's final build: the whole suite, smoke, certified soaks (2-D, volumes, long fibres), the pinned-rung subsets by environment
+  timeout 1200 python -m pytest tests -m gpu -x -q --durations=10 > $OUT/pytest_default.log 2>&1; echo "default: $(tail -1 $OUT/pytest_default.log)" | tee $OUT/summary.txt
+  python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; tail -1 $OUT/smoke.log | tee -a $OUT/summary.txt
+  FILES="tests/test_gpu_chunk_repair.py tests/test_gpu_parity_2d.py tests/test_gpu_parity_nd.py tests/test_gpu_boundary.py"
+  for m in 0 1 3; do PROXTV_CHUNK_MODE=$m timeout 900 python -m pytest $FILES -m gpu -x -q > $OUT/pytest_mode$m.log 2>&1; echo "pinned rung $m: $(tail -1 $OUT/pytest_mode$m.log)" | tee -a $OUT/summary.txt; done
+  PROXTV_REPAIR_JOBS=2 timeout 900 python -m pytest $FILES -m gpu -x -q > $OUT/pytest_jobs2.log 2>&1; echo "repair_jobs=2: $(tail -1 $OUT/pytest_jobs2.log)" | tee -a $OUT/summary.txt
+  PROXTV_RUNS=0 PROXTV_OPTIMISTIC=0 timeout 900 python -m pytest $FILES tests/test_gpu_large.py -m gpu -x -q > $OUT/pytest_plain.log 2>&1; echo "runs=0 optimistic=0: $(tail -1 $OUT/pytest_plain.log)" | tee -a $OUT/summary.txt
+  { python tools/fuzz.py 300 641; python tools/fuzz.py 300 642; python tools/fuzz.py 60 643 nd; python tools/fuzz.py 200 644 long; } > $OUT/fuzz.txt 2>&1; grep "^fuzz\|MISMATCH\|Error" $OUT/fuzz.txt | tee -a $OUT/summary.txt
+  ;;
 *) echo "unknown session $S";;
 esac
