@@ -212,3 +212,26 @@ def test_bench_two_ranks_full_shard_and_no_gather():
     c5n = run(["--c5-images", "8", "--no-gather"])
     assert c5n["ranks"] == 2 and c5n["images"] == 16 and c5n["gather_ms"] is None and c5n["gather_bytes"] is None
     assert "skipped" in c5n["gather"] and c5n["solve_ms"] > 0
+
+
+def test_full_size_solves_under_the_certifier(ptv, clib, glarge):
+    """Configs #2 and #3 and a full-size PD2 with option certify on: every one of their sweeps -- 72 per DR solve, the late iterates with
+    their near-ties included -- is checked against the optimality conditions of the prox, fibre by fibre (4096 fibres of 4096 samples a
+    sweep).  No fibre fails, and the results are the reference's."""
+    rng = np.random.default_rng(0)
+    X = np.asfortranarray(rng.standard_normal((4096, 4096)))
+    W1 = np.asfortranarray(rng.uniform(0.05, 0.15, (4095, 4096)))
+    W2 = np.asfortranarray(rng.uniform(0.05, 0.15, (4096, 4095)))
+    c = {k: clib.proxtv_debug_counter(k) for k in (b"certify_sweeps", b"certify_failures", b"certify_skipped")}
+    before = clib.proxtv_set_option(b"certify", 1)
+    try:
+        _check_digest(ptv.tv1_2d(X, 0.1), glarge, "c2/dr2")
+        _check_digest(ptv.tv1w_2d(X, W1, W2), glarge, "c3/dr2w")
+        y = ptv.tv1_2d(X, 0.1, method="pd")
+        _check_digest(ptv.tv1_2d(X, 1.0), glarge, "lam1/dr2")          # (the pinning rung)
+    finally:
+        clib.proxtv_set_option(b"certify", before)
+    assert abs(y.mean() - X.mean()) < 1e-9
+    assert clib.proxtv_debug_counter(b"certify_failures") == c[b"certify_failures"]
+    assert clib.proxtv_debug_counter(b"certify_sweeps") - c[b"certify_sweeps"] >= 3 * 71
+    assert clib.proxtv_debug_counter(b"certify_skipped") == c[b"certify_skipped"]
