@@ -61,7 +61,7 @@ struct Options {
                               // their sweeps: a sweep that leaves anything marks a sticky word, and a solve whose word is set is run again
                               // with the repairs (sweep.hpp: OptimisticScope); 0: a repair launch behind every chunked sweep
     int certify = 0;          // 1: every fibre sweep is followed by a check of the prox's optimality conditions on what it wrote, fibre by fibre;
-                              // a fibre that fails is re-solved by the sequential walk and counted (sweep_kernels.hpp: certify_*_kernel)
+                              // a fibre that fails is re-solved by the sequential walk and counted (kernel_certify.hpp)
     int verbose = 0;
     int profile = 0;    // per-kernel-family hipEvent timing
     int why = 0;        // tuning aid: count what marks sweeps dirty (proxtv_debug_why)

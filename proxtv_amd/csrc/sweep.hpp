@@ -19,7 +19,7 @@ void launch_sweep(OpId op, bool weighted, const SweepArgs &args, const FibreGeom
                   bool allow_chunked);
 
 // The certificate alone (option certify runs it behind every sweep): the number of fibres for which what a sweep of `op` wrote is NOT
-// the prox of what it read -- the optimality conditions of the 1-D problem, checked per fibre (sweep_kernels.hpp, kernel 4) -- or -1 when
+// the prox of what it read -- the optimality conditions of the 1-D problem, checked per fibre (kernel_certify.hpp) -- or -1 when
 // the sweep cannot be checked (lambda <= 0, an output aliasing an operand).  Synchronises `stream`.
 long certify_sweep(OpId op, bool weighted, const SweepArgs &args, const FibreGeom &g, hipStream_t stream);
 

@@ -1,6 +1,6 @@
 // walk_asm.hpp -- the interior walk of a chunk (chunkcore.hpp: walk_interior) written out in gfx950 assembly: four loops,
 // unweighted / weighted (per-edge penalties from a second LDS plane), each dividing by v_rcp_f64 + Newton or by table
-// (walk_interior_asm, _tab, _w, _w_tab; sweep_kernels.hpp: walk_chunk picks).  Same state machine, same arithmetic and operation
+// (walk_interior_asm, _tab, _w, _w_tab; sweep_window.hpp: walk_chunk picks).  Same state machine, same arithmetic and operation
 // order as the C++ form, which stays the specification: the host harness runs it, tests/test_walk_asm_emulated.py interprets these
 // loops against it, and -DPTV_NO_ASM_WALK substitutes it on the device.  What the hand version buys is the schedule --
 //   * the three LDS reads of a trip (next sample; the two samples a rewinding bend restarts from) are issued before the
