@@ -449,9 +449,9 @@ __device__ __forceinline__ void rebuild_owned(Win &win, const ChunkRec &rec, int
 // state right after a bend depends on the bend alone: the stretch between two such edges -- a RUN -- is a problem of its own, with the
 // string's height given at both ends.  On the headline's data 78 % of the edges qualify, and the runs are short:
 //   * one sample (61 % of all samples): a piece of its own, nothing to decide;
-//   * two samples (27 %): the one edge inside bends or does not, and a compare says which -- with d the edge's jump and s0, s2 the
-//     bend types at the run's ends: both CEIL: it bends (CEIL) iff d < 0 ; both FLOOR: (FLOOR) iff d > 0 ; otherwise iff |d| > 2 lambda,
-//     with the jump's sign.  (The walk from the first bend makes exactly these decisions in its two trips: a CEIL start has
+//   * two samples (27 %): the one edge inside bends or does not, and a compare says which -- with d the edge's jump (|d| <= 4 lambda: it
+//     is not a bend known a priori) and s0, s2 the bend types at the run's ends: both CEIL: it bends (CEIL) iff d < 0 ; both FLOOR:
+//     (FLOOR) iff d > 0 ; otherwise iff |d| > 2 lambda, with the jump's sign.  (The walk from the first bend makes exactly these decisions in its two trips: a CEIL start has
 //     h1 = -lambda - d, h2 = 3 lambda - d at the second sample -- it bends there iff d < -2 lambda, and touches the floor, klo = the
 //     second sample, iff d >= 0, which is where the closing bend then breaks; symmetrically for a FLOOR start.  Ties on the last bit
 //     may fall differently: a knot with a jump of zero up to rounding, both cuts of which are the prox to rounding.)
@@ -474,7 +474,12 @@ __device__ __forceinline__ EdgeMasks own_edges(const Win &win, int cs, double la
 #pragma unroll
     for (int u = 0; u <= C; u++) yv[u] = win.y(cs - 1 + u);
     EdgeMasks m;
-    const double t4 = 4.0000001 * lam, t2 = 2 * lam;
+    // (4 lambda EXACTLY, not certain_bend_before's 4.0000001: the rule for two-sample runs below rests on "an edge that is not known
+    //  a priori jumps by 4 lambda at most" -- with a margin on the threshold an inner edge of -4.00000006 lambda between two FLOOR bends,
+    //  which bends CEIL, was left unbent: 3e-9 off in two rows of one fibre of a 4096^2 PD2 solve, found by the certifier
+    //  (tests/golden/sliver_edge_fibre.npz).  |d| > 4 lambda is a bend in exact arithmetic; within rounding of 4 lambda its jump is zero
+    //  within rounding, and either cut is the prox to rounding.)
+    const double t4 = 4 * lam, t2 = 2 * lam;
 #pragma unroll
     for (int u = C - 1; u >= 0; u--) {
         const double d = yv[u + 1] - yv[u];
@@ -499,7 +504,7 @@ __device__ __forceinline__ EdgeMasks own_edges(const Win &win, int cs, double la
 // one edge on its own (the few around a segment that no chunk owns)
 __device__ __forceinline__ void one_edge(double ya, double yb, double lam, unsigned &k, unsigned &pp, unsigned &nn, unsigned &bb) {
     const double d = yb - ya, a = fabs(d);
-    k = (unsigned)(a > 4.0000001 * lam);
+    k = (unsigned)(a > 4 * lam);
     bb = (unsigned)(a > 2 * lam);
     pp = (unsigned)(d > 0);
     nn = (unsigned)(d < 0);

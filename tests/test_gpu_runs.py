@@ -110,3 +110,32 @@ def test_whole_solves_and_the_certifier(ptv, clib, oracle, why):
     finally:
         clib.proxtv_set_option(b"certify", 0)
     assert clib.proxtv_debug_counter(b"certify_failures") == c0
+
+
+def test_edges_within_a_hair_of_four_lambda(ptv, clib, oracle, why):
+    """tests/golden/sliver_edge_fibre.npz (found by the certifier in a full-size PD2 solve, round 6): an inner edge of -4.00000006 lambda
+    between two FLOOR bends.  As columns among noise, and planted in numbers; the certifier agrees."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sliver_edge_fibre.npz"))
+    y, lam, want = g["y"], float(g["lam"]), g["expected"]
+    rng = np.random.default_rng(95)
+    cols = np.asfortranarray(rng.standard_normal((y.size, 64)))
+    cols[:, ::4] = y[:, None]
+    want_cols = np.apply_along_axis(lambda f: oracle.tv1_hybrid(np.ascontiguousarray(f), lam), 0, cols)
+    assert np.max(np.abs(want_cols[:, 0] - want)) <= 1e-14
+    c0 = clib.proxtv_debug_counter(b"certify_failures")
+    clib.proxtv_set_option(b"certify", 1)
+    try:
+        why()
+        assert_close(_columns(ptv, cols, lam), want_cols, tol=1e-13, what="the captured fibre as columns")
+        assert why()[5] > 100
+        Y = rng.standard_normal((3400, 64)) * 2.0
+        for k in range(40, 3300, 23):
+            Y[k] = Y[k - 1] + rng.choice([-1.0, 1.0], 64) * (5.0 + rng.random(64)) * lam
+            Y[k + 1] = Y[k] + rng.choice([-1.0, 1.0], 64) * 4.0 * lam * (1.0 + rng.choice([0.0, 6e-9, -6e-9, 5e-8, -5e-8, 2e-7], 64))
+            Y[k + 2] = Y[k + 1] + rng.choice([-1.0, 1.0], 64) * (5.0 + rng.random(64)) * lam
+        wantY = np.apply_along_axis(lambda f: oracle.tv1_hybrid(np.ascontiguousarray(f), lam), 0, Y)
+        assert_close(_columns(ptv, Y, lam), wantY, tol=1e-13, what="planted edges")
+    finally:
+        clib.proxtv_set_option(b"certify", 0)
+    assert clib.proxtv_debug_counter(b"certify_failures") == c0

@@ -111,3 +111,29 @@ def test_runs_that_cross_segment_boundaries(harness, oracle):
             assert np.max(np.abs(x - truth)) <= 1e-13 * np.max(np.abs(y)), (width, t, st)
             if want_solved: assert st[0] >= 2, (width, st)
             else:           assert st[1] >= 2, (width, st)
+
+
+def test_edges_within_a_hair_of_four_lambda(harness, oracle):
+    """Round 6, found by the certifier in a full-size PD2 solve (tests/golden/sliver_edge_fibre.npz): the inner edge of a two-sample run
+    that jumps by -4.00000006 lambda between two FLOOR bends must bend CEIL.  With certain_bend_before's threshold of 4.0000001 lambda
+    in the edge masks it was neither a bend known a priori nor covered by the rule for two-sample runs ("an edge not known a priori
+    jumps by 4 lambda at most"): 3e-9 off in two rows.  The masks cut at 4 lambda exactly.  The captured fibre, and planted ones: inner
+    edges at 4 lambda (1 +- a few 1e-8, and exactly) in every combination of bend types around them."""
+    g = np.load(os.path.join(HERE, "golden", "sliver_edge_fibre.npz"))
+    y, lam = np.ascontiguousarray(g["y"]), float(g["lam"])
+    x, st = runs(harness, y, lam)
+    assert st[0] >= 3
+    assert np.max(np.abs(x - g["expected"])) <= 1e-13
+    rng = np.random.default_rng(5)
+    for t in range(60):
+        lam = float(rng.choice([0.1, 0.25, 0.07]))
+        y = rng.standard_normal(3400) * 2.0
+        for k in range(40, 3300, 23):
+            s_in, s_out = rng.choice([-1.0, 1.0], 2)
+            eps = float(rng.choice([0.0, 6e-9, -6e-9, 5e-8, -5e-8, 2e-7]))
+            y[k] = y[k - 1] + s_in * (5.0 + rng.random()) * lam          # a bend known a priori into the run
+            y[k + 1] = y[k] + float(rng.choice([-1.0, 1.0])) * 4.0 * lam * (1.0 + eps)   # the inner edge, a hair from 4 lambda
+            y[k + 2] = y[k + 1] + s_out * (5.0 + rng.random()) * lam     # ... and one out of it
+        x, st = runs(harness, y, lam)
+        truth = oracle.tv1_linearized(y, lam)
+        assert np.max(np.abs(x - truth)) <= 1e-13 * np.max(np.abs(y)), (t, lam, st)

@@ -112,5 +112,16 @@ final)  # the round's final build: the whole suite, smoke, certified soaks (2-D,
   PROXTV_RUNS=0 PROXTV_OPTIMISTIC=0 timeout 900 python -m pytest $FILES tests/test_gpu_large.py -m gpu -x -q > $OUT/pytest_plain.log 2>&1; echo "runs=0 optimistic=0: $(tail -1 $OUT/pytest_plain.log)" | tee -a $OUT/summary.txt
   { python tools/fuzz.py 300 641; python tools/fuzz.py 300 642; python tools/fuzz.py 60 643 nd; python tools/fuzz.py 200 644 long; } > $OUT/fuzz.txt 2>&1; grep "^fuzz\|MISMATCH\|Error" $OUT/fuzz.txt | tee -a $OUT/summary.txt
   ;;
+final2)  # after the split of sweep_kernels.hpp (same code, new build id): the whole suite, smoke, a longer certified soak
+  timeout 1200 python -m pytest tests -m gpu -x -q --durations=10 > $OUT/pytest_default.log 2>&1; echo "default: $(tail -1 $OUT/pytest_default.log)" | tee $OUT/summary.txt
+  python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; tail -1 $OUT/smoke.log | tee -a $OUT/summary.txt
+  { for sd in 651 652 653; do python tools/fuzz.py 240 $sd; done; python tools/fuzz.py 120 654 nd; python tools/fuzz.py 300 655 long; } > $OUT/fuzz.txt 2>&1; grep "^fuzz\|MISMATCH\|Error" $OUT/fuzz.txt | tee -a $OUT/summary.txt
+  ;;
+final3)  # the edge masks cut at 4 lambda exactly: the runs tests, the certified full-size solves, the whole suite, certified campaigns at full size, soak
+  timeout 600 python -m pytest tests/test_gpu_runs.py tests/test_gpu_large.py -m gpu -x -q > $OUT/pytest_new.log 2>&1; echo "runs + large: $(tail -1 $OUT/pytest_new.log)" | tee $OUT/summary.txt
+  timeout 1200 python -m pytest tests -m gpu -x -q > $OUT/pytest_default.log 2>&1; echo "default: $(tail -1 $OUT/pytest_default.log)" | tee -a $OUT/summary.txt
+  for sd in 1 2 3; do python tools/certified_campaign.py 150 $sd > $OUT/campaign_$sd.txt 2>&1; tail -1 $OUT/campaign_$sd.txt | tee -a $OUT/summary.txt; grep "certify:" $OUT/campaign_$sd.txt | cut -c1-260 | head -10 | tee -a $OUT/summary.txt; done
+  { python tools/fuzz.py 200 661; python tools/fuzz.py 200 662 long; } > $OUT/fuzz.txt 2>&1; grep "^fuzz\|MISMATCH\|Error" $OUT/fuzz.txt | tee -a $OUT/summary.txt
+  ;;
 *) echo "unknown session $S";;
 esac
