@@ -30,10 +30,23 @@ while time.time() < t_end:
     else:           X = np.cumsum(rng.standard_normal(shape), axis=int(rng.integers(0, 2))) * 0.1 + rng.standard_normal(shape)
     scale = float(np.std(np.diff(X, axis=0)))
     lam = float(scale * 10 ** rng.uniform(-1.6, -0.2))      # from "every edge is a bend" to pieces of a few samples
-    method = ["dr", "pd", "yang", "dr"][int(rng.integers(0, 4))]
-    xd = device.to_colmajor(torch.from_numpy(X).cuda())
+    method = ["dr", "pd", "yang", "dr", "drw", "vol"][int(rng.integers(0, 6))]
     c0 = lib.proxtv_debug_counter(b"certify_failures"); s0 = lib.proxtv_debug_counter(b"certify_sweeps")
-    device.tv1_2d(xd, lam, method=method)
+    if method == "vol":      # a volume through PD_TV (three terms) or Yang3: prox sweeps along every dimension, short and long fibres
+        shape = [(512, 512, 64), (1200, 300, 40), (96, 2300, 60)][int(rng.integers(0, 3))]
+        V = rng.standard_normal(shape) * (1.0 if kind != 2 else 1.0)
+        if kind == 2: V = np.round(V * 4) * 0.25
+        vd = device.to_colmajor(torch.from_numpy(V).cuda())
+        lams = [float(lam * f) for f in rng.uniform(0.5, 1.5, 3)]
+        device.tvgen(vd, lams, [1, 2, 3], method="yang" if rng.random() < 0.4 else None)
+    else:
+        xd = device.to_colmajor(torch.from_numpy(X).cuda())
+        if method == "drw":
+            w1 = device.to_colmajor(torch.from_numpy(rng.uniform(0.5 * lam, 1.5 * lam, (shape[0] - 1, shape[1]))).cuda())
+            w2 = device.to_colmajor(torch.from_numpy(rng.uniform(0.5 * lam, 1.5 * lam, (shape[0], shape[1] - 1))).cuda())
+            device.tv1w_2d(xd, w1, w2)
+        else:
+            device.tv1_2d(xd, lam, method=method)
     f = lib.proxtv_debug_counter(b"certify_failures") - c0
     bad += f
     n += 1
