@@ -170,7 +170,8 @@ void proxtv_release_scratch(void);
                       from the same sampled statistics as the rung) ; 2: on the plain tile too ; 0: never (the reference's split).
                       Same iterates either way, to a few ulps
      "pin"            1 (default): rung 3 is the pinning solver ; 0: the global-memory chunk kernel
-     "pin_seed"       1 (default): the pinning solver (rung 3) starts from the knots known a priori, 0: from the fibre ends alone
+     "pin_seed"       the pinning solver (rung 3) starts from the knots known a priori: 2 (default) jumps above 4 lambda and the
+                      deepest knots of windows of 4 / 16 / 64 knots, 1: the jumps alone, 0: from the fibre ends alone
      "repair_jobs"    failed links across the workgroups of a chunked sweep are first repaired one lane per failure, four to a
                       fibre; what that leaves goes to the sequential repair: 1 (default) where the sampled statistic of the sweep's
                       input says such links fail in numbers (an unsampled input counts as such), 2 always ; 0: the sequential repair

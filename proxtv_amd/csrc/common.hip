@@ -80,7 +80,7 @@ namespace {
 std::atomic<long> g_counters[CNT_COUNT];
 constexpr const char *kCounterNames[CNT_COUNT] = {"sweep_launches", "repair_launches", "repair_jobs_launches", "pin_sweeps",
                                                   "pin_cap_next_rung", "tv2_long_fibres", "optimistic_solves", "optimistic_redone", "certify_sweeps", "certify_failures",
-                                                  "certify_skipped"};
+                                                  "certify_skipped", "reprobes"};
 }  // namespace
 void count_event(Counter c, long n) { g_counters[c].fetch_add(n, std::memory_order_relaxed); }
 long counter_value(const char *name) {

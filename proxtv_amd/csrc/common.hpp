@@ -46,7 +46,7 @@ struct Options {
     int repair_jobs = 1;      // chunked sweeps: failed links across workgroups are repaired one lane per failure first (sweep_repair_jobs_kernel), what that
                               // leaves by the sequential repair kernel: 1 = where the sampled certain fraction says such links fail in numbers
                               // (policy.hpp: kSeedJobs), 2 = always, 0 = the sequential repair alone
-    int pin_seed = 1;         // the pinning solver starts from the knots known a priori (|dy| > 4 lambda) instead of the fibre ends alone
+    int pin_seed = 2;         // the pinning solver starts from the knots known a priori instead of the fibre ends alone: 1 = jumps above 4 lambda, 2 = windows as well
     int whole = 1;            // fibres of 16 .. chunk_min_len samples: 1 = by length and data (sequential up to 32 samples; one block of the
                               // chunk kernel on noisy data, else whole fibres in LDS), 2 = the whole-fibre-in-LDS kernel, 0 = the sequential kernel
     int chunk_min_len = 96;   // fibres shorter than this take the sequential kernel (measured crossover: 512x512xL volumes, L ~ 96)
@@ -86,6 +86,7 @@ enum Counter {
     CNT_CERTIFY_SWEEPS,        // option certify: sweeps whose output was checked against the optimality conditions of the prox
     CNT_CERTIFY_FAILURES,      // ... fibres that failed the check and were re-solved by the sequential walk
     CNT_CERTIFY_SKIPPED,       // ... sweeps that could not be checked (an output aliases an operand; lambda <= 0)
+    CNT_REPROBES,              // mid-solve samples of sweep operands (policy_reprobe: Dykstra / ADMM loops)
     CNT_COUNT
 };
 void count_event(Counter c, long n = 1);

@@ -120,12 +120,63 @@ __global__ __launch_bounds__(kPinThreads) void sweep_pin_kernel(SweepArgs p, Fib
             own[k] = acc;
         }
     }
+    group_sync<G>();   // the sums are in place; `red` is free again
+    PinLane<P> ln;
+    Sh sh{Sp, Wp, own, Wp + Geo::lane_base(t), {}, p.lam, mx, arg};
+    if (Sh::kCached) {
+#pragma unroll
+        for (int k = 0; k < (Sh::kCached ? P : 1); k++) sh.cached[k] = own[k];
+    }
+    ln.init(n, t, sh);
+    // knots known by windows (pincore.hpp: sixteen knots a lane, one penalty), coarse to fine, a stage only where the one before found
+    // a knot somewhere in the wave; windows that span lanes are joined by lane shuffles -- the few that also span waves are left to
+    // the levels
+    if constexpr (P == 16 && !WEIGHTED) {
+        if (seeded >= 2 && p.lam > 0.0) {
+            using Lane = PinLane<P>;
+            using Win = typename Lane::Win;
+            using Mask = typename Lane::Mask;
+            const int l = t & 63;
+            auto Sk = [&](int j) { return Sp[Geo::sa(j < 0 ? 0 : (j > n ? n : j))]; };
+            auto shfl_win = [](Win w, int src) { return Win{__shfl(w.mx, src), __shfl(w.mn, src)}; };
+            Mask up = 0, lo = 0;
+            {
+                const int qa = t & 3, qb = (t + 2) & 3;
+                const Win pa = ln.win64_part(sh, Sk((t - qa) * P), Sk((t - qa) * P + 64), qa);
+                const Win pb = ln.win64_part(sh, Sk((t - qb) * P), Sk((t - qb) * P + 64), qb);
+                Win all_a = Lane::wjoin(pa, shfl_win(pa, l ^ 1));
+                all_a = Lane::wjoin(all_a, shfl_win(all_a, l ^ 2));
+                Win all_b = Lane::wjoin(pb, shfl_win(pb, l ^ 1));
+                const int partner = qb < 2 ? l + 2 : l - 2;
+                all_b = Lane::wjoin(all_b, shfl_win(all_b, partner & 63));
+                ln.win64_take(p.lam, all_a, true, qa, 4, up, lo);
+                ln.win64_take(p.lam, all_b, partner >= 0 && partner < 64, qb, 2, up, lo);
+            }
+            if (__ballot((up | lo) != 0) != 0ull) {
+                const double Sl = Sk(t * P);
+                Mask up16 = 0, lo16 = 0;
+                Win tail, head;
+                ln.win16_parts(sh, p.lam, Sl, Sk(t * P + 24), Sk(t * P - 8), up16, lo16, tail, head);
+                ln.win16_take(p.lam, tail, shfl_win(head, (l + 1) & 63), l < 63, shfl_win(tail, (l + 63) & 63), head, l > 0, up16, lo16);
+                up |= up16;
+                lo |= lo16;
+                if (__ballot((up16 | lo16) != 0) != 0ull) {
+                    int give;
+                    ln.win4_all(sh, p.lam, Sl, Sk(t * P + P + 1), Sk(t * P + P + 2), up, lo, give);
+                    ln.win4_take(__shfl(give, (l + 63) & 63), l > 0, up, lo);
+                }
+            }
+            if (t * P < n) {
+                seedU |= up;
+                seedL |= lo & ~seedU;
+            }
+        }
+    }
     // the nearest seeded knot on either side of the lane's range, and the string's height there (read before any lane settles:
     // settle() turns the sum of a pinned knot into that height in place)
     int s_la = 0, s_rb = n;
     double s_hl = 0.0, s_hr = 0.0;
     if (seeded) {
-        group_sync<G>();   // the sums are in place; `red` is free again
         using Mask = typename PinLane<P>::Mask;
         const Mask both = seedU | seedL;
         const int j0 = 1 + t * P;
@@ -157,13 +208,6 @@ __global__ __launch_bounds__(kPinThreads) void sweep_pin_kernel(SweepArgs p, Fib
     group_sync<G>();
 
     // ---- levels ----------------------------------------------------------------------------------------------------------------------
-    PinLane<P> ln;
-    Sh sh{Sp, Wp, own, Wp + Geo::lane_base(t), {}, p.lam, mx, arg};
-    if (Sh::kCached) {
-#pragma unroll
-        for (int k = 0; k < (Sh::kCached ? P : 1); k++) sh.cached[k] = own[k];
-    }
-    ln.init(n, t, sh);
     if (seeded && t * P < n) ln.seed(seedU, seedL, s_la, s_hl, s_rb, s_hr);
     bool capped = false;
 #pragma unroll 1
@@ -226,7 +270,7 @@ struct GaveUp {
     }
 };
 static thread_local GaveUp g_gaveup[kMaxDevices];
-static thread_local int g_seeded = 1;   // this sweep starts from the knots known a priori (launch_pin's argument, for the launchers below)
+static thread_local int g_seeded = 2;   // this sweep starts from the knots known a priori: 1 = jumps above 4 lambda, 2 = windows as well (launch_pin's argument, for the launchers below)
 
 template <int OP, bool WEIGHTED, int P, int G>
 void launch_geom(const SweepArgs &args, const FibreGeom &g, hipStream_t stream, int *pieces) {
@@ -274,8 +318,8 @@ void launch_op(const SweepArgs &args, const FibreGeom &g, hipStream_t stream, in
 
 }  // namespace
 
-bool launch_pin(OpId op, bool weighted, const SweepArgs &args, const FibreGeom &g, hipStream_t stream, int *pieces, bool seeds) {
-    g_seeded = seeds ? 1 : 0;
+bool launch_pin(OpId op, bool weighted, const SweepArgs &args, const FibreGeom &g, hipStream_t stream, int *pieces, int seeds) {
+    g_seeded = seeds;
     if (!pin_supports(op, weighted, g, args.lam)) {
         set_error("launch_pin: sweep not supported (len %d, inc %ld, weighted %d)", g.len, g.inc, (int)weighted);
         throw HipFailure{hipErrorInvalidValue};

@@ -56,6 +56,11 @@ PTV_PIN_FN double pin_max(double a, double b) {   // one v_max_f64: the builtin 
     asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
+PTV_PIN_FN double pin_min(double a, double b) {
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 // a / b for a positive integer-valued b: reciprocal + one Newton step, then one residual correction of the quotient (within one
 // ulp of the IEEE quotient at a third of the instructions of the full division sequence; the values of this solver carry the
 // rounding of their running sums anyway -- see "Numerics" above)
@@ -71,6 +76,7 @@ inline double pin_div(double a, double b) { return a / b; }
 inline unsigned long long pin_bits(double v) { unsigned long long b; std::memcpy(&b, &v, 8); return b; }
 inline double pin_double(unsigned long long b) { double v; std::memcpy(&v, &b, 8); return v; }
 inline double pin_max(double a, double b) { return a > b ? a : b; }
+inline double pin_min(double a, double b) { return a < b ? a : b; }
 #endif
 
 // A violation carries the lane-local index of its knot in the lowest bits of its mantissa (log2 P bits: a relative
@@ -166,6 +172,135 @@ struct PinLane {
     template <class Sh>
     PTV_PIN_FN double height(const Sh &sh, int j, bool lower) const {
         return lower ? sh.S(j) - sh.r(j) : sh.S(j) + sh.r(j);
+    }
+
+    // ---- knots known before the first level, by windows (round 6) ------------------------------------------------------------
+    // The 4 lambda rule above is the smallest case of a rule about ANY window of knots a < b, pinned or not:
+    //     let l be the line through the upper wall at a and b, and k the interior knot where the wall lies deepest below it;
+    //     if that depth exceeds the tube's width at both ends, V = l_k - (S_k + r_k) > max(2 r_a, 2 r_b), the string touches the
+    //     upper wall at k (and symmetrically the lower wall where it rises highest above its own line).
+    // Proof.  Let P be the string and g = l - P on [a, b].  At the ends P is inside the tube, so g(a) <= l_a - (S_a - r_a) = 2 r_a
+    // < V, likewise g(b) < V.  If P passed strictly below the wall at k, g(k) > V: the maximum of g over [a, b] is then larger
+    // than V and attained at an interior knot k*, where P is convex (its slope grows) -- and a taut string grows its slope only
+    // where it touches the upper wall, so g(k*) = l_k* - (S_k* + r_k*) <= V by the choice of k.  Contradiction.  (Nothing is
+    // assumed about the string at a and b: the window needs no pins.  Adjacent knots a = k - 1, b = k + 1 with one penalty:
+    // V = |y_k - y_{k-1}| / 2 > 2 lambda is the 4 lambda rule.)
+    // With one penalty for all interior knots both walls are copies of the sums, so ONE number per knot serves both walls:
+    // W (chord_S(j) - S_j) = (S_a - S_j) W + (S_b - S_a)(j - a), above 2 lambda W: upper contact; below -2 lambda W: lower.
+    // Windows used (unit noise at lambda = 1: pieces of 4-10 samples; tools measured on DR iterates: 10-12 levels become 4-6):
+    // 4, 16 and 64 knots, each on its own grid and on the grid shifted by half a window.  P = 16, unweighted; windows that
+    // touch the fibre ends (r = 0 there: the walls are not copies of the sums) are left out.
+    // A lane evaluates its own knots; windows that span lanes are joined by the caller.  Values carry the knot's distance from
+    // the window start in the low six bits of their mantissa (as PinTag does), so that "deepest and where" is one max and one
+    // min per knot.
+    struct Win {
+        double mx, mn;
+    };
+    PTV_PIN_FN static double wtag(double v, int d) { return pin_double((pin_bits(v) & ~63ull) | (unsigned long long)d); }
+    PTV_PIN_FN static int wdist(double v) { return (int)(pin_bits(v) & 63ull); }
+    PTV_PIN_FN static double wmin(double a, double b) { return pin_min(a, b); }
+    PTV_PIN_FN static Win wjoin(Win a, Win b) { return Win{pin_max(a.mx, b.mx), wmin(a.mn, b.mn)}; }
+    // window of W knots starting at own index e = A (own knot e, 1 <= e <= P, is knot t P + e; e = 0 and e > P are the
+    // neighbours'): the part over own knots e = E0 .. E1.  Sa, Sb: the sums at the window's ends.
+    template <int W, int A, int E0, int E1, class Sh>
+    PTV_PIN_FN Win win_part(const Sh &sh, double Sa, double Sb) const {
+        const double dl = Sb - Sa;
+        double lin = dl * (double)(E0 - A);
+        Win w{0.0, 0.0};
+#pragma unroll
+        for (int e = E0; e <= E1; e++) {
+            const double v = wtag((Sa - sh.own(t, e - 1)) * (double)W + lin, e - A);
+            w.mx = pin_max(w.mx, v);
+            w.mn = wmin(w.mn, v);
+            lin += dl;
+        }
+        return w;
+    }
+    // the deepest knots of a finished window, if deep enough and this lane's own (own index e = A + distance in 1 .. P)
+    template <int W, int A>
+    PTV_PIN_FN void win_take(Win w, bool valid, double thr, Mask &up, Mask &lo) const {
+        const int eu = A + wdist(w.mx), el = A + wdist(w.mn);
+        if (valid && w.mx > thr * (double)W && eu >= 1 && eu <= P) up |= (Mask)1 << (eu - 1);
+        if (valid && -w.mn > thr * (double)W && el >= 1 && el <= P) lo |= (Mask)1 << (el - 1);
+    }
+    // Three stages, coarse to fine: 64-knot windows, then 16, then 4.  A stage runs only where the stage before it found a knot
+    // somewhere in the lane's wave (the caller's ballot): features deep enough for a small window show in the large ones around
+    // them, and data whose pieces are far longer than any window (lambda many times the noise) pay for one stage, not three.
+    // Each stage: the lane's parts -> the caller joins them with the neighbours' (lane shuffles on the device, arrays in the
+    // host harness; what would cross a wave is left to the levels) -> the lane takes what is its own.
+    PTV_PIN_FN static double seed_threshold(double lam) { return 2.0000002 * lam; }
+    // -- 64 knots: four lanes a window on the plain grid (lanes 4 m ..) and on the shifted grid (lanes 4 m + 2 ..); lane q of the
+    // four holds the distances 16 q + 1 .. 16 q + 16 from the window's start (the last one is the window's end: left out).
+    // Sa, Sb: the sums at the window's ends.
+    template <class Sh>
+    PTV_PIN_FN Win win64_part(const Sh &sh, double Sa, double Sb, int q) const {
+        static_assert(P == 16, "window seeds: sixteen knots per lane");
+        const double dl = Sb - Sa;
+        double lin = dl * (double)(16 * q + 1);
+        Win w{0.0, 0.0};
+#pragma unroll
+        for (int e = 1; e <= P; e++) {
+            double v = wtag((Sa - sh.own(t, e - 1)) * 64.0 + lin, (16 * q + e) & 63);
+            if (e == P) v = (q == 3) ? 0.0 : v;   // (distance 64: the window's own end)
+            w.mx = pin_max(w.mx, v);
+            w.mn = wmin(w.mn, v);
+            lin += dl;
+        }
+        return w;
+    }
+    // all: the joined parts of the window's four lanes; q: the lane's place among them; first: the first lane index such a window
+    // may start at (4 on the plain grid, 2 on the shifted one: the windows before touch the fibre's first knot)
+    PTV_PIN_FN void win64_take(double lam, Win all, bool in_reach, int q, int first, Mask &up, Mask &lo) const {
+        const double thr = seed_threshold(lam) * 64.0;
+        const int a = -16 * q;   // own index of the window's start
+        const bool valid = in_reach && t - q >= first && a + 64 <= n - 1 - t * P;
+        const int eu = a + wdist(all.mx), el = a + wdist(all.mn);
+        if (valid && all.mx > thr && eu >= 1 && eu <= P) up |= (Mask)1 << (eu - 1);
+        if (valid && -all.mn > thr && el >= 1 && el <= P) lo |= (Mask)1 << (el - 1);
+    }
+    // -- 16 knots: the lane's own window 0-16 (Sl = S(t P), the knot before the lane's first); of the shifted grid the first half
+    // of 8-24 (Sfar = S(t P + 24)) and the second half of (-8)-8 (Sback = S(t P - 8))
+#define PTV_S_AT(e) ((e) == 0 ? Sl : sh.own(t, ((e) > 0 ? (e) : 1) - 1))   // (a macro: the index stays a compile-time constant)
+    template <class Sh>
+    PTV_PIN_FN void win16_parts(const Sh &sh, double lam, double Sl, double Sfar, double Sback, Mask &up, Mask &lo, Win &tail, Win &head) const {
+        const Win w = win_part<16, 0, 1, 15>(sh, Sl, PTV_S_AT(16));
+        win_take<16, 0>(w, t > 0 && 16 <= n - 1 - t * P, seed_threshold(lam), up, lo);   // (the knot before lane 0's first is the fibre end)
+        tail = win_part<16, 8, 9, 16>(sh, PTV_S_AT(8), Sfar);
+        head = win_part<16, -8, 1, 7>(sh, Sback, PTV_S_AT(8));
+    }
+    PTV_PIN_FN void win16_take(double lam, Win tail, Win next_head, bool has_next, Win prev_tail, Win head, bool has_prev, Mask &up, Mask &lo) const {
+        const int room = n - 1 - t * P;
+        win_take<16, 8>(wjoin(tail, next_head), has_next && 24 <= room, seed_threshold(lam), up, lo);
+        win_take<16, -8>(wjoin(prev_tail, head), has_prev && t * P >= 9 && 8 <= room, seed_threshold(lam), up, lo);
+    }
+    // -- 4 knots: plain grid 0-4, 4-8, 8-12, 12-16; shifted 2-6, 6-10, 10-14, and 14-18, which the lane evaluates alone with the next
+    // lane's first two knots (Sr1, Sr2 = S(t P + 17), S(t P + 18)); give: 1 / 2 = the NEXT lane's first knot touches the upper / lower wall
+    template <class Sh>
+    PTV_PIN_FN void win4_all(const Sh &sh, double lam, double Sl, double Sr1, double Sr2, Mask &up, Mask &lo, int &give) const {
+        const double thr = seed_threshold(lam);
+        const int room = n - 1 - t * P;
+#define PTV_WIN4(A)                                                                                        \
+        {                                                                                                  \
+            const Win w = win_part<4, A, A + 1, A + 3>(sh, PTV_S_AT(A), PTV_S_AT(A + 4));                   \
+            win_take<4, A>(w, (A > 0 || t > 0) && A + 4 <= room, thr, up, lo);                              \
+        }
+        PTV_WIN4(0) PTV_WIN4(4) PTV_WIN4(8) PTV_WIN4(12) PTV_WIN4(2) PTV_WIN4(6) PTV_WIN4(10)
+#undef PTV_WIN4
+        const double Sa = PTV_S_AT(14), dl = Sr2 - Sa;
+        Win w = win_part<4, 14, 15, 16>(sh, Sa, Sr2);
+        const double v = wtag((Sa - Sr1) * 4.0 + dl * 3.0, 3);
+        w.mx = pin_max(w.mx, v);
+        w.mn = wmin(w.mn, v);
+        const bool valid = 18 <= room;
+        win_take<4, 14>(w, valid, thr, up, lo);
+        give = 0;
+        if (valid && w.mx > thr * 4.0 && wdist(w.mx) == 3) give = 1;
+        if (valid && -w.mn > thr * 4.0 && wdist(w.mn) == 3) give |= 2;
+    }
+#undef PTV_S_AT
+    PTV_PIN_FN void win4_take(int prev_give, bool has_prev, Mask &up, Mask &lo) const {
+        if (has_prev && (prev_give & 1)) up |= (Mask)1;
+        if (has_prev && (prev_give & 2)) lo |= (Mask)1;
     }
 
     // ---- scan -------------------------------------------------------------------------------------------------------------

@@ -482,8 +482,9 @@ __device__ __forceinline__ int probe_key(double v) {
     return (int)(key < 0 ? 0 : (key >= kProbeBins ? kProbeBins - 1 : key));
 }
 
+// (y2 != null: the sampled array is y + c2 y2 -- the operand of a sweep whose input functor adds a second array: policy_reprobe)
 __global__ __launch_bounds__(kThreads) void edge_hist_kernel(const double *y, const double *w, long n, long inc, int len, long runs,
-                                                             long run_stride, unsigned *hist) {
+                                                             long run_stride, unsigned *hist, const double *y2, double c2) {
     __shared__ unsigned bins[2 * (kProbeBins + 1)];
     for (int b = threadIdx.x; b < 2 * (kProbeBins + 1); b += kThreads) bins[b] = 0u;
     __syncthreads();
@@ -500,7 +501,7 @@ __global__ __launch_bounds__(kThreads) void edge_hist_kernel(const double *y, co
             const int pos = (int)(q % len);
             if (pos < len - 1) {
                 valid = true;
-                v = fabs(y[e + inc] - y[e]);
+                v = y2 ? fabs((y[e + inc] + c2 * y2[e + inc]) - (y[e] + c2 * y2[e])) : fabs(y[e + inc] - y[e]);
                 if (w) {
                     const double we = w[(q / len) * inc * (len - 1) + (long)pos * inc + e % inc];
                     v = we > 0.0 ? v / we : (v > 0.0 ? 1e300 : 0.0);
@@ -545,7 +546,7 @@ namespace {
 // consecutive edges of ITS fibre.  Sampled: up to kProbeRuns (fibre group, position) sites spread evenly.
 __global__ __launch_bounds__(kThreads) void stretch_hist_kernel(const double *y, const double *w, long inc, int len, long slabs,
                                                                 long sites, long groups_per_slab, int starts_per_fibre,
-                                                                unsigned *hist) {
+                                                                unsigned *hist, const double *y2, double c2) {
     __shared__ unsigned bins[kProbeBins + 1];
     for (int b = threadIdx.x; b <= kProbeBins; b += kThreads) bins[b] = 0u;
     __syncthreads();
@@ -560,10 +561,11 @@ __global__ __launch_bounds__(kThreads) void stretch_hist_kernel(const double *y,
         const int pos0 = (int)(((long)st * (len - 17)) / (starts_per_fibre > 1 ? starts_per_fibre - 1 : 1));
         if (off < inc && slab < slabs) {
             const long base = slab * inc * len + off, wbase = slab * inc * (len - 1) + off;
-            double tv = 0.0, prev = y[base + (long)pos0 * inc];
+            auto at = [&](long e) { return y2 ? y[e] + c2 * y2[e] : y[e]; };
+            double tv = 0.0, prev = at(base + (long)pos0 * inc);
 #pragma unroll 4
             for (int k = 1; k <= 16; k++) {
-                const double cur = y[base + (long)(pos0 + k) * inc];
+                const double cur = at(base + (long)(pos0 + k) * inc);
                 double v = fabs(cur - prev);
                 if (w) {
                     const double we = w[wbase + (long)(pos0 + k - 1) * inc];
@@ -582,7 +584,7 @@ __global__ __launch_bounds__(kThreads) void stretch_hist_kernel(const double *y,
 }
 }  // namespace
 
-void edge_histogram(const double *y, const double *w, long n, long inc, int len, unsigned *hist, hipStream_t s) {
+void edge_histogram(const double *y, const double *w, long n, long inc, int len, unsigned *hist, hipStream_t s, const double *y2, double c2) {
     if (n <= 0 || len < 2) return;
     if (inc > 1 && len >= 18) {
         const long slabs = n / (inc * (long)len), groups = (inc + 63) / 64;
@@ -595,7 +597,7 @@ void edge_histogram(const double *y, const double *w, long n, long inc, int len,
             sites = slabs_used * groups * starts;
         }
         hipLaunchKernelGGL(stretch_hist_kernel, dim3((unsigned)((sites + kThreads / 64 - 1) / (kThreads / 64))), dim3(kThreads), 0, s, y, w,
-                           inc, len, slabs_used, sites, groups, starts, hist);
+                           inc, len, slabs_used, sites, groups, starts, hist, y2, c2);
         PTV_HIP(hipGetLastError());
     }
     long runs = (n + 63) / 64;
@@ -605,7 +607,7 @@ void edge_histogram(const double *y, const double *w, long n, long inc, int len,
         runs = kProbeRuns;
     }
     const unsigned blocks = (unsigned)((runs + kProbeRunsPerBlock - 1) / kProbeRunsPerBlock);
-    hipLaunchKernelGGL(edge_hist_kernel, dim3(blocks), dim3(kThreads), 0, s, y, w, n, inc, len, runs, stride, hist);
+    hipLaunchKernelGGL(edge_hist_kernel, dim3(blocks), dim3(kThreads), 0, s, y, w, n, inc, len, runs, stride, hist, y2, c2);
     PTV_HIP(hipGetLastError());
 }
 

@@ -58,7 +58,8 @@ inline int probe_bin(double v) {   // host side of the same binning
     const long k = (long)((b & 0x7fffffffffffffffull) >> 49) - ((long)kProbeLowExp << 3);
     return k < 0 ? 0 : (k >= kProbeBins ? kProbeBins - 1 : (int)k);
 }
-void edge_histogram(const double *y, const double *w, long n, long inc, int len, unsigned *hist, hipStream_t s);
+// (y2 != null: of the array y + c2 y2)
+void edge_histogram(const double *y, const double *w, long n, long inc, int len, unsigned *hist, hipStream_t s, const double *y2 = nullptr, double c2 = 0.0);
 // dst = src, 8 bytes per lane (counter calibration only)
 void calib_copy(const double *src, double *dst, long n, hipStream_t s);
 // Yang X update (src/TV2Dopt.cpp:832-833 ; src/TVNDopt.cpp:729-730): X = (Y + sum U_k + rho sum Z_k) / (1 + D rho)

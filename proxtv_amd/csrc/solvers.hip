@@ -253,6 +253,11 @@ SolveInfo pd2(const double *y, const double *lambdas, const double *dims, double
             tv2_fibres(po, z.d(), ns, nds, d0, lambdas[0], s);
             lincomb(po, pi, 1.0, xc, 1.0, z.d(), -1.0, nullptr, 0, n, s);
         } else {
+            if (reprobe_at(iters + 1)) {   // (the operand x + p is not the solve's input; the loop reads a value back every iteration anyway)
+                const double *as[1] = {xc}, *bs[1] = {pi};
+                const double cs[1] = {1.0};
+                policy_reprobe(1, as, bs, cs, ns, nds, &d0, s);
+            }
             SweepArgs a;
             a.a = xc; a.b = pi; a.o0 = z.d(); a.o1 = po; a.lam = lambdas[0];
             launch_sweep(OP_PD2_A, false, a, g0, s, fam_of_dim(d0), true);
@@ -265,6 +270,11 @@ SolveInfo pd2(const double *y, const double *lambdas, const double *dims, double
                 tv2_fibres(qo, xn, ns, nds, d1, lambdas[1], s);
                 lincomb(qo, qi, 1.0, z.d(), 1.0, xn, -1.0, nullptr, 0, n, s);
             } else {
+                if (reprobe_at(iters + 1)) {
+                    const double *as[1] = {z.d()}, *bs[1] = {qi};
+                    const double cs[1] = {1.0};
+                    policy_reprobe(1, as, bs, cs, ns, nds, &d1, s);
+                }
                 SweepArgs b;
                 b.a = z.d(); b.b = qi; b.o0 = xn; b.o1 = qo; b.lam = lambdas[1];
                 launch_sweep(OP_PD2_B, false, b, g1, s, fam_of_dim(d1), true);
@@ -339,6 +349,20 @@ SolveInfo pd_like(bool dr_variant, const double *y, const double *lambdas, const
     double stop = dr_variant ? 0.0 : DBL_MAX;
     int iters = 0;
     while ((dr_variant || stop > STOP_PD) && iters < maxIters) {
+        if (reprobe_at(iters + 1) && npen <= 8) {   // the operands z_i drift away from the solve's input
+            std::vector<const double *> as((size_t)npen);
+            std::vector<int> ds((size_t)npen);
+            int m = 0;
+            for (int i = 0; i < npen; i++) {
+                if (norms && norms[i] == 2) continue;
+                bool dup = false;   // (several terms along one dimension share a record: the first one speaks for it)
+                for (int j = 0; j < m; j++) dup = dup || ds[(size_t)j] == (int)(dims[i] - 1);
+                if (dup) continue;
+                as[(size_t)m] = z.ptr[(size_t)i];
+                ds[(size_t)m++] = (int)(dims[i] - 1);
+            }
+            if (m > 0) policy_reprobe(m, as.data(), nullptr, nullptr, ns, nds, ds.data(), s);
+        }
         for (int i = 0; i < npen; i++) {
             const int d = (int)(dims[i] - 1);
             if (norms && norms[i] == 2) {
@@ -401,6 +425,16 @@ SolveInfo yang(const int *ns, int nds, const int *order, const double *lambdas, 
         {
             FamilyTimer tm(FAM_OTHER, s);
             yang_x(Y, Uin, Z.pack, X, nds, rho, n, s);
+        }
+        if (reprobe_at(it)) {   // the sweeps' operands, X - U_k / rho, are not the solve's input: which rung they want is theirs to say
+            const double *as[kMaxTerms], *bs[kMaxTerms];
+            double cs[kMaxTerms];
+            for (int k = 0; k < nds; k++) {
+                as[k] = X;
+                bs[k] = Uin.v[k];
+                cs[k] = -1.0 / rho;
+            }
+            policy_reprobe(nds, as, bs, cs, ns, nds, order, s);
         }
         for (int k = 0; k < nds; k++) {
             SweepArgs a;

@@ -86,6 +86,7 @@ void policy_probe(const double *y, const double *const *weights, const int *ns, 
         edge_histogram(y, w, (long)g.len * g.count, g.inc, g.len, dev, s);
         ChunkScratch::Probe &p = st.probes[st.nprobes++];
         p.inc = g.inc; p.len = g.len; p.count = g.count; p.weighted = (w != nullptr);
+        p.iterate = false;
     }
     if (st.nprobes == first) return;
     // one copy for all the dimensions sampled by this call (the records are contiguous on both sides)
@@ -94,6 +95,33 @@ void policy_probe(const double *y, const double *const *weights, const int *ns, 
         PTV_HIP(hipMemcpyAsync(st.probes[k].hist, st.probe_dev->as<unsigned>() + kWords * (size_t)k, sizeof(unsigned) * kWords,
                                hipMemcpyDeviceToHost, s));
     PTV_HIP(hipStreamSynchronize(s));
+}
+
+// Mid-solve: the operands of the next sweeps along `dims` are a[k] + c[k] b[k] (b[k] may be null) -- sample THEM, in place of what
+// policy_probe recorded for these dimensions.  The iterates of Dykstra / ADMM loops drift away from the solve's input: Yang's sweeps
+// run at lambda / rho on averages of smoothed copies (4096^2 unit noise at lambda = 1 on the rung the input asks for: 129 ms a solve,
+// at lambda = 3: seven seconds; on the rung the operands ask for: 29 ms).  A function of the data alone, like the first probe: the
+// same solve takes the same kernels every time.  One read-back for all the dimensions given.
+void policy_reprobe(int count, const double *const *a, const double *const *b, const double *c, const int *ns, int nds, const int *dims,
+                    hipStream_t s) {
+    if (options().chunk_mode >= 0) return;
+    ChunkScratch &st = chunk_state();
+    constexpr size_t kWords = kProbeWords;
+    bool any = false;
+    for (int k = 0; k < count; k++) {
+        const FibreGeom g = fibres_along(ns, nds, dims[k]);
+        const ChunkScratch::Probe *found = st.find_probe(g, false);
+        if (!found) continue;   // (not sampled at the start either: too small, or the kernel is not a matter of choice)
+        const size_t slot = (size_t)(found - st.probes);
+        unsigned *dev = st.probe_dev->as<unsigned>() + kWords * slot;
+        PTV_HIP(hipMemsetAsync(dev, 0, sizeof(unsigned) * kWords, s));
+        edge_histogram(a[k], nullptr, (long)g.len * g.count, g.inc, g.len, dev, s, b ? b[k] : nullptr, c ? c[k] : 0.0);
+        PTV_HIP(hipMemcpyAsync(st.probes[slot].hist, dev, sizeof(unsigned) * kWords, hipMemcpyDeviceToHost, s));
+        st.probes[slot].iterate = true;
+        any = true;
+    }
+    if (any) PTV_HIP(hipStreamSynchronize(s));
+    count_event(CNT_REPROBES);
 }
 
 // The rung (0 or 1) a strided sweep of this geometry will take on the 64-fibre tile, -1 when it will not run there (transposed

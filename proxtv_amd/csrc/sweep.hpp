@@ -28,6 +28,10 @@ long certify_sweep(OpId op, bool weighted, const SweepArgs &args, const FibreGeo
 // reads them back (one small copy + stream synchronisation per call).  Dimensions whose fibres never reach the chunked
 // kernels, or that this solve has already sampled, are skipped.  Call after chunk_stats_reset(), before the first sweep.
 void policy_probe(const double *y, const double *const *weights, const int *ns, int nds, const int *dims, int ndims, hipStream_t s);
+// mid-solve: the operands of the next sweeps along dims[k] are a[k] + c[k] b[k] (b / c may be null): sample them in place of the solve's input
+void policy_reprobe(int count, const double *const *a, const double *const *b, const double *c, const int *ns, int nds, const int *dims, hipStream_t s);
+// ... before the sweeps of these iterations (1-based) of a loop: 2, 3, 5, 9, 17, 33, ... -- iterates move fast at first
+inline bool reprobe_at(int it) { return it >= 2 && ((it - 1) & (it - 2)) == 0; }
 
 // Fibres that the chunked path had to re-solve sequentially (unproven chunk links) since the last reset, on this thread.
 void chunk_stats_reset(hipStream_t s);

@@ -112,6 +112,7 @@ struct ChunkScratch {
         long chunks_done = 0;    // chunks processed (host-side count, cumulative per solve)
         long chunks_seen = 0;    // ... at the last evaluation
         int rewritten_seen = 0;
+        double shown_f = -2.0;   // (option verbose: the certain fraction last printed)
     } pol[FAM_COUNT];
 
     // Edge statistics of this solve's input, one record per swept dimension (policy_probe): the seed of the policy.
@@ -119,6 +120,7 @@ struct ChunkScratch {
         long inc = 0, count = 0;
         int len = 0;
         bool weighted = false;
+        bool iterate = false;              // sampled mid-solve from the operand of a Dykstra / ADMM sweep (policy_reprobe), not from the solve's input
         unsigned hist[kProbeWords] = {};   // edges | stretches (pointwise.hpp)
     };
     static constexpr int kMaxProbes = 8;
@@ -131,18 +133,20 @@ struct ChunkScratch {
                 return &probes[k];
         return nullptr;
     }
-    // fraction of the sampled edges at which the string is known to bend at this penalty (-1: this sweep's input was not sampled)
-    double certain_fraction(const FibreGeom &g, double lam, bool weighted) const {
+    // fraction of the sampled edges above `mult` penalties (-1: this sweep's input was not sampled)
+    double edge_fraction_above(const FibreGeom &g, double lam, bool weighted, double mult) const {
         const Probe *p = find_probe(g, weighted);
         if (!p || p->hist[kProbeBins] == 0) return -1.0;
         if (!weighted && !(lam > 0.0)) return 1.0;
         // (edges in the threshold's own bin do not count: an edge of exactly 4 lambda -- a checkerboard of +-2 lambda -- is not a
         // bend known a priori, and the kernels' test is strict)
-        const int b = probe_bin(weighted ? 4.0 : 4.0 * lam);
+        const int b = probe_bin(weighted ? mult : mult * lam);
         unsigned long above = 0;
         for (int k = b + 1; k < kProbeBins; k++) above += p->hist[k];
         return (double)above / (double)p->hist[kProbeBins];
     }
+    // fraction of the sampled edges at which the string is known to bend at this penalty (-1: this sweep's input was not sampled)
+    double certain_fraction(const FibreGeom &g, double lam, bool weighted) const { return edge_fraction_above(g, lam, weighted, 4.0); }
     // fraction of the sampled 16-edge stretches whose total variation is below 2 lambda: stretches the string crosses (all
     // but) flat -- nothing there for a speculative walk to meet the true one at (-1: not sampled)
     double flat_fraction(const FibreGeom &g, double lam, bool weighted) const {
@@ -162,7 +166,8 @@ struct ChunkScratch {
         // Spatially uneven data (half an image flat, sparse spikes on a constant background): whatever the average says, the
         // quiet stretches have pieces far longer than any zone and every chunk in them would go to the repair kernel.
         if (flat_fraction(g, lam, weighted) > kSeedFlat) return 3;
-        return rung_from_certain_fraction(f);
+        const Probe *p = find_probe(g, weighted);
+        return rung_from_certain_fraction(f, p && p->iterate);
     }
 
     static constexpr int kSlots = 8, kCounters = 2 * FAM_COUNT;
@@ -540,9 +545,10 @@ void launch_chunk(const SweepArgs &args, const FibreGeom &g, hipStream_t stream,
         // rung whose cost and exactness do not depend on the data
         mode = seed >= 0 ? seed : (pin_ok ? 3 : 0);
         if (mode == 1 && WEIGHTED && !pl.available(1, true)) mode = pl.up(mode);
-        if (options().verbose && (pl.sweeps == 0 || mode != pl.mode))
-            fprintf(stderr, "[proxtv_amd] policy: family %d (len %d x %ld fibres, lambda %g): seed %d -> mode %d\n", fam, g.len, g.count,
-                    args.lam, seed, mode);
+        if (options().verbose && (pl.sweeps == 0 || mode != pl.mode || seed_f != pl.shown_f))
+            fprintf(stderr, "[proxtv_amd] policy: family %d sweep %ld (len %d x %ld fibres, lambda %g): certain fraction %.4f, seed %d -> mode %d\n", fam,
+                    pl.sweeps, g.len, g.count, args.lam, seed_f, seed, mode);
+        pl.shown_f = seed_f;
         pl.mode = mode;
     } else {
         st.ensure_host();
@@ -569,7 +575,10 @@ void launch_chunk(const SweepArgs &args, const FibreGeom &g, hipStream_t stream,
         // hit the level cap on periodic data) -- the global-memory chunks below take the sweep
         // (knots known a priori: none to be had where the sampled input shows no edge above 4 lambda -- lambda = 3 on unit noise: the
         // search costs 3-6 % of such a sweep; unsampled inputs search)
-        const bool seeds = options().pin_seed && (seed_f < 0.0 || seed_f >= kSeedPins);
+        // (2, the default: knots known by windows as well -- pincore.hpp -- which find knots where no jump reaches 4 lambda: on unit noise
+        // up to lambda ~ 3; where hardly an edge of the input reaches half a penalty the windows have nothing to find either)
+        const double half_f = st.edge_fraction_above(g, args.lam, WEIGHTED, 0.5);
+        const int seeds = (options().pin_seed >= 2 && (half_f < 0.0 || half_f >= kSeedWindows)) ? 2 : ((options().pin_seed && (seed_f < 0.0 || seed_f >= kSeedPins)) ? 1 : 0);
         pinned_done = launch_pin((OpId)OP, WEIGHTED, args, g, stream, pieces, seeds);
         count_event(pinned_done ? CNT_PIN_SWEEPS : CNT_PIN_CAP_NEXT_RUNG);
         if (pinned_done) count_event(CNT_SWEEP_LAUNCHES);

@@ -298,14 +298,14 @@ struct PinHostShared {
 };
 
 template <int P, bool W, class Key = unsigned>
-static int pin_fibre(const double *y, const double *w, double lam, double *x, int n, bool seeded = false) {
+static int pin_fibre(const double *y, const double *w, double lam, double *x, int n, int seeded = 0, int *nseeds = nullptr) {
     PinHostShared<P, W, Key> sh;
     const int lanes = (n + P - 1) / P;
     double mean = 0;
     for (int i = 0; i < n; i++) mean += y[i];
     mean /= n;
-    sh.s.assign((size_t)n + 1 + P, 0.0);    // (+ P: a lane may read the slots of knots it does not have)
-    sh.rr.assign((size_t)n + 1 + P, 0.0);
+    sh.s.assign((size_t)(lanes + 64) * P + 2, 0.0);    // (a lane may read the slots of knots it does not have; the window seeds run whole waves)
+    sh.rr.assign((size_t)(lanes + 64) * P + 2, 0.0);
     for (int i = 0; i < n; i++) sh.s[(size_t)i + 1] = sh.s[(size_t)i] + (y[i] - mean);
     for (int j = 1; j < n; j++) sh.rr[(size_t)j] = w ? w[j - 1] : lam;
     std::vector<PinLane<P, Key>> lane((size_t)lanes);
@@ -323,6 +323,78 @@ static int pin_fibre(const double *y, const double *w, double lam, double *x, in
                 ok = rm >= 0.0 && r0 > 0.0 && rp >= 0.0;
             }
             if (ok && std::fabs(d) > thr) wall[(size_t)j] = d > 0 ? 0 : 1;
+        }
+        // knots known by windows (pincore.hpp: win64 / win16 / win4): the lanes of a wave exchange their parts through arrays where the
+        // kernel shuffles, a stage runs in the waves where the one before it found a knot (the kernel's ballots); what spans waves is
+        // left out there, and here
+        if constexpr (P == 16 && !W) {
+            if (seeded >= 2 && lam > 0.0) {
+                using Lane = PinLane<P, Key>;
+                using Win = typename Lane::Win;
+                using Mask = typename Lane::Mask;
+                auto Sk = [&](int j) { return sh.S(j < 0 ? 0 : (j > n ? n : j)); };
+                const int padded = (lanes + 63) / 64 * 64;   // (lanes beyond the fibre run the same code on the device; their parts are never used)
+                std::vector<Mask> ups((size_t)padded, 0), los((size_t)padded, 0), up16((size_t)padded, 0), lo16((size_t)padded, 0);
+                std::vector<Lane> ghost((size_t)padded);
+                std::vector<Win> pa((size_t)padded), pb((size_t)padded), tail((size_t)padded), head((size_t)padded);
+                std::vector<int> give((size_t)padded, 0);
+                for (int t = 0; t < padded; t++) {
+                    ghost[(size_t)t].init(n, t, sh);
+                    const int qa = t & 3, qb = (t + 2) & 3;
+                    pa[(size_t)t] = ghost[(size_t)t].win64_part(sh, Sk((t - qa) * P), Sk((t - qa) * P + 64), qa);
+                    pb[(size_t)t] = ghost[(size_t)t].win64_part(sh, Sk((t - qb) * P), Sk((t - qb) * P + 64), qb);
+                }
+                auto wave_any = [&](int base, const std::vector<Mask> &a, const std::vector<Mask> &b) {
+                    bool any = false;
+                    for (int l = 0; l < 64; l++) any = any || (a[(size_t)(base + l)] | b[(size_t)(base + l)]) != 0;
+                    return any;
+                };
+                for (int t = 0; t < padded; t++) {
+                    const int l = t & 63, base = t - l, qa = t & 3, qb = (t + 2) & 3;
+                    auto in_wave = [&](int lane_in_wave) { return (size_t)(base + (lane_in_wave & 63)); };
+                    const int m = l ^ 2;   // (second step of the butterfly: the partner's joined pair)
+                    const Win all_a = Lane::wjoin(Lane::wjoin(pa[in_wave(l)], pa[in_wave(l ^ 1)]), Lane::wjoin(pa[in_wave(m)], pa[in_wave(m ^ 1)]));
+                    const int partner = qb < 2 ? l + 2 : l - 2, mb = partner & 63;
+                    const Win all_b = Lane::wjoin(Lane::wjoin(pb[in_wave(l)], pb[in_wave(l ^ 1)]), Lane::wjoin(pb[in_wave(mb)], pb[in_wave(mb ^ 1)]));
+                    ghost[(size_t)t].win64_take(lam, all_a, true, qa, 4, ups[(size_t)t], los[(size_t)t]);
+                    ghost[(size_t)t].win64_take(lam, all_b, partner >= 0 && partner < 64, qb, 2, ups[(size_t)t], los[(size_t)t]);
+                }
+                for (int base = 0; base < padded; base += 64) {
+                    if (!wave_any(base, ups, los)) continue;
+                    for (int t = base; t < base + 64; t++)
+                        ghost[(size_t)t].win16_parts(sh, lam, Sk(t * P), Sk(t * P + 24), Sk(t * P - 8), up16[(size_t)t], lo16[(size_t)t], tail[(size_t)t], head[(size_t)t]);
+                    for (int t = base; t < base + 64; t++) {
+                        const int l = t - base;
+                        ghost[(size_t)t].win16_take(lam, tail[(size_t)t], head[(size_t)(base + ((l + 1) & 63))], l < 63, tail[(size_t)(base + ((l + 63) & 63))],
+                                                    head[(size_t)t], l > 0, up16[(size_t)t], lo16[(size_t)t]);
+                    }
+                    const bool finer = wave_any(base, up16, lo16);
+                    for (int t = base; t < base + 64; t++) {
+                        ups[(size_t)t] |= up16[(size_t)t];
+                        los[(size_t)t] |= lo16[(size_t)t];
+                    }
+                    if (!finer) continue;
+                    for (int t = base; t < base + 64; t++)
+                        ghost[(size_t)t].win4_all(sh, lam, Sk(t * P), Sk(t * P + P + 1), Sk(t * P + P + 2), ups[(size_t)t], los[(size_t)t], give[(size_t)t]);
+                    for (int t = base; t < base + 64; t++) {
+                        const int l = t - base;
+                        ghost[(size_t)t].win4_take(give[(size_t)(base + ((l + 63) & 63))], l > 0, ups[(size_t)t], los[(size_t)t]);
+                    }
+                }
+                for (int t = 0; t < lanes; t++) {
+                    if (t * P >= n) continue;
+                    for (int k = 0; k < P; k++) {
+                        const int j = 1 + t * P + k;
+                        if (j >= n || wall[(size_t)j] >= 0) continue;
+                        if ((ups[(size_t)t] >> k) & 1) wall[(size_t)j] = 0;
+                        else if ((los[(size_t)t] >> k) & 1) wall[(size_t)j] = 1;
+                    }
+                }
+            }
+        }
+        if (nseeds) {
+            *nseeds = 0;
+            for (int j = 1; j < n; j++) *nseeds += wall[(size_t)j] >= 0;
         }
         for (int t = 0; t < lanes; t++) {
             PinLane<P, Key> &L = lane[(size_t)t];
@@ -646,11 +718,17 @@ int host_pin_fibre_long(const double *y, const double *w, double lam, double *x,
 }
 
 // the same, starting from the knots known a priori
+// seeded with the knots known by windows as well (sixteen knots a lane, one penalty: the kernel's option pin_seed = 2); *nseeds: how many knots
+// the levels started from
+int host_pin_fibre_windows(const double *y, double lam, double *x, int n, int *nseeds) {
+    return pin_fibre<16, false>(y, nullptr, lam, x, n, 2, nseeds);
+}
+
 int host_pin_fibre_seeded(const double *y, const double *w, double lam, double *x, int n, int P) {
-    if (P == 16) return w ? pin_fibre<16, true>(y, w, lam, x, n, true) : pin_fibre<16, false>(y, w, lam, x, n, true);
-    if (P == 32) return w ? pin_fibre<32, true>(y, w, lam, x, n, true) : pin_fibre<32, false>(y, w, lam, x, n, true);
-    if (P == 64) return w ? pin_fibre<64, true>(y, w, lam, x, n, true) : pin_fibre<64, false>(y, w, lam, x, n, true);
-    if (P == 4) return w ? pin_fibre<4, true>(y, w, lam, x, n, true) : pin_fibre<4, false>(y, w, lam, x, n, true);
+    if (P == 16) return w ? pin_fibre<16, true>(y, w, lam, x, n, 1) : pin_fibre<16, false>(y, w, lam, x, n, 1);
+    if (P == 32) return w ? pin_fibre<32, true>(y, w, lam, x, n, 1) : pin_fibre<32, false>(y, w, lam, x, n, 1);
+    if (P == 64) return w ? pin_fibre<64, true>(y, w, lam, x, n, 1) : pin_fibre<64, false>(y, w, lam, x, n, 1);
+    if (P == 4) return w ? pin_fibre<4, true>(y, w, lam, x, n, 1) : pin_fibre<4, false>(y, w, lam, x, n, 1);
     return -1;
 }
 

@@ -212,7 +212,7 @@ def test_level_cap_long_fibre_takes_the_next_rung(ptv, clib, oracle, rung3):
     assert handed_on >= 1
 
 
-@pytest.mark.parametrize("seed", [1, 0])
+@pytest.mark.parametrize("seed", [2, 1, 0])
 def test_a_priori_pins(ptv, clib, oracle, rung3, seed):
     """The switch of the pinning rung against the oracle: pin_seed (the levels start from the knots known a priori -- |dy| > 4 lambda,
     weighted r_{j+1} + 2 r_j + r_{j-1} -- instead of the fibre ends alone).  Tall images (4096+ strided fibres); lambdas with many,
@@ -233,3 +233,35 @@ def test_a_priori_pins(ptv, clib, oracle, rung3, seed):
                     assert_close(ptv.tv1_1d(x, lam), oracle.tv1_hybrid(x, lam), tol=1e-11, what=f"{name} n={n} lam={lam}")
     finally:
         clib.proxtv_set_option(b"pin_seed", before[0])
+
+
+def test_knots_known_by_windows(ptv, clib, oracle, rung3):
+    """pin_seed = 2 (the default): the levels also start from the deepest knots of windows of 4 / 16 / 64 knots (pincore.hpp: seed_phase1 /
+    seed_phase2; fibres of up to 4096 samples, one penalty).  Images whose fibres fill the 256-lane group, half of it, a wave and less, with
+    lengths on and off the lane / window grids; penalties around the noise level, where no jump reaches 4 lambda and windows find a third
+    of the string's knots; every outer loop; the result may not depend on the switch beyond the rounding of the running sums."""
+    rng = np.random.default_rng(310)
+    assert clib.proxtv_set_option(b"pin_seed", 2) in (0, 1, 2)
+    try:
+        for (M, N), lam in (((4096, 150), 1.0), ((4095, 70), 0.8), ((2048, 300), 1.3), ((1041, 200), 0.7), ((1024, 256), 1.0), ((1000, 333), 2.0),
+                            ((300, 4096), 1.0), ((80, 500), 0.9)):
+            X = rng.standard_normal((M, N))
+            want = oracle.dr2(X, lam, max_iters=4)[0]
+            got = ptv.tv1_2d(X, lam, max_iters=4)
+            assert_close(got, want, tol=1e-9, what=f"dr2 {M}x{N} lam {lam}")
+            clib.proxtv_set_option(b"pin_seed", 1)
+            plain = ptv.tv1_2d(X, lam, max_iters=4)
+            clib.proxtv_set_option(b"pin_seed", 2)
+            assert np.abs(got - plain).max() <= 1e-10, (M, N, lam, np.abs(got - plain).max())
+            assert_close(ptv.tv1_2d(X, lam, method="pd", max_iters=3), oracle.pd2(X, [lam, lam], [1, 2], max_iters=3)[0], tol=1e-9,
+                         what=f"pd2 {M}x{N} lam {lam}")
+        for n in (17, 64, 96, 1000, 1025, 2048, 4000, 4096):
+            for name, x in _families(rng, n):
+                for lam in (0.05, 0.4, 1.0, 3.0):
+                    assert_close(ptv.tv1_1d(x, lam), oracle.tv1_hybrid(x, lam), tol=1e-11, what=f"{name} n={n} lam={lam}")
+        # quarter-integer samples: depths that sit exactly on the threshold
+        for n, lam in ((4096, 0.5), (4096, 1.0), (1024, 0.25), (2048, 2.0)):
+            X = rng.integers(-8, 9, (n, 64)) / 4.0
+            assert_close(ptv.tv1_2d(X, lam, max_iters=3), oracle.dr2(X, lam, max_iters=3)[0], tol=1e-9, what=f"ties {n} lam {lam}")
+    finally:
+        clib.proxtv_set_option(b"pin_seed", 2)

@@ -22,6 +22,8 @@ def harness():
     lib.host_pin_fibre.restype = C.c_int
     lib.host_pin_fibre_seeded.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_int, C.c_int]
     lib.host_pin_fibre_seeded.restype = C.c_int
+    lib.host_pin_fibre_windows.argtypes = [C.c_void_p, C.c_double, C.c_void_p, C.c_int, C.c_void_p]
+    lib.host_pin_fibre_windows.restype = C.c_int
     lib.host_pin_fibre_long.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_int]
     lib.host_pin_fibre_long.restype = C.c_int
     lib.host_pin_fibre_threads.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_int, C.c_int]
@@ -43,6 +45,16 @@ def pin_seeded(lib, y, lam, w=None, P=16):
     levels = lib.host_pin_fibre_seeded(y.ctypes.data, None if w is None else w.ctypes.data, lam, x.ctypes.data, y.size, P)
     assert levels >= 1
     return x, levels
+
+
+def pin_windows(lib, y, lam):
+    """seeded with the knots known by windows as well (the kernel's pin_seed = 2): values, levels, knots the levels started from"""
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    x = np.full(y.size, np.nan)
+    seeds = C.c_int(0)
+    levels = lib.host_pin_fibre_windows(y.ctypes.data, lam, x.ctypes.data, y.size, C.byref(seeds))
+    assert levels >= 1
+    return x, levels, seeds.value
 
 
 def tol(y):
@@ -211,3 +223,74 @@ def test_pinning_on_fibres_with_zero_jump_knots(harness, oracle):
             assert levels <= 64
             xs, _ = pin_seeded(harness, y, lam, P=P)
             assert np.abs(xs - want).max() <= tol(y), ("seeded", n, lam, P, np.abs(xs - want).max())
+
+
+def _dr_operands(oracle, rng, n, lam, iterations):
+    """Operands of the column / row sweeps of a DR solve on an n x n unit-noise image (oracle/tvnd_oracle.c: dr_generic), a few fibres each."""
+    U = rng.standard_normal((n, n))
+    t = np.full((n, n), 2 * U.mean())
+    prox = lambda T: np.stack([oracle.tv1_linearized(np.ascontiguousarray(T[:, j]), lam) for j in range(n)], axis=1)
+    out = []
+    for it in range(1, iterations + 1):
+        out += [np.ascontiguousarray(t[:, j]) for j in range(0, n, n // 3)]
+        s = 2 * (t - prox(t)) - t
+        v = U - s
+        out += [np.ascontiguousarray(v[j, :]) for j in range(0, n, n // 3)]
+        tb = 2 * (U - (v - prox(v.T.copy()).T)) - s
+        t = 0.5 * (t + tb)
+    return out
+
+
+def test_window_seeds_equal_oracle(harness, oracle):
+    """Knots known by windows (pincore.hpp: seed_phase1 / seed_phase2 -- the deepest knot of a window of 4 / 16 / 64 knots touches its
+    wall when it lies more than the tube's width below the line through the wall at the window's ends): same string, every family,
+    lengths around the lane (16), wave (1024) and window grids, penalties from a hundredth to a hundred times the noise."""
+    rng = np.random.default_rng(21)
+    for trial in range(500):
+        name = list(FAMILIES)[trial % len(FAMILIES)]
+        n = int(rng.choice([2, 5, 16, 17, 18, 31, 33, 63, 64, 65, 80, 100, 257, 1000, 1023, 1024, 1025, 1041, 2048, 3000, 4095, 4096]))
+        y = FAMILIES[name](rng, n)
+        lam = float(10 ** rng.uniform(-2, 2))
+        want = oracle.tv1_linearized(y.copy(), lam)
+        x, levels, seeds = pin_windows(harness, y, lam)
+        assert np.abs(x - want).max() <= tol(y), (name, n, lam, seeds, np.abs(x - want).max())
+        assert levels <= 64
+
+
+def test_window_seeds_on_ties_and_slivers(harness, oracle):
+    """Where depths sit ON the threshold: quarter-integer samples with penalties that make 2 lambda W a sum of them (the rule is strict: a
+    knot exactly the tube's width deep is not pinned by it -- and pinning it would be right as well), and fibres built backwards from
+    strings that touch their tube to the last bit."""
+    from test_chunk_host import _zero_jump_fibre
+    rng = np.random.default_rng(22)
+    for trial in range(300):
+        n = int(rng.choice([64, 100, 257, 1000, 1025, 4096]))
+        y = rng.integers(-8, 9, n) / 4.0
+        lam = float(rng.choice([0.125, 0.25, 0.5, 0.75, 1.0, 1.5, 2.0, 4.0]))
+        want = oracle.tv1_linearized(y.copy(), lam)
+        x, _, _ = pin_windows(harness, y, lam)
+        assert np.abs(x - want).max() <= tol(y), ("ties", n, lam, np.abs(x - want).max())
+    for trial in range(200):
+        n = int(rng.choice([64, 100, 257, 1000, 1025, 4096]))
+        lam = float(rng.choice([0.05, 0.5, 3.0, 6.0]) * (0.5 + rng.random()))
+        y, _ = _zero_jump_fibre(rng, n, lam)
+        want = oracle.tv1_linearized(y.copy(), lam)
+        x, _, _ = pin_windows(harness, y, lam)
+        assert np.abs(x - want).max() <= tol(y), ("zero jumps", n, lam, np.abs(x - want).max())
+
+
+def test_window_seeds_halve_the_levels_of_dr_operands(harness, oracle):
+    """What they are for: the operands of DR sweeps at lambda ~ the noise level have no jump above 4 lambda to start from (10-12 levels);
+    windows find a third to a half of the knots of the string before the first level."""
+    rng = np.random.default_rng(23)
+    plain = seeded = 0
+    for y in _dr_operands(oracle, rng, 1024, 1.0, 4):
+        want = oracle.tv1_linearized(y.copy(), 1.0)
+        _, l1 = pin_seeded(harness, y, 1.0)
+        x, l2, seeds = pin_windows(harness, y, 1.0)
+        assert np.abs(x - want).max() <= tol(y)
+        pieces = 1 + np.count_nonzero(np.abs(np.diff(want)) > 1e-12)
+        assert seeds <= pieces - 1 + 8, (seeds, pieces)     # (seeds are knots of the string; a few touch a wall without a bend)
+        plain += l1
+        seeded += l2
+    assert seeded <= 0.62 * plain, (seeded, plain)

@@ -123,5 +123,24 @@ final3)  # the edge masks cut at 4 lambda exactly: the runs tests, the certified
   for sd in 1 2 3; do python tools/certified_campaign.py 150 $sd > $OUT/campaign_$sd.txt 2>&1; tail -1 $OUT/campaign_$sd.txt | tee -a $OUT/summary.txt; grep "certify:" $OUT/campaign_$sd.txt | cut -c1-260 | head -10 | tee -a $OUT/summary.txt; done
   { python tools/fuzz.py 200 661; python tools/fuzz.py 200 662 long; } > $OUT/fuzz.txt 2>&1; grep "^fuzz\|MISMATCH\|Error" $OUT/fuzz.txt | tee -a $OUT/summary.txt
   ;;
+w1)   # knots known by windows (pin_seed = 2): the pinning tests, A/B by option over lambda, the rungs side by side
+  timeout 900 python -m pytest tests/test_gpu_pin.py -m gpu -x -q > $OUT/pytest_pin.log 2>&1; echo "pin tests: $(tail -1 $OUT/pytest_pin.log)" | tee $OUT/summary.txt
+  ab --reps 5 --rounds 2 --cases c2@0.7,c2@0.8,c2@1.0,c2@1.5,c2@3,c2@10,pd2@1.0,s2048@1.0,s1024@1.0 base jumps,pin_seed=1 > $OUT/ab_windows.txt 2>&1; cat $OUT/ab_windows.txt
+  python tools/lambda_probe.py --modes 1,3 --lams 0.5,0.6,0.65,0.7 > $OUT/probe_mid.txt 2>&1; cat $OUT/probe_mid.txt
+  ;;
+w2)   # the window stages gated (wave ballots; the policy's half-penalty fraction): tests, A/B by option, the bench line
+  timeout 900 python -m pytest tests/test_gpu_pin.py tests/test_gpu_large.py -m gpu -x -q > $OUT/pytest_pin.log 2>&1; echo "pin + large tests: $(tail -1 $OUT/pytest_pin.log)" | tee $OUT/summary.txt
+  ab --reps 5 --rounds 2 --cases c2@0.8,c2@1.0,c2@1.5,c2@3,c2@5,c2@10,pd2@1.0,yang2@1.0,s2048@1.0,c4@1.0 base jumps,pin_seed=1 > $OUT/ab_windows.txt 2>&1; cat $OUT/ab_windows.txt
+  python bench.py --steps 10 --warmup 3 > $OUT/bench.json 2> $OUT/bench.err; python - <<'P' | tee -a $OUT/summary.txt
+import json
+d=json.loads(open('gpurun_out/r6/w2/bench.json').read().strip().splitlines()[-1])
+print('headline ms', d['ms_per_step'], {k:round(v['avg_launch_ms']*1e3,1) for k,v in d['roofline']['by_kernel'].items()})
+print({k:(round(d[k]['ms'],2), d[k]['ok']) for k in ('c3','lambda_1','hard')}, {k:(round(v['ms'],2), v['ok']) for k,v in d['c4'].items() if isinstance(v,dict)})
+P
+  ;;
+w4)   # operands of Dykstra / ADMM loops sampled mid-solve (policy_reprobe): parity files, then PD2 / Yang over lambda against the pinned rungs
+  timeout 1200 python -m pytest tests/test_gpu_parity_2d.py tests/test_gpu_parity_nd.py tests/test_gpu_pin.py tests/test_gpu_large.py tests/test_gpu_boundary.py -m gpu -x -q > $OUT/pytest.log 2>&1; echo "parity + pin + large: $(tail -1 $OUT/pytest.log)" | tee $OUT/summary.txt
+  ab --reps 3 --rounds 1 --cases pd2@0.1,pd2@0.3,pd2@0.5,pd2@0.7,pd2@1.0,yang2@0.1,yang2@0.3,yang2@0.5,yang2@1.0,yang2@3,c4y,c4,c4y@1.0,c4@1.0,c2@3,c2@5 base m1,chunk_mode=1 m3,chunk_mode=3 > $OUT/ab_pd_yang.txt 2>&1; cat $OUT/ab_pd_yang.txt
+  ;;
 *) echo "unknown session $S";;
 esac
