@@ -82,7 +82,7 @@ __global__ __launch_bounds__(kPinThreads) void sweep_pin_kernel(SweepArgs p, Fib
     // samples own[k] and the one after it (the lane's last knot looks at its neighbour's first sample: the barriers of the sums
     // below come before anybody overwrites a sample)
     typename PinLane<P>::Mask seedU = 0, seedL = 0;
-    if (seeded) {
+    if (seeded & 1) {
         double prev = cnt > 0 ? own[0] : 0.0;
 #pragma unroll
         for (int k = 0; k < P; k++) {
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(kPinThreads) void sweep_pin_kernel(SweepArgs p, Fib
     // a knot somewhere in the wave; windows that span lanes are joined by lane shuffles -- the few that also span waves are left to
     // the levels
     if constexpr (P == 16 && !WEIGHTED) {
-        if (seeded >= 2 && p.lam > 0.0) {
+        if ((seeded & 2) && p.lam > 0.0) {
             using Lane = PinLane<P>;
             using Win = typename Lane::Win;
             using Mask = typename Lane::Mask;
@@ -140,19 +140,21 @@ __global__ __launch_bounds__(kPinThreads) void sweep_pin_kernel(SweepArgs p, Fib
             auto Sk = [&](int j) { return Sp[Geo::sa(j < 0 ? 0 : (j > n ? n : j))]; };
             auto shfl_win = [](Win w, int src) { return Win{__shfl(w.mx, src), __shfl(w.mn, src)}; };
             Mask up = 0, lo = 0;
-            {
+            {   // 64 knots: the plain grid first; the shifted one where that found a knot somewhere in the wave
                 const int qa = t & 3, qb = (t + 2) & 3;
                 const Win pa = ln.win64_part(sh, Sk((t - qa) * P), Sk((t - qa) * P + 64), qa);
-                const Win pb = ln.win64_part(sh, Sk((t - qb) * P), Sk((t - qb) * P + 64), qb);
                 Win all_a = Lane::wjoin(pa, shfl_win(pa, l ^ 1));
                 all_a = Lane::wjoin(all_a, shfl_win(all_a, l ^ 2));
-                Win all_b = Lane::wjoin(pb, shfl_win(pb, l ^ 1));
-                const int partner = qb < 2 ? l + 2 : l - 2;
-                all_b = Lane::wjoin(all_b, shfl_win(all_b, partner & 63));
                 ln.win64_take(p.lam, all_a, true, qa, 4, up, lo);
-                ln.win64_take(p.lam, all_b, partner >= 0 && partner < 64, qb, 2, up, lo);
+                if (__ballot((up | lo) != 0) != 0ull) {
+                    const Win pb = ln.win64_part(sh, Sk((t - qb) * P), Sk((t - qb) * P + 64), qb);
+                    Win all_b = Lane::wjoin(pb, shfl_win(pb, l ^ 1));
+                    const int partner = qb < 2 ? l + 2 : l - 2;
+                    all_b = Lane::wjoin(all_b, shfl_win(all_b, partner & 63));
+                    ln.win64_take(p.lam, all_b, partner >= 0 && partner < 64, qb, 2, up, lo);
+                }
             }
-            if (__ballot((up | lo) != 0) != 0ull) {
+            if (__popcll(__ballot((up | lo) != 0)) >= kSeedStage16) {
                 const double Sl = Sk(t * P);
                 Mask up16 = 0, lo16 = 0;
                 Win tail, head;
@@ -160,7 +162,7 @@ __global__ __launch_bounds__(kPinThreads) void sweep_pin_kernel(SweepArgs p, Fib
                 ln.win16_take(p.lam, tail, shfl_win(head, (l + 1) & 63), l < 63, shfl_win(tail, (l + 63) & 63), head, l > 0, up16, lo16);
                 up |= up16;
                 lo |= lo16;
-                if (__ballot((up16 | lo16) != 0) != 0ull) {
+                if (__popcll(__ballot((up16 | lo16) != 0)) >= kSeedStage4) {
                     int give;
                     ln.win4_all(sh, p.lam, Sl, Sk(t * P + P + 1), Sk(t * P + P + 2), up, lo, give);
                     ln.win4_take(__shfl(give, (l + 63) & 63), l > 0, up, lo);
@@ -176,8 +178,10 @@ __global__ __launch_bounds__(kPinThreads) void sweep_pin_kernel(SweepArgs p, Fib
     // settle() turns the sum of a pinned knot into that height in place)
     int s_la = 0, s_rb = n;
     double s_hl = 0.0, s_hr = 0.0;
+    using SeedMask = typename PinLane<P>::Mask;
+    if (seeded) seeded = group_any<G>((seedU | seedL) != 0) ? seeded : 0;   // (nothing found anywhere in the fibre: the levels start from its ends)
     if (seeded) {
-        using Mask = typename PinLane<P>::Mask;
+        using Mask = SeedMask;
         const Mask both = seedU | seedL;
         const int j0 = 1 + t * P;
         int last = 0, first = 0x7fffffff;
@@ -270,7 +274,7 @@ struct GaveUp {
     }
 };
 static thread_local GaveUp g_gaveup[kMaxDevices];
-static thread_local int g_seeded = 2;   // this sweep starts from the knots known a priori: 1 = jumps above 4 lambda, 2 = windows as well (launch_pin's argument, for the launchers below)
+static thread_local int g_seeded = 3;   // this sweep starts from the knots known a priori: bit 0 = jumps above 4 lambda, bit 1 = the deepest knots of windows (launch_pin's argument, for the launchers below)
 
 template <int OP, bool WEIGHTED, int P, int G>
 void launch_geom(const SweepArgs &args, const FibreGeom &g, hipStream_t stream, int *pieces) {

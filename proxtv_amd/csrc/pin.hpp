@@ -49,11 +49,11 @@ inline bool pin_supports(OpId op, bool weighted, const FibreGeom &g, double lam)
 // Returns true when the sweep is done (fibres that hit the level cap included: launch_seq_gated finishes them on the
 // stream), false when NOTHING was written and the caller has to run another rung: the grid-wide variant found that its
 // instantiation does not fit the device after all, or hit the level cap.
-// seeds: start the levels from the knots known a priori (pincore.hpp: PinLane::seed): 1 = jumps above 4 lambda -- finding them costs
-// about a third of a level, so the caller says 0 where the input has none --, 2 = knots known by windows of 4 / 16 / 64 knots as
-// well (unweighted fibres of up to 4096 samples; about a level's work for five or six levels less on noise at lambda ~ 1).  The
-// one-workgroup kernels only; the grid-wide variant starts from the fibre ends.
-bool launch_pin(OpId op, bool weighted, const SweepArgs &args, const FibreGeom &g, hipStream_t stream, int *pieces = nullptr, int seeds = 2);
+// seeds: start the levels from the knots known a priori (pincore.hpp: PinLane::seed): bit 0 = jumps above 4 lambda -- finding them costs
+// about a third of a level, so the caller leaves it out where the input has none --, bit 1 = the deepest knots of windows of 4 / 16 / 64
+// knots (unweighted fibres of up to 4096 samples; a third of a level to a level's work -- the stages gate themselves wave by wave -- for
+// five or six levels less on noise at lambda ~ 1).  The one-workgroup kernels only; the grid-wide variant starts from the fibre ends.
+bool launch_pin(OpId op, bool weighted, const SweepArgs &args, const FibreGeom &g, hipStream_t stream, int *pieces = nullptr, int seeds = 3);
 // (the grid-wide variant behind it, for fibres beyond kPinMaxLen: pinlong.hip)
 bool launch_pin_long(OpId op, bool weighted, const SweepArgs &args, const FibreGeom &g, hipStream_t stream, int *pieces);
 

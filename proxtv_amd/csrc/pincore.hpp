@@ -89,6 +89,11 @@ struct PinTag {
     PTV_PIN_FN static int index(double v) { return (int)(pin_bits(v) & kMask); }
 };
 
+// window seeds: lanes of a wave (of 64: 1024 knots) that must have found a knot with 64-knot windows for the 16-knot stage to run, and with
+// 16-knot windows for the 4-knot stage (operands of DR sweeps on unit noise, lanes with a knot per stage 64 / 16 / 4: lambda 0.8: 27 / 43 / 21;
+// 1: 24 / 29 / 6; 1.5: 11 / 8 / 0; 2: 6 / 3 / 0; 3: 2 / 0 / 0 -- a stage costs a third of a level, a handful of knots does not save one)
+constexpr int kSeedStage16 = 8, kSeedStage4 = 24;
+
 // Shared-memory side of a group (concept `Sh`):
 //     static constexpr bool kWeighted          per-knot half-widths (else r(j) is one constant)
 //     double S(int j)                          running sum at knot j (0 <= j <= n)
@@ -223,9 +228,10 @@ struct PinLane {
         if (valid && w.mx > thr * (double)W && eu >= 1 && eu <= P) up |= (Mask)1 << (eu - 1);
         if (valid && -w.mn > thr * (double)W && el >= 1 && el <= P) lo |= (Mask)1 << (el - 1);
     }
-    // Three stages, coarse to fine: 64-knot windows, then 16, then 4.  A stage runs only where the stage before it found a knot
-    // somewhere in the lane's wave (the caller's ballot): features deep enough for a small window show in the large ones around
-    // them, and data whose pieces are far longer than any window (lambda many times the noise) pay for one stage, not three.
+    // Three stages, coarse to fine: 64-knot windows, then 16, then 4.  A stage runs only where the stage before it found knots in
+    // enough lanes of the lane's wave (kSeedStage16 / kSeedStage4; the caller's ballot): features deep enough for a small window
+    // show in the large ones around them, and data whose pieces are far longer than any window (lambda many times the noise) pay
+    // for one stage, not three.
     // Each stage: the lane's parts -> the caller joins them with the neighbours' (lane shuffles on the device, arrays in the
     // host harness; what would cross a wave is left to the levels) -> the lane takes what is its own.
     PTV_PIN_FN static double seed_threshold(double lam) { return 2.0000002 * lam; }

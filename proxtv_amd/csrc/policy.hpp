@@ -61,9 +61,6 @@ constexpr double kSeedNoisy = 0.45;   // f at or above: rung 0
 constexpr double kSeedMid = 0.03;     // f at or above: rung 1 ; below: rung 3  (as sampled -- edges in the threshold's own eighth-octave bin do not count -- lambda = 0.7 on unit noise gives 0.034, 0.75-0.8 gives 0.022; at 0.8: 35.0 ms on rung 1, 34.0 on rung 3)
 constexpr double kSeedPins = 0.001;    // rung 3: the pinning solver searches for knots known a priori when f is at least this (lambda = 1 on unit noise: 0.005,
                                        // 29.4 against 30.0 ms per 4096^2 DR solve; 0.8: 25.3 against 31.8; 3: none to find, 18.3 against 19.1 with the search)
-constexpr double kSeedWindows = 0.33;  // rung 3: ... and for knots known by windows (pincore.hpp) when at least this fraction of the edges is above HALF a penalty
-                                       // (unit noise: 0.48 at lambda = 2, 0.29 at 3, 0.08 at 5; 4096^2 DR with / without the windows: lambda 1 21.3 / 29.2 ms,
-                                       // 1.5 23.3 / 25.3, 3 19.4 / 18.2, 5 15.4 / 14.3 -- late iterates at lambda >= 3 have pieces of hundreds of samples)
 constexpr double kSeedJobs = 0.055;    // rung 1, option "repair_jobs" = 1: f below (as sampled: lambda >= 0.65 on unit noise -- 0.6 gives 0.065, 0.65 gives 0.048) the failed
                                        // links across workgroups go one lane each (4096^2 DR: lambda 0.6 14.27 -> 14.42 ms, 0.65 17.67 -> 17.33, 0.7 21.41 -> 19.97)
 constexpr double kSeedRuns = 0.70;     // rung 0, dimension-0 sweeps, f at or above: interior segments are cut at the bends known a priori and solved run by run
@@ -73,11 +70,13 @@ constexpr double kSeedFlat = 0.02;     // more than this fraction of the sampled
 // DR2L1W: the second form of the iteration (ops.hpp, OP_DR_COL_V) pays below this certain fraction only -- the weighted column
 // sweep is the heavier one to begin with (4096^2, weights U(0.5, 1.5) lambda: lambda = 0.4: 17.4 -> 18.1 ms, 0.6: 25.3 -> 24.0)
 constexpr double kSeedDrFormWeighted = 0.2;
-// ... of the operands of Dykstra / ADMM sweeps, sampled mid-solve (sweep.hip: policy_reprobe): x + p walks like noisier data than its certain
+// ... of the operands of Dykstra sweeps, sampled mid-solve (sweep.hip: policy_reprobe): x + p walks like noisier data than its certain
 // fraction says (4096^2 PD2 on unit noise, rung 1 / rung 3: lambda 0.5, f = 0.022: 20.4 / 28.5 ms; 0.6, f = 0.009: 23.8 / 29.3; 0.7, f = 0.001:
-// 39.0 / 29.9 -- where a DR solve at f = 0.022 takes 31.2 / 20.0)
-constexpr double kSeedMidIterate = 0.004;
-inline int rung_from_certain_fraction(double f, bool iterate = false) { return f >= kSeedNoisy ? 0 : (f >= (iterate ? kSeedMidIterate : kSeedMid) ? 1 : 3); }
+// 39.0 / 29.9 -- where a DR solve at f = 0.022 takes 31.2 / 20.0).  The operands of Yang's ADMM sweeps, X - U / rho, keep the general threshold:
+// their certain fraction falls all through the solve (lambda = 2: 0.35 at iteration 3, 0.005 at 9, 0 at 33), and rung 1 at 0.005 on its way
+// to 0 cost 73 ms a solve against 30.
+constexpr double kSeedMidDykstra = 0.004;
+inline int rung_from_certain_fraction(double f, bool dykstra = false) { return f >= kSeedNoisy ? 0 : (f >= (dykstra ? kSeedMidDykstra : kSeedMid) ? 1 : 3); }
 
 struct GeometryPolicy {
     int mode = 0;            // incumbent geometry

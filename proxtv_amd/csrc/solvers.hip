@@ -256,7 +256,7 @@ SolveInfo pd2(const double *y, const double *lambdas, const double *dims, double
             if (reprobe_at(iters + 1)) {   // (the operand x + p is not the solve's input; the loop reads a value back every iteration anyway)
                 const double *as[1] = {xc}, *bs[1] = {pi};
                 const double cs[1] = {1.0};
-                policy_reprobe(1, as, bs, cs, ns, nds, &d0, s);
+                policy_reprobe(1, 1, as, bs, cs, ns, nds, &d0, s);
             }
             SweepArgs a;
             a.a = xc; a.b = pi; a.o0 = z.d(); a.o1 = po; a.lam = lambdas[0];
@@ -273,7 +273,7 @@ SolveInfo pd2(const double *y, const double *lambdas, const double *dims, double
                 if (reprobe_at(iters + 1)) {
                     const double *as[1] = {z.d()}, *bs[1] = {qi};
                     const double cs[1] = {1.0};
-                    policy_reprobe(1, as, bs, cs, ns, nds, &d1, s);
+                    policy_reprobe(1, 1, as, bs, cs, ns, nds, &d1, s);
                 }
                 SweepArgs b;
                 b.a = z.d(); b.b = qi; b.o0 = xn; b.o1 = qo; b.lam = lambdas[1];
@@ -361,7 +361,7 @@ SolveInfo pd_like(bool dr_variant, const double *y, const double *lambdas, const
                 as[(size_t)m] = z.ptr[(size_t)i];
                 ds[(size_t)m++] = (int)(dims[i] - 1);
             }
-            if (m > 0) policy_reprobe(m, as.data(), nullptr, nullptr, ns, nds, ds.data(), s);
+            if (m > 0) policy_reprobe(1, m, as.data(), nullptr, nullptr, ns, nds, ds.data(), s);
         }
         for (int i = 0; i < npen; i++) {
             const int d = (int)(dims[i] - 1);
@@ -426,7 +426,7 @@ SolveInfo yang(const int *ns, int nds, const int *order, const double *lambdas, 
             FamilyTimer tm(FAM_OTHER, s);
             yang_x(Y, Uin, Z.pack, X, nds, rho, n, s);
         }
-        if (reprobe_at(it)) {   // the sweeps' operands, X - U_k / rho, are not the solve's input: which rung they want is theirs to say
+        if (reprobe_at(it, true)) {   // the sweeps' operands, X - U_k / rho, are not the solve's input: which rung they want is theirs to say
             const double *as[kMaxTerms], *bs[kMaxTerms];
             double cs[kMaxTerms];
             for (int k = 0; k < nds; k++) {
@@ -434,7 +434,7 @@ SolveInfo yang(const int *ns, int nds, const int *order, const double *lambdas, 
                 bs[k] = Uin.v[k];
                 cs[k] = -1.0 / rho;
             }
-            policy_reprobe(nds, as, bs, cs, ns, nds, order, s);
+            policy_reprobe(2, nds, as, bs, cs, ns, nds, order, s);
         }
         for (int k = 0; k < nds; k++) {
             SweepArgs a;

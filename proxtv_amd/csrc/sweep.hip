@@ -86,7 +86,7 @@ void policy_probe(const double *y, const double *const *weights, const int *ns, 
         edge_histogram(y, w, (long)g.len * g.count, g.inc, g.len, dev, s);
         ChunkScratch::Probe &p = st.probes[st.nprobes++];
         p.inc = g.inc; p.len = g.len; p.count = g.count; p.weighted = (w != nullptr);
-        p.iterate = false;
+        p.iterate = 0;
     }
     if (st.nprobes == first) return;
     // one copy for all the dimensions sampled by this call (the records are contiguous on both sides)
@@ -102,7 +102,7 @@ void policy_probe(const double *y, const double *const *weights, const int *ns, 
 // run at lambda / rho on averages of smoothed copies (4096^2 unit noise at lambda = 1 on the rung the input asks for: 129 ms a solve,
 // at lambda = 3: seven seconds; on the rung the operands ask for: 29 ms).  A function of the data alone, like the first probe: the
 // same solve takes the same kernels every time.  One read-back for all the dimensions given.
-void policy_reprobe(int count, const double *const *a, const double *const *b, const double *c, const int *ns, int nds, const int *dims,
+void policy_reprobe(int kind, int count, const double *const *a, const double *const *b, const double *c, const int *ns, int nds, const int *dims,
                     hipStream_t s) {
     if (options().chunk_mode >= 0) return;
     ChunkScratch &st = chunk_state();
@@ -117,7 +117,7 @@ void policy_reprobe(int count, const double *const *a, const double *const *b, c
         PTV_HIP(hipMemsetAsync(dev, 0, sizeof(unsigned) * kWords, s));
         edge_histogram(a[k], nullptr, (long)g.len * g.count, g.inc, g.len, dev, s, b ? b[k] : nullptr, c ? c[k] : 0.0);
         PTV_HIP(hipMemcpyAsync(st.probes[slot].hist, dev, sizeof(unsigned) * kWords, hipMemcpyDeviceToHost, s));
-        st.probes[slot].iterate = true;
+        st.probes[slot].iterate = kind;
         any = true;
     }
     if (any) PTV_HIP(hipStreamSynchronize(s));

@@ -29,9 +29,11 @@ long certify_sweep(OpId op, bool weighted, const SweepArgs &args, const FibreGeo
 // kernels, or that this solve has already sampled, are skipped.  Call after chunk_stats_reset(), before the first sweep.
 void policy_probe(const double *y, const double *const *weights, const int *ns, int nds, const int *dims, int ndims, hipStream_t s);
 // mid-solve: the operands of the next sweeps along dims[k] are a[k] + c[k] b[k] (b / c may be null): sample them in place of the solve's input
-void policy_reprobe(int count, const double *const *a, const double *const *b, const double *c, const int *ns, int nds, const int *dims, hipStream_t s);
-// ... before the sweeps of these iterations (1-based) of a loop: 2, 3, 5, 9, 17, 33, ... -- iterates move fast at first
-inline bool reprobe_at(int it) { return it >= 2 && ((it - 1) & (it - 2)) == 0; }
+// (kind: 1 = a Dykstra loop's x + p, 2 = an ADMM loop's X - U / rho: policy.hpp reads their certain fractions differently)
+void policy_reprobe(int kind, int count, const double *const *a, const double *const *b, const double *c, const int *ns, int nds, const int *dims, hipStream_t s);
+// ... before the sweeps of these iterations (1-based) of a loop: 2, 3, 5, 9, 17, 33, ... -- Dykstra's operands settle within a few iterations;
+// `steady`: and every fourth one from 9 on -- ADMM's keep drifting
+inline bool reprobe_at(int it, bool steady = false) { return it >= 2 && (((it - 1) & (it - 2)) == 0 || (steady && it > 9 && (it - 9) % 4 == 0)); }
 
 // Fibres that the chunked path had to re-solve sequentially (unproven chunk links) since the last reset, on this thread.
 void chunk_stats_reset(hipStream_t s);

@@ -120,7 +120,7 @@ struct ChunkScratch {
         long inc = 0, count = 0;
         int len = 0;
         bool weighted = false;
-        bool iterate = false;              // sampled mid-solve from the operand of a Dykstra / ADMM sweep (policy_reprobe), not from the solve's input
+        int iterate = 0;                   // sampled mid-solve from the operand of a sweep (policy_reprobe), not from the solve's input: 1 = Dykstra (x + p), 2 = ADMM (Yang)
         unsigned hist[kProbeWords] = {};   // edges | stretches (pointwise.hpp)
     };
     static constexpr int kMaxProbes = 8;
@@ -167,7 +167,7 @@ struct ChunkScratch {
         // quiet stretches have pieces far longer than any zone and every chunk in them would go to the repair kernel.
         if (flat_fraction(g, lam, weighted) > kSeedFlat) return 3;
         const Probe *p = find_probe(g, weighted);
-        return rung_from_certain_fraction(f, p && p->iterate);
+        return rung_from_certain_fraction(f, p && p->iterate == 1);
     }
 
     static constexpr int kSlots = 8, kCounters = 2 * FAM_COUNT;
@@ -575,10 +575,12 @@ void launch_chunk(const SweepArgs &args, const FibreGeom &g, hipStream_t stream,
         // hit the level cap on periodic data) -- the global-memory chunks below take the sweep
         // (knots known a priori: none to be had where the sampled input shows no edge above 4 lambda -- lambda = 3 on unit noise: the
         // search costs 3-6 % of such a sweep; unsampled inputs search)
-        // (2, the default: knots known by windows as well -- pincore.hpp -- which find knots where no jump reaches 4 lambda: on unit noise
-        // up to lambda ~ 3; where hardly an edge of the input reaches half a penalty the windows have nothing to find either)
-        const double half_f = st.edge_fraction_above(g, args.lam, WEIGHTED, 0.5);
-        const int seeds = (options().pin_seed >= 2 && (half_f < 0.0 || half_f >= kSeedWindows)) ? 2 : ((options().pin_seed && (seed_f < 0.0 || seed_f >= kSeedPins)) ? 1 : 0);
+        // (option pin_seed: 0 none; 1 jumps above 4 lambda, where the sampled input has any; 2, the default: the deepest knots of windows as well
+        // -- pincore.hpp --, which find knots where no jump reaches 4 lambda.  No statistic of the input's EDGES says whether windows will: a
+        // smooth image under a little noise has none above half a penalty and a knot in every 64-knot window (4096^2 DR, smooth field + 0.1 N(0,1)
+        // at lambda = 0.5: 31.6 ms without them, 21.3 with) -- so they always run, and gate their stages themselves, wave by wave: 3 us a sweep
+        // where the first stage finds nothing.  Unsampled inputs search both ways.)
+        const int seeds = ((options().pin_seed >= 1 && (seed_f < 0.0 || seed_f >= kSeedPins)) ? 1 : 0) | (options().pin_seed >= 2 ? 2 : 0);
         pinned_done = launch_pin((OpId)OP, WEIGHTED, args, g, stream, pieces, seeds);
         count_event(pinned_done ? CNT_PIN_SWEEPS : CNT_PIN_CAP_NEXT_RUNG);
         if (pinned_done) count_event(CNT_SWEEP_LAUNCHES);

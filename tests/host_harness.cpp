@@ -344,23 +344,30 @@ static int pin_fibre(const double *y, const double *w, double lam, double *x, in
                     pa[(size_t)t] = ghost[(size_t)t].win64_part(sh, Sk((t - qa) * P), Sk((t - qa) * P + 64), qa);
                     pb[(size_t)t] = ghost[(size_t)t].win64_part(sh, Sk((t - qb) * P), Sk((t - qb) * P + 64), qb);
                 }
-                auto wave_any = [&](int base, const std::vector<Mask> &a, const std::vector<Mask> &b) {
-                    bool any = false;
-                    for (int l = 0; l < 64; l++) any = any || (a[(size_t)(base + l)] | b[(size_t)(base + l)]) != 0;
-                    return any;
+                auto wave_has = [&](int base, const std::vector<Mask> &a, const std::vector<Mask> &b, int lanes_needed) {
+                    int found = 0;
+                    for (int l = 0; l < 64; l++) found += (a[(size_t)(base + l)] | b[(size_t)(base + l)]) != 0;
+                    return found >= lanes_needed;
                 };
-                for (int t = 0; t < padded; t++) {
-                    const int l = t & 63, base = t - l, qa = t & 3, qb = (t + 2) & 3;
+                for (int t = 0; t < padded; t++) {   // 64 knots, the plain grid
+                    const int l = t & 63, base = t - l, qa = t & 3;
                     auto in_wave = [&](int lane_in_wave) { return (size_t)(base + (lane_in_wave & 63)); };
                     const int m = l ^ 2;   // (second step of the butterfly: the partner's joined pair)
                     const Win all_a = Lane::wjoin(Lane::wjoin(pa[in_wave(l)], pa[in_wave(l ^ 1)]), Lane::wjoin(pa[in_wave(m)], pa[in_wave(m ^ 1)]));
-                    const int partner = qb < 2 ? l + 2 : l - 2, mb = partner & 63;
-                    const Win all_b = Lane::wjoin(Lane::wjoin(pb[in_wave(l)], pb[in_wave(l ^ 1)]), Lane::wjoin(pb[in_wave(mb)], pb[in_wave(mb ^ 1)]));
                     ghost[(size_t)t].win64_take(lam, all_a, true, qa, 4, ups[(size_t)t], los[(size_t)t]);
-                    ghost[(size_t)t].win64_take(lam, all_b, partner >= 0 && partner < 64, qb, 2, ups[(size_t)t], los[(size_t)t]);
+                }
+                for (int base = 0; base < padded; base += 64) {   // ... the shifted grid, in the waves where the plain one found a knot
+                    if (!wave_has(base, ups, los, 1)) continue;
+                    for (int t = base; t < base + 64; t++) {
+                        const int l = t - base, qb = (t + 2) & 3;
+                        auto in_wave = [&](int lane_in_wave) { return (size_t)(base + (lane_in_wave & 63)); };
+                        const int partner = qb < 2 ? l + 2 : l - 2, mb = partner & 63;
+                        const Win all_b = Lane::wjoin(Lane::wjoin(pb[in_wave(l)], pb[in_wave(l ^ 1)]), Lane::wjoin(pb[in_wave(mb)], pb[in_wave(mb ^ 1)]));
+                        ghost[(size_t)t].win64_take(lam, all_b, partner >= 0 && partner < 64, qb, 2, ups[(size_t)t], los[(size_t)t]);
+                    }
                 }
                 for (int base = 0; base < padded; base += 64) {
-                    if (!wave_any(base, ups, los)) continue;
+                    if (!wave_has(base, ups, los, kSeedStage16)) continue;
                     for (int t = base; t < base + 64; t++)
                         ghost[(size_t)t].win16_parts(sh, lam, Sk(t * P), Sk(t * P + 24), Sk(t * P - 8), up16[(size_t)t], lo16[(size_t)t], tail[(size_t)t], head[(size_t)t]);
                     for (int t = base; t < base + 64; t++) {
@@ -368,7 +375,7 @@ static int pin_fibre(const double *y, const double *w, double lam, double *x, in
                         ghost[(size_t)t].win16_take(lam, tail[(size_t)t], head[(size_t)(base + ((l + 1) & 63))], l < 63, tail[(size_t)(base + ((l + 63) & 63))],
                                                     head[(size_t)t], l > 0, up16[(size_t)t], lo16[(size_t)t]);
                     }
-                    const bool finer = wave_any(base, up16, lo16);
+                    const bool finer = wave_has(base, up16, lo16, kSeedStage4);
                     for (int t = base; t < base + 64; t++) {
                         ups[(size_t)t] |= up16[(size_t)t];
                         los[(size_t)t] |= lo16[(size_t)t];

@@ -11,6 +11,7 @@ Cases (device-resident, 4096^2 unit noise unless said otherwise):
     c2[@lam]   tv1_2d DR, 35 iterations (default lambda 0.1)      c3[@scale]  weighted DR, w ~ U(0.5, 1.5) * scale * 0.1
     pd2        tv1_2d PD2                                          yang2      tv1_2d Yang
     c4 / c4y   tvgen PD_TV / Yang3 on 512 x 512 x 64               s<N>       tv1_2d DR on an N x N image (small images)
+    hard[@lam] tv1_2d DR on 8 x 8 random blocks + 0.2 N(0,1) (default lambda 0.5)
     prox0 / prox1 [@lam]   one OP_PROX sweep along dim 0 / 1      wprox0 / wprox1   weighted
 Per case: min and median wall time of the call, and -- from a second pass with option "profile" -- the mean launch time of the
 column / row sweep families in microseconds (hipEvent pairs on the library's stream).
@@ -59,6 +60,14 @@ def child(cases, reps, knobs):
             sc = (float(arg) if arg else 1.0) * 0.1
             W1, W2 = dev(cache["w"][0] * sc), dev(cache["w"][1] * sc)
             return lambda: device.tv1w_2d(X, W1, W2, out=out), 4096 * 4096
+        if name == "hard":   # bench.py's back-tracking image: 8 x 8 random blocks + 0.2 N(0,1), lambda 0.5 unless said otherwise
+            if "hard" not in cache:
+                r7 = np.random.default_rng(7)
+                cache["hard"] = (dev(np.kron(r7.standard_normal((8, 8)), np.ones((512, 512))) + 0.2 * r7.standard_normal((4096, 4096))),
+                                 device.colmajor_empty((4096, 4096)))
+            Xh, hout = cache["hard"]
+            hl = float(arg) if arg else 0.5
+            return lambda: device.tv1_2d(Xh, hl, out=hout), 4096 * 4096
         if name in ("pd2", "yang2"):
             X, out = image(4096)
             return lambda: device.tv1_2d(X, lam, method="pd" if name == "pd2" else "yang", out=out), 4096 * 4096

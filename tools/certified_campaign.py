@@ -2,7 +2,10 @@
 """Full-size solves under the certifier (option certify): every sweep of every iteration -- late iterates with their near-ties included --
 is checked against the optimality conditions of the prox, fibre by fibre.  Prints one line per solve; exits non-zero if a fibre failed.
 
-    python tools/certified_campaign.py [seconds] [seed]
+    python tools/certified_campaign.py [seconds] [seed] [high]
+
+high: penalties from 0.4 to 4 times the edges' spread -- pieces of tens to hundreds of samples: the pinning rung with its knots known by
+windows, and the mid-solve samples of the Dykstra / ADMM operands that send a solve there.
 
 (Round 6: the first full-size certified PD2 solve found an edge of -4.00000006 lambda that the known-runs path mishandled, 3e-9 off in
 two rows -- tests/golden/sliver_edge_fibre.npz.)"""
@@ -14,6 +17,7 @@ from proxtv_amd import _lib, device
 lib = _lib.require_device()
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+high = len(sys.argv) > 3 and sys.argv[3] == "high"
 rng = np.random.default_rng(seed)
 lib.proxtv_set_option(b"certify", 1)
 lib.proxtv_set_option(b"verbose", 1)
@@ -29,7 +33,7 @@ while time.time() < t_end:
     elif kind == 2: X = np.round(rng.standard_normal(shape) * 4) * 0.25
     else:           X = np.cumsum(rng.standard_normal(shape), axis=int(rng.integers(0, 2))) * 0.1 + rng.standard_normal(shape)
     scale = float(np.std(np.diff(X, axis=0)))
-    lam = float(scale * 10 ** rng.uniform(-1.6, -0.2))      # from "every edge is a bend" to pieces of a few samples
+    lam = float(scale * 10 ** (rng.uniform(-0.4, 0.6) if high else rng.uniform(-1.6, -0.2)))      # from "every edge is a bend" to pieces of a few samples
     method = ["dr", "pd", "yang", "dr", "drw", "vol"][int(rng.integers(0, 6))]
     c0 = lib.proxtv_debug_counter(b"certify_failures"); s0 = lib.proxtv_debug_counter(b"certify_sweeps")
     if method == "vol":      # a volume through PD_TV (three terms) or Yang3: prox sweeps along every dimension, short and long fibres

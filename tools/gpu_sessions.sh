@@ -142,5 +142,22 @@ w4)   # operands of Dykstra / ADMM loops sampled mid-solve (policy_reprobe): par
   timeout 1200 python -m pytest tests/test_gpu_parity_2d.py tests/test_gpu_parity_nd.py tests/test_gpu_pin.py tests/test_gpu_large.py tests/test_gpu_boundary.py -m gpu -x -q > $OUT/pytest.log 2>&1; echo "parity + pin + large: $(tail -1 $OUT/pytest.log)" | tee $OUT/summary.txt
   ab --reps 3 --rounds 1 --cases pd2@0.1,pd2@0.3,pd2@0.5,pd2@0.7,pd2@1.0,yang2@0.1,yang2@0.3,yang2@0.5,yang2@1.0,yang2@3,c4y,c4,c4y@1.0,c4@1.0,c2@3,c2@5 base m1,chunk_mode=1 m3,chunk_mode=3 > $OUT/ab_pd_yang.txt 2>&1; cat $OUT/ab_pd_yang.txt
   ;;
+w6)   # window seeds + mid-solve samples, the whole suite; PD2 / Yang / DR over lambda under the default policy against the pinned rungs
+  timeout 1500 python -m pytest tests -m gpu -x -q --durations=8 > $OUT/pytest_default.log 2>&1; echo "default: $(tail -1 $OUT/pytest_default.log)" | tee $OUT/summary.txt
+  ab --reps 3 --rounds 1 --cases pd2@0.4,pd2@0.5,pd2@0.6,pd2@0.7,pd2@1.0,pd2@3,yang2@0.5,yang2@1.0,yang2@3,yang2@10,c4y,c4 base m1,chunk_mode=1 m3,chunk_mode=3 > $OUT/ab_pd_yang.txt 2>&1; cat $OUT/ab_pd_yang.txt
+  python tools/lambda_probe.py --modes -1 --lams 0.1,0.3,0.4,0.5,0.6,0.65,0.7,0.8,1.0,1.5,2.0,3.0,10.0,30.0 > $OUT/lambda_sweep.txt 2>&1; cat $OUT/lambda_sweep.txt
+  ;;
+w8)   # stages need two lanes; the policy's gate at 0.15; Yang sampled every fourth iteration and read with the general threshold
+  timeout 900 python -m pytest tests/test_gpu_pin.py tests/test_gpu_parity_2d.py -m gpu -x -q > $OUT/pytest.log 2>&1; echo "pin + parity 2d: $(tail -1 $OUT/pytest.log)" | tee $OUT/summary.txt
+  ab --reps 3 --rounds 1 --cases c2@1.0,c2@2,c2@3,c2@5,hard,hard@1.0,yang2@1.0,yang2@2,yang2@3,pd2@0.6,pd2@3 base jumps,pin_seed=1 m3,chunk_mode=3 > $OUT/ab.txt 2>&1; cat $OUT/ab.txt
+  ;;
+final4)  # window seeds (always on, stages gated wave by wave) + mid-solve samples: the whole suite, smoke, soaks with the options drawn at random, a certified campaign
+  timeout 1500 python -m pytest tests -m gpu -x -q --durations=8 > $OUT/pytest_default.log 2>&1; echo "default: $(tail -1 $OUT/pytest_default.log)" | tee $OUT/summary.txt
+  python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; tail -1 $OUT/smoke.log | tee -a $OUT/summary.txt
+  PROXTV_CHUNK_MODE=3 timeout 900 python -m pytest tests/test_gpu_chunk_repair.py tests/test_gpu_parity_2d.py tests/test_gpu_parity_nd.py tests/test_gpu_boundary.py tests/test_gpu_large.py -m gpu -x -q > $OUT/pytest_mode3.log 2>&1; echo "pinned rung 3: $(tail -1 $OUT/pytest_mode3.log)" | tee -a $OUT/summary.txt
+  { python tools/fuzz.py 240 671; python tools/fuzz.py 240 672; python tools/fuzz.py 60 673 nd; python tools/fuzz.py 120 674 long; } > $OUT/fuzz.txt 2>&1; grep "^fuzz\|MISMATCH\|Error" $OUT/fuzz.txt | tee -a $OUT/summary.txt
+  python tools/certified_campaign.py 100 5 > $OUT/campaign_5.txt 2>&1; tail -1 $OUT/campaign_5.txt | tee -a $OUT/summary.txt
+  python tools/certified_campaign.py 150 6 high > $OUT/campaign_6_high.txt 2>&1; tail -1 $OUT/campaign_6_high.txt | tee -a $OUT/summary.txt; grep "certify:" $OUT/campaign_6_high.txt | cut -c1-260 | head -10 | tee -a $OUT/summary.txt
+  ;;
 *) echo "unknown session $S";;
 esac
