@@ -61,6 +61,8 @@ constexpr double kSeedNoisy = 0.45;   // f at or above: rung 0
 constexpr double kSeedMid = 0.03;     // f at or above: rung 1 ; below: rung 3  (as sampled -- edges in the threshold's own eighth-octave bin do not count -- lambda = 0.7 on unit noise gives 0.034, 0.75-0.8 gives 0.022; at 0.8: 35.0 ms on rung 1, 34.0 on rung 3)
 constexpr double kSeedPins = 0.001;    // rung 3: the pinning solver searches for knots known a priori when f is at least this (lambda = 1 on unit noise: 0.005,
                                        // 29.4 against 30.0 ms per 4096^2 DR solve; 0.8: 25.3 against 31.8; 3: none to find, 18.3 against 19.1 with the search)
+constexpr double kSeedLongZones = 0.1;  // rung 3 on fibres of more than 16384 samples (the grid-wide pinning solver): 64-sample zones instead when at least this fraction
+                                       // of the edges is above ONE penalty (one fibre of 4 M samples, unit noise, rung 2 / rung 3: lambda 1: 0.13 / 27 ms, 2: 0.18 / 26, 3: 36 / 26)
 constexpr double kSeedJobs = 0.055;    // rung 1, option "repair_jobs" = 1: f below (as sampled: lambda >= 0.65 on unit noise -- 0.6 gives 0.065, 0.65 gives 0.048) the failed
                                        // links across workgroups go one lane each (4096^2 DR: lambda 0.6 14.27 -> 14.42 ms, 0.65 17.67 -> 17.33, 0.7 21.41 -> 19.97)
 constexpr double kSeedRuns = 0.70;     // rung 0, dimension-0 sweeps, f at or above: interior segments are cut at the bends known a priori and solved run by run

@@ -545,6 +545,13 @@ void launch_chunk(const SweepArgs &args, const FibreGeom &g, hipStream_t stream,
         // rung whose cost and exactness do not depend on the data
         mode = seed >= 0 ? seed : (pin_ok ? 3 : 0);
         if (mode == 1 && WEIGHTED && !pl.available(1, true)) mode = pl.up(mode);
+        // Fibres beyond one workgroup's LDS: the pinning solver is then a cooperative grid with grid-wide barriers between its steps (25 ms
+        // for 4 M samples whatever the data), and the along-fibre kernel with 64-sample zones a few thousand independent waves: 0.13-0.19 ms
+        // on noise at lambda = 1-2 -- until walks stop meeting within a zone (lambda = 3: 31-36 ms, every chunk through the repair kernel).
+        // Where a tenth of the edges still exceeds ONE penalty (unit noise: lambda <= 2.3) the zones have it.
+        if (mode == 3 && pin_ok && !WEIGHTED && TRANSPOSED && options().along && pin_is_long(false, g) &&
+            st.edge_fraction_above(g, args.lam, false, 1.0) >= kSeedLongZones)
+            mode = 2;
         if (options().verbose && (pl.sweeps == 0 || mode != pl.mode || seed_f != pl.shown_f))
             fprintf(stderr, "[proxtv_amd] policy: family %d sweep %ld (len %d x %ld fibres, lambda %g): certain fraction %.4f, seed %d -> mode %d\n", fam,
                     pl.sweeps, g.len, g.count, args.lam, seed_f, seed, mode);

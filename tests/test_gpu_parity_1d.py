@@ -117,6 +117,21 @@ def test_heavy_backtracking_long_fibre(ptv, oracle):
         assert_close(ptv.tv1_1d(x, lam), oracle.tv1_hybrid(x, lam), what=f"blocks lam={lam}")
 
 
+def test_long_fibres_at_penalties_around_the_noise_level(ptv, clib, oracle):
+    """Fibres beyond one workgroup's LDS (16384 samples) under the default policy: where the certain fraction asks for the pinning rung --
+    there a cooperative grid, milliseconds whatever the data -- but a tenth of the edges still exceeds one penalty, 64-sample zones take
+    the sweep (rung 2: a fraction of a millisecond); with longer pieces the pinning solver.  Exact either way."""
+    rng = np.random.default_rng(8)
+    for n in (20000, 300000):
+        x = rng.standard_normal(n) + 0.05 * np.cumsum(rng.standard_normal(n))
+        for lam, rung in ((0.5, 1), (1.0, 2), (2.0, 2), (6.0, 3)):
+            assert_close(ptv.tv1_1d(x, lam), oracle.tv1_hybrid(x, lam), what=f"n={n} lam={lam}")
+            assert clib.proxtv_chunk_mode() == rung, (n, lam, clib.proxtv_chunk_mode())
+    x = np.repeat(rng.standard_normal(60), 5000) + 0.3 * rng.standard_normal(300000)     # blocks: lively edges, pieces of thousands
+    for lam in (0.4, 1.0, 3.0):
+        assert_close(ptv.tv1_1d(x, lam), oracle.tv1_hybrid(x, lam), what=f"blocks lam={lam}")
+
+
 def test_classic_offset_symbol(clib, oracle):
     rng = np.random.default_rng(6)
     x = rng.standard_normal(300)
