@@ -78,7 +78,15 @@ constexpr double kSeedDrFormWeighted = 0.2;
 // their certain fraction falls all through the solve (lambda = 2: 0.35 at iteration 3, 0.005 at 9, 0 at 33), and rung 1 at 0.005 on its way
 // to 0 cost 73 ms a solve against 30.
 constexpr double kSeedMidDykstra = 0.004;
-inline int rung_from_certain_fraction(double f, bool dykstra = false) { return f >= kSeedNoisy ? 0 : (f >= (dykstra ? kSeedMidDykstra : kSeedMid) ? 1 : 3); }
+// Small sweeps (up to kSmallSweep samples: 1024^2): a repair launch costs what it costs whatever the image, a sweep of the pinning solver a
+// sixteenth of what it costs at 4096^2 -- the chunk kernels give way earlier (1024^2 unit noise, rung 1 / rung 3: DR at lambda = 0.7, f = 0.034:
+// 6.0 / 3.3 ms; PD2 at lambda = 0.5, f = 0.022: 6.4 / 5.4 ms; DR at lambda = 0.5, f = 0.16: 2.4 / 3.1)
+constexpr long kSmallSweep = 1L << 21;
+constexpr double kSeedMidSmall = 0.06;
+inline int rung_from_certain_fraction(double f, bool dykstra = false, bool small = false) {
+    const double mid = small ? kSeedMidSmall : (dykstra ? kSeedMidDykstra : kSeedMid);
+    return f >= kSeedNoisy ? 0 : (f >= mid ? 1 : 3);
+}
 
 struct GeometryPolicy {
     int mode = 0;            // incumbent geometry

@@ -102,9 +102,9 @@ void policy_probe(const double *y, const double *const *weights, const int *ns, 
 // run at lambda / rho on averages of smoothed copies (4096^2 unit noise at lambda = 1 on the rung the input asks for: 129 ms a solve,
 // at lambda = 3: seven seconds; on the rung the operands ask for: 29 ms).  A function of the data alone, like the first probe: the
 // same solve takes the same kernels every time.  One read-back for all the dimensions given.
-void policy_reprobe(int kind, int count, const double *const *a, const double *const *b, const double *c, const int *ns, int nds, const int *dims,
-                    hipStream_t s) {
-    if (options().chunk_mode >= 0) return;
+bool policy_reprobe(int kind, int count, const double *const *a, const double *const *b, const double *c, const double *lams, const int *ns, int nds,
+                    const int *dims, hipStream_t s) {
+    if (options().chunk_mode >= 0) return true;   // (a pinned rung: nothing to decide, now or later)
     ChunkScratch &st = chunk_state();
     constexpr size_t kWords = kProbeWords;
     bool any = false;
@@ -120,8 +120,16 @@ void policy_reprobe(int kind, int count, const double *const *a, const double *c
         st.probes[slot].iterate = kind;
         any = true;
     }
-    if (any) PTV_HIP(hipStreamSynchronize(s));
+    if (!any) return true;
+    PTV_HIP(hipStreamSynchronize(s));
     count_event(CNT_REPROBES);
+    // every sampled dimension on the rung whose cost does not depend on the data: the loop need not ask again (its iterates only get smoother)
+    bool top = true;
+    for (int k = 0; k < count; k++) {
+        const FibreGeom g = fibres_along(ns, nds, dims[k]);
+        if (st.find_probe(g, false)) top = top && st.seed(g, lams[k], false) >= 3;
+    }
+    return top;
 }
 
 // The rung (0 or 1) a strided sweep of this geometry will take on the 64-fibre tile, -1 when it will not run there (transposed

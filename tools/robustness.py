@@ -60,9 +60,10 @@ def child(mode, n, only):
             V, out = dev(np.random.default_rng(0).standard_normal((512, 512, 64))), device.colmajor_empty((512, 512, 64))
             run = lambda: device.tvgen(V, [lam, lam, lam / 2], [1, 2, 3], method="yang" if method == "yang3" else None, out=out)
         elif method == "batch":
-            B = torch.stack([ims[im][: n // 2, : n // 2].clone() for _ in range(8)])
-            Bx = torch.empty_strided((8, n // 2, n // 2), (n * n // 4, 1, n // 2), dtype=torch.float64, device="cuda")
-            Bx.copy_(B)
+            m = n // 2
+            Bx = torch.empty_strided((m, m, 8), (1, m, m * m), dtype=torch.float64, device="cuda")
+            for b in range(8):
+                Bx[:, :, b] = ims[im][(b % 2) * m:(b % 2 + 1) * m, (b // 2 % 2) * m:(b // 2 % 2 + 1) * m]
             bout = torch.empty_strided(Bx.shape, Bx.stride(), dtype=torch.float64, device="cuda")
             run = lambda: device.tv1_2d_batch(Bx, lam, out=bout)
         else:
