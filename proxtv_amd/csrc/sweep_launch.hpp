@@ -549,7 +549,7 @@ void launch_chunk(const SweepArgs &args, const FibreGeom &g, hipStream_t stream,
         // for 4 M samples whatever the data), and the along-fibre kernel with 64-sample zones a few thousand independent waves: 0.13-0.19 ms
         // on noise at lambda = 1-2 -- until walks stop meeting within a zone (lambda = 3: 31-36 ms, every chunk through the repair kernel).
         // Where a tenth of the edges still exceeds ONE penalty (unit noise: lambda <= 2.3) the zones have it.
-        if (mode == 3 && pin_ok && !WEIGHTED && TRANSPOSED && options().along && pin_is_long(false, g) &&
+        if (mode == 3 && pin_ok && !WEIGHTED && options().along && g.len >= kAlongMinLen && pin_is_long(false, g) &&
             st.edge_fraction_above(g, args.lam, false, 1.0) >= kSeedLongZones)
             mode = 2;
         if (options().verbose && (pl.sweeps == 0 || mode != pl.mode || seed_f != pl.shown_f))

@@ -127,6 +127,10 @@ def test_long_fibres_at_penalties_around_the_noise_level(ptv, clib, oracle):
         for lam, rung in ((0.5, 1), (1.0, 2), (2.0, 2), (6.0, 3)):
             assert_close(ptv.tv1_1d(x, lam), oracle.tv1_hybrid(x, lam), what=f"n={n} lam={lam}")
             assert clib.proxtv_chunk_mode() == rung, (n, lam, clib.proxtv_chunk_mode())
+    X = rng.standard_normal((24, 40000))                                                 # long STRIDED fibres (rows), and long columns
+    for lam in (1.0, 4.0):
+        assert_close(ptv.tv1_2d(X, lam, max_iters=3), oracle.dr2(X, lam, max_iters=3)[0], tol=1e-9, what=f"24 x 40000 lam={lam}")
+        assert_close(ptv.tv1_2d(X.T.copy(), lam, max_iters=3), oracle.dr2(X.T.copy(), lam, max_iters=3)[0], tol=1e-9, what=f"40000 x 24 lam={lam}")
     x = np.repeat(rng.standard_normal(60), 5000) + 0.3 * rng.standard_normal(300000)     # blocks: lively edges, pieces of thousands
     for lam in (0.4, 1.0, 3.0):
         assert_close(ptv.tv1_1d(x, lam), oracle.tv1_hybrid(x, lam), what=f"blocks lam={lam}")
