@@ -247,7 +247,7 @@ SolveInfo pd2(const double *y, const double *lambdas, const double *dims, double
 
     double stop = DBL_MAX;
     int iters = 0;
-    bool settled0 = false, settled1 = false;   // (that term's sweeps are on the pinning rung: no more samples of its operand)
+    bool settled0 = false, settled1 = false;   // (that term's sweeps are on the pinning rung, or its operand has stopped moving: no more samples of it)
     while (stop > STOP_PD && (npen > 1 || !iters) && iters < maxIters) {   // :157
         if (l2a) {   // z = prox2(x + p) ; p += x - z     (unfused: the TV-L2 prox is its own kernel)
             lincomb(po, xc, 1.0, pi, 1.0, nullptr, 0, nullptr, 0, n, s);
@@ -257,7 +257,7 @@ SolveInfo pd2(const double *y, const double *lambdas, const double *dims, double
             if (!settled0 && reprobe_at(iters + 1)) {   // (the operand x + p is not the solve's input; the loop reads a value back every iteration anyway)
                 const double *as[1] = {xc}, *bs[1] = {pi};
                 const double cs[1] = {1.0};
-                settled0 = policy_reprobe(1, 1, as, bs, cs, &lambdas[0], ns, nds, &d0, s);
+                settled0 = policy_reprobe(1, 1, as, bs, cs, &lambdas[0], ns, nds, &d0, s) != kReprobeAskAgain;
             }
             SweepArgs a;
             a.a = xc; a.b = pi; a.o0 = z.d(); a.o1 = po; a.lam = lambdas[0];
@@ -274,7 +274,7 @@ SolveInfo pd2(const double *y, const double *lambdas, const double *dims, double
                 if (!settled1 && reprobe_at(iters + 1)) {
                     const double *as[1] = {z.d()}, *bs[1] = {qi};
                     const double cs[1] = {1.0};
-                    settled1 = policy_reprobe(1, 1, as, bs, cs, &lambdas[1], ns, nds, &d1, s);
+                    settled1 = policy_reprobe(1, 1, as, bs, cs, &lambdas[1], ns, nds, &d1, s) != kReprobeAskAgain;
                 }
                 SweepArgs b;
                 b.a = z.d(); b.b = qi; b.o0 = xn; b.o1 = qo; b.lam = lambdas[1];
@@ -349,7 +349,7 @@ SolveInfo pd_like(bool dr_variant, const double *y, const double *lambdas, const
     }
     double stop = dr_variant ? 0.0 : DBL_MAX;
     int iters = 0;
-    bool settled = false;   // (every term's sweeps are on the pinning rung: no more samples of the operands)
+    bool settled = false;   // (every term's sweeps are on the pinning rung, or the operands have stopped moving: no more samples of them)
     while ((dr_variant || stop > STOP_PD) && iters < maxIters) {
         if (!settled && reprobe_at(iters + 1) && npen <= 8) {   // the operands z_i drift away from the solve's input
             std::vector<const double *> as((size_t)npen);
@@ -365,7 +365,7 @@ SolveInfo pd_like(bool dr_variant, const double *y, const double *lambdas, const
                 ls[(size_t)m] = lambdas[i];
                 ds[(size_t)m++] = (int)(dims[i] - 1);
             }
-            if (m > 0) settled = policy_reprobe(1, m, as.data(), nullptr, nullptr, ls.data(), ns, nds, ds.data(), s);
+            if (m > 0) settled = policy_reprobe(1, m, as.data(), nullptr, nullptr, ls.data(), ns, nds, ds.data(), s) != kReprobeAskAgain;
         }
         for (int i = 0; i < npen; i++) {
             const int d = (int)(dims[i] - 1);
@@ -425,13 +425,14 @@ SolveInfo yang(const int *ns, int nds, const int *order, const double *lambdas, 
     PTV_HIP(hipMemcpyAsync(X, Y, bytes, hipMemcpyDeviceToDevice, s));
     policy_probe(Y, nullptr, ns, nds, order, nds, s);
     bool settled = false;   // (every dimension on the pinning rung: no more samples)
+    bool steady = true;     // (sample every fourth iteration from the ninth on, not only at 17 and 33: unless the last sample was calm)
 
     for (int it = 1; it <= maxit; it++) {
         {
             FamilyTimer tm(FAM_OTHER, s);
             yang_x(Y, Uin, Z.pack, X, nds, rho, n, s);
         }
-        if (!settled && reprobe_at(it, true)) {   // the sweeps' operands, X - U_k / rho, are not the solve's input: which rung they want is theirs to say
+        if (!settled && reprobe_at(it, steady)) {   // the sweeps' operands, X - U_k / rho, are not the solve's input: which rung they want is theirs to say
             const double *as[kMaxTerms], *bs[kMaxTerms];
             double cs[kMaxTerms], ls[kMaxTerms];
             for (int k = 0; k < nds; k++) {
@@ -440,7 +441,9 @@ SolveInfo yang(const int *ns, int nds, const int *order, const double *lambdas, 
                 cs[k] = -1.0 / rho;
                 ls[k] = lambdas[k] / rho;
             }
-            settled = policy_reprobe(2, nds, as, bs, cs, ls, ns, nds, order, s);
+            const int status = policy_reprobe(2, nds, as, bs, cs, ls, ns, nds, order, s);
+            settled = status == kReprobeSettled;
+            steady = status != kReprobeCalm;
         }
         for (int k = 0; k < nds; k++) {
             SweepArgs a;

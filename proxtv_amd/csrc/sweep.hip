@@ -102,14 +102,18 @@ void policy_probe(const double *y, const double *const *weights, const int *ns, 
 // run at lambda / rho on averages of smoothed copies (4096^2 unit noise at lambda = 1 on the rung the input asks for: 129 ms a solve,
 // at lambda = 3: seven seconds; on the rung the operands ask for: 29 ms).  A function of the data alone, like the first probe: the
 // same solve takes the same kernels every time.  One read-back for all the dimensions given.
-bool policy_reprobe(int kind, int count, const double *const *a, const double *const *b, const double *c, const double *lams, const int *ns, int nds,
-                    const int *dims, hipStream_t s) {
-    if (options().chunk_mode >= 0) return true;   // (a pinned rung: nothing to decide, now or later)
+int policy_reprobe(int kind, int count, const double *const *a, const double *const *b, const double *c, const double *lams, const int *ns, int nds,
+                   const int *dims, hipStream_t s) {
+    if (options().chunk_mode >= 0) return kReprobeSettled;   // (a pinned rung: nothing to decide, now or later)
     ChunkScratch &st = chunk_state();
     constexpr size_t kWords = kProbeWords;
     bool any = false;
-    for (int k = 0; k < count; k++) {
+    double f_before[ChunkScratch::kMaxProbes];
+    int seed_before[ChunkScratch::kMaxProbes];
+    for (int k = 0; k < count && k < ChunkScratch::kMaxProbes; k++) {
         const FibreGeom g = fibres_along(ns, nds, dims[k]);
+        f_before[k] = st.certain_fraction(g, lams[k], false);
+        seed_before[k] = st.seed(g, lams[k], false);
         const ChunkScratch::Probe *found = st.find_probe(g, false);
         if (!found) continue;   // (not sampled at the start either: too small, or the kernel is not a matter of choice)
         const size_t slot = (size_t)(found - st.probes);
@@ -120,16 +124,24 @@ bool policy_reprobe(int kind, int count, const double *const *a, const double *c
         st.probes[slot].iterate = kind;
         any = true;
     }
-    if (!any) return true;
+    if (!any) return kReprobeSettled;
     PTV_HIP(hipStreamSynchronize(s));
     count_event(CNT_REPROBES);
-    // every sampled dimension on the rung whose cost does not depend on the data: the loop need not ask again (its iterates only get smoother)
-    bool top = true;
-    for (int k = 0; k < count; k++) {
+    // settled: every sampled dimension on the rung whose cost does not depend on the data (the iterates only get smoother).
+    // calm: Dykstra operands that stopped moving (same rung as before this sample, certain fraction within 15 %) ; ADMM operands
+    // deep in rung-0 territory (their certain fraction falls slowly from there: lambda / rho = 0.04-0.07 on unit noise: 0.90 -> 0.52 .. 0.84 -> 0.14
+    // over 32 iterations).
+    bool top = true, calm = true;
+    for (int k = 0; k < count && k < ChunkScratch::kMaxProbes; k++) {
         const FibreGeom g = fibres_along(ns, nds, dims[k]);
-        if (st.find_probe(g, false)) top = top && st.seed(g, lams[k], false) >= 3;
+        if (!st.find_probe(g, false)) continue;
+        const int seed = st.seed(g, lams[k], false);
+        const double f = st.certain_fraction(g, lams[k], false);
+        top = top && seed >= 3;
+        if (kind == 2) calm = calm && f >= kReprobeCalmAdmm;
+        else calm = calm && seed == seed_before[k] && f_before[k] >= 0.0 && fabs(f - f_before[k]) <= 0.15 * fmax(f_before[k], 1e-3);
     }
-    return top;
+    return top ? kReprobeSettled : (calm ? kReprobeCalm : kReprobeAskAgain);
 }
 
 // The rung (0 or 1) a strided sweep of this geometry will take on the 64-fibre tile, -1 when it will not run there (transposed

@@ -30,10 +30,13 @@ long certify_sweep(OpId op, bool weighted, const SweepArgs &args, const FibreGeo
 void policy_probe(const double *y, const double *const *weights, const int *ns, int nds, const int *dims, int ndims, hipStream_t s);
 // mid-solve: the operands of the next sweeps along dims[k] are a[k] + c[k] b[k] (b / c may be null): sample them in place of the solve's input
 // (kind: 1 = a Dykstra loop's x + p, 2 = an ADMM loop's X - U / rho: policy.hpp reads their certain fractions differently)
-// lams[k]: the penalty of the sweeps along dims[k].  Returns true when there is nothing left to ask: every sampled dimension now seeds the pinning
-// rung (or none was sampled, or the rung is pinned) -- the loop may stop sampling.
-bool policy_reprobe(int kind, int count, const double *const *a, const double *const *b, const double *c, const double *lams, const int *ns, int nds,
-                    const int *dims, hipStream_t s);
+// lams[k]: the penalty of the sweeps along dims[k].  Returns kReprobeSettled when there is nothing left to ask -- every sampled dimension now
+// seeds the pinning rung (or none was sampled, or the rung is pinned) --, kReprobeCalm when the operands have stopped moving (Dykstra: a loop
+// may stop sampling) or sit deep in rung-0 territory (ADMM: the sparse schedule will do), kReprobeAskAgain otherwise.
+constexpr int kReprobeAskAgain = 0, kReprobeSettled = 1, kReprobeCalm = 2;
+constexpr double kReprobeCalmAdmm = 0.7;
+int policy_reprobe(int kind, int count, const double *const *a, const double *const *b, const double *c, const double *lams, const int *ns, int nds,
+                   const int *dims, hipStream_t s);
 // ... before the sweeps of these iterations (1-based) of a loop: 2, 3, 5, 9, 17, 33, ... -- Dykstra's operands settle within a few iterations;
 // `steady`: and every fourth one from 9 on -- ADMM's keep drifting
 inline bool reprobe_at(int it, bool steady = false) { return it >= 2 && (((it - 1) & (it - 2)) == 0 || (steady && it > 9 && (it - 9) % 4 == 0)); }
