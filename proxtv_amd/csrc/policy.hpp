@@ -88,6 +88,11 @@ inline int rung_from_certain_fraction(double f, bool dykstra = false, bool small
     return f >= kSeedNoisy ? 0 : (f >= mid ? 1 : 3);
 }
 
+// Mid-solve samples of the operands of Dykstra / ADMM sweeps (sweep.hip: policy_reprobe) are taken before the sweeps of these iterations
+// (1-based) of a loop: 2, 3, 5, 9, 17, 33, ... -- Dykstra's operands settle within a few iterations; `steady`: and every fourth one from 9 on --
+// ADMM's keep drifting
+inline bool reprobe_at(int it, bool steady = false) { return it >= 2 && (((it - 1) & (it - 2)) == 0 || (steady && it > 9 && (it - 9) % 4 == 0)); }
+
 struct GeometryPolicy {
     int mode = 0;            // incumbent geometry
     double t_mode = 0.0;     // ms of its last measured sweep

@@ -37,9 +37,7 @@ constexpr int kReprobeAskAgain = 0, kReprobeSettled = 1, kReprobeCalm = 2;
 constexpr double kReprobeCalmAdmm = 0.7;
 int policy_reprobe(int kind, int count, const double *const *a, const double *const *b, const double *c, const double *lams, const int *ns, int nds,
                    const int *dims, hipStream_t s);
-// ... before the sweeps of these iterations (1-based) of a loop: 2, 3, 5, 9, 17, 33, ... -- Dykstra's operands settle within a few iterations;
-// `steady`: and every fourth one from 9 on -- ADMM's keep drifting
-inline bool reprobe_at(int it, bool steady = false) { return it >= 2 && (((it - 1) & (it - 2)) == 0 || (steady && it > 9 && (it - 9) % 4 == 0)); }
+// (the schedule of the samples: policy.hpp, reprobe_at)
 
 // Fibres that the chunked path had to re-solve sequentially (unproven chunk links) since the last reset, on this thread.
 void chunk_stats_reset(hipStream_t s);

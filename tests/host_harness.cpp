@@ -747,6 +747,11 @@ int host_pin_fibre(const double *y, const double *w, double lam, double *x, int 
     return -1;
 }
 
+// the seeded policy's pure functions (policy.hpp): rung of a sweep from the certain fraction of its (sampled) input; iterations before
+// whose sweeps a Dykstra / ADMM loop samples its operands again
+int policy_rung(double f, int dykstra, int small) { return rung_from_certain_fraction(f, dykstra != 0, small != 0); }
+int policy_reprobe_at(int it, int steady) { return reprobe_at(it, steady != 0) ? 1 : 0; }
+
 // (the same without a pinning rung: rung 3 is the global-memory chunk kernel)
 int policy_sim(const double *cost, const double *frac, int switch_at, int solves, int sweeps, int len, int weighted,
                int start_mode, double *total_ms, int *trace) {

@@ -293,3 +293,19 @@ def test_both_forms_of_the_dr_iteration_on_the_host(harness, oracle):
         ref = oracle.dr2w(U, W1, W2)[0]
         for form in (0, 1):
             assert np.max(np.abs(dr(U, 0.0, 0.0, 35, form, W1, W2) - ref)) <= 1e-12 * np.max(np.abs(U)), (M, N, form)
+
+
+def test_seeded_policy_rungs_and_sample_schedule(harness):
+    """policy.hpp's pure functions: the rung a sampled certain fraction asks for -- general thresholds, the Dykstra operands' (x + p walks like
+    noisier data than its certain fraction says), small sweeps' (a repair launch costs what it costs whatever the image) -- and the iterations
+    before whose sweeps a loop samples its operands again."""
+    lib = harness
+    lib.policy_rung.argtypes = [C.c_double, C.c_int, C.c_int]
+    lib.policy_reprobe_at.argtypes = [C.c_int, C.c_int]
+    rung = lambda f, dykstra=0, small=0: lib.policy_rung(f, dykstra, small)
+    assert [rung(f) for f in (0.78, 0.45, 0.44, 0.03, 0.029, 0.0)] == [0, 0, 1, 1, 3, 3]
+    assert [rung(f, dykstra=1) for f in (0.5, 0.022, 0.009, 0.004, 0.0039, 0.001)] == [0, 1, 1, 1, 3, 3]
+    assert [rung(f, small=1) for f in (0.5, 0.16, 0.06, 0.059, 0.034)] == [0, 1, 1, 3, 3]
+    assert [rung(f, dykstra=1, small=1) for f in (0.16, 0.022)] == [1, 3]           # (small sweeps: one threshold for all operands)
+    assert [it for it in range(1, 40) if lib.policy_reprobe_at(it, 0)] == [2, 3, 5, 9, 17, 33]
+    assert [it for it in range(1, 40) if lib.policy_reprobe_at(it, 1)] == [2, 3, 5, 9, 13, 17, 21, 25, 29, 33, 37]
