@@ -131,40 +131,43 @@ __global__ __launch_bounds__(kPinThreads) void sweep_pin_kernel(SweepArgs p, Fib
     // knots known by windows (pincore.hpp: sixteen knots a lane, one penalty), coarse to fine, a stage only where the one before found
     // a knot somewhere in the wave; windows that span lanes are joined by lane shuffles -- the few that also span waves are left to
     // the levels
-    if constexpr (P == 16 && !WEIGHTED) {
-        if ((seeded & 2) && p.lam > 0.0) {
+    if constexpr (P == 16) {
+        if ((seeded & 2) && (WEIGHTED || p.lam > 0.0)) {
             using Lane = PinLane<P>;
             using Win = typename Lane::Win;
             using Mask = typename Lane::Mask;
             const int l = t & 63;
             auto Sk = [&](int j) { return Sp[Geo::sa(j < 0 ? 0 : (j > n ? n : j))]; };
+            auto Rk = [&](int j) { return WEIGHTED ? Wp[Geo::sa(j < 1 ? 1 : (j > n - 1 ? n - 1 : j))] : p.lam; };   // (windows that reach a fibre end are not taken)
             auto shfl_win = [](Win w, int src) { return Win{__shfl(w.mx, src), __shfl(w.mn, src)}; };
             Mask up = 0, lo = 0;
             {   // 64 knots: the plain grid first; the shifted one where that found a knot somewhere in the wave
                 const int qa = t & 3, qb = (t + 2) & 3;
-                const Win pa = ln.win64_part(sh, Sk((t - qa) * P), Sk((t - qa) * P + 64), qa);
+                const int a0 = (t - qa) * P, b0 = (t - qb) * P;
+                const Win pa = ln.win64_part(sh, Sk(a0), Rk(a0), Sk(a0 + 64), Rk(a0 + 64), qa);
                 Win all_a = Lane::wjoin(pa, shfl_win(pa, l ^ 1));
                 all_a = Lane::wjoin(all_a, shfl_win(all_a, l ^ 2));
-                ln.win64_take(p.lam, all_a, true, qa, 4, up, lo);
+                ln.win64_take(Lane::seed_threshold(Rk(a0), Rk(a0 + 64)), all_a, true, qa, 4, up, lo);
                 if (__ballot((up | lo) != 0) != 0ull) {
-                    const Win pb = ln.win64_part(sh, Sk((t - qb) * P), Sk((t - qb) * P + 64), qb);
+                    const Win pb = ln.win64_part(sh, Sk(b0), Rk(b0), Sk(b0 + 64), Rk(b0 + 64), qb);
                     Win all_b = Lane::wjoin(pb, shfl_win(pb, l ^ 1));
                     const int partner = qb < 2 ? l + 2 : l - 2;
                     all_b = Lane::wjoin(all_b, shfl_win(all_b, partner & 63));
-                    ln.win64_take(p.lam, all_b, partner >= 0 && partner < 64, qb, 2, up, lo);
+                    ln.win64_take(Lane::seed_threshold(Rk(b0), Rk(b0 + 64)), all_b, partner >= 0 && partner < 64, qb, 2, up, lo);
                 }
             }
             if (__popcll(__ballot((up | lo) != 0)) >= kSeedStage16) {
-                const double Sl = Sk(t * P);
+                const double Sl = Sk(t * P), rl = Rk(t * P);
                 Mask up16 = 0, lo16 = 0;
                 Win tail, head;
-                ln.win16_parts(sh, p.lam, Sl, Sk(t * P + 24), Sk(t * P - 8), up16, lo16, tail, head);
-                ln.win16_take(p.lam, tail, shfl_win(head, (l + 1) & 63), l < 63, shfl_win(tail, (l + 63) & 63), head, l > 0, up16, lo16);
+                double thr_tail, thr_head;
+                ln.win16_parts(sh, Sl, rl, Sk(t * P + 24), Rk(t * P + 24), Sk(t * P - 8), Rk(t * P - 8), up16, lo16, tail, head, thr_tail, thr_head);
+                ln.win16_take(tail, thr_tail, shfl_win(head, (l + 1) & 63), l < 63, shfl_win(tail, (l + 63) & 63), head, thr_head, l > 0, up16, lo16);
                 up |= up16;
                 lo |= lo16;
                 if (__popcll(__ballot((up16 | lo16) != 0)) >= kSeedStage4) {
                     int give;
-                    ln.win4_all(sh, p.lam, Sl, Sk(t * P + P + 1), Sk(t * P + P + 2), up, lo, give);
+                    ln.win4_all(sh, Sl, rl, Sk(t * P + P + 1), Rk(t * P + P + 1), Sk(t * P + P + 2), Rk(t * P + P + 2), up, lo, give);
                     ln.win4_take(__shfl(give, (l + 63) & 63), l > 0, up, lo);
                 }
             }

@@ -193,8 +193,8 @@ struct PinLane {
     // With one penalty for all interior knots both walls are copies of the sums, so ONE number per knot serves both walls:
     // W (chord_S(j) - S_j) = (S_a - S_j) W + (S_b - S_a)(j - a), above 2 lambda W: upper contact; below -2 lambda W: lower.
     // Windows used (unit noise at lambda = 1: pieces of 4-10 samples; tools measured on DR iterates: 10-12 levels become 4-6):
-    // 4, 16 and 64 knots, each on its own grid and on the grid shifted by half a window.  P = 16, unweighted; windows that
-    // touch the fibre ends (r = 0 there: the walls are not copies of the sums) are left out.
+    // 4, 16 and 64 knots, each on its own grid and on the grid shifted by half a window.  P = 16; windows that touch the
+    // fibre ends (r = 0 there) are left out.  With per-knot penalties the two walls are evaluated separately.
     // A lane evaluates its own knots; windows that span lanes are joined by the caller.  Values carry the knot's distance from
     // the window start in the low six bits of their mantissa (as PinTag does), so that "deepest and where" is one max and one
     // min per knot.
@@ -206,18 +206,33 @@ struct PinLane {
     PTV_PIN_FN static double wmin(double a, double b) { return pin_min(a, b); }
     PTV_PIN_FN static Win wjoin(Win a, Win b) { return Win{pin_max(a.mx, b.mx), wmin(a.mn, b.mn)}; }
     // window of W knots starting at own index e = A (own knot e, 1 <= e <= P, is knot t P + e; e = 0 and e > P are the
-    // neighbours'): the part over own knots e = E0 .. E1.  Sa, Sb: the sums at the window's ends.
+    // neighbours'): the part over own knots e = E0 .. E1.  (Sa, ra), (Sb, rb): the sums and half-widths at the window's ends.
+    // One penalty: one number per knot (see above).  Per-knot penalties: the upper wall's depth below its line in mx, the lower
+    // wall's height above its own -- negated -- in mn.
     template <int W, int A, int E0, int E1, class Sh>
-    PTV_PIN_FN Win win_part(const Sh &sh, double Sa, double Sb) const {
-        const double dl = Sb - Sa;
-        double lin = dl * (double)(E0 - A);
+    PTV_PIN_FN Win win_part(const Sh &sh, double Sa, double ra, double Sb, double rb) const {
         Win w{0.0, 0.0};
+        if constexpr (!Sh::kWeighted) {
+            const double dl = Sb - Sa;
+            double lin = dl * (double)(E0 - A);
 #pragma unroll
-        for (int e = E0; e <= E1; e++) {
-            const double v = wtag((Sa - sh.own(t, e - 1)) * (double)W + lin, e - A);
-            w.mx = pin_max(w.mx, v);
-            w.mn = wmin(w.mn, v);
-            lin += dl;
+            for (int e = E0; e <= E1; e++) {
+                const double v = wtag((Sa - sh.own(t, e - 1)) * (double)W + lin, e - A);
+                w.mx = pin_max(w.mx, v);
+                w.mn = wmin(w.mn, v);
+                lin += dl;
+            }
+        } else {
+            const double Ua = Sa + ra, La = Sa - ra, du = (Sb + rb) - Ua, dw = (Sb - rb) - La;
+            double linu = du * (double)(E0 - A), linl = dw * (double)(E0 - A);
+#pragma unroll
+            for (int e = E0; e <= E1; e++) {
+                const double sj = sh.own(t, e - 1), rj = sh.rown(t, e - 1);
+                w.mx = pin_max(w.mx, wtag((Ua - (sj + rj)) * (double)W + linu, e - A));
+                w.mn = wmin(w.mn, wtag((La - (sj - rj)) * (double)W + linl, e - A));
+                linu += du;
+                linl += dw;
+            }
         }
         return w;
     }
@@ -234,69 +249,99 @@ struct PinLane {
     // for one stage, not three.
     // Each stage: the lane's parts -> the caller joins them with the neighbours' (lane shuffles on the device, arrays in the
     // host harness; what would cross a wave is left to the levels) -> the lane takes what is its own.
-    PTV_PIN_FN static double seed_threshold(double lam) { return 2.0000002 * lam; }
+    // A window's threshold: the tube's width at its wider end (and a hair: rounding of the sums must not pin a knot ON the threshold).
+    PTV_PIN_FN static double seed_threshold(double ra, double rb) { return 2.0000002 * (ra > rb ? ra : rb); }
     // -- 64 knots: four lanes a window on the plain grid (lanes 4 m ..) and on the shifted grid (lanes 4 m + 2 ..); lane q of the
     // four holds the distances 16 q + 1 .. 16 q + 16 from the window's start (the last one is the window's end: left out).
-    // Sa, Sb: the sums at the window's ends.
     template <class Sh>
-    PTV_PIN_FN Win win64_part(const Sh &sh, double Sa, double Sb, int q) const {
+    PTV_PIN_FN Win win64_part(const Sh &sh, double Sa, double ra, double Sb, double rb, int q) const {
         static_assert(P == 16, "window seeds: sixteen knots per lane");
-        const double dl = Sb - Sa;
-        double lin = dl * (double)(16 * q + 1);
         Win w{0.0, 0.0};
+        if constexpr (!Sh::kWeighted) {
+            const double dl = Sb - Sa;
+            double lin = dl * (double)(16 * q + 1);
 #pragma unroll
-        for (int e = 1; e <= P; e++) {
-            double v = wtag((Sa - sh.own(t, e - 1)) * 64.0 + lin, (16 * q + e) & 63);
-            if (e == P) v = (q == 3) ? 0.0 : v;   // (distance 64: the window's own end)
-            w.mx = pin_max(w.mx, v);
-            w.mn = wmin(w.mn, v);
-            lin += dl;
+            for (int e = 1; e <= P; e++) {
+                double v = wtag((Sa - sh.own(t, e - 1)) * 64.0 + lin, (16 * q + e) & 63);
+                if (e == P) v = (q == 3) ? 0.0 : v;   // (distance 64: the window's own end)
+                w.mx = pin_max(w.mx, v);
+                w.mn = wmin(w.mn, v);
+                lin += dl;
+            }
+        } else {
+            const double Ua = Sa + ra, La = Sa - ra, du = (Sb + rb) - Ua, dw = (Sb - rb) - La;
+            double linu = du * (double)(16 * q + 1), linl = dw * (double)(16 * q + 1);
+#pragma unroll
+            for (int e = 1; e <= P; e++) {
+                const double sj = sh.own(t, e - 1), rj = sh.rown(t, e - 1);
+                double vu = wtag((Ua - (sj + rj)) * 64.0 + linu, (16 * q + e) & 63), vl = wtag((La - (sj - rj)) * 64.0 + linl, (16 * q + e) & 63);
+                if (e == P) {
+                    vu = (q == 3) ? 0.0 : vu;
+                    vl = (q == 3) ? 0.0 : vl;
+                }
+                w.mx = pin_max(w.mx, vu);
+                w.mn = wmin(w.mn, vl);
+                linu += du;
+                linl += dw;
+            }
         }
         return w;
     }
-    // all: the joined parts of the window's four lanes; q: the lane's place among them; first: the first lane index such a window
-    // may start at (4 on the plain grid, 2 on the shifted one: the windows before touch the fibre's first knot)
-    PTV_PIN_FN void win64_take(double lam, Win all, bool in_reach, int q, int first, Mask &up, Mask &lo) const {
-        const double thr = seed_threshold(lam) * 64.0;
+    // all: the joined parts of the window's four lanes; thr: the window's threshold; q: the lane's place among the four; first: the first
+    // lane index such a window may start at (4 on the plain grid, 2 on the shifted one: the windows before touch the fibre's first knot)
+    PTV_PIN_FN void win64_take(double thr, Win all, bool in_reach, int q, int first, Mask &up, Mask &lo) const {
         const int a = -16 * q;   // own index of the window's start
         const bool valid = in_reach && t - q >= first && a + 64 <= n - 1 - t * P;
         const int eu = a + wdist(all.mx), el = a + wdist(all.mn);
-        if (valid && all.mx > thr && eu >= 1 && eu <= P) up |= (Mask)1 << (eu - 1);
-        if (valid && -all.mn > thr && el >= 1 && el <= P) lo |= (Mask)1 << (el - 1);
+        if (valid && all.mx > thr * 64.0 && eu >= 1 && eu <= P) up |= (Mask)1 << (eu - 1);
+        if (valid && -all.mn > thr * 64.0 && el >= 1 && el <= P) lo |= (Mask)1 << (el - 1);
     }
-    // -- 16 knots: the lane's own window 0-16 (Sl = S(t P), the knot before the lane's first); of the shifted grid the first half
-    // of 8-24 (Sfar = S(t P + 24)) and the second half of (-8)-8 (Sback = S(t P - 8))
-#define PTV_S_AT(e) ((e) == 0 ? Sl : sh.own(t, ((e) > 0 ? (e) : 1) - 1))   // (a macro: the index stays a compile-time constant)
+    // -- 16 knots: the lane's own window 0-16 ((Sl, rl): knot t P, the one before the lane's first); of the shifted grid the first
+    // half of 8-24 ((Sfar, rfar): knot t P + 24) and the second half of (-8)-8 ((Sback, rback): knot t P - 8).  thr_tail / thr_head:
+    // the thresholds of the two shared windows, for win16_take.
+#define PTV_S_AT(e) ((e) == 0 ? Sl : sh.own(t, ((e) > 0 ? (e) : 1) - 1))   // (macros: the index stays a compile-time constant)
+#define PTV_R_AT(e) ((e) == 0 ? rl : sh.rown(t, ((e) > 0 ? (e) : 1) - 1))
     template <class Sh>
-    PTV_PIN_FN void win16_parts(const Sh &sh, double lam, double Sl, double Sfar, double Sback, Mask &up, Mask &lo, Win &tail, Win &head) const {
-        const Win w = win_part<16, 0, 1, 15>(sh, Sl, PTV_S_AT(16));
-        win_take<16, 0>(w, t > 0 && 16 <= n - 1 - t * P, seed_threshold(lam), up, lo);   // (the knot before lane 0's first is the fibre end)
-        tail = win_part<16, 8, 9, 16>(sh, PTV_S_AT(8), Sfar);
-        head = win_part<16, -8, 1, 7>(sh, Sback, PTV_S_AT(8));
+    PTV_PIN_FN void win16_parts(const Sh &sh, double Sl, double rl, double Sfar, double rfar, double Sback, double rback, Mask &up, Mask &lo,
+                                Win &tail, Win &head, double &thr_tail, double &thr_head) const {
+        const Win w = win_part<16, 0, 1, 15>(sh, Sl, rl, PTV_S_AT(16), PTV_R_AT(16));
+        win_take<16, 0>(w, t > 0 && 16 <= n - 1 - t * P, seed_threshold(rl, PTV_R_AT(16)), up, lo);   // (the knot before lane 0's first is the fibre end)
+        tail = win_part<16, 8, 9, 16>(sh, PTV_S_AT(8), PTV_R_AT(8), Sfar, rfar);
+        head = win_part<16, -8, 1, 7>(sh, Sback, rback, PTV_S_AT(8), PTV_R_AT(8));
+        thr_tail = seed_threshold(PTV_R_AT(8), rfar);
+        thr_head = seed_threshold(rback, PTV_R_AT(8));
     }
-    PTV_PIN_FN void win16_take(double lam, Win tail, Win next_head, bool has_next, Win prev_tail, Win head, bool has_prev, Mask &up, Mask &lo) const {
+    PTV_PIN_FN void win16_take(Win tail, double thr_tail, Win next_head, bool has_next, Win prev_tail, Win head, double thr_head, bool has_prev,
+                               Mask &up, Mask &lo) const {
         const int room = n - 1 - t * P;
-        win_take<16, 8>(wjoin(tail, next_head), has_next && 24 <= room, seed_threshold(lam), up, lo);
-        win_take<16, -8>(wjoin(prev_tail, head), has_prev && t * P >= 9 && 8 <= room, seed_threshold(lam), up, lo);
+        win_take<16, 8>(wjoin(tail, next_head), has_next && 24 <= room, thr_tail, up, lo);
+        win_take<16, -8>(wjoin(prev_tail, head), has_prev && t * P >= 9 && 8 <= room, thr_head, up, lo);
     }
     // -- 4 knots: plain grid 0-4, 4-8, 8-12, 12-16; shifted 2-6, 6-10, 10-14, and 14-18, which the lane evaluates alone with the next
-    // lane's first two knots (Sr1, Sr2 = S(t P + 17), S(t P + 18)); give: 1 / 2 = the NEXT lane's first knot touches the upper / lower wall
+    // lane's first two knots ((Sr1, rr1), (Sr2, rr2): knots t P + 17, t P + 18); give: 1 / 2 = the NEXT lane's first knot touches the
+    // upper / lower wall
     template <class Sh>
-    PTV_PIN_FN void win4_all(const Sh &sh, double lam, double Sl, double Sr1, double Sr2, Mask &up, Mask &lo, int &give) const {
-        const double thr = seed_threshold(lam);
+    PTV_PIN_FN void win4_all(const Sh &sh, double Sl, double rl, double Sr1, double rr1, double Sr2, double rr2, Mask &up, Mask &lo, int &give) const {
         const int room = n - 1 - t * P;
-#define PTV_WIN4(A)                                                                                        \
-        {                                                                                                  \
-            const Win w = win_part<4, A, A + 1, A + 3>(sh, PTV_S_AT(A), PTV_S_AT(A + 4));                   \
-            win_take<4, A>(w, (A > 0 || t > 0) && A + 4 <= room, thr, up, lo);                              \
+#define PTV_WIN4(A)                                                                                                        \
+        {                                                                                                                  \
+            const Win w = win_part<4, A, A + 1, A + 3>(sh, PTV_S_AT(A), PTV_R_AT(A), PTV_S_AT(A + 4), PTV_R_AT(A + 4));    \
+            win_take<4, A>(w, (A > 0 || t > 0) && A + 4 <= room, seed_threshold(PTV_R_AT(A), PTV_R_AT(A + 4)), up, lo);     \
         }
         PTV_WIN4(0) PTV_WIN4(4) PTV_WIN4(8) PTV_WIN4(12) PTV_WIN4(2) PTV_WIN4(6) PTV_WIN4(10)
 #undef PTV_WIN4
-        const double Sa = PTV_S_AT(14), dl = Sr2 - Sa;
-        Win w = win_part<4, 14, 15, 16>(sh, Sa, Sr2);
-        const double v = wtag((Sa - Sr1) * 4.0 + dl * 3.0, 3);
-        w.mx = pin_max(w.mx, v);
-        w.mn = wmin(w.mn, v);
+        const double Sa = PTV_S_AT(14), ra = PTV_R_AT(14);
+        Win w = win_part<4, 14, 15, 16>(sh, Sa, ra, Sr2, rr2);
+        if constexpr (!Sh::kWeighted) {
+            const double v = wtag((Sa - Sr1) * 4.0 + (Sr2 - Sa) * 3.0, 3);
+            w.mx = pin_max(w.mx, v);
+            w.mn = wmin(w.mn, v);
+        } else {
+            const double Ua = Sa + ra, La = Sa - ra;
+            w.mx = pin_max(w.mx, wtag((Ua - (Sr1 + rr1)) * 4.0 + ((Sr2 + rr2) - Ua) * 3.0, 3));
+            w.mn = wmin(w.mn, wtag((La - (Sr1 - rr1)) * 4.0 + ((Sr2 - rr2) - La) * 3.0, 3));
+        }
+        const double thr = seed_threshold(ra, rr2);
         const bool valid = 18 <= room;
         win_take<4, 14>(w, valid, thr, up, lo);
         give = 0;
@@ -304,6 +349,7 @@ struct PinLane {
         if (valid && -w.mn > thr * 4.0 && wdist(w.mn) == 3) give |= 2;
     }
 #undef PTV_S_AT
+#undef PTV_R_AT
     PTV_PIN_FN void win4_take(int prev_give, bool has_prev, Mask &up, Mask &lo) const {
         if (has_prev && (prev_give & 1)) up |= (Mask)1;
         if (has_prev && (prev_give & 2)) lo |= (Mask)1;

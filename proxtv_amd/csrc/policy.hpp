@@ -83,8 +83,12 @@ constexpr double kSeedMidDykstra = 0.004;
 // 6.0 / 3.3 ms; PD2 at lambda = 0.5, f = 0.022: 6.4 / 5.4 ms; DR at lambda = 0.5, f = 0.16: 2.4 / 3.1)
 constexpr long kSmallSweep = 1L << 21;
 constexpr double kSeedMidSmall = 0.06;
-inline int rung_from_certain_fraction(double f, bool dykstra = false, bool small = false) {
-    const double mid = small ? kSeedMidSmall : (dykstra ? kSeedMidDykstra : kSeedMid);
+// Weighted sweeps: the robust tile of a weighted row sweep runs at half the unweighted one's occupancy (two LDS planes), and the pinning solver
+// starts from knots known by windows there too: the chunk kernels give way earlier (4096^2 weighted DR, penalties U(0.5, 1.5) x s, rung 1 /
+// rung 3: s = 0.6, f = 0.095: 21.5 / 29.8 ms; 0.7, f = 0.060: 29.4 / 30.9; 0.8, f = 0.038: 45.6 / 32.0)
+constexpr double kSeedMidWeighted = 0.055;
+inline int rung_from_certain_fraction(double f, bool dykstra = false, bool small = false, bool weighted = false) {
+    const double mid = small ? kSeedMidSmall : (weighted ? kSeedMidWeighted : (dykstra ? kSeedMidDykstra : kSeedMid));
     return f >= kSeedNoisy ? 0 : (f >= mid ? 1 : 3);
 }
 

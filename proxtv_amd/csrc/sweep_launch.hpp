@@ -167,7 +167,7 @@ struct ChunkScratch {
         // quiet stretches have pieces far longer than any zone and every chunk in them would go to the repair kernel.
         if (flat_fraction(g, lam, weighted) > kSeedFlat) return 3;
         const Probe *p = find_probe(g, weighted);
-        return rung_from_certain_fraction(f, p && p->iterate == 1, (long)g.len * g.count <= kSmallSweep);
+        return rung_from_certain_fraction(f, p && p->iterate == 1, (long)g.len * g.count <= kSmallSweep, weighted);
     }
 
     static constexpr int kSlots = 8, kCounters = 2 * FAM_COUNT;

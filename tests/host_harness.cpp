@@ -327,22 +327,24 @@ static int pin_fibre(const double *y, const double *w, double lam, double *x, in
         // knots known by windows (pincore.hpp: win64 / win16 / win4): the lanes of a wave exchange their parts through arrays where the
         // kernel shuffles, a stage runs in the waves where the one before it found a knot (the kernel's ballots); what spans waves is
         // left out there, and here
-        if constexpr (P == 16 && !W) {
-            if (seeded >= 2 && lam > 0.0) {
+        if constexpr (P == 16) {
+            if (seeded >= 2 && (W || lam > 0.0)) {
                 using Lane = PinLane<P, Key>;
                 using Win = typename Lane::Win;
                 using Mask = typename Lane::Mask;
                 auto Sk = [&](int j) { return sh.S(j < 0 ? 0 : (j > n ? n : j)); };
+                auto Rk = [&](int j) { return W ? sh.r(j < 1 ? 1 : (j > n - 1 ? n - 1 : j)) : lam; };
                 const int padded = (lanes + 63) / 64 * 64;   // (lanes beyond the fibre run the same code on the device; their parts are never used)
                 std::vector<Mask> ups((size_t)padded, 0), los((size_t)padded, 0), up16((size_t)padded, 0), lo16((size_t)padded, 0);
                 std::vector<Lane> ghost((size_t)padded);
                 std::vector<Win> pa((size_t)padded), pb((size_t)padded), tail((size_t)padded), head((size_t)padded);
+                std::vector<double> thr_tail((size_t)padded, 0.0), thr_head((size_t)padded, 0.0);
                 std::vector<int> give((size_t)padded, 0);
                 for (int t = 0; t < padded; t++) {
                     ghost[(size_t)t].init(n, t, sh);
-                    const int qa = t & 3, qb = (t + 2) & 3;
-                    pa[(size_t)t] = ghost[(size_t)t].win64_part(sh, Sk((t - qa) * P), Sk((t - qa) * P + 64), qa);
-                    pb[(size_t)t] = ghost[(size_t)t].win64_part(sh, Sk((t - qb) * P), Sk((t - qb) * P + 64), qb);
+                    const int qa = t & 3, qb = (t + 2) & 3, a0 = (t - qa) * P, b0 = (t - qb) * P;
+                    pa[(size_t)t] = ghost[(size_t)t].win64_part(sh, Sk(a0), Rk(a0), Sk(a0 + 64), Rk(a0 + 64), qa);
+                    pb[(size_t)t] = ghost[(size_t)t].win64_part(sh, Sk(b0), Rk(b0), Sk(b0 + 64), Rk(b0 + 64), qb);
                 }
                 auto wave_has = [&](int base, const std::vector<Mask> &a, const std::vector<Mask> &b, int lanes_needed) {
                     int found = 0;
@@ -350,30 +352,31 @@ static int pin_fibre(const double *y, const double *w, double lam, double *x, in
                     return found >= lanes_needed;
                 };
                 for (int t = 0; t < padded; t++) {   // 64 knots, the plain grid
-                    const int l = t & 63, base = t - l, qa = t & 3;
+                    const int l = t & 63, base = t - l, qa = t & 3, a0 = (t - qa) * P;
                     auto in_wave = [&](int lane_in_wave) { return (size_t)(base + (lane_in_wave & 63)); };
                     const int m = l ^ 2;   // (second step of the butterfly: the partner's joined pair)
                     const Win all_a = Lane::wjoin(Lane::wjoin(pa[in_wave(l)], pa[in_wave(l ^ 1)]), Lane::wjoin(pa[in_wave(m)], pa[in_wave(m ^ 1)]));
-                    ghost[(size_t)t].win64_take(lam, all_a, true, qa, 4, ups[(size_t)t], los[(size_t)t]);
+                    ghost[(size_t)t].win64_take(Lane::seed_threshold(Rk(a0), Rk(a0 + 64)), all_a, true, qa, 4, ups[(size_t)t], los[(size_t)t]);
                 }
                 for (int base = 0; base < padded; base += 64) {   // ... the shifted grid, in the waves where the plain one found a knot
                     if (!wave_has(base, ups, los, 1)) continue;
                     for (int t = base; t < base + 64; t++) {
-                        const int l = t - base, qb = (t + 2) & 3;
+                        const int l = t - base, qb = (t + 2) & 3, b0 = (t - qb) * P;
                         auto in_wave = [&](int lane_in_wave) { return (size_t)(base + (lane_in_wave & 63)); };
                         const int partner = qb < 2 ? l + 2 : l - 2, mb = partner & 63;
                         const Win all_b = Lane::wjoin(Lane::wjoin(pb[in_wave(l)], pb[in_wave(l ^ 1)]), Lane::wjoin(pb[in_wave(mb)], pb[in_wave(mb ^ 1)]));
-                        ghost[(size_t)t].win64_take(lam, all_b, partner >= 0 && partner < 64, qb, 2, ups[(size_t)t], los[(size_t)t]);
+                        ghost[(size_t)t].win64_take(Lane::seed_threshold(Rk(b0), Rk(b0 + 64)), all_b, partner >= 0 && partner < 64, qb, 2, ups[(size_t)t], los[(size_t)t]);
                     }
                 }
                 for (int base = 0; base < padded; base += 64) {
                     if (!wave_has(base, ups, los, kSeedStage16)) continue;
                     for (int t = base; t < base + 64; t++)
-                        ghost[(size_t)t].win16_parts(sh, lam, Sk(t * P), Sk(t * P + 24), Sk(t * P - 8), up16[(size_t)t], lo16[(size_t)t], tail[(size_t)t], head[(size_t)t]);
+                        ghost[(size_t)t].win16_parts(sh, Sk(t * P), Rk(t * P), Sk(t * P + 24), Rk(t * P + 24), Sk(t * P - 8), Rk(t * P - 8), up16[(size_t)t], lo16[(size_t)t],
+                                                     tail[(size_t)t], head[(size_t)t], thr_tail[(size_t)t], thr_head[(size_t)t]);
                     for (int t = base; t < base + 64; t++) {
                         const int l = t - base;
-                        ghost[(size_t)t].win16_take(lam, tail[(size_t)t], head[(size_t)(base + ((l + 1) & 63))], l < 63, tail[(size_t)(base + ((l + 63) & 63))],
-                                                    head[(size_t)t], l > 0, up16[(size_t)t], lo16[(size_t)t]);
+                        ghost[(size_t)t].win16_take(tail[(size_t)t], thr_tail[(size_t)t], head[(size_t)(base + ((l + 1) & 63))], l < 63, tail[(size_t)(base + ((l + 63) & 63))],
+                                                    head[(size_t)t], thr_head[(size_t)t], l > 0, up16[(size_t)t], lo16[(size_t)t]);
                     }
                     const bool finer = wave_has(base, up16, lo16, kSeedStage4);
                     for (int t = base; t < base + 64; t++) {
@@ -382,7 +385,8 @@ static int pin_fibre(const double *y, const double *w, double lam, double *x, in
                     }
                     if (!finer) continue;
                     for (int t = base; t < base + 64; t++)
-                        ghost[(size_t)t].win4_all(sh, lam, Sk(t * P), Sk(t * P + P + 1), Sk(t * P + P + 2), ups[(size_t)t], los[(size_t)t], give[(size_t)t]);
+                        ghost[(size_t)t].win4_all(sh, Sk(t * P), Rk(t * P), Sk(t * P + P + 1), Rk(t * P + P + 1), Sk(t * P + P + 2), Rk(t * P + P + 2), ups[(size_t)t], los[(size_t)t],
+                                                  give[(size_t)t]);
                     for (int t = base; t < base + 64; t++) {
                         const int l = t - base;
                         ghost[(size_t)t].win4_take(give[(size_t)(base + ((l + 63) & 63))], l > 0, ups[(size_t)t], los[(size_t)t]);
@@ -730,6 +734,10 @@ int host_pin_fibre_long(const double *y, const double *w, double lam, double *x,
 int host_pin_fibre_windows(const double *y, double lam, double *x, int n, int *nseeds) {
     return pin_fibre<16, false>(y, nullptr, lam, x, n, 2, nseeds);
 }
+// ... with per-edge penalties w (n - 1 of them)
+int host_pin_fibre_windows_weighted(const double *y, const double *w, double *x, int n, int *nseeds) {
+    return pin_fibre<16, true>(y, w, 0.0, x, n, 2, nseeds);
+}
 
 int host_pin_fibre_seeded(const double *y, const double *w, double lam, double *x, int n, int P) {
     if (P == 16) return w ? pin_fibre<16, true>(y, w, lam, x, n, 1) : pin_fibre<16, false>(y, w, lam, x, n, 1);
@@ -749,7 +757,7 @@ int host_pin_fibre(const double *y, const double *w, double lam, double *x, int 
 
 // the seeded policy's pure functions (policy.hpp): rung of a sweep from the certain fraction of its (sampled) input; iterations before
 // whose sweeps a Dykstra / ADMM loop samples its operands again
-int policy_rung(double f, int dykstra, int small) { return rung_from_certain_fraction(f, dykstra != 0, small != 0); }
+int policy_rung(double f, int dykstra, int small, int weighted) { return rung_from_certain_fraction(f, dykstra != 0, small != 0, weighted != 0); }
 int policy_reprobe_at(int it, int steady) { return reprobe_at(it, steady != 0) ? 1 : 0; }
 
 // (the same without a pinning rung: rung 3 is the global-memory chunk kernel)

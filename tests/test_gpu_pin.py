@@ -265,3 +265,33 @@ def test_knots_known_by_windows(ptv, clib, oracle, rung3):
             assert_close(ptv.tv1_2d(X, lam, max_iters=3), oracle.dr2(X, lam, max_iters=3)[0], tol=1e-9, what=f"ties {n} lam {lam}")
     finally:
         clib.proxtv_set_option(b"pin_seed", 2)
+
+
+def test_knots_known_by_windows_weighted(ptv, clib, oracle, rung3):
+    """The windows on weighted fibres (per-edge penalties: each wall against the line through its own ends, a window's threshold the tube's
+    width at its wider end).  Weighted DR on images whose fibres fill the group geometries of sixteen knots a lane, penalties around the noise
+    level; free edges (penalty 0); weighted single fibres; the switch may not move the result beyond the rounding of the running sums."""
+    rng = np.random.default_rng(330)
+    assert clib.proxtv_set_option(b"pin_seed", 2) in (0, 1, 2)
+    try:
+        for (M, N), lam in (((4096, 60), 1.0), ((2048, 200), 1.5), ((1000, 300), 0.8), ((300, 4096), 1.0), ((4095, 33), 2.5)):
+            X = rng.standard_normal((M, N))
+            W1, W2 = rng.uniform(0.4 * lam, 1.6 * lam, (M - 1, N)), rng.uniform(0.4 * lam, 1.6 * lam, (M, N - 1))
+            if M == 1000:
+                W1[rng.integers(0, M - 1, 50), rng.integers(0, N, 50)] = 0.0
+                W2[rng.integers(0, M, 50), rng.integers(0, N - 1, 50)] = 0.0
+            before = clib.proxtv_debug_counter(b"pin_sweeps")
+            got = ptv.tv1w_2d(X, W1, W2, max_iters=4)
+            assert clib.proxtv_debug_counter(b"pin_sweeps") > before
+            assert_close(got, oracle.dr2w(X, W1, W2, max_iters=4)[0], tol=1e-9, what=f"dr2w {M}x{N} lam {lam}")
+            clib.proxtv_set_option(b"pin_seed", 1)
+            plain = ptv.tv1w_2d(X, W1, W2, max_iters=4)
+            clib.proxtv_set_option(b"pin_seed", 2)
+            assert np.abs(got - plain).max() <= 1e-10, (M, N, lam, np.abs(got - plain).max())
+        for n in (64, 1000, 2048, 4096):
+            for name, x in _families(rng, n):
+                for lam in (0.3, 1.0, 3.0):
+                    w = rng.uniform(0.3 * lam, 1.7 * lam, n - 1)
+                    assert_close(ptv.tv1w_1d(x, w), oracle.tv1_weighted(x, w), tol=1e-11, what=f"weighted {name} n={n} lam={lam}")
+    finally:
+        clib.proxtv_set_option(b"pin_seed", 2)

@@ -24,6 +24,8 @@ def harness():
     lib.host_pin_fibre_seeded.restype = C.c_int
     lib.host_pin_fibre_windows.argtypes = [C.c_void_p, C.c_double, C.c_void_p, C.c_int, C.c_void_p]
     lib.host_pin_fibre_windows.restype = C.c_int
+    lib.host_pin_fibre_windows_weighted.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    lib.host_pin_fibre_windows_weighted.restype = C.c_int
     lib.host_pin_fibre_long.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_int]
     lib.host_pin_fibre_long.restype = C.c_int
     lib.host_pin_fibre_threads.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_int, C.c_int]
@@ -294,3 +296,30 @@ def test_window_seeds_halve_the_levels_of_dr_operands(harness, oracle):
         plain += l1
         seeded += l2
     assert seeded <= 0.62 * plain, (seeded, plain)
+
+
+def test_window_seeds_with_per_edge_penalties(harness, oracle):
+    """The same windows on weighted fibres: the walls are no copies of the sums any more (upper wall S + r, lower S - r, each against the line
+    through its own ends), a window's threshold is the tube's width at its wider end.  Penalties spread over a decade, free edges (r = 0: the
+    string is cut there), penalties around the noise level where the windows find most."""
+    rng = np.random.default_rng(24)
+    found = plain_levels = seeded_levels = 0
+    for trial in range(400):
+        name = list(FAMILIES)[trial % len(FAMILIES)]
+        n = int(rng.choice([5, 17, 33, 64, 65, 100, 257, 1000, 1024, 1025, 2048, 4000, 4096]))
+        y = FAMILIES[name](rng, n)
+        w = 10 ** rng.uniform(-1.5, 1.0) * rng.uniform(0.3, 1.7, n - 1)
+        if trial % 4 == 0:
+            w[rng.integers(0, n - 1, max(1, n // 20))] = 0.0
+        if trial % 7 == 0:
+            w = np.full(n - 1, float(w[0]))          # one penalty, through the weighted code
+        want = oracle.tv1_weighted(y.copy(), w)
+        x = np.full(n, np.nan)
+        seeds = C.c_int(0)
+        levels = harness.host_pin_fibre_windows_weighted(y.ctypes.data, w.ctypes.data, x.ctypes.data, n, C.byref(seeds))
+        assert np.abs(x - want).max() <= tol(y), (name, n, float(w.mean()), seeds.value, np.abs(x - want).max())
+        _, l1 = pin_seeded(harness, y, 0.0, w=w)
+        found += seeds.value
+        plain_levels += l1
+        seeded_levels += levels
+    assert found > 0 and seeded_levels < 0.9 * plain_levels, (found, seeded_levels, plain_levels)

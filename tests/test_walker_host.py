@@ -300,12 +300,13 @@ def test_seeded_policy_rungs_and_sample_schedule(harness):
     noisier data than its certain fraction says), small sweeps' (a repair launch costs what it costs whatever the image) -- and the iterations
     before whose sweeps a loop samples its operands again."""
     lib = harness
-    lib.policy_rung.argtypes = [C.c_double, C.c_int, C.c_int]
+    lib.policy_rung.argtypes = [C.c_double, C.c_int, C.c_int, C.c_int]
     lib.policy_reprobe_at.argtypes = [C.c_int, C.c_int]
-    rung = lambda f, dykstra=0, small=0: lib.policy_rung(f, dykstra, small)
+    rung = lambda f, dykstra=0, small=0, weighted=0: lib.policy_rung(f, dykstra, small, weighted)
     assert [rung(f) for f in (0.78, 0.45, 0.44, 0.03, 0.029, 0.0)] == [0, 0, 1, 1, 3, 3]
     assert [rung(f, dykstra=1) for f in (0.5, 0.022, 0.009, 0.004, 0.0039, 0.001)] == [0, 1, 1, 1, 3, 3]
     assert [rung(f, small=1) for f in (0.5, 0.16, 0.06, 0.059, 0.034)] == [0, 1, 1, 3, 3]
     assert [rung(f, dykstra=1, small=1) for f in (0.16, 0.022)] == [1, 3]           # (small sweeps: one threshold for all operands)
+    assert [rung(f, weighted=1) for f in (0.5, 0.095, 0.055, 0.054, 0.038)] == [0, 1, 1, 3, 3]
     assert [it for it in range(1, 40) if lib.policy_reprobe_at(it, 0)] == [2, 3, 5, 9, 17, 33]
     assert [it for it in range(1, 40) if lib.policy_reprobe_at(it, 1)] == [2, 3, 5, 9, 13, 17, 21, 25, 29, 33, 37]

@@ -159,5 +159,21 @@ final4)  # window seeds (always on, stages gated wave by wave) + mid-solve sampl
   python tools/certified_campaign.py 100 5 > $OUT/campaign_5.txt 2>&1; tail -1 $OUT/campaign_5.txt | tee -a $OUT/summary.txt
   python tools/certified_campaign.py 150 6 high > $OUT/campaign_6_high.txt 2>&1; tail -1 $OUT/campaign_6_high.txt | tee -a $OUT/summary.txt; grep "certify:" $OUT/campaign_6_high.txt | cut -c1-260 | head -10 | tee -a $OUT/summary.txt
   ;;
+final5)  # the round's last build: the whole suite, smoke, the two-rank dry run of bench.py on one GPU, soaks, a certified campaign at large penalties
+  timeout 1500 python -m pytest tests -m gpu -x -q --durations=6 > $OUT/pytest_default.log 2>&1; echo "default: $(tail -1 $OUT/pytest_default.log)" | tee $OUT/summary.txt
+  python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; tail -1 $OUT/smoke.log | tee -a $OUT/summary.txt
+  PROXTV_BENCH_SHARED_GPU=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 3 --warmup 1 --no-cpu-baseline > $OUT/bench2.json 2> $OUT/bench2.err; python -c "
+import json;d=json.loads(open('$OUT/bench2.json').read().strip().splitlines()[-1]);print('2 ranks on one GPU (dry run):',d['n_gpus'],'ranks',round(d['ms_per_step'],2),'ms per step, c5 gather checked',d['c5'].get('gather_checked'))" | tee -a $OUT/summary.txt
+  { python tools/fuzz.py 200 681; python tools/fuzz.py 200 682; python tools/fuzz.py 50 683 nd; python tools/fuzz.py 80 684 long; } > $OUT/fuzz.txt 2>&1; grep "^fuzz\|MISMATCH\|Error" $OUT/fuzz.txt | tee -a $OUT/summary.txt
+  python tools/certified_campaign.py 200 7 high > $OUT/campaign_7_high.txt 2>&1; tail -1 $OUT/campaign_7_high.txt | tee -a $OUT/summary.txt; grep "certify:" $OUT/campaign_7_high.txt | cut -c1-260 | head -10 | tee -a $OUT/summary.txt
+  python tools/certified_campaign.py 100 8 > $OUT/campaign_8.txt 2>&1; tail -1 $OUT/campaign_8.txt | tee -a $OUT/summary.txt
+  ;;
+final6)  # windows on weighted fibres + the weighted threshold: the whole suite, smoke, weighted DR over its penalties, soaks, a certified campaign at large penalties
+  timeout 1500 python -m pytest tests -m gpu -x -q --durations=6 > $OUT/pytest_default.log 2>&1; echo "default: $(tail -1 $OUT/pytest_default.log)" | tee $OUT/summary.txt
+  python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; tail -1 $OUT/smoke.log | tee -a $OUT/summary.txt
+  timeout 600 python tools/weighted_rungs.py > $OUT/weighted_rungs.txt 2>&1; grep RESULT $OUT/weighted_rungs.txt | tee -a $OUT/summary.txt
+  { python tools/fuzz.py 150 691; python tools/fuzz.py 150 692; python tools/fuzz.py 40 693 nd; python tools/fuzz.py 60 694 long; } > $OUT/fuzz.txt 2>&1; grep "^fuzz\|MISMATCH\|Error" $OUT/fuzz.txt | tee -a $OUT/summary.txt
+  python tools/certified_campaign.py 180 9 high > $OUT/campaign_9_high.txt 2>&1; tail -1 $OUT/campaign_9_high.txt | tee -a $OUT/summary.txt; grep "certify:" $OUT/campaign_9_high.txt | cut -c1-260 | head -10 | tee -a $OUT/summary.txt
+  ;;
 *) echo "unknown session $S";;
 esac
