@@ -439,8 +439,9 @@ void ccp_step(const CcpArgs &a, bool first, hipStream_t s) {
 namespace {
 // element (r, c) of a rows x cols block at in[r + ld_in c] -> out[c + ld_out r]; slab z of the grid is slab_in / slab_out elements on
 __global__ __launch_bounds__(256) void slab_transpose_kernel(const double *in, double *out, long rows, long cols, long ld_in, long ld_out,
-                                                             long slab_in, long slab_out) {
+                                                             long slab_in, long slab_out, const int *gate) {
     __shared__ double tile[32][33];
+    if (gate && *gate == 0) return;   // (the copies around a gated sweep: a no-op like the sweep itself)
     in += (long)blockIdx.z * slab_in;
     out += (long)blockIdx.z * slab_out;
     const long r0 = (long)blockIdx.x * 32, c0 = (long)blockIdx.y * 32;
@@ -457,10 +458,10 @@ __global__ __launch_bounds__(256) void slab_transpose_kernel(const double *in, d
 }
 }  // namespace
 
-void slab_transpose(const double *in, double *out, long rows, long cols, long slabs, hipStream_t s) {
+void slab_transpose(const double *in, double *out, long rows, long cols, long slabs, hipStream_t s, const int *gate) {
     if (rows <= 0 || cols <= 0 || slabs <= 0) return;
     const dim3 grid((unsigned)((rows + 31) / 32), (unsigned)((cols + 31) / 32), (unsigned)slabs);
-    hipLaunchKernelGGL(slab_transpose_kernel, grid, dim3(256), 0, s, in, out, rows, cols, rows, cols, rows * cols, rows * cols);
+    hipLaunchKernelGGL(slab_transpose_kernel, grid, dim3(256), 0, s, in, out, rows, cols, rows, cols, rows * cols, rows * cols, gate);
     PTV_HIP(hipGetLastError());
 }
 
@@ -468,7 +469,7 @@ void slab_transpose(const double *in, double *out, long rows, long cols, long sl
 void block_transpose(const double *in, double *out, long rows, long cols, long ld_in, long ld_out, hipStream_t s) {
     if (rows <= 0 || cols <= 0) return;
     const dim3 grid((unsigned)((rows + 31) / 32), (unsigned)((cols + 31) / 32), 1u);
-    hipLaunchKernelGGL(slab_transpose_kernel, grid, dim3(256), 0, s, in, out, rows, cols, ld_in, ld_out, 0L, 0L);
+    hipLaunchKernelGGL(slab_transpose_kernel, grid, dim3(256), 0, s, in, out, rows, cols, ld_in, ld_out, 0L, 0L, (const int *)nullptr);
     PTV_HIP(hipGetLastError());
 }
 
@@ -647,30 +648,38 @@ TransposedOperands::TransposedOperands(const SweepArgs &args, unsigned in_mask, 
     if (out_mask & 2u) { o1_.reset(new Scratch(bytes_)); t_.o1 = o1_->d(); }
 }
 
+// A gated sweep (SweepArgs::gate: the loops that enqueue all their iterations and end on a device-side flag -- Kolmogorov2_TV,
+// CondatChambollePock2_TV) is a no-op when its gate is closed, and so must the copies around it be: until round 6 the transposition BACK
+// ran regardless and wrote the scratch array the skipped kernel never filled over the loop's result (a 2 x 96 image at lambda = 12.7: off by
+// 2.75 from the third iteration on -- tools/fuzz.py, seed 701; tests/test_gpu_parity_2d.py).  Gated sweeps keep their copies to themselves
+// (no cache: a copy made behind a closed gate is not a copy).
 const double *TransposedOperands::input(const double *src, std::unique_ptr<Scratch> &own, int len) {
     TransposeCache &cache = transpose_cache();
-    if (cache.active)
+    const bool cached = cache.active && !orig_.gate;
+    if (cached)
         if (Scratch *c = cache.find(src, shape(len))) return c->d();
     std::unique_ptr<Scratch> copy(new Scratch(sizeof(double) * (size_t)g_.count * (size_t)len));
-    slab_transpose(src, copy->d(), g_.inc, len, slabs_, s_);
+    slab_transpose(src, copy->d(), g_.inc, len, slabs_, s_, orig_.gate);
     const double *p = copy->d();
-    if (cache.active) cache.remember(src, shape(len), std::move(copy));
+    if (cached) cache.remember(src, shape(len), std::move(copy));
     else own = std::move(copy);
     return p;
 }
 
 void TransposedOperands::finish() {
     TransposeCache &cache = transpose_cache();
+    const bool cached = cache.active && !orig_.gate;
     if (out_mask_ & 1u) {
-        slab_transpose(o0_->d(), orig_.o0, g_.len, g_.inc, slabs_, s_);
-        if (cache.active) cache.remember(orig_.o0, shape(g_.len), std::move(o0_));   // (what was just written, in the form the next strided sweep wants)
+        slab_transpose(o0_->d(), orig_.o0, g_.len, g_.inc, slabs_, s_, orig_.gate);
+        if (cached) cache.remember(orig_.o0, shape(g_.len), std::move(o0_));   // (what was just written, in the form the next strided sweep wants)
+        else if (cache.active) cache.forget(orig_.o0);                           // (a copy of the array's old content must not outlive it)
     }
     if (out_mask_ & 2u) {
-        slab_transpose(o1_->d(), orig_.o1, g_.len, g_.inc, slabs_, s_);
-        if (cache.active) cache.remember(orig_.o1, shape(g_.len), std::move(o1_));
+        slab_transpose(o1_->d(), orig_.o1, g_.len, g_.inc, slabs_, s_, orig_.gate);
+        if (cached) cache.remember(orig_.o1, shape(g_.len), std::move(o1_));
+        else if (cache.active) cache.forget(orig_.o1);
     }
 }
-
 
 void warm_pointwise() {
     hipFuncAttributes attr;

@@ -39,7 +39,8 @@ void lincomb(double *out, const double *a, double ca, const double *b, double cb
 // Tiled transpose of `slabs` column-major matrices stored back to back: out (cols x rows) = in (rows x cols)^T per slab.
 // Sweeps along a strided dimension use it to run as dimension-0 sweeps on transposed copies: fibre j = slab * inc + off
 // sits at j * len after the transposition of every (inc x len) slab.
-void slab_transpose(const double *in, double *out, long rows, long cols, long slabs, hipStream_t s);
+// (gate != null: a no-op when *gate == 0, like the gated sweep the copy belongs to)
+void slab_transpose(const double *in, double *out, long rows, long cols, long slabs, hipStream_t s, const int *gate = nullptr);
 void block_transpose(const double *in, double *out, long rows, long cols, long ld_in, long ld_out, hipStream_t s);
 // Edge statistics of an array along one dimension -- what the geometry policy (sweep.hip) is seeded with: a histogram of
 // |y[e + inc] - y[e]| (weighted: divided by the edge's penalty) over a fixed sample of edges, kProbeBins bins of an eighth

@@ -1,5 +1,7 @@
 """HIP path vs golden vectors and vs the CPU oracle: 2-D solvers (DR2_TV, DR2L1W_TV, PD2_TV, Yang2_TV) through the
 prox_tv-compatible surface and the C symbols, including info[] / return-code conventions."""
+import os
+
 import numpy as np
 import pytest
 
@@ -81,6 +83,32 @@ def test_golden_yang2(ptv, clib, g2d):
         want = g2d[f"{name}/yang2_info"]
         assert rc == int(g2d[f"{name}/yang2_rc"]) == 1
         assert info[0] == want[0] == 36 and info[1] == -7.0 and info[2] == 0   # maxit + 1, gap untouched
+
+
+def test_gated_sweeps_through_transposed_copies(ptv, clib, oracle):
+    """Loops that end on a device-side flag (Kolmogorov2_TV, CondatChambollePock2_TV) enqueue all their iterations; once the flag is down
+    the remaining kernels are no-ops -- and so must be the copies around a strided sweep that goes through transposed operands (the pinning
+    rung, which a problem too small to sample takes): until round 6 the transposition BACK ran regardless and wrote a scratch array nobody had
+    filled over the result.  The fixture is the case tools/fuzz.py found (seed 701, case 2681): a 2 x 96 image of 1.5 with a few spikes at
+    lambda = 12.67, whose iterates stop moving at the third iteration -- off by 2.75 from there on."""
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "gated_transposed_sweep.npz"))
+    X, lam = d["X"], float(d["lam"])
+    for mode in (-1, 3, 2, 1):
+        before = clib.proxtv_set_option(b"chunk_mode", mode)
+        try:
+            for its in (1, 2, 3, 4, 7, 12, 0):
+                assert_close(ptv.tv1_2d(X, lam, method="kolmogorov", max_iters=its), oracle.kolmogorov2(X, lam, its)[0], tol=1e-12,
+                             what=f"kolmogorov mode {mode} its {its}")
+            for alg, method in ((0, "condat"), (1, "chambolle-pock"), (2, "chambolle-pock-acc")):
+                for its in (3, 12, 0):
+                    assert_close(ptv.tv1_2d(X, lam, method=method, max_iters=its), oracle.ccp2(X, lam, alg, its)[0], tol=1e-12,
+                                 what=f"{method} mode {mode} its {its}")
+        finally:
+            clib.proxtv_set_option(b"chunk_mode", before)
+    rng = np.random.default_rng(77)   # the same kind of image with fibres for every group geometry of the pinning solver
+    for shape in ((3, 300), (5, 1100), (2, 4200)):
+        Y = np.full(shape, 1.5) + (rng.random(shape) < 0.01) * 8.0
+        assert_close(ptv.tv1_2d(Y, 25.0, method="kolmogorov", max_iters=9), oracle.kolmogorov2(Y, 25.0, 9)[0], tol=1e-12, what=f"kolmogorov {shape}")
 
 
 def test_golden_kolmogorov_and_condat_chambolle_pock(ptv, clib, gpd):

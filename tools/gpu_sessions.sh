@@ -175,5 +175,10 @@ final6)  # windows on weighted fibres + the weighted threshold: the whole suite,
   { python tools/fuzz.py 150 691; python tools/fuzz.py 150 692; python tools/fuzz.py 40 693 nd; python tools/fuzz.py 60 694 long; } > $OUT/fuzz.txt 2>&1; grep "^fuzz\|MISMATCH\|Error" $OUT/fuzz.txt | tee -a $OUT/summary.txt
   python tools/certified_campaign.py 180 9 high > $OUT/campaign_9_high.txt 2>&1; tail -1 $OUT/campaign_9_high.txt | tee -a $OUT/summary.txt; grep "certify:" $OUT/campaign_9_high.txt | cut -c1-260 | head -10 | tee -a $OUT/summary.txt
   ;;
+soak1)  # the round's last build (4700b7897a11) once more: certified campaigns at large and at the usual penalties, option soaks
+  python tools/certified_campaign.py 360 10 high > $OUT/campaign_10_high.txt 2>&1; tail -1 $OUT/campaign_10_high.txt | tee $OUT/summary.txt; grep "certify:" $OUT/campaign_10_high.txt | cut -c1-260 | head -10 | tee -a $OUT/summary.txt
+  python tools/certified_campaign.py 240 11 > $OUT/campaign_11.txt 2>&1; tail -1 $OUT/campaign_11.txt | tee -a $OUT/summary.txt
+  { python tools/fuzz.py 240 701; python tools/fuzz.py 240 702; python tools/fuzz.py 100 703 long; } > $OUT/fuzz.txt 2>&1; grep "^fuzz\|MISMATCH\|Error" $OUT/fuzz.txt | tee -a $OUT/summary.txt
+  ;;
 *) echo "unknown session $S";;
 esac
